@@ -1,0 +1,184 @@
+"""ctypes mirror of include/cda.h (struct layouts and constants).
+
+Kept free of any library loading so that both the product binding (`_lib.py`) and the test-only
+oracle loader (`tests/oracle_lib.py`) can share the struct definitions.
+"""
+import ctypes as C
+
+K_ROWS = 10
+SNAPSHOT_DIM = 42
+RAW_DIM = 40
+MAX_HIST = 16
+MAX_AGENTS = 16
+BOOK_CAP = 256
+NUM_REWARD_TERMS = 5
+
+OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = -1, -2, -3, -4, -5
+
+FLAG_BOOK_OVERFLOW, FLAG_INT_OVERFLOW, FLAG_DEC_DOMAIN = 1, 2, 4
+
+T_MARKET, T_LIMIT, T_MODIFY, T_CANCEL = 0, 1, 2, 3
+S_BID, S_ASK = 0, 1
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("num_agents", C.c_int32), ("max_step", C.c_int32), ("n_hist", C.c_int32), ("tick_size", C.c_int32),
+        ("init_cash", C.c_int64),
+        ("initial_price_min", C.c_int32), ("initial_price_max", C.c_int32),
+        ("min_size", C.c_int32), ("mkt_max_size", C.c_int32), ("limit_size_multiple", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("order_penalty", C.c_double), ("trade_penalty", C.c_double), ("drawdown_penalty", C.c_double),
+        ("passive_bonus", C.c_double), ("loss_multiplier", C.c_double),
+    ]
+
+
+class Dec(C.Structure):
+    _fields_ = [("w", C.c_uint32 * 3), ("exp", C.c_int16), ("sign", C.c_uint8), ("pad", C.c_uint8)]
+
+
+INFO_FIELDS = [
+    # name, element ctype, per-agent?, trailing dims
+    ("nav", Dec, True, ()),
+    ("num_trades", C.c_int32, True, ()),
+    ("net_position", C.c_int32, True, ()),
+    ("vwap", C.c_double, True, ()),
+    ("cash", C.c_double, True, ()),
+    ("cash_on_hold", C.c_double, True, ()),
+    ("position_val", C.c_double, True, ()),
+    ("drawdown", C.c_double, True, ()),
+    ("max_nav", C.c_double, True, ()),
+    ("num_trades_step", C.c_int32, True, ()),
+    ("num_passive_fills_step", C.c_int32, True, ()),
+    ("order_step_placed", C.c_int32, True, ()),
+    ("num_rejected_step", C.c_int32, True, ()),
+    ("is_pass_action", C.c_uint8, True, ()),
+    ("reward_terms", C.c_double, True, (NUM_REWARD_TERMS,)),
+    ("last_price", C.c_double, False, ()),
+    ("best_bid", C.c_double, False, ()),
+    ("best_ask", C.c_double, False, ()),
+    ("spread", C.c_double, False, ()),
+]
+
+
+class InfoPtrs(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _t, _pa, _d in INFO_FIELDS]
+
+
+class Order(C.Structure):
+    _fields_ = [("price", C.c_int32), ("qty", C.c_int32), ("owner", C.c_int32),
+                ("order_id", C.c_int32), ("timestamp", C.c_int32)]
+
+
+class AccountState(C.Structure):
+    _fields_ = [("cash", Dec), ("cash_on_hold", Dec), ("position_val", Dec), ("vwap", Dec),
+                ("nav", Dec), ("prev_nav", Dec), ("max_nav", Dec),
+                ("net_position", C.c_int32), ("num_trades", C.c_int32),
+                ("num_trades_step", C.c_int32), ("num_passive_fills_step", C.c_int32),
+                ("order_step_placed", C.c_int32), ("num_rejected_step", C.c_int32)]
+
+
+class MarketState(C.Structure):
+    _fields_ = [
+        ("rng_state_hi", C.c_uint64), ("rng_state_lo", C.c_uint64),
+        ("rng_inc_hi", C.c_uint64), ("rng_inc_lo", C.c_uint64),
+        ("rng_has_uint32", C.c_uint32), ("rng_uinteger", C.c_uint32),
+        ("t_step", C.c_int32), ("lob_time", C.c_int32), ("next_order_id", C.c_int32),
+        ("last_price", C.c_int32), ("has_trade", C.c_int32), ("last_trade_price", C.c_int32),
+        ("done_mask", C.c_uint32), ("flags", C.c_uint32),
+        ("n_bids", C.c_int32), ("n_asks", C.c_int32),
+        ("bids", Order * BOOK_CAP), ("asks", Order * BOOK_CAP),
+        ("acc", AccountState * MAX_AGENTS),
+        ("hist", C.c_float * (MAX_HIST * SNAPSHOT_DIM)),
+    ]
+
+
+# config/env_defaults.json:8-27 of the reference
+ENV_DEFAULTS = {
+    "num_of_agents": 5,
+    "init_cash": 1000000,
+    "tick_size": 1,
+    "tape_display_length": 10,
+    "max_step": 64,
+    "is_render": True,
+    "n_hist": 4,
+    "initial_price_min": 10,
+    "initial_price_max": 100,
+    "min_size": 1,
+    "mkt_max_size": 100,
+    "limit_size_multiple": 10,
+    "order_penalty": 0.1,
+    "trade_penalty": 0.05,
+    "drawdown_penalty": 0.2,
+    "passive_bonus": 0.1,
+    "loss_multiplier": 1.5,
+}
+
+
+def make_config(config=None):
+    """Env-config dict (reference keys, continuousDoubleAuction_env.py:27-55) -> Config struct.
+
+    Unknown keys raise; missing keys take the reference's standalone defaults."""
+    cfg = dict(ENV_DEFAULTS)
+    for k, v in (config or {}).items():
+        if k not in cfg:
+            raise KeyError(f"unknown env config key {k!r}; known: {sorted(cfg)}")
+        cfg[k] = v
+    init_cash = cfg["init_cash"]
+    if int(init_cash) != init_cash:
+        raise ValueError("init_cash must be integer valued")
+    if cfg["tick_size"] != 1:
+        raise ValueError("only tick_size == 1 is supported (integer tick grid)")
+    c = Config()
+    c.num_agents = int(cfg["num_of_agents"])
+    c.max_step = int(cfg["max_step"])
+    c.n_hist = int(cfg["n_hist"])
+    c.tick_size = 1
+    c.init_cash = int(init_cash)
+    c.initial_price_min = int(cfg["initial_price_min"])
+    c.initial_price_max = int(cfg["initial_price_max"])
+    c.min_size = int(cfg["min_size"])
+    c.mkt_max_size = int(cfg["mkt_max_size"])
+    c.limit_size_multiple = int(cfg["limit_size_multiple"])
+    c.order_penalty = float(cfg["order_penalty"])
+    c.trade_penalty = float(cfg["trade_penalty"])
+    c.drawdown_penalty = float(cfg["drawdown_penalty"])
+    c.passive_bonus = float(cfg["passive_bonus"])
+    c.loss_multiplier = float(cfg["loss_multiplier"])
+    return c, cfg
+
+
+def dec_to_int_exp(d):
+    """Dec struct (or numpy structured row) -> (sign, coefficient:int, exp)."""
+    w = d.w if hasattr(d, "w") else d["w"]
+    coeff = int(w[0]) | (int(w[1]) << 32) | (int(w[2]) << 64)
+    sign = int(d.sign if hasattr(d, "sign") else d["sign"])
+    exp = int(d.exp if hasattr(d, "exp") else d["exp"])
+    return sign, coeff, exp
+
+
+def dec_to_decimal(d):
+    """Exact `decimal.Decimal` with the same sign/coefficient/exponent triple."""
+    import decimal
+    sign, coeff, exp = dec_to_int_exp(d)
+    return decimal.Decimal((sign, tuple(int(ch) for ch in str(coeff)), exp))
+
+
+def dec_to_str(d):
+    """`str(Decimal)` of the triple - what info["NAV"] carries (info_helper.py:54)."""
+    return str(dec_to_decimal(d))
+
+
+def decimal_to_dec(x):
+    """decimal.Decimal -> Dec struct (coefficient must be < 2^96)."""
+    sign, digits, exp = x.as_tuple()
+    coeff = int("".join(map(str, digits)) or "0")
+    assert coeff < (1 << 96)
+    d = Dec()
+    d.w[0] = coeff & 0xFFFFFFFF
+    d.w[1] = (coeff >> 32) & 0xFFFFFFFF
+    d.w[2] = (coeff >> 64) & 0xFFFFFFFF
+    d.exp = exp
+    d.sign = sign
+    return d

@@ -1,0 +1,213 @@
+/*
+ * cda.h - C-ABI of the MI355X-native vectorised continuous-double-auction environment.
+ *
+ * This is the drop-in boundary for ONE hot path of ChuaCheowHuan/gym-continuousDoubleAuction:
+ * reset()/step() of the multi-agent limit-order-book env, batched over N independent markets.
+ * The reference has no FFI; its boundary is the Python class
+ *   gym_continuousDoubleAuction/envs/continuousDoubleAuction_env.py:21  (continuousDoubleAuctionEnv)
+ * bound at gym_continuousDoubleAuction/train/train.py:441-443 (tune.register_env) and
+ * gym_continuousDoubleAuction/__init__.py:18-21 (gymnasium.register).  Each entry point below
+ * names the reference method it replaces.  A maintainer binds it with ctypes;
+ * the in-tree Python host side (gym_continuousdoubleauction_amd/vec_env.py, env.py) is that binding.
+ *
+ * Conventions
+ *  - every function returns CDA_OK (0) or a negative cda_status; nothing throws or exits;
+ *  - array arguments are caller-owned DEVICE pointers (e.g. torch tensors' data_ptr()) unless the
+ *    name ends in _host; the library owns only the opaque cda_env arena;
+ *  - kernels are enqueued on the caller's HIP stream (`stream` is a hipStream_t, NULL = default
+ *    stream) and are asynchronous; calls on one cda_env are not re-entrant;
+ *  - there is NO CPU fallback: cda_create fails with CDA_ERR_NO_DEVICE when no gfx950 GPU is present.
+ */
+#ifndef CDA_H
+#define CDA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Observation layout: config/tunable_constants.json:8-10 (k_rows 10, book_rows 4, extra_dim 2). */
+#define CDA_K_ROWS        10
+#define CDA_BOOK_ROWS     4
+#define CDA_EXTRA_DIM     2
+#define CDA_SNAPSHOT_DIM  42            /* book_rows*k_rows + extra_dim */
+#define CDA_RAW_DIM       40            /* agg_LOB_raw: state_helper.py:159-160 */
+#define CDA_MAX_HIST      16            /* n_hist upper bound of this build (reference default 4) */
+#define CDA_MAX_AGENTS    16            /* agents per market upper bound of this build */
+#define CDA_BOOK_CAP      256           /* resting orders per side per market (reference: unbounded) */
+#define CDA_NUM_REWARD_TERMS 5          /* reward_helper.py:75-81 */
+
+typedef enum cda_status {
+    CDA_OK = 0,
+    CDA_ERR_INVALID = -1,       /* bad argument / config outside the supported domain */
+    CDA_ERR_NO_DEVICE = -2,     /* no HIP device (the product path has no CPU fallback) */
+    CDA_ERR_HIP = -3,           /* a HIP runtime call failed; see cda_strerror */
+    CDA_ERR_UNSUPPORTED = -4,   /* e.g. tick_size != 1 */
+    CDA_ERR_NOMEM = -5
+} cda_status;
+
+/* Per-market sticky flag bits reported by cda_last_flags. */
+#define CDA_FLAG_BOOK_OVERFLOW   0x1u   /* a rest was dropped: side already held CDA_BOOK_CAP orders */
+#define CDA_FLAG_INT_OVERFLOW    0x2u   /* a size/position/price left the int32 / 2^24 domain */
+#define CDA_FLAG_DEC_DOMAIN      0x4u   /* a ledger value left the 28-digit / exponent domain */
+
+/*
+ * Env config: the 17 keys of continuousDoubleAuction_env.py:27-55 with the defaults of
+ * config/env_defaults.json:8-27 (is_render and tape_display_length do not reach the numeric path).
+ */
+typedef struct cda_config {
+    int32_t num_agents;          /* num_of_agents        (5)       */
+    int32_t max_step;            /* max_step             (64)      */
+    int32_t n_hist;              /* n_hist               (4)       */
+    int32_t tick_size;           /* tick_size            (1) - only 1 is supported */
+    int64_t init_cash;           /* init_cash            (1000000) - integer, > -2^62 */
+    int32_t initial_price_min;   /* initial_price_min    (10)      */
+    int32_t initial_price_max;   /* initial_price_max    (100)     */
+    int32_t min_size;            /* min_size             (1)       */
+    int32_t mkt_max_size;        /* mkt_max_size         (100)     */
+    int32_t limit_size_multiple; /* limit_size_multiple  (10)      */
+    int32_t reserved0;
+    double  order_penalty;       /* 0.1  */
+    double  trade_penalty;       /* 0.05 */
+    double  drawdown_penalty;    /* 0.2  */
+    double  passive_bonus;       /* 0.1  */
+    double  loss_multiplier;     /* 1.5  */
+} cda_config;
+
+/*
+ * A ledger value: Python `Decimal` (prec 28, ROUND_HALF_EVEN) as sign / coefficient / exponent.
+ * value = (-1)^sign * (w[0] + w[1]*2^32 + w[2]*2^64) * 10^exp, coefficient < 10^28.
+ * `str(Decimal)` is reproduced on the host from this triple (info["NAV"], info_helper.py:54).
+ */
+typedef struct cda_dec {
+    uint32_t w[3];
+    int16_t  exp;
+    uint8_t  sign;
+    uint8_t  pad;
+} cda_dec;
+
+/* Optional SoA outputs mirroring Info_Helper.set_info (info_helper.py:30-116). Any pointer may be NULL. */
+typedef struct cda_info_ptrs {
+    cda_dec* nav;                    /* [N,A]  exact NAV (info["NAV"] = str of this)        */
+    int32_t* num_trades;             /* [N,A]                                                */
+    int32_t* net_position;           /* [N,A]                                                */
+    double*  vwap;                   /* [N,A]  float(acc.VWAP)                               */
+    double*  cash;                   /* [N,A]                                                */
+    double*  cash_on_hold;           /* [N,A]                                                */
+    double*  position_val;           /* [N,A]                                                */
+    double*  drawdown;               /* [N,A]                                                */
+    double*  max_nav;                /* [N,A]                                                */
+    int32_t* num_trades_step;        /* [N,A]  read before zeroing (exchg_helper.py:116-120)  */
+    int32_t* num_passive_fills_step; /* [N,A]                                                */
+    int32_t* order_step_placed;      /* [N,A]                                                */
+    int32_t* num_rejected_step;      /* [N,A]                                                */
+    uint8_t* is_pass_action;         /* [N,A]                                                */
+    double*  reward_terms;           /* [N,A,5] nav_term, order, trade, drawdown, passive    */
+    double*  last_price;             /* [N]                                                  */
+    double*  best_bid;               /* [N]  NaN encodes None                                */
+    double*  best_ask;               /* [N]  NaN encodes None                                */
+    double*  spread;                 /* [N]  NaN encodes None                                */
+} cda_info_ptrs;
+
+/* ---- parity dump of one market (host struct) ------------------------------------------- */
+typedef struct cda_order {
+    int32_t price;      /* integer ticks (the book's Decimal('<price>.0')) */
+    int32_t qty;
+    int32_t owner;      /* trader index = Order.trade_id (order.py:17)      */
+    int32_t order_id;
+    int32_t timestamp;
+} cda_order;
+
+typedef struct cda_account_state {
+    cda_dec cash, cash_on_hold, position_val, vwap, nav, prev_nav, max_nav;
+    int32_t net_position, num_trades;
+    int32_t num_trades_step, num_passive_fills_step, order_step_placed, num_rejected_step;
+} cda_account_state;
+
+typedef struct cda_market_state {
+    uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;  /* numpy PCG64 */
+    uint32_t rng_has_uint32, rng_uinteger;
+    int32_t  t_step, lob_time, next_order_id;
+    int32_t  last_price;          /* env.last_price (integer valued at tick_size 1) */
+    int32_t  has_trade;           /* len(LOB.tape) > 0 */
+    int32_t  last_trade_price;    /* LOB.tape[-1]['price'] */
+    uint32_t done_mask;           /* env.done_set as a bit mask */
+    uint32_t flags;
+    int32_t  n_bids, n_asks;
+    cda_order bids[CDA_BOOK_CAP]; /* queue order: best price first, FIFO inside a level */
+    cda_order asks[CDA_BOOK_CAP];
+    cda_account_state acc[CDA_MAX_AGENTS];
+    float    hist[CDA_MAX_HIST * CDA_SNAPSHOT_DIM];  /* oldest frame first */
+} cda_market_state;
+
+typedef struct cda_env cda_env;
+
+/* Fill `cfg` with config/env_defaults.json:8-27. */
+int cda_default_config(cda_config* cfg);
+
+/* Replaces continuousDoubleAuctionEnv.__init__ (continuousDoubleAuction_env.py:27-119) for
+ * n_markets independent envs on HIP device `device`. */
+int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env** out);
+int cda_destroy(cda_env* env);
+
+/* Replaces reset(seed=...) (continuousDoubleAuction_env.py:175-231).
+ *  seeds : u64[N] device, or NULL = seed=None (every selected market keeps its RNG stream;
+ *          a market that was never seeded is seeded with its index);
+ *  mask  : u8[N] device, or NULL = all markets;   obs_out : f32[N, n_hist*42] (rows of unselected
+ *          markets are left untouched). */
+int cda_reset(cda_env* env, const uint64_t* seeds, const uint8_t* mask, float* obs_out, void* stream);
+
+/* Replaces step(action_dict) (continuousDoubleAuction_env.py:265-309).
+ *  category i32[N,A], size_mean f32[N,A], size_sigma f32[N,A], price i32[N,A], price_offset i32[N,A]:
+ *  the Dict action of action_helper.py:126-138; `present` u8[N,A] or NULL (= every agent acts)
+ *  encodes an action dict holding a subset of the agents, iterated in ascending agent order.
+ *  Out: obs f32[N,n_hist*42] (one shared vector per market, state_helper.py:76,109),
+ *  reward f64[N,A], terminated u8[N] / truncated u8[N] (the "__all__" flags, done_helper.py:20-54),
+ *  info (nullable). */
+int cda_step(cda_env* env,
+             const int32_t* category, const float* size_mean, const float* size_sigma,
+             const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+             float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+             const cda_info_ptrs* info_out, void* stream);
+
+/* Test/diagnostic hook: Trader.place_order (agent/trader.py:49-106) for ONE decoded order on one
+ * market, bypassing decode and the RNG. type: 0 market, 1 limit, 2 modify, 3 cancel; side: 0 bid,
+ * 1 ask; price in ticks (ignored for market). Synchronous. */
+int cda_place_order(cda_env* env, int32_t market, int32_t trader, int32_t type, int32_t side,
+                    int32_t size, int32_t price);
+/* Test/diagnostic hook: Exchg_Helper.mark_to_mkt (exchg_helper.py:56-66) on one market. Synchronous. */
+int cda_mark_to_mkt(cda_env* env, int32_t market);
+
+/* Parity dump / restore of one market (synchronous; host struct). */
+int cda_get_state(cda_env* env, int32_t market, cda_market_state* out_host);
+int cda_set_state(cda_env* env, int32_t market, const cda_market_state* in_host);
+
+/* Pre-step raw top-10 snapshot agg_LOB_raw f32[N,40] (state_helper.py:159-160) -> device buffer. */
+int cda_get_raw_snapshot(cda_env* env, float* raw_out, void* stream);
+
+/* Per-market sticky flags u32[N] -> device buffer. */
+int cda_last_flags(cda_env* env, uint32_t* flags_out, void* stream);
+
+/* Device self-tests of the ledger arithmetic and the RNG (host pointers; synchronous).
+ * op: 0 add, 1 sub, 2 mul, 3 div, 4 cmp (result in out[i].w[0]: 0 lt, 1 eq, 2 gt), 5 to-double
+ * (bits in out[i].w[0..1]). For mul/div `b` must be integer valued with coefficient < 2^32. */
+int cda_selftest_dec(int32_t device, int32_t op, int32_t n, const cda_dec* a_host, const cda_dec* b_host,
+                     cda_dec* out_host);
+/* Draw, on the device, the env's RNG schedule for one seed: one integers(lo,hi+1), then `n_steps`
+ * times {n_normals standard normals, one permutation(perm_n)}. Outputs host arrays. */
+int cda_selftest_rng(int32_t device, uint64_t seed, int32_t lo, int32_t hi, int32_t n_steps,
+                     int32_t n_normals, int32_t perm_n, int32_t* first_int_host,
+                     double* normals_host /*[n_steps*n_normals]*/, int32_t* perms_host /*[n_steps*perm_n]*/,
+                     uint64_t* final_state_host /*[6]: state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger*/);
+
+const char* cda_strerror(int status);
+int32_t cda_num_markets(const cda_env* env);
+int32_t cda_obs_dim(const cda_env* env);
+/* Bytes the arena keeps per market in HBM. */
+int64_t cda_state_bytes_per_market(const cda_env* env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDA_H */

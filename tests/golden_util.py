@@ -1,0 +1,180 @@
+"""Shared golden-trace checker: drives any batched env (the CPU oracle or the HIP product) with the
+action streams recorded in tests/golden/trace_*.npz and compares every recorded field bit for bit.
+
+An "env" here is anything with
+    reset(seeds=None, mask=None) -> obs[N,obs_dim]           (numpy)
+    step(cat, mean, sigma, price, off, present) -> (obs, reward, term, trunc, info dict of numpy arrays)
+    get_state(i) -> _capi.MarketState
+    raw_snapshot() -> f32[N,40]
+"""
+import glob
+import json
+import os
+
+import numpy as np
+
+from gym_continuousdoubleauction_amd import _capi as K
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ACC_FIELDS = ["cash", "cash_on_hold", "position_val", "vwap", "nav", "prev_nav", "max_nav"]
+INFO_FLOATS = ["vwap", "cash", "cash_on_hold", "position_val", "drawdown", "max_nav"]
+COUNTERS = ["num_trades_step", "num_passive_fills_step", "order_step_placed", "num_rejected_step"]
+
+
+def trace_names():
+    return sorted(os.path.basename(p)[len("trace_"):-4] for p in glob.glob(os.path.join(GOLD, "trace_*.npz")))
+
+
+def load(name):
+    with np.load(os.path.join(GOLD, f"trace_{name}.npz")) as z:
+        rec = {k: z[k] for k in z.files}
+    rec["config"] = json.loads(str(rec["config"]))
+    rec["name"] = name
+    return rec
+
+
+def f32_bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def f64_bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def group_by_config(names):
+    groups = {}
+    for n in names:
+        rec = load(n)
+        key = json.dumps(rec["config"], sort_keys=True)
+        groups.setdefault(key, []).append(rec)
+    return groups
+
+
+def _eq(what, got, exp, ctx):
+    got = np.asarray(got)
+    exp = np.asarray(exp)
+    if got.shape != exp.shape or not np.array_equal(got, exp):
+        raise AssertionError(f"{ctx}: {what} mismatch\n got {got!r}\n exp {exp!r}")
+
+
+def check_state(state, rec, t, A, ctx, n_hist):
+    """Compare a MarketState dump with the golden record after step t."""
+    _eq("lob_time", state.lob_time, rec["lob_time"][t], ctx)
+    _eq("next_order_id", state.next_order_id, rec["next_order_id"][t], ctx)
+    _eq("has_trade", state.has_trade, int(rec["tape_len"][t] > 0), ctx)
+    if rec["tape_len"][t] > 0:
+        _eq("last_trade_price", state.last_trade_price, rec["last_trade_price"][t], ctx)
+    _eq("last_price", float(state.last_price), rec["market"][t, 0], ctx)
+    _eq("done_mask", state.done_mask, rec["done_mask"][t], ctx)
+    _eq("t_step", state.t_step, rec["t_step"][t], ctx)
+    _eq("flags", state.flags, 0, ctx)
+    off, nb, na = (int(x) for x in rec["book_off"][t])
+    _eq("n_bids", state.n_bids, nb, ctx)
+    _eq("n_asks", state.n_asks, na, ctx)
+    gb = np.array([[o.price, o.qty, o.owner, o.order_id, o.timestamp] for o in state.bids[:nb]], np.int32).reshape(-1, 5)
+    ga = np.array([[o.price, o.qty, o.owner, o.order_id, o.timestamp] for o in state.asks[:na]], np.int32).reshape(-1, 5)
+    _eq("bids", gb, rec["book"][off:off + nb], ctx)
+    _eq("asks", ga, rec["book"][off + nb:off + nb + na], ctx)
+    r = rec["rng"][t]
+    _eq("rng_state", [state.rng_state_hi, state.rng_state_lo], r[:2], ctx)
+    if not any(rt <= t and rs >= 0 for (rt, rs) in rec["resets"]):   # a re-seed changes the increment
+        _eq("rng_inc", [state.rng_inc_hi, state.rng_inc_lo], rec["rng_inc"], ctx)
+    _eq("rng_has_uint32", state.rng_has_uint32, r[2], ctx)
+    if r[2]:
+        _eq("rng_uinteger", state.rng_uinteger, r[3], ctx)
+    for a in range(A):
+        acc = state.acc[a]
+        for j, f in enumerate(ACC_FIELDS):
+            d = getattr(acc, f)
+            got = (int(d.sign), int(d.exp), int(d.w[0]), int(d.w[1]), int(d.w[2]))
+            exp = (int(rec["acc_sign"][t, a, j]), int(rec["acc_exp"][t, a, j]), *(int(x) for x in rec["acc_coeff"][t, a, j]))
+            if got != exp:
+                raise AssertionError(f"{ctx}: agent {a} {f} (sign,exp,w0,w1,w2) got {got} exp {exp}")
+        _eq(f"net_position[{a}]", acc.net_position, rec["net_position"][t, a], ctx)
+        _eq(f"num_trades[{a}]", acc.num_trades, rec["num_trades"][t, a], ctx)
+    hist = np.ctypeslib.as_array(state.hist)[: n_hist * K.SNAPSHOT_DIM]
+    _eq("hist", f32_bits(hist), f32_bits(rec["obs"][t]), ctx)
+
+
+def run_group(env, recs, state_every=1, trace_getter=None, max_steps=None):
+    """Drive `env` (N == len(recs) markets, one golden trace per market) and compare everything."""
+    N = len(recs)
+    A = recs[0]["cat"].shape[1]
+    n_hist = recs[0]["obs"].shape[1] // K.SNAPSHOT_DIM
+    T = max(r["cat"].shape[0] for r in recs)
+    if max_steps:
+        T = min(T, max_steps)
+    seeds = np.array([int(r["seed"]) for r in recs], np.uint64)
+    obs = env.reset(seeds=seeds)
+    for i, r in enumerate(recs):
+        _eq("obs0", f32_bits(obs[i]), f32_bits(r["obs0"]), f"{r['name']} reset")
+        st = env.get_state(i)
+        _eq("last_price0", float(st.last_price), float(r["last_price0"]), f"{r['name']} reset")
+        _eq("rng0", [st.rng_state_hi, st.rng_state_lo], r["rng0"][:2], f"{r['name']} reset")
+    live = np.ones(N, bool)
+    for t in range(T):
+        # mid-trace resets recorded by the generator (seed=None keeps the stream)
+        for i, r in enumerate(recs):
+            for (rt, rs) in r["resets"]:
+                if rt == t:
+                    mask = np.zeros(N, np.uint8)
+                    mask[i] = 1
+                    if rs < 0:
+                        o = env.reset(seeds=None, mask=mask)
+                    else:
+                        sd = seeds.copy()
+                        sd[i] = rs
+                        o = env.reset(seeds=sd, mask=mask)
+                    _eq("reset obs", f32_bits(o[i]), f32_bits(r[f"reset_obs_{t}"]), f"{r['name']} reset@{t}")
+        cat = np.zeros((N, A), np.int32)
+        mean = np.zeros((N, A), np.float32)
+        sigma = np.zeros((N, A), np.float32)
+        price = np.zeros((N, A), np.int32)
+        off = np.zeros((N, A), np.int32)
+        present = np.zeros((N, A), np.uint8)
+        for i, r in enumerate(recs):
+            live[i] = t < r["cat"].shape[0]
+            if live[i]:
+                cat[i], mean[i], sigma[i], price[i], off[i], present[i] = (
+                    r["cat"][t], r["mean"][t], r["sigma"][t], r["price"][t], r["off"][t], r["present"][t])
+        raw = env.raw_snapshot()
+        obs, reward, term, trunc, info = env.step(cat, mean, sigma, price, off, present)
+        traces = trace_getter() if trace_getter else None
+        for i, r in enumerate(recs):
+            if not live[i]:
+                continue
+            ctx = f"{r['name']} step {t}"
+            _eq("raw_pre", f32_bits(raw[i]), f32_bits(r["raw_pre"][t]), ctx)
+            if traces is not None:
+                tr = traces[i]
+                for a in range(A):
+                    if r["dec_type"][t, a] != -9:
+                        got = (tr.dec_type[a], tr.dec_side[a], tr.dec_size[a], tr.dec_price[a])
+                        exp = tuple(int(x) for x in (r["dec_type"][t, a], r["dec_side"][t, a], r["dec_size"][t, a], r["dec_price"][t, a]))
+                        if got != exp:
+                            raise AssertionError(f"{ctx}: decoded order of agent {a}: got {got} exp {exp}")
+                _eq("n_acts", tr.n_acts, r["n_acts"][t], ctx)
+                _eq("exec_order", list(tr.exec_order[: tr.n_acts]), r["exec_order"][t][: tr.n_acts], ctx)
+            _eq("obs", f32_bits(obs[i]), f32_bits(r["obs"][t]), ctx)
+            _eq("reward", f64_bits(reward[i]), f64_bits(r["reward"][t]), ctx)
+            _eq("terminated", int(term[i]), r["term"][t], ctx)
+            _eq("truncated", int(trunc[i]), r["trunc"][t], ctx)
+            for j, f in enumerate(INFO_FLOATS):
+                _eq(f"info.{f}", f64_bits(info[f][i]), f64_bits(r["info_floats"][t, :, j]), ctx)
+            for j, f in enumerate(COUNTERS):
+                _eq(f"info.{f}", info[f][i], r["counters"][t, :, j], ctx)
+            _eq("info.is_pass_action", info["is_pass_action"][i], r["is_pass"][t], ctx)
+            _eq("info.reward_terms", f64_bits(info["reward_terms"][i]), f64_bits(r["reward_terms"][t]), ctx)
+            _eq("info.num_trades", info["num_trades"][i], r["num_trades"][t], ctx)
+            _eq("info.net_position", info["net_position"][i], r["net_position"][t], ctx)
+            mk = np.array([info["last_price"][i], info["best_bid"][i], info["best_ask"][i], info["spread"][i]])
+            _eq("info.market", f64_bits(mk), f64_bits(r["market"][t]), ctx)
+            for a in range(A):
+                d = info["nav"][i, a]
+                got = (int(d["sign"]), int(d["exp"]), *(int(x) for x in d["w"]))
+                exp = (int(r["acc_sign"][t, a, 4]), int(r["acc_exp"][t, a, 4]), *(int(x) for x in r["acc_coeff"][t, a, 4]))
+                if got != exp:
+                    raise AssertionError(f"{ctx}: info.nav agent {a} got {got} exp {exp}")
+            if state_every and (t % state_every == 0 or t == r["cat"].shape[0] - 1):
+                check_state(env.get_state(i), r, t, A, ctx, n_hist)
+    return T
