@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py - agent-steps/sec of the vectorised CDA env step on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one env step() of every market of the batch (one launch of the k_step kernel per rank).
+Workload (BASELINE.json configs[2], the configuration the >=1M agent-steps/s target is quoted on):
+4096 independent markets x 4 synthetic random agents PER GPU (weak scaling: markets are sharded,
+there is no collective on the simulation path); for N > 1 the per-rank obs/reward shards are
+all-gathered over RCCL each step - the hand-back to a central learner that north_star names.
+Actions are pre-generated on the device (uniform random-agent law, train/model/model_handler.py:38-53
+of the reference) so that the timed region starts with every input resident in HBM.
+
+Prints ONE JSON line on rank 0; see the fields `roofline` and `cpu_baseline` in DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_CONST = 1444      # B(A) = 1444 + 324*A bytes per market-step
+ALG_BYTES_PER_AGENT = 324
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=1000)
+    p.add_argument("--warmup", type=int, default=64)
+    p.add_argument("--markets", type=int, default=4096, help="markets per GPU")
+    p.add_argument("--agents", type=int, default=4)
+    p.add_argument("--info", action="store_true", help="also emit the info tensors every step")
+    p.add_argument("--no-gather", action="store_true", help="N>1: skip the obs/reward all-gather")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline sample")
+    return p.parse_args()
+
+
+def gen_actions(torch, n, a, steps, device, seed):
+    """Uniform random-agent law, generated on the device, [steps, n, a] per field."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cat = torch.randint(0, 9, (steps, n, a), generator=g, device=device, dtype=torch.int32)
+    price = torch.randint(0, 10, (steps, n, a), generator=g, device=device, dtype=torch.int32)
+    off = torch.randint(0, 3, (steps, n, a), generator=g, device=device, dtype=torch.int32)
+    mean = torch.rand((steps, n, a), generator=g, device=device, dtype=torch.float32) * 2.0 - 1.0
+    sigma = torch.rand((steps, n, a), generator=g, device=device, dtype=torch.float32)
+    return cat, mean, sigma, price, off
+
+
+def cpu_baseline(markets, agents, budget_s, max_step):
+    """The CPU oracle (a plain-C port of the reference path, bit-identical to it on the golden
+    vectors) timed on the host cores: markets partitioned over one thread per core."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = min(markets, 1024)
+    cfg = {"num_of_agents": agents, "init_cash": 1000000, "max_step": max_step, "is_render": False}
+    env = O.OracleEnv(cfg, n_markets=n)
+    env.reset(seeds=np.arange(1000, 1000 + n, dtype=np.uint64))
+    rng = np.random.default_rng(2024)
+    T = 64
+    acts = [(rng.integers(0, 9, (n, agents)).astype(np.int32), rng.uniform(-1, 1, (n, agents)).astype(np.float32),
+             rng.uniform(0, 1, (n, agents)).astype(np.float32), rng.integers(0, 10, (n, agents)).astype(np.int32),
+             rng.integers(0, 3, (n, agents)).astype(np.int32)) for _ in range(T)]
+    import ctypes as C
+    lib = O.lib()
+    bounds = [(i * n // cores, (i + 1) * n // cores) for i in range(cores)]
+    bounds = [(lo, hi) for lo, hi in bounds if hi > lo]
+
+    def run_steps(count):
+        def work(lo, hi):
+            for t in range(count):
+                cat, mean, sigma, price, off = acts[t % T]
+                lib.oracle_step_range(env.h, lo, hi - lo, cat.ctypes.data, mean.ctypes.data, sigma.ctypes.data,
+                                      price.ctypes.data, off.ctypes.data, None, env.obs.ctypes.data, env.reward.ctypes.data,
+                                      env.term.ctypes.data, env.trunc.ctypes.data, None, None)
+        th = [threading.Thread(target=work, args=b) for b in bounds]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return time.perf_counter() - t0
+
+    dt = run_steps(8)                      # calibration
+    per_step = dt / 8
+    steps = int(max(16, min(4000, budget_s / max(per_step, 1e-6))))
+    dt = run_steps(steps)
+    value = n * agents * steps / dt
+    env.close()
+    return {"value": value, "unit": "agent-steps/s", "cores": len(bounds), "kind": "port",
+            "sample": f"{n} markets x {agents} agents x {steps} steps ({dt:.1f} s wall), C oracle, "
+                      f"{len(bounds)} threads, obs+reward outputs only"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    n_gpus = world
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+
+    N, A, K, W = args.markets, args.agents, args.steps, args.warmup
+    max_step = max(4096, K + W + 1)                   # no truncation inside the run
+    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
+    env = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=args.info)
+    first_market = rank * N                           # global market index -> seed, independent of the GPU count
+    seeds = (1000 + first_market + torch.arange(N, dtype=torch.int64)).numpy().astype("uint64")
+    env.reset(seed=seeds)
+    # action stream: chunks of <= 256 steps keep the resident set small (20 B per agent-step)
+    chunk = min(256, K + W)
+    acts = gen_actions(torch, N, A, chunk, device, 2024 + rank)
+    gather = world > 1 and not args.no_gather
+    if gather:
+        packed = torch.empty((N, env.obs_dim + 2 * A), dtype=torch.float32, device=device)   # obs + reward(f64 as 2 x f32)
+        gathered = torch.empty((world * N, env.obs_dim + 2 * A), dtype=torch.float32, device=device)
+
+    def one_step(t):
+        i = t % chunk
+        obs, rew, term, trunc, _ = env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+        if gather:
+            packed[:, : env.obs_dim].copy_(obs)
+            packed[:, env.obs_dim:].copy_(rew.view(torch.float32))
+            dist.all_gather_into_tensor(gathered, packed)
+
+    for t in range(W):
+        one_step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    t0 = time.perf_counter()
+    for t in range(K):
+        # HIP events on the stream the kernel is launched on (torch's current stream) bracket the launch
+        ev0[t].record()
+        i = (W + t) % chunk
+        env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+        ev1[t].record()
+        if gather:
+            packed[:, : env.obs_dim].copy_(env.obs)
+            packed[:, env.obs_dim:].copy_(env.reward.view(torch.float32))
+            dist.all_gather_into_tensor(gathered, packed)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / K
+    flags = env.flags()
+    n_flagged = int((flags != 0).sum().item())
+
+    if rank == 0:
+        total_agent_steps = float(world) * N * A * K
+        value = total_agent_steps / elapsed
+        alg_bytes = (ALG_BYTES_CONST + ALG_BYTES_PER_AGENT * A) * N            # per launch (one rank)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "agent-steps/sec (whole node), 4 agents x N parallel markets",
+            "value": value, "unit": "agent-steps/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32+dec28+f64", "data": "synthetic",
+            "config": {"workload": f"{N} markets x {A} random agents per GPU, book capacity {256} orders/side "
+                                   f"(BASELINE configs[2]); global {world * N} markets",
+                       "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info),
+                       "collective": "all_gather(obs,reward)" if gather else "none",
+                       "flagged_markets": n_flagged},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_step", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, A, args.cpu_seconds, max_step)
+            except Exception as e:  # noqa: BLE001 - the baseline is a reported extra, never the measured path
+                out["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""Loads the HIP shared library (libcda_hip.so, built in-tree by __graft_entry__.build()) and binds
+the C-ABI of include/cda.h with ctypes.  There is no CPU fallback: a missing library or a missing
+GPU raises."""
+import ctypes as C
+import os
+
+from . import _capi as K
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcda_hip.so")
+
+_lib = None
+
+# every symbol include/cda.h declares
+SYMBOLS = [
+    "cda_default_config", "cda_create", "cda_destroy", "cda_reset", "cda_step", "cda_place_order",
+    "cda_mark_to_mkt", "cda_get_state", "cda_set_state", "cda_get_raw_snapshot", "cda_last_flags",
+    "cda_selftest_dec", "cda_selftest_rng", "cda_strerror", "cda_num_markets", "cda_obs_dim",
+    "cda_state_bytes_per_market",
+]
+
+
+class CDAError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CDAError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    L.cda_default_config.argtypes = [C.POINTER(K.Config)]
+    L.cda_create.argtypes = [C.POINTER(K.Config), i32, i32, C.POINTER(vp)]
+    L.cda_destroy.argtypes = [vp]
+    L.cda_reset.argtypes = [vp, vp, vp, vp, vp]
+    L.cda_step.argtypes = [vp] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), vp]
+    L.cda_place_order.argtypes = [vp] + [i32] * 6
+    L.cda_mark_to_mkt.argtypes = [vp, i32]
+    L.cda_get_state.argtypes = [vp, i32, C.POINTER(K.MarketState)]
+    L.cda_set_state.argtypes = [vp, i32, C.POINTER(K.MarketState)]
+    L.cda_get_raw_snapshot.argtypes = [vp, vp, vp]
+    L.cda_last_flags.argtypes = [vp, vp, vp]
+    L.cda_selftest_dec.argtypes = [i32, i32, i32, vp, vp, vp]
+    L.cda_selftest_rng.argtypes = [i32, u64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.cda_strerror.argtypes = [C.c_int]
+    L.cda_strerror.restype = C.c_char_p
+    L.cda_num_markets.argtypes = [vp]
+    L.cda_obs_dim.argtypes = [vp]
+    L.cda_state_bytes_per_market.argtypes = [vp]
+    L.cda_state_bytes_per_market.restype = i64
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("cda_strerror",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().cda_strerror(rc).decode()
+        raise CDAError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,306 @@
+// cda_dec.hpp - device-side 28-digit decimal ledger arithmetic for gfx950 (HIP).
+//
+// The reference keeps every account in Python `decimal.Decimal` (default context: prec 28,
+// ROUND_HALF_EVEN; account/account.py:12-53).  Rewards, NAV strings and observations' downstream
+// consumers see the 28-digit rounding noise, so the device ledger reproduces the General Decimal
+// Arithmetic operations exactly: a value is (sign, coefficient < 10^28 < 2^94, exponent); wide
+// intermediates (<= 58 digits) live in 8 x u32 limbs held in VGPRs.  There is no MFMA-shaped work
+// here: it is carry chains, compares and constant-divisor divisions.
+//
+// Call-site facts this file exploits: every multiplication has one operand that is a
+// plain integer (< 2^32) or a tick price, and every division is by an integer position size.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned __int128 u128;
+
+namespace cda {
+
+struct W { uint32_t w[8]; };          // 256-bit unsigned, little endian
+
+struct D {                            // a Decimal in registers
+    uint32_t w0, w1, w2;
+    int32_t exp;
+    int32_t sign;
+};
+
+// ---- compile-time tables ----------------------------------------------------------------
+struct Pow10Tab { uint32_t v[60][8]; };
+constexpr Pow10Tab make_pow10() {
+    Pow10Tab t{};
+    t.v[0][0] = 1;
+    for (int k = 1; k < 60; k++) {
+        uint64_t c = 0;
+        for (int i = 0; i < 8; i++) { c += (uint64_t)t.v[k - 1][i] * 10u; t.v[k][i] = (uint32_t)c; c >>= 32; }
+    }
+    return t;
+}
+struct Pow5Tab { uint64_t lo[56], hi[56]; };
+constexpr Pow5Tab make_pow5() {
+    Pow5Tab t{};
+    u128 v = 1;
+    for (int k = 0; k < 56; k++) { t.lo[k] = (uint64_t)v; t.hi[k] = (uint64_t)(v >> 64); v *= 5; }
+    return t;
+}
+__device__ const Pow10Tab POW10 = make_pow10();
+__device__ const Pow5Tab POW5 = make_pow5();
+__device__ const uint32_t POW10_U32[10] = {1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u, 100000000u, 1000000000u};
+__device__ const double POW10_F64[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                         1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+// ---- wide integer helpers ----------------------------------------------------------------
+__device__ __forceinline__ W w_zero() {
+    W r;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) r.w[i] = 0;
+    return r;
+}
+__device__ __forceinline__ W w_from3(uint32_t a, uint32_t b, uint32_t c) { W r = w_zero(); r.w[0] = a; r.w[1] = b; r.w[2] = c; return r; }
+__device__ __forceinline__ bool w_is_zero(const W& a) {
+    uint32_t o = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.w[i];
+    return o == 0;
+}
+__device__ __forceinline__ int w_cmp(const W& a, const W& b) {
+    int r = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) { if (a.w[i] != b.w[i]) r = a.w[i] < b.w[i] ? -1 : 1; }   // highest differing limb wins
+    return r;
+}
+__device__ __forceinline__ W w_add(const W& a, const W& b) {
+    W r; uint64_t c = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) { c += (uint64_t)a.w[i] + b.w[i]; r.w[i] = (uint32_t)c; c >>= 32; }
+    return r;
+}
+__device__ __forceinline__ W w_sub(const W& a, const W& b) {   // a >= b
+    W r; int64_t c = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) { c += (int64_t)a.w[i] - (int64_t)b.w[i]; r.w[i] = (uint32_t)c; c >>= 32; }
+    return r;
+}
+__device__ __forceinline__ void w_mul_small(W& x, uint32_t m) {
+    uint64_t c = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) { c += (uint64_t)x.w[i] * m; x.w[i] = (uint32_t)c; c >>= 32; }
+}
+__device__ __forceinline__ void w_mul_pow10(W& x, int k) {
+    while (k >= 9) { w_mul_small(x, 1000000000u); k -= 9; }
+    if (k > 0) w_mul_small(x, POW10_U32[k]);
+}
+__device__ __forceinline__ void w_inc(W& x) {
+    uint64_t c = 1;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) { c += x.w[i]; x.w[i] = (uint32_t)c; c >>= 32; }
+}
+// x /= DV (compile-time divisor -> multiply-high sequences), returns the remainder
+template <uint32_t DV>
+__device__ __forceinline__ uint32_t w_divc(W& x) {
+    uint64_t rem = 0;
+    #pragma unroll
+    for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | x.w[i]; uint64_t q = cur / DV; x.w[i] = (uint32_t)q; rem = cur - q * DV; }
+    return (uint32_t)rem;
+}
+__device__ __noinline__ uint32_t w_div_pow10_small(W& x, int r) {   // r in 1..9
+    switch (r) {
+        case 1: return w_divc<10u>(x);
+        case 2: return w_divc<100u>(x);
+        case 3: return w_divc<1000u>(x);
+        case 4: return w_divc<10000u>(x);
+        case 5: return w_divc<100000u>(x);
+        case 6: return w_divc<1000000u>(x);
+        case 7: return w_divc<10000000u>(x);
+        case 8: return w_divc<100000000u>(x);
+        default: return w_divc<1000000000u>(x);
+    }
+}
+// x /= d for a run-time 32-bit divisor, returns the remainder
+__device__ __forceinline__ uint32_t w_div_u32(W& x, uint32_t d) {
+    uint64_t rem = 0;
+    #pragma unroll
+    for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | x.w[i]; uint64_t q = cur / d; x.w[i] = (uint32_t)q; rem = cur - q * d; }
+    return (uint32_t)rem;
+}
+__device__ __forceinline__ int w_bits(const W& a) {
+    int b = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) if (a.w[i]) b = 32 * i + 32 - __clz(a.w[i]);
+    return b;
+}
+__device__ __forceinline__ W w_pow10(int k) {
+    W r;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) r.w[i] = POW10.v[k][i];
+    return r;
+}
+// len(str(x)) (1 for zero): floor(bits*log10(2)) then one table compare
+__device__ __forceinline__ int w_ndigits(const W& x) {
+    int b = w_bits(x);
+    if (b == 0) return 1;
+    int t = (b * 1233) >> 12;
+    W p = w_pow10(t);
+    return t + (w_cmp(x, p) >= 0 ? 1 : 0);
+}
+
+// ---- Decimal ------------------------------------------------------------------------------
+__device__ __forceinline__ D d_make(uint32_t w0, uint32_t w1, uint32_t w2, int exp, int sign) { D d; d.w0 = w0; d.w1 = w1; d.w2 = w2; d.exp = exp; d.sign = sign; return d; }
+__device__ __forceinline__ D d_zero() { return d_make(0, 0, 0, 0, 0); }
+__device__ __forceinline__ D d_from_i64(int64_t v) {
+    uint64_t a = v < 0 ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+    return d_make((uint32_t)a, (uint32_t)(a >> 32), 0, 0, v < 0);
+}
+__device__ __forceinline__ D d_from_u32(uint32_t v) { return d_make(v, 0, 0, 0, 0); }
+// a tick price as the book holds it: Decimal(str(float(p))) = Decimal('p.0') (orderbook.py:52,239)
+__device__ __forceinline__ D d_price(int32_t p) { uint64_t a = (uint64_t)(uint32_t)p * 10u; return d_make((uint32_t)a, (uint32_t)(a >> 32), 0, -1, 0); }
+__device__ __forceinline__ bool d_is_zero(const D& a) { return (a.w0 | a.w1 | a.w2) == 0; }
+__device__ __forceinline__ W d_wide(const D& a) { return w_from3(a.w0, a.w1, a.w2); }
+__device__ __forceinline__ D d_neg(D a) { a.sign ^= 1; return a; }
+// sign of a compared with 0: -1, 0, 1
+__device__ __forceinline__ int d_sgn(const D& a) { return d_is_zero(a) ? 0 : (a.sign ? -1 : 1); }
+
+// Decimal._fix (_pydecimal.py:1661): round a wide coefficient to 28 digits, half-even
+__device__ __noinline__ D d_fix(int sign, W x, int exp) {
+    if (w_is_zero(x)) return d_make(0, 0, 0, exp, sign);
+    int nd = w_ndigits(x);
+    if (nd > 28) {
+        int drop = nd - 28;
+        bool sticky = false;
+        int k = drop - 1;
+        while (k >= 9) { sticky |= (w_divc<1000000000u>(x) != 0); k -= 9; }
+        if (k > 0) sticky |= (w_div_pow10_small(x, k) != 0);
+        uint32_t dg = w_divc<10u>(x);
+        bool up = dg > 5 || (dg == 5 && (sticky || (x.w[0] & 1u)));
+        if (up) {
+            w_inc(x);
+            W p28 = w_pow10(28);
+            if (w_cmp(x, p28) == 0) { x = w_pow10(27); drop += 1; }
+        }
+        exp += drop;
+    }
+    return d_make(x.w[0], x.w[1], x.w[2], exp, sign);
+}
+
+// Decimal.__add__ (_pydecimal.py:1157) with _normalize (:5640) and _rescale (:2612)
+__device__ __noinline__ D d_add(D a, D b) {
+    int exp = a.exp < b.exp ? a.exp : b.exp;
+    bool az = d_is_zero(a), bz = d_is_zero(b);
+    if (az && bz) return d_make(0, 0, 0, exp, a.sign < b.sign ? a.sign : b.sign);
+    if (az || bz) {
+        D o = az ? b : a;
+        int e = exp > o.exp - 29 ? exp : o.exp - 29;
+        W x = d_wide(o);
+        w_mul_pow10(x, o.exp - e);
+        return d_fix(o.sign, x, e);
+    }
+    // t = the operand with the larger exponent (ties: a), o = the other one
+    bool swp = a.exp < b.exp;
+    D dt = swp ? b : a, dO = swp ? a : b;
+    W xt = d_wide(dt), xo = d_wide(dO);
+    int et = dt.exp, eo = dO.exp;
+    if (et != eo) {
+        int tmp_len = w_ndigits(xt), oth_len = w_ndigits(xo);
+        int m = tmp_len - 30; if (m > -1) m = -1;
+        int e = et + m;
+        if (oth_len + eo - 1 < e) { xo = w_from3(1, 0, 0); eo = e; }
+        w_mul_pow10(xt, et - eo);
+    }
+    W r; int rs;
+    if (dt.sign != dO.sign) {
+        int c = w_cmp(xt, xo);
+        if (c == 0) return d_make(0, 0, 0, exp, 0);
+        if (c > 0) { r = w_sub(xt, xo); rs = dt.sign; } else { r = w_sub(xo, xt); rs = dO.sign; }
+    } else { r = w_add(xt, xo); rs = dt.sign; }
+    return d_fix(rs, r, eo);
+}
+__device__ __forceinline__ D d_sub(D a, D b) { return d_add(a, d_neg(b)); }
+
+// Decimal.__mul__ (_pydecimal.py:1267) for b = (+) m * 10^mexp with m < 2^32
+__device__ __noinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
+    int exp = a.exp + mexp;
+    if (d_is_zero(a) || m == 0) return d_make(0, 0, 0, exp, a.sign);
+    W x = d_wide(a);
+    w_mul_small(x, m);
+    return d_fix(a.sign, x, exp);
+}
+// int * Decimal: Decimal(n) * a, n >= 0
+__device__ __forceinline__ D d_mul_int(D a, uint32_t n) { return d_mul_u32(a, n, 0); }
+
+// Decimal.__truediv__ (_pydecimal.py:1324) for b = Decimal(n), n > 0 an integer < 2^32
+__device__ __noinline__ D d_div_u32(D a, uint32_t n) {
+    if (d_is_zero(a)) return d_make(0, 0, 0, a.exp, a.sign);
+    W x = d_wide(a);
+    W nn = w_from3(n, 0, 0);
+    int shift = w_ndigits(nn) - w_ndigits(x) + 29;      // >= 2
+    int exp = a.exp - shift;
+    w_mul_pow10(x, shift);
+    uint32_t rem = w_div_u32(x, n);
+    if (rem != 0) {
+        W t = x; if (w_divc<5u>(t) == 0) w_inc(x);
+    } else {
+        int ideal = a.exp;
+        while (exp + 9 <= ideal) { W t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; exp += 9; }
+        while (exp < ideal) { W t = x; if (w_divc<10u>(t) != 0) break; x = t; exp += 1; }
+    }
+    return d_fix(a.sign, x, exp);
+}
+
+// Decimal._cmp (_pydecimal.py:817): -1, 0, 1
+__device__ __noinline__ int d_cmp(D a, D b) {
+    bool az = d_is_zero(a), bz = d_is_zero(b);
+    if (az) return bz ? 0 : (b.sign ? 1 : -1);
+    if (bz) return a.sign ? -1 : 1;
+    if (a.sign != b.sign) return a.sign ? -1 : 1;
+    int s = a.sign ? -1 : 1;
+    W xa = d_wide(a), xb = d_wide(b);
+    int aa = w_ndigits(xa) + a.exp, ba = w_ndigits(xb) + b.exp;
+    if (aa != ba) return aa > ba ? s : -s;
+    if (a.exp > b.exp) w_mul_pow10(xa, a.exp - b.exp); else if (b.exp > a.exp) w_mul_pow10(xb, b.exp - a.exp);
+    int c = w_cmp(xa, xb);
+    return c == 0 ? 0 : (c > 0 ? s : -s);
+}
+
+// Decimal.__float__ (_pydecimal.py:1610) = correctly rounded nearest double of coeff * 10^exp.
+// Domain: exp in [-54, 0] (wider sets *domain_err).
+__device__ __noinline__ double d_to_double(D a, uint32_t* domain_err) {
+    if (d_is_zero(a)) return a.sign ? -0.0 : 0.0;
+    int k = -a.exp;
+    u128 c = ((u128)a.w2 << 64) | ((u128)a.w1 << 32) | a.w0;
+    double r;
+    if (k < 0 || k > 54) {
+        if (domain_err) *domain_err |= 0x4u;
+        r = (double)(uint64_t)(c >> 64) * 18446744073709551616.0 + (double)(uint64_t)c;
+        r = r * pow(10.0, (double)a.exp);
+        return a.sign ? -r : r;
+    }
+    if ((c >> 53) == 0 && k <= 22) {
+        r = (double)(uint64_t)c / POW10_F64[k];          // both exact -> one correctly rounded division
+        return a.sign ? -r : r;
+    }
+    // exact path: value = c / (5^k * 2^k); restoring division for 57 quotient bits + sticky
+    u128 dv = ((u128)POW5.hi[k] << 64) | POW5.lo[k];
+    int bn = 128 - ((uint64_t)(c >> 64) ? __clzll((uint64_t)(c >> 64)) : 64 + __clzll((uint64_t)c));
+    int bd = 128 - ((uint64_t)(dv >> 64) ? __clzll((uint64_t)(dv >> 64)) : 64 + __clzll((uint64_t)dv));
+    int t = bn - bd;
+    u128 rr = c, dn = dv;
+    if (t >= 0) dn <<= t; else rr <<= (-t);
+    uint64_t q = 0;
+    for (int i = 0; i < 57; i++) {
+        q <<= 1;
+        if (rr >= dn) { rr -= dn; q |= 1; }
+        rr <<= 1;
+    }
+    // q holds quotient bits of weights 2^t .. 2^(t-56); its top set bit is bit 56 or 55
+    int nb = 64 - __clzll(q);
+    int sh = nb - 53;
+    uint64_t mant = q >> sh;
+    uint64_t low = q & (((uint64_t)1 << sh) - 1);
+    uint64_t half = (uint64_t)1 << (sh - 1);
+    bool sticky = rr != 0;
+    if (low > half || (low == half && (sticky || (mant & 1)))) mant += 1;
+    r = ldexp((double)mant, t - 56 + sh - k);
+    return a.sign ? -r : r;
+}
+
+}  // namespace cda

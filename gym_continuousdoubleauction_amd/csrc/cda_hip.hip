@@ -1,0 +1,622 @@
+// cda_hip.hip - kernels + the C-ABI of include/cda.h (gfx950 only; no CPU fallback, no shims).
+//
+// Kernels (all: one wave64 per market, WPB markets per workgroup, no inter-wave communication):
+//   k_reset         reset(seed)            continuousDoubleAuction_env.py:175-231
+//   k_step          step(actions)          continuousDoubleAuction_env.py:265-309  <- the hot kernel
+//   k_place_order   Trader.place_order     agent/trader.py:49-106   (test hook, 1 market)
+//   k_mark_to_mkt   Exchg_Helper.mark_to_mkt                         (test hook, 1 market)
+//   k_raw_snapshot  agg_LOB_raw            exchg/state_helper.py:159-160
+//   k_selftest_dec / k_selftest_rng        device self-tests of the ledger arithmetic and the RNG
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/cda.h"
+#include "cda_dec.hpp"
+#include "cda_market.hpp"
+
+using namespace cda;
+
+#ifndef CDA_WPB
+#define CDA_WPB 4            // markets (waves) per workgroup
+#endif
+
+// ------------------------------------------------------------------------------------------
+// device helpers shared by the kernels
+// ------------------------------------------------------------------------------------------
+struct MarketPtrs {
+    uint32_t* hdr; uint32_t* acc; float* hist; int32_t* book;
+};
+__device__ __forceinline__ MarketPtrs market_ptrs(uint8_t* arena, const Params& P, int mi) {
+    uint8_t* rec = arena + (size_t)mi * (size_t)P.lay.stride;
+    MarketPtrs r;
+    r.hdr = (uint32_t*)rec; r.acc = (uint32_t*)(rec + P.lay.acc_off);
+    r.hist = (float*)(rec + P.lay.hist_off); r.book = (int32_t*)(rec + P.lay.book_off);
+    return r;
+}
+__device__ __forceinline__ void load_market(const MarketPtrs& mp, const Params& P, Lds& L, Mkt& m, int lane) {
+    load_header(mp.hdr, m, lane);
+    load_book(mp.book, L.book, m, lane);
+    copy_words((uint32_t*)&L.acc[0], mp.acc, P.cfg.num_agents * (int)(sizeof(Acc) / 4), lane);
+    CDA_WSYNC();
+}
+__device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params& P, Lds& L, const Mkt& m, int lane) {
+    CDA_WSYNC();
+    store_header(mp.hdr, m, lane);
+    store_book(mp.book, L.book, m, lane);
+    copy_words(mp.acc, (const uint32_t*)&L.acc[0], P.cfg.num_agents * (int)(sizeof(Acc) / 4), lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// reset
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out) {
+    __shared__ Lds lds[CDA_WPB];
+    int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    int mi = (int)blockIdx.x * CDA_WPB + wave;
+    if (mi >= P.n_markets) return;
+    if (mask && !mask[mi]) return;
+    Lds& L = lds[wave];
+    MarketPtrs mp = market_ptrs(arena, P, mi);
+    Mkt m;
+    load_header(mp.hdr, m, lane);
+    if (seeds) { rng_seed(m, seeds[mi]); m.seeded = 1; }
+    else if (!m.seeded) { rng_seed(m, (uint64_t)mi); m.seeded = 1; }
+    m.n[0] = 0; m.n[1] = 0;
+    m.t_step = 0; m.lob_time = 0; m.next_oid = 0; m.has_trade = 0; m.last_trade_price = 0; m.done_mask = 0; m.flags = 0;
+    m.last_price = rng_integers(m, P.cfg.initial_price_min, P.cfg.initial_price_max);
+    int A = P.cfg.num_agents;
+    if (lane < A) {                                     // Account.reset_acc (account/account.py:55-82)
+        Acc& a = L.acc[lane];
+        uint32_t f = 0;
+        D cash = d_from_i64(P.cfg.init_cash), z = d_zero();
+        st_dec(a.cash, cash, f); st_dec(a.hold, z, f); st_dec(a.posval, z, f); st_dec(a.vwap, z, f);
+        st_dec(a.nav, cash, f); st_dec(a.prev_nav, cash, f); st_dec(a.max_nav, cash, f);
+        a.net_position = 0; a.num_trades = 0; a.num_trades_step = 0; a.num_passive_fills_step = 0;
+        a.order_step_placed = 0; a.num_rejected_step = 0; a.pad[0] = 0; a.pad[1] = 0;
+    }
+    aggregate_levels(L, m, lane);
+    int H = P.cfg.n_hist;
+    if (lane < CDA_SNAPSHOT_DIM) {
+        float v = snapshot_value(L, m, P.cfg.tick_size, lane);
+        for (int h = 0; h < H; h++) {
+            mp.hist[h * CDA_SNAPSHOT_DIM + lane] = v;
+            if (obs_out) obs_out[(size_t)mi * (size_t)(H * CDA_SNAPSHOT_DIM) + (size_t)(h * CDA_SNAPSHOT_DIM + lane)] = v;
+        }
+    }
+    m.hist_head = 0;
+    store_market(mp, P, L, m, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// step - the hot kernel
+// ------------------------------------------------------------------------------------------
+struct StepArgs {
+    const int32_t* category; const float* size_mean; const float* size_sigma;
+    const int32_t* price; const int32_t* price_offset; const uint8_t* present;
+    float* obs_out; double* reward_out; uint8_t* terminated_out; uint8_t* truncated_out;
+    cda_info_ptrs info; int has_info;
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(64 * CDA_WPB) void k_step(uint8_t* arena, Params P, StepArgs S) {
+    __shared__ Lds lds[CDA_WPB];
+    int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    int mi = (int)blockIdx.x * CDA_WPB + wave;
+    if (mi >= P.n_markets) return;
+    Lds& L = lds[wave];
+    MarketPtrs mp = market_ptrs(arena, P, mi);
+    Mkt m;
+    const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
+    load_market(mp, P, L, m, lane);
+
+    // my action (lane a = agent a) - coalesced loads
+    size_t ao = (size_t)mi * (size_t)A + (size_t)(lane < A ? lane : 0);
+    int my_cat = 0, my_level = 0, my_off = 1, my_present = 0; float my_mean = 0.f, my_sigma = 0.f;
+    if (lane < A) {
+        my_cat = clampi(S.category[ao], 0, 8); my_mean = clampf(S.size_mean[ao], -1.0f, 1.0f); my_sigma = clampf(S.size_sigma[ao], 0.0f, 1.0f);
+        my_level = clampi(S.price[ao], 0, CDA_K_ROWS - 1); my_off = clampi(S.price_offset[ao], 0, 2);
+        my_present = S.present ? (S.present[ao] != 0) : 1;
+    }
+    // 1. pre-step snapshot (continuousDoubleAuction_env.py:274): prices of ALL orders resolve against it
+    aggregate_levels(L, m, lane);
+    // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order
+    uint32_t present_mask = (uint32_t)__ballot(my_present != 0);
+    uint32_t act_mask = 0, pass_mask = 0;
+    int my_type = 0, my_side = S_NONE; int32_t my_size = 0, my_price = -1;
+    for (int a = 0; a < A; a++) {
+        if (!((present_mask >> a) & 1u)) continue;
+        int cat = __shfl(my_cat, a, WAVE);
+        float mean = __shfl(my_mean, a, WAVE), sigma = __shfl(my_sigma, a, WAVE);
+        int level = __shfl(my_level, a, WAVE), off = __shfl(my_off, a, WAVE) - 1;
+        int side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
+        int type = cat == 0 ? T_MARKET : ((cat - 1) & 3);
+        float locf = (type == T_MARKET ? P.mkt_mul : P.lim_mul) * mean;      // float32 product (numpy NEP 50)
+        double z = rng_std_normal(m);
+        double prod = (double)sigma * z;
+        double sample = (double)locf + prod;                                   // built with -ffp-contract=off
+        double rs = rint(fabs(sample));
+        if (rs > 1.0e9) { rs = 1.0e9; m.flags |= CDA_FLAG_INT_OVERFLOW; }
+        int32_t size = (int32_t)rs + P.cfg.min_size;
+        int32_t pr = -1;
+        if (type != T_MARKET) {                                                // _set_price (action_helper.py:341-397)
+            if (side == S_BID) {
+                int32_t p = L.lvl_px[0][level];
+                int32_t base = p == 0 ? m.last_price - (level + 1) * tick : p;
+                pr = base + off * tick;
+            } else {
+                int32_t p = L.lvl_px[1][level];
+                int32_t base = p == 0 ? m.last_price + (level + 1) * tick : p;
+                pr = base - off * tick;
+            }
+            if (pr < tick) pr = tick;
+            if (pr >= (1 << 24)) m.flags |= CDA_FLAG_INT_OVERFLOW;
+        }
+        if (lane == a) { my_type = type; my_side = side; my_size = size; my_price = pr; }
+        if (side != S_NONE) act_mask |= 1u << a; else pass_mask |= 1u << a;
+    }
+    // 3. rand_exec_seq (action_helper.py:174-199): Fisher-Yates over the n non-pass orders, nibble-packed
+    int n_acts = __popc(act_mask);
+    uint64_t perm = 0xFEDCBA9876543210ull;
+    for (int i = n_acts - 1; i >= 1; i--) {
+        int j = (int)rng_interval(m, (uint32_t)i);
+        uint64_t vi = (perm >> (4 * i)) & 0xFull, vj = (perm >> (4 * j)) & 0xFull;
+        perm &= ~((0xFull << (4 * i)) | (0xFull << (4 * j)));
+        perm |= (vj << (4 * i)) | (vi << (4 * j));
+    }
+    // 4. do_actions (action_helper.py:201-239): sequential, order dependent
+    for (int i = 0; i < n_acts; i++) {
+        int k = (int)((perm >> (4 * i)) & 0xFull);
+        uint32_t mk = act_mask;
+        for (int s = 0; s < k; s++) mk &= mk - 1;                             // drop k lowest set bits
+        int tr = __ffs((int)mk) - 1;
+        int type = __shfl(my_type, tr, WAVE), side = __shfl(my_side, tr, WAVE);
+        int32_t size = __shfl(my_size, tr, WAVE), pr = __shfl(my_price, tr, WAVE);
+        place_order(L, m, tr, type, side, size, pr, lane);
+    }
+    // 5. mark_to_mkt
+    mark_to_mkt(L, m, A, lane);
+    // 6. prep_next_state (state_helper.py:80-92): new frame, history ring, stacked observation
+    aggregate_levels(L, m, lane);
+    {
+        size_t ob = (size_t)mi * (size_t)(H * CDA_SNAPSHOT_DIM);
+        if (lane < CDA_SNAPSHOT_DIM) {
+            float v = snapshot_value(L, m, tick, lane);
+            int head = m.hist_head;                       // slot of the oldest frame = the one to overwrite
+            for (int j = 0; j < H - 1; j++) {
+                int slot = head + 1 + j; if (slot >= H) slot -= H;
+                S.obs_out[ob + (size_t)(j * CDA_SNAPSHOT_DIM + lane)] = mp.hist[slot * CDA_SNAPSHOT_DIM + lane];
+            }
+            S.obs_out[ob + (size_t)((H - 1) * CDA_SNAPSHOT_DIM + lane)] = v;
+            mp.hist[head * CDA_SNAPSHOT_DIM + lane] = v;
+        }
+        m.hist_head = m.hist_head + 1 >= H ? 0 : m.hist_head + 1;
+    }
+    // 7. set_step_outputs (exchg_helper.py:93-124)
+    uint32_t ferr = 0;
+    bool bankrupt = false;
+    if (lane < A) {
+        Acc& a = L.acc[lane];
+        size_t ix = (size_t)mi * (size_t)A + (size_t)lane;
+        D nav = ld_dec(a.nav), prev = ld_dec(a.prev_nav), mx = ld_dec(a.max_nav);
+        // Reward_Helper.set_reward (exchg/reward_helper.py:35-102)
+        double nav_change = d_to_double(d_sub(nav, prev), &ferr);
+        double nav_term = nav_change * (nav_change < 0 ? P.cfg.loss_multiplier : 1.0);
+        D dd = d_sub(mx, nav);
+        double drawdown = d_sgn(dd) > 0 ? d_to_double(dd, &ferr) : 0.0;
+        double t0 = nav_term;
+        double t1 = -(P.cfg.order_penalty * (double)a.order_step_placed);
+        double t2 = -(P.cfg.trade_penalty * (double)a.num_trades_step);
+        double t3 = -(P.cfg.drawdown_penalty * drawdown);
+        double t4 = P.cfg.passive_bonus * (double)a.num_passive_fills_step;
+        double r = 0.0; r += t0; r += t1; r += t2; r += t3; r += t4;          // left to right (reward_helper.py:92-94)
+        S.reward_out[ix] = r;
+        bankrupt = d_sgn(nav) <= 0;                                            // Done_Helper.set_done (done_helper.py:3-18)
+        if (S.has_info) {                                                      // Info_Helper.set_info (info_helper.py:30-116)
+            const cda_info_ptrs& I = S.info;
+            if (I.nav) I.nav[ix] = a.nav;
+            if (I.num_trades) I.num_trades[ix] = a.num_trades;
+            if (I.net_position) I.net_position[ix] = a.net_position;
+            if (I.vwap) I.vwap[ix] = d_to_double(ld_dec(a.vwap), &ferr);
+            if (I.cash) I.cash[ix] = d_to_double(ld_dec(a.cash), &ferr);
+            if (I.cash_on_hold) I.cash_on_hold[ix] = d_to_double(ld_dec(a.hold), &ferr);
+            if (I.position_val) I.position_val[ix] = d_to_double(ld_dec(a.posval), &ferr);
+            if (I.drawdown) I.drawdown[ix] = drawdown;
+            if (I.max_nav) I.max_nav[ix] = d_to_double(mx, &ferr);
+            if (I.num_trades_step) I.num_trades_step[ix] = a.num_trades_step;
+            if (I.num_passive_fills_step) I.num_passive_fills_step[ix] = a.num_passive_fills_step;
+            if (I.order_step_placed) I.order_step_placed[ix] = a.order_step_placed;
+            if (I.num_rejected_step) I.num_rejected_step[ix] = a.num_rejected_step;
+            if (I.is_pass_action) I.is_pass_action[ix] = (uint8_t)((pass_mask >> lane) & 1u);
+            if (I.reward_terms) { double* rt = I.reward_terms + ix * 5; rt[0] = t0; rt[1] = t1; rt[2] = t2; rt[3] = t3; rt[4] = t4; }
+        }
+        a.num_trades_step = 0; a.num_passive_fills_step = 0; a.order_step_placed = 0; a.num_rejected_step = 0;
+    }
+    if (__ballot(ferr != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
+    m.done_mask |= (uint32_t)__ballot(bankrupt);
+    if (lane == 0) {
+        if (S.has_info) {
+            const cda_info_ptrs& I = S.info;
+            double bb = m.n[0] ? (double)L.book.price[0][0] : __longlong_as_double(0x7ff8000000000000LL);
+            double ba = m.n[1] ? (double)L.book.price[1][0] : __longlong_as_double(0x7ff8000000000000LL);
+            if (I.last_price) I.last_price[mi] = (double)m.last_price;
+            if (I.best_bid) I.best_bid[mi] = bb;
+            if (I.best_ask) I.best_ask[mi] = ba;
+            if (I.spread) I.spread[mi] = (m.n[0] && m.n[1]) ? ba - bb : __longlong_as_double(0x7ff8000000000000LL);
+        }
+        // Done_Helper.set_all_done (done_helper.py:20-54)
+        S.terminated_out[mi] = (uint8_t)(__popc(m.done_mask) == A);
+        S.truncated_out[mi] = (uint8_t)(m.t_step + 1 >= P.cfg.max_step);
+    }
+    m.t_step += 1;
+    store_market(mp, P, L, m, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// test hooks and small kernels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, int mi, int tr, int type, int side, int size, int price) {
+    __shared__ Lds lds1;
+    int lane = lane_id();
+    MarketPtrs mp = market_ptrs(arena, P, mi);
+    Mkt m;
+    load_market(mp, P, lds1, m, lane);
+    place_order(lds1, m, tr, type, side, size, price, lane);
+    store_market(mp, P, lds1, m, lane);
+}
+__global__ __launch_bounds__(64) void k_mark_to_mkt(uint8_t* arena, Params P, int mi) {
+    __shared__ Lds lds1;
+    int lane = lane_id();
+    MarketPtrs mp = market_ptrs(arena, P, mi);
+    Mkt m;
+    load_market(mp, P, lds1, m, lane);
+    mark_to_mkt(lds1, m, P.cfg.num_agents, lane);
+    store_market(mp, P, lds1, m, lane);
+}
+__global__ __launch_bounds__(64 * CDA_WPB) void k_raw_snapshot(uint8_t* arena, Params P, float* raw_out) {
+    __shared__ Lds lds[CDA_WPB];
+    int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    int mi = (int)blockIdx.x * CDA_WPB + wave;
+    if (mi >= P.n_markets) return;
+    Lds& L = lds[wave];
+    MarketPtrs mp = market_ptrs(arena, P, mi);
+    Mkt m;
+    load_header(mp.hdr, m, lane);
+    load_book(mp.book, L.book, m, lane);
+    CDA_WSYNC();
+    aggregate_levels(L, m, lane);
+    if (lane < CDA_RAW_DIM) raw_out[(size_t)mi * CDA_RAW_DIM + (size_t)lane] = raw_value(L, lane);
+}
+__global__ void k_flags(uint8_t* arena, Params P, uint32_t* out) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < P.n_markets) out[i] = ((const uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride))[H_FLAGS];
+}
+__global__ void k_init_arena(uint8_t* arena, Params P) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < P.n_markets) {
+        uint32_t* h = (uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride);
+        for (int k = 0; k < H_WORDS; k++) h[k] = 0;
+    }
+}
+
+__global__ void k_selftest_dec(int op, int n, const cda_dec* a, const cda_dec* b, cda_dec* out) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    D x = ld_dec(a[i]);
+    D y = b ? ld_dec(b[i]) : d_zero();
+    cda_dec o; o.w[0] = o.w[1] = o.w[2] = 0; o.exp = 0; o.sign = 0; o.pad = 0;
+    uint32_t f = 0;
+    uint32_t yc = y.w0;   // integer-valued small operand for mul/div
+    switch (op) {
+        case 0: st_dec(o, d_add(x, y), f); break;
+        case 1: st_dec(o, d_sub(x, y), f); break;
+        case 2: { D r = d_mul_u32(x, yc, y.exp); r.sign ^= y.sign; st_dec(o, r, f); break; }
+        case 3: { D r = d_div_u32(x, yc); r.sign ^= y.sign; st_dec(o, r, f); break; }
+        case 4: o.w[0] = (uint32_t)(d_cmp(x, y) + 1); break;
+        default: { double d = d_to_double(x, &f); unsigned long long bits = (unsigned long long)__double_as_longlong(d); o.w[0] = (uint32_t)bits; o.w[1] = (uint32_t)(bits >> 32); o.w[2] = f; break; }
+    }
+    out[i] = o;
+}
+__global__ void k_selftest_rng(uint64_t seed, int lo, int hi, int n_steps, int n_normals, int perm_n,
+                               int32_t* first_int, double* normals, int32_t* perms, uint64_t* final_state) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Mkt m; rng_seed(m, seed);
+    *first_int = rng_integers(m, lo, hi);
+    for (int s = 0; s < n_steps; s++) {
+        for (int k = 0; k < n_normals; k++) normals[(size_t)s * (size_t)n_normals + (size_t)k] = rng_std_normal(m);
+        int32_t* p = perms + (size_t)s * (size_t)perm_n;
+        for (int i = 0; i < perm_n; i++) p[i] = i;
+        for (int i = perm_n - 1; i >= 1; i--) { int j = (int)rng_interval(m, (uint32_t)i); int32_t t = p[i]; p[i] = p[j]; p[j] = t; }
+    }
+    final_state[0] = (uint64_t)(m.rng_state >> 64); final_state[1] = (uint64_t)m.rng_state;
+    final_state[2] = (uint64_t)(m.rng_inc >> 64); final_state[3] = (uint64_t)m.rng_inc;
+    final_state[4] = m.has_u32; final_state[5] = m.uinteger;
+}
+
+// ==========================================================================================
+// host side: the C-ABI
+// ==========================================================================================
+struct cda_env {
+    Params P;
+    int device;
+    uint8_t* arena;
+    size_t arena_bytes;
+};
+
+static thread_local char g_err[256] = "";
+static int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return CDA_ERR_HIP;
+}
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return hip_fail(_e, #x); } while (0)
+
+extern "C" {
+
+const char* cda_strerror(int status) {
+    switch (status) {
+        case CDA_OK: return "ok";
+        case CDA_ERR_INVALID: return "invalid argument or config outside the supported domain";
+        case CDA_ERR_NO_DEVICE: return "no HIP device: this library has no CPU fallback";
+        case CDA_ERR_HIP: return g_err[0] ? g_err : "HIP runtime error";
+        case CDA_ERR_UNSUPPORTED: return "unsupported configuration (only tick_size == 1)";
+        case CDA_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+int cda_default_config(cda_config* c) {
+    if (!c) return CDA_ERR_INVALID;
+    memset(c, 0, sizeof *c);
+    c->num_agents = 5; c->max_step = 64; c->n_hist = 4; c->tick_size = 1; c->init_cash = 1000000;
+    c->initial_price_min = 10; c->initial_price_max = 100; c->min_size = 1; c->mkt_max_size = 100; c->limit_size_multiple = 10;
+    c->order_penalty = 0.1; c->trade_penalty = 0.05; c->drawdown_penalty = 0.2; c->passive_bonus = 0.1; c->loss_multiplier = 1.5;
+    return CDA_OK;
+}
+
+static int cfg_ok(const cda_config* c) {
+    if (c->num_agents < 1 || c->num_agents > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+    if (c->n_hist < 1 || c->n_hist > CDA_MAX_HIST) return CDA_ERR_INVALID;
+    if (c->tick_size != 1) return CDA_ERR_UNSUPPORTED;
+    if (c->initial_price_max < c->initial_price_min || c->initial_price_min < 0) return CDA_ERR_INVALID;
+    if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;
+    if (c->init_cash > (1LL << 62) || c->init_cash < -(1LL << 62)) return CDA_ERR_INVALID;
+    return CDA_OK;
+}
+
+static dim3 grid_for(int n) { return dim3((unsigned)((n + CDA_WPB - 1) / CDA_WPB)); }
+
+int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env** out) {
+    if (!cfg || !out || n_markets < 1) return CDA_ERR_INVALID;
+    int rc = cfg_ok(cfg); if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CDA_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(device));
+    cda_env* e = (cda_env*)calloc(1, sizeof *e);
+    if (!e) return CDA_ERR_NOMEM;
+    e->device = device;
+    Params& P = e->P;
+    P.cfg = *cfg; P.n_markets = n_markets;
+    P.mkt_mul = (float)((double)(cfg->mkt_max_size - cfg->min_size) / 2.0);
+    P.lim_mul = (float)((double)(cfg->mkt_max_size * cfg->limit_size_multiple - cfg->min_size) / 2.0);
+    int off = HEADER_BYTES;
+    P.lay.acc_off = off; off += cfg->num_agents * (int)sizeof(Acc);
+    P.lay.hist_off = off; off += cfg->n_hist * CDA_SNAPSHOT_DIM * 4; off = (off + 15) & ~15;
+    P.lay.book_off = off; off += BOOK_BYTES;
+    P.lay.stride = (off + 255) & ~255;
+    e->arena_bytes = (size_t)P.lay.stride * (size_t)n_markets;
+    hipError_t he = hipMalloc((void**)&e->arena, e->arena_bytes);
+    if (he != hipSuccess) { free(e); return he == hipErrorOutOfMemory ? CDA_ERR_NOMEM : hip_fail(he, "hipMalloc"); }
+    hipLaunchKernelGGL(k_init_arena, dim3((unsigned)((n_markets + 255) / 256)), dim3(256), 0, 0, e->arena, P);
+    he = hipDeviceSynchronize();
+    if (he != hipSuccess) { (void)hipFree(e->arena); free(e); return hip_fail(he, "k_init_arena"); }
+    *out = e;
+    return CDA_OK;
+}
+
+int cda_destroy(cda_env* e) {
+    if (!e) return CDA_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipFree(e->arena);
+    free(e);
+    return CDA_OK;
+}
+
+int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs_out, void* stream) {
+    if (!e) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_reset, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), 0, (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+
+int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const float* size_sigma,
+             const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+             float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+             const cda_info_ptrs* info_out, void* stream) {
+    if (!e || !category || !size_mean || !size_sigma || !price || !price_offset) return CDA_ERR_INVALID;
+    if (!obs_out || !reward_out || !terminated_out || !truncated_out) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    StepArgs S;
+    S.category = category; S.size_mean = size_mean; S.size_sigma = size_sigma; S.price = price; S.price_offset = price_offset;
+    S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
+    if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
+    hipLaunchKernelGGL(k_step, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), 0, (hipStream_t)stream, e->arena, e->P, S);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+
+int cda_place_order(cda_env* e, int32_t market, int32_t trader, int32_t type, int32_t side, int32_t size, int32_t price) {
+    if (!e || market < 0 || market >= e->P.n_markets || trader < 0 || trader >= e->P.cfg.num_agents) return CDA_ERR_INVALID;
+    if (type < 0 || type > 3 || side < 0 || side > 1 || size < 1) return CDA_ERR_INVALID;
+    if (type != 0 && price < 1) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_place_order, dim3(1), dim3(64), 0, 0, e->arena, e->P, market, trader, type, side, size, price);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return CDA_OK;
+}
+int cda_mark_to_mkt(cda_env* e, int32_t market) {
+    if (!e || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_mark_to_mkt, dim3(1), dim3(64), 0, 0, e->arena, e->P, market);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return CDA_OK;
+}
+
+int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
+    if (!e || !s || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    const Params& P = e->P;
+    uint8_t* rec = (uint8_t*)malloc((size_t)P.lay.stride);
+    if (!rec) return CDA_ERR_NOMEM;
+    HIPCHK(hipDeviceSynchronize());
+    hipError_t he = hipMemcpy(rec, e->arena + (size_t)market * (size_t)P.lay.stride, (size_t)P.lay.stride, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { free(rec); return hip_fail(he, "hipMemcpy D2H"); }
+    memset(s, 0, sizeof *s);
+    const uint32_t* h = (const uint32_t*)rec;
+    s->rng_state_lo = (uint64_t)h[H_RNG_STATE_LO] | ((uint64_t)h[H_RNG_STATE_LO + 1] << 32);
+    s->rng_state_hi = (uint64_t)h[H_RNG_STATE_HI] | ((uint64_t)h[H_RNG_STATE_HI + 1] << 32);
+    s->rng_inc_lo = (uint64_t)h[H_RNG_INC_LO] | ((uint64_t)h[H_RNG_INC_LO + 1] << 32);
+    s->rng_inc_hi = (uint64_t)h[H_RNG_INC_HI] | ((uint64_t)h[H_RNG_INC_HI + 1] << 32);
+    s->rng_has_uint32 = h[H_HAS_U32]; s->rng_uinteger = h[H_UINTEGER];
+    s->t_step = (int32_t)h[H_T_STEP]; s->lob_time = (int32_t)h[H_LOB_TIME]; s->next_order_id = (int32_t)h[H_NEXT_OID];
+    s->last_price = (int32_t)h[H_LAST_PRICE]; s->has_trade = (int32_t)h[H_HAS_TRADE]; s->last_trade_price = (int32_t)h[H_LAST_TRADE_PRICE];
+    s->done_mask = h[H_DONE_MASK]; s->flags = h[H_FLAGS];
+    s->n_bids = (int32_t)h[H_N_BIDS]; s->n_asks = (int32_t)h[H_N_ASKS];
+    const int32_t* bp = (const int32_t*)(rec + P.lay.book_off);
+    for (int sd = 0; sd < 2; sd++) {
+        int n = sd == 0 ? s->n_bids : s->n_asks;
+        const int32_t* sp = bp + sd * 5 * CAP;
+        for (int i = 0; i < n && i < CAP; i++) {
+            cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
+            o->price = sp[0 * CAP + i]; o->qty = sp[1 * CAP + i]; o->owner = sp[2 * CAP + i]; o->order_id = sp[3 * CAP + i]; o->timestamp = sp[4 * CAP + i];
+        }
+    }
+    const Acc* ap = (const Acc*)(rec + P.lay.acc_off);
+    for (int a = 0; a < P.cfg.num_agents; a++) {
+        cda_account_state* o = &s->acc[a];
+        o->cash = ap[a].cash; o->cash_on_hold = ap[a].hold; o->position_val = ap[a].posval; o->vwap = ap[a].vwap;
+        o->nav = ap[a].nav; o->prev_nav = ap[a].prev_nav; o->max_nav = ap[a].max_nav;
+        o->net_position = ap[a].net_position; o->num_trades = ap[a].num_trades;
+        o->num_trades_step = ap[a].num_trades_step; o->num_passive_fills_step = ap[a].num_passive_fills_step;
+        o->order_step_placed = ap[a].order_step_placed; o->num_rejected_step = ap[a].num_rejected_step;
+    }
+    const float* hp = (const float*)(rec + P.lay.hist_off);
+    int H = P.cfg.n_hist, head = (int)h[H_HIST_HEAD];
+    for (int j = 0; j < H; j++) {
+        int slot = (head + j) % H;
+        memcpy(s->hist + j * CDA_SNAPSHOT_DIM, hp + slot * CDA_SNAPSHOT_DIM, sizeof(float) * CDA_SNAPSHOT_DIM);
+    }
+    free(rec);
+    return CDA_OK;
+}
+
+int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
+    if (!e || !s || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
+    if (s->n_bids < 0 || s->n_bids > CAP || s->n_asks < 0 || s->n_asks > CAP) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    const Params& P = e->P;
+    uint8_t* rec = (uint8_t*)calloc(1, (size_t)P.lay.stride);
+    if (!rec) return CDA_ERR_NOMEM;
+    uint32_t* h = (uint32_t*)rec;
+    h[H_RNG_STATE_LO] = (uint32_t)s->rng_state_lo; h[H_RNG_STATE_LO + 1] = (uint32_t)(s->rng_state_lo >> 32);
+    h[H_RNG_STATE_HI] = (uint32_t)s->rng_state_hi; h[H_RNG_STATE_HI + 1] = (uint32_t)(s->rng_state_hi >> 32);
+    h[H_RNG_INC_LO] = (uint32_t)s->rng_inc_lo; h[H_RNG_INC_LO + 1] = (uint32_t)(s->rng_inc_lo >> 32);
+    h[H_RNG_INC_HI] = (uint32_t)s->rng_inc_hi; h[H_RNG_INC_HI + 1] = (uint32_t)(s->rng_inc_hi >> 32);
+    h[H_HAS_U32] = s->rng_has_uint32; h[H_UINTEGER] = s->rng_uinteger;
+    h[H_T_STEP] = (uint32_t)s->t_step; h[H_LOB_TIME] = (uint32_t)s->lob_time; h[H_NEXT_OID] = (uint32_t)s->next_order_id;
+    h[H_LAST_PRICE] = (uint32_t)s->last_price; h[H_HAS_TRADE] = (uint32_t)s->has_trade; h[H_LAST_TRADE_PRICE] = (uint32_t)s->last_trade_price;
+    h[H_DONE_MASK] = s->done_mask; h[H_FLAGS] = s->flags; h[H_N_BIDS] = (uint32_t)s->n_bids; h[H_N_ASKS] = (uint32_t)s->n_asks;
+    h[H_SEEDED] = 1; h[H_HIST_HEAD] = 0;
+    int32_t* bp = (int32_t*)(rec + P.lay.book_off);
+    for (int sd = 0; sd < 2; sd++) {
+        int n = sd == 0 ? s->n_bids : s->n_asks;
+        int32_t* sp = bp + sd * 5 * CAP;
+        for (int i = 0; i < n; i++) {
+            const cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
+            sp[0 * CAP + i] = o->price; sp[1 * CAP + i] = o->qty; sp[2 * CAP + i] = o->owner; sp[3 * CAP + i] = o->order_id; sp[4 * CAP + i] = o->timestamp;
+        }
+    }
+    Acc* ap = (Acc*)(rec + P.lay.acc_off);
+    for (int a = 0; a < P.cfg.num_agents; a++) {
+        const cda_account_state* o = &s->acc[a];
+        ap[a].cash = o->cash; ap[a].hold = o->cash_on_hold; ap[a].posval = o->position_val; ap[a].vwap = o->vwap;
+        ap[a].nav = o->nav; ap[a].prev_nav = o->prev_nav; ap[a].max_nav = o->max_nav;
+        ap[a].net_position = o->net_position; ap[a].num_trades = o->num_trades;
+        ap[a].num_trades_step = o->num_trades_step; ap[a].num_passive_fills_step = o->num_passive_fills_step;
+        ap[a].order_step_placed = o->order_step_placed; ap[a].num_rejected_step = o->num_rejected_step;
+    }
+    memcpy(rec + P.lay.hist_off, s->hist, sizeof(float) * (size_t)P.cfg.n_hist * CDA_SNAPSHOT_DIM);
+    hipError_t he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = hipMemcpy(e->arena + (size_t)market * (size_t)P.lay.stride, rec, (size_t)P.lay.stride, hipMemcpyHostToDevice);
+    free(rec);
+    if (he != hipSuccess) return hip_fail(he, "hipMemcpy H2D");
+    return CDA_OK;
+}
+
+int cda_get_raw_snapshot(cda_env* e, float* raw_out, void* stream) {
+    if (!e || !raw_out) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_raw_snapshot, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), 0, (hipStream_t)stream, e->arena, e->P, raw_out);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+int cda_last_flags(cda_env* e, uint32_t* flags_out, void* stream) {
+    if (!e || !flags_out) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_flags, dim3((unsigned)((e->P.n_markets + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->arena, e->P, flags_out);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+
+int cda_selftest_dec(int32_t device, int32_t op, int32_t n, const cda_dec* a_host, const cda_dec* b_host, cda_dec* out_host) {
+    if (n < 0 || !a_host || !out_host || op < 0 || op > 5) return CDA_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CDA_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    if (n == 0) return CDA_OK;
+    cda_dec *da = NULL, *db = NULL, *dout = NULL;
+    size_t bytes = (size_t)n * sizeof(cda_dec);
+    HIPCHK(hipMalloc((void**)&da, bytes)); HIPCHK(hipMalloc((void**)&dout, bytes));
+    HIPCHK(hipMemcpy(da, a_host, bytes, hipMemcpyHostToDevice));
+    if (b_host) { HIPCHK(hipMalloc((void**)&db, bytes)); HIPCHK(hipMemcpy(db, b_host, bytes, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_selftest_dec, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, n, da, db, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_host, dout, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    return CDA_OK;
+}
+
+int cda_selftest_rng(int32_t device, uint64_t seed, int32_t lo, int32_t hi, int32_t n_steps, int32_t n_normals, int32_t perm_n,
+                     int32_t* first_int_host, double* normals_host, int32_t* perms_host, uint64_t* final_state_host) {
+    if (n_steps < 0 || n_normals < 0 || perm_n < 0 || !first_int_host || !final_state_host) return CDA_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CDA_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    int32_t* dfi = NULL; double* dn = NULL; int32_t* dp = NULL; uint64_t* dfs = NULL;
+    size_t nb = sizeof(double) * (size_t)n_steps * (size_t)n_normals + 8, pb = sizeof(int32_t) * (size_t)n_steps * (size_t)perm_n + 8;
+    HIPCHK(hipMalloc((void**)&dfi, 8)); HIPCHK(hipMalloc((void**)&dn, nb)); HIPCHK(hipMalloc((void**)&dp, pb)); HIPCHK(hipMalloc((void**)&dfs, 64));
+    hipLaunchKernelGGL(k_selftest_rng, dim3(1), dim3(64), 0, 0, seed, lo, hi, n_steps, n_normals, perm_n, dfi, dn, dp, dfs);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(first_int_host, dfi, 4, hipMemcpyDeviceToHost));
+    if (normals_host && n_steps * n_normals) HIPCHK(hipMemcpy(normals_host, dn, nb - 8, hipMemcpyDeviceToHost));
+    if (perms_host && n_steps * perm_n) HIPCHK(hipMemcpy(perms_host, dp, pb - 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(final_state_host, dfs, 48, hipMemcpyDeviceToHost));
+    (void)hipFree(dfi); (void)hipFree(dn); (void)hipFree(dp); (void)hipFree(dfs);
+    return CDA_OK;
+}
+
+int32_t cda_num_markets(const cda_env* e) { return e ? e->P.n_markets : 0; }
+int32_t cda_obs_dim(const cda_env* e) { return e ? e->P.cfg.n_hist * CDA_SNAPSHOT_DIM : 0; }
+int64_t cda_state_bytes_per_market(const cda_env* e) { return e ? (int64_t)e->P.lay.stride : 0; }
+
+}  // extern "C"

@@ -1,0 +1,635 @@
+// cda_market.hpp - one wavefront steps one market (gfx950 / CDNA4, wave64).
+//
+// Execution model: a 64-lane wave owns one independent market for the whole step.  The market's
+// order book (two sides, queue-ordered SoA arrays) and its accounts are staged HBM -> LDS at kernel
+// entry and written back at exit.  Lanes are used for
+//   * the order pool: searches (`_get_order_ID`), insert position, shift on insert / removal and the
+//     top-10 level aggregation are 64-wide scans over the queue-ordered arrays (ballot + popcount);
+//   * the ledger: lane a owns account a; a fill settles its two parties in two lanes at once and
+//     mark-to-market / reward / info run on A lanes in parallel (28-digit decimal, cda_dec.hpp);
+//   * the observation: 42 lanes compute one snapshot frame.
+// The A order operations inside a step are inherently sequential (price-time priority); everything
+// wave-uniform (RNG, decode, matching loop control) is executed redundantly by all lanes.
+//
+// Reference citations are relative to /root/reference/gym_continuousDoubleAuction/envs/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cda.h"
+#include "cda_dec.hpp"
+
+#define CDA_ZIG_QUAL __device__ const
+#include "ziggurat_tables.h"
+
+namespace cda {
+
+constexpr int WAVE = 64;
+constexpr int CAP = CDA_BOOK_CAP;
+enum { T_MARKET = 0, T_LIMIT = 1, T_MODIFY = 2, T_CANCEL = 3 };
+enum { S_BID = 0, S_ASK = 1, S_NONE = 2 };
+
+// Cross-lane visibility of LDS written by other lanes of the same wave: the hardware executes a
+// wave's LDS operations in order, so only the compiler has to be stopped from forwarding values.
+#define CDA_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// ---- HBM record of one market (see DESIGN.md "Data layout") --------------------------------
+// header words (u32)
+enum {
+    H_RNG_STATE_LO = 0, H_RNG_STATE_HI = 2, H_RNG_INC_LO = 4, H_RNG_INC_HI = 6, H_HAS_U32 = 8, H_UINTEGER = 9,
+    H_T_STEP = 10, H_LOB_TIME = 11, H_NEXT_OID = 12, H_LAST_PRICE = 13, H_HAS_TRADE = 14, H_LAST_TRADE_PRICE = 15,
+    H_DONE_MASK = 16, H_FLAGS = 17, H_N_BIDS = 18, H_N_ASKS = 19, H_SEEDED = 20, H_HIST_HEAD = 21, H_WORDS = 32
+};
+constexpr int HEADER_BYTES = H_WORDS * 4;   // 128
+
+struct Acc {                     // 144 B, 16-byte aligned; lane a owns account a
+    cda_dec cash, hold, posval, vwap, nav, prev_nav, max_nav;     // 7 x 16 B
+    int32_t net_position, num_trades;
+    int32_t num_trades_step, num_passive_fills_step, order_step_placed, num_rejected_step;
+    int32_t pad[2];
+};
+static_assert(sizeof(Acc) == 144, "Acc layout");
+
+struct Book {                    // LDS image of the two sides, queue order (best first, FIFO in a level)
+    int32_t price[2][CAP];
+    int32_t qty[2][CAP];
+    int32_t owner[2][CAP];
+    int32_t oid[2][CAP];
+    int32_t ts[2][CAP];
+};
+constexpr int BOOK_BYTES = sizeof(Book);   // 10240
+
+struct Lds {                     // per-wave LDS
+    Book book;
+    Acc acc[CDA_MAX_AGENTS];
+    int32_t lvl_px[2][CDA_K_ROWS];
+    int32_t lvl_sz[2][CDA_K_ROWS];
+};
+
+struct Layout {                  // byte offsets inside a market record
+    int32_t acc_off, hist_off, book_off, stride;
+};
+
+struct Params {
+    cda_config cfg;
+    Layout lay;
+    int32_t n_markets;
+    float mkt_mul, lim_mul;
+};
+
+// ---- uniform (per-wave) market scalars kept in registers -----------------------------------
+struct Mkt {
+    u128 rng_state, rng_inc;
+    uint32_t has_u32, uinteger;
+    int32_t t_step, lob_time, next_oid, last_price, has_trade, last_trade_price;
+    uint32_t done_mask, flags;
+    int32_t n[2];
+    int32_t seeded, hist_head;
+};
+
+__device__ __forceinline__ D ld_dec(const cda_dec& p) { return d_make(p.w[0], p.w[1], p.w[2], (int)p.exp, (int)p.sign); }
+__device__ __forceinline__ void st_dec(cda_dec& p, const D& d, uint32_t& flags) {
+    p.w[0] = d.w0; p.w[1] = d.w1; p.w[2] = d.w2;
+    if (d.exp < -32768 || d.exp > 32767) flags |= CDA_FLAG_DEC_DOMAIN;
+    p.exp = (int16_t)d.exp; p.sign = (uint8_t)d.sign; p.pad = 0;
+}
+
+// ======================================================================================
+// numpy RNG: PCG64 XSL-RR, half-word buffered 32-bit draws, Lemire bounded ints,
+// masked-rejection intervals, ziggurat normal.  Wave-uniform: every lane computes the same stream.
+// ======================================================================================
+__device__ __forceinline__ u128 pcg_mult() { return ((u128)0x2360ed051fc65da4ULL << 64) | 0x4385df649fccf645ULL; }
+__device__ __forceinline__ uint64_t rng_next64(Mkt& m) {
+    m.rng_state = m.rng_state * pcg_mult() + m.rng_inc;
+    uint64_t hi = (uint64_t)(m.rng_state >> 64), lo = (uint64_t)m.rng_state, x = hi ^ lo;
+    unsigned rot = (unsigned)(hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+__device__ __forceinline__ uint32_t rng_next32(Mkt& m) {
+    if (m.has_u32) { m.has_u32 = 0; return m.uinteger; }
+    uint64_t v = rng_next64(m);
+    m.has_u32 = 1; m.uinteger = (uint32_t)(v >> 32);
+    return (uint32_t)v;
+}
+__device__ __forceinline__ double rng_double(Mkt& m) { return (double)(rng_next64(m) >> 11) * (1.0 / 9007199254740992.0); }
+
+__device__ __forceinline__ uint32_t ss_hashmix(uint32_t value, uint32_t& hc) { value ^= hc; hc *= 0x931e8875u; value *= hc; value ^= value >> 16; return value; }
+__device__ __forceinline__ uint32_t ss_mix(uint32_t x, uint32_t y) { uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y; r ^= r >> 16; return r; }
+// Generator(PCG64(SeedSequence(seed))) for an integer seed < 2^64
+__device__ void rng_seed(Mkt& m, uint64_t seed) {
+    uint32_t e0 = (uint32_t)seed, e1 = (uint32_t)(seed >> 32);
+    uint32_t pool[4], hc = 0x43b0d7e5u;
+    pool[0] = ss_hashmix(e0, hc);
+    pool[1] = ss_hashmix(e1, hc);      // entropy word 1 (0 when the seed fits 32 bits: same as padding)
+    pool[2] = ss_hashmix(0u, hc);
+    pool[3] = ss_hashmix(0u, hc);
+    #pragma unroll
+    for (int s = 0; s < 4; s++) {
+        #pragma unroll
+        for (int d = 0; d < 4; d++) if (s != d) pool[d] = ss_mix(pool[d], ss_hashmix(pool[s], hc));
+    }
+    uint32_t hb = 0x8b51f9ddu, st[8];
+    #pragma unroll
+    for (int i = 0; i < 8; i++) { uint32_t v = pool[i & 3]; v ^= hb; hb *= 0x58f38dedu; v *= hb; v ^= v >> 16; st[i] = v; }
+    uint64_t v0 = (uint64_t)st[0] | ((uint64_t)st[1] << 32), v1 = (uint64_t)st[2] | ((uint64_t)st[3] << 32);
+    uint64_t v2 = (uint64_t)st[4] | ((uint64_t)st[5] << 32), v3 = (uint64_t)st[6] | ((uint64_t)st[7] << 32);
+    u128 initstate = ((u128)v0 << 64) | v1, initseq = ((u128)v2 << 64) | v3;
+    m.rng_inc = (initseq << 1) | 1;
+    m.rng_state = m.rng_inc;                         // 0 * mult + inc
+    m.rng_state += initstate;
+    m.rng_state = m.rng_state * pcg_mult() + m.rng_inc;
+    m.has_u32 = 0; m.uinteger = 0;
+}
+__device__ int32_t rng_integers(Mkt& m, int32_t lo, int32_t hi_incl) {
+    uint32_t rng = (uint32_t)(hi_incl - lo);
+    if (rng == 0) return lo;
+    uint32_t rng_excl = rng + 1u;
+    uint64_t mm = (uint64_t)rng_next32(m) * rng_excl;
+    uint32_t leftover = (uint32_t)mm;
+    if (leftover < rng_excl) {
+        uint32_t threshold = (0xFFFFFFFFu - rng) % rng_excl;
+        while (leftover < threshold) { mm = (uint64_t)rng_next32(m) * rng_excl; leftover = (uint32_t)mm; }
+    }
+    return lo + (int32_t)(mm >> 32);
+}
+__device__ __forceinline__ uint32_t rng_interval(Mkt& m, uint32_t max) {
+    uint32_t mask = max, v;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    do { v = rng_next32(m) & mask; } while (v > max);
+    return v;
+}
+// log1p as glibc 2.35 computes it (sysdeps/ieee754/dbl-64/s_log1p.c: the fdlibm algorithm with the
+// split polynomial evaluation), restated so that the ziggurat tail `r + xx` of numpy - which calls the
+// host libm - is reproduced bit for bit on the device (checked against glibc on 2e7 inputs in the build
+// container; built with -ffp-contract=off).  Finite x > -1 only.
+__device__ __forceinline__ int32_t f64_hi(double x) { return (int32_t)((unsigned long long)__double_as_longlong(x) >> 32); }
+__device__ __forceinline__ double f64_set_hi(double x, int32_t h) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    b = (b & 0xffffffffull) | ((unsigned long long)(uint32_t)h << 32);
+    return __longlong_as_double((long long)b);
+}
+__device__ double glibc_log1p(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+                 Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+                 Lp7 = 1.479819860511658591e-01;
+    double hfsq, f = 0.0, c = 0.0, s, z, R, u;
+    int32_t k = 1, hx = f64_hi(x), hu = 0, ax = hx & 0x7fffffff;
+    if (hx < 0x3FDA827A) {
+        if (ax >= 0x3ff00000) return x == -1.0 ? -__longlong_as_double(0x7ff0000000000000LL) : __longlong_as_double(0x7ff8000000000000LL);
+        if (ax < 0x3e200000) return ax < 0x3c900000 ? x : x - x * x * 0.5;
+        if (hx > 0 || hx <= (int32_t)0xbfd2bec3) { k = 0; f = x; hu = 1; }
+    }
+    if (k != 0) {
+        if (hx < 0x43400000) {
+            u = 1.0 + x; hu = f64_hi(u); k = (hu >> 20) - 1023;
+            c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+            c /= u;
+        } else { u = x; hu = f64_hi(u); k = (hu >> 20) - 1023; c = 0.0; }
+        hu &= 0x000fffff;
+        if (hu < 0x6a09e) u = f64_set_hi(u, hu | 0x3ff00000);
+        else { k += 1; u = f64_set_hi(u, hu | 0x3fe00000); hu = (0x00100000 - hu) >> 2; }
+        f = u - 1.0;
+    }
+    hfsq = 0.5 * f * f;
+    if (hu == 0) {
+        if (f == 0.0) { if (k == 0) return 0.0; c += k * ln2_lo; return k * ln2_hi + c; }
+        R = hfsq * (1.0 - 0.66666666666666666 * f);
+        if (k == 0) return f - R;
+        return k * ln2_hi - ((R - (k * ln2_lo + c)) - f);
+    }
+    s = f / (2.0 + f); z = s * s;
+    double R1 = z * Lp1, z2 = z * z, R2 = Lp2 + z * Lp3, z4 = z2 * z2, R3 = Lp4 + z * Lp5, z6 = z4 * z2, R4 = Lp6 + z * Lp7;
+    R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
+}
+__device__ double rng_std_normal(Mkt& m) {
+    const double zr = 3.6541528853610087963519472518, inv_r = 0.27366123732975827203338247596;
+    for (;;) {
+        uint64_t u = rng_next64(m);
+        int idx = (int)(u & 0xff); u >>= 8;
+        int sign = (int)(u & 1);
+        uint64_t rabs = (u >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * __longlong_as_double((long long)cda_zig_wi_bits[idx]);
+        if (sign) x = -x;
+        if (rabs < cda_zig_ki[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                double xx = -inv_r * glibc_log1p(-rng_double(m));
+                double yy = -glibc_log1p(-rng_double(m));
+                if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(zr + xx) : zr + xx;
+            }
+        } else {
+            double f1 = __longlong_as_double((long long)cda_zig_fi_bits[idx - 1]);
+            double f0 = __longlong_as_double((long long)cda_zig_fi_bits[idx]);
+            if ((f1 - f0) * rng_double(m) + f0 < exp(-0.5 * x * x)) return x;
+        }
+    }
+}
+
+// ======================================================================================
+// HBM <-> LDS staging
+// ======================================================================================
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+
+__device__ void load_header(const uint32_t* hp, Mkt& m, int lane) {
+    uint32_t v = lane < H_WORDS ? hp[lane] : 0u;
+    #define RL(i) ((uint32_t)__builtin_amdgcn_readlane((int)v, (i)))
+    uint64_t slo = (uint64_t)RL(H_RNG_STATE_LO) | ((uint64_t)RL(H_RNG_STATE_LO + 1) << 32);
+    uint64_t shi = (uint64_t)RL(H_RNG_STATE_HI) | ((uint64_t)RL(H_RNG_STATE_HI + 1) << 32);
+    uint64_t ilo = (uint64_t)RL(H_RNG_INC_LO) | ((uint64_t)RL(H_RNG_INC_LO + 1) << 32);
+    uint64_t ihi = (uint64_t)RL(H_RNG_INC_HI) | ((uint64_t)RL(H_RNG_INC_HI + 1) << 32);
+    m.rng_state = ((u128)shi << 64) | slo; m.rng_inc = ((u128)ihi << 64) | ilo;
+    m.has_u32 = RL(H_HAS_U32); m.uinteger = RL(H_UINTEGER);
+    m.t_step = (int32_t)RL(H_T_STEP); m.lob_time = (int32_t)RL(H_LOB_TIME); m.next_oid = (int32_t)RL(H_NEXT_OID);
+    m.last_price = (int32_t)RL(H_LAST_PRICE); m.has_trade = (int32_t)RL(H_HAS_TRADE); m.last_trade_price = (int32_t)RL(H_LAST_TRADE_PRICE);
+    m.done_mask = RL(H_DONE_MASK); m.flags = RL(H_FLAGS);
+    m.n[0] = (int32_t)RL(H_N_BIDS); m.n[1] = (int32_t)RL(H_N_ASKS);
+    m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD);
+    #undef RL
+}
+__device__ void store_header(uint32_t* hp, const Mkt& m, int lane) {
+    if (lane == 0) {
+        hp[H_RNG_STATE_LO] = (uint32_t)m.rng_state; hp[H_RNG_STATE_LO + 1] = (uint32_t)(m.rng_state >> 32);
+        hp[H_RNG_STATE_HI] = (uint32_t)(m.rng_state >> 64); hp[H_RNG_STATE_HI + 1] = (uint32_t)(m.rng_state >> 96);
+        hp[H_RNG_INC_LO] = (uint32_t)m.rng_inc; hp[H_RNG_INC_LO + 1] = (uint32_t)(m.rng_inc >> 32);
+        hp[H_RNG_INC_HI] = (uint32_t)(m.rng_inc >> 64); hp[H_RNG_INC_HI + 1] = (uint32_t)(m.rng_inc >> 96);
+        hp[H_HAS_U32] = m.has_u32; hp[H_UINTEGER] = m.uinteger;
+        hp[H_T_STEP] = (uint32_t)m.t_step; hp[H_LOB_TIME] = (uint32_t)m.lob_time; hp[H_NEXT_OID] = (uint32_t)m.next_oid;
+        hp[H_LAST_PRICE] = (uint32_t)m.last_price; hp[H_HAS_TRADE] = (uint32_t)m.has_trade; hp[H_LAST_TRADE_PRICE] = (uint32_t)m.last_trade_price;
+        hp[H_DONE_MASK] = m.done_mask; hp[H_FLAGS] = m.flags;
+        hp[H_N_BIDS] = (uint32_t)m.n[0]; hp[H_N_ASKS] = (uint32_t)m.n[1];
+        hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head;
+    }
+}
+// book record in HBM: [side][field][CAP] int32 ; only the live prefix of each side moves
+__device__ void load_book(const int32_t* bp, Book& bk, const Mkt& m, int lane) {
+    #pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int32_t* sp = bp + s * 5 * CAP;
+        for (int i = lane; i < m.n[s]; i += WAVE) {
+            bk.price[s][i] = sp[0 * CAP + i]; bk.qty[s][i] = sp[1 * CAP + i]; bk.owner[s][i] = sp[2 * CAP + i];
+            bk.oid[s][i] = sp[3 * CAP + i]; bk.ts[s][i] = sp[4 * CAP + i];
+        }
+    }
+}
+__device__ void store_book(int32_t* bp, const Book& bk, const Mkt& m, int lane) {
+    #pragma unroll
+    for (int s = 0; s < 2; s++) {
+        int32_t* sp = bp + s * 5 * CAP;
+        for (int i = lane; i < m.n[s]; i += WAVE) {
+            sp[0 * CAP + i] = bk.price[s][i]; sp[1 * CAP + i] = bk.qty[s][i]; sp[2 * CAP + i] = bk.owner[s][i];
+            sp[3 * CAP + i] = bk.oid[s][i]; sp[4 * CAP + i] = bk.ts[s][i];
+        }
+    }
+}
+__device__ void copy_words(uint32_t* dst, const uint32_t* src, int nwords, int lane) {
+    for (int i = lane; i < nwords; i += WAVE) dst[i] = src[i];
+}
+
+// ======================================================================================
+// Order book primitives (OrderTree / OrderList, orderbook/ordertree.py, orderlist.py)
+// ======================================================================================
+// remove `cnt` entries starting at `idx` (shift the tail down)
+__device__ void book_remove(Book& bk, int s, int& n, int idx, int cnt, int lane) {
+    for (int base = idx - (idx % WAVE); base < n - cnt; base += WAVE) {
+        int i = base + lane;
+        bool mv = i >= idx && i < n - cnt;
+        int p = 0, q = 0, o = 0, d = 0, t = 0;
+        if (mv) { p = bk.price[s][i + cnt]; q = bk.qty[s][i + cnt]; o = bk.owner[s][i + cnt]; d = bk.oid[s][i + cnt]; t = bk.ts[s][i + cnt]; }
+        CDA_WSYNC();
+        if (mv) { bk.price[s][i] = p; bk.qty[s][i] = q; bk.owner[s][i] = o; bk.oid[s][i] = d; bk.ts[s][i] = t; }
+        CDA_WSYNC();
+    }
+    n -= cnt;
+}
+// OrderTree.insert_order (ordertree.py:44-58): tail of its price level.  false = side full.
+__device__ bool book_insert(Book& bk, int s, int& n, int price, int qty, int owner, int oid, int ts, int lane) {
+    if (n >= CAP) return false;
+    int pos = 0;
+    for (int base = 0; base < n; base += WAVE) {
+        int i = base + lane;
+        bool c = false;
+        if (i < n) { int rp = bk.price[s][i]; c = (s == S_BID) ? (rp >= price) : (rp <= price); }
+        pos += __popcll(__ballot(c));
+    }
+    for (int base = n - (n % WAVE); base >= 0; base -= WAVE) {
+        int i = base + lane;
+        bool mv = i > pos && i <= n;
+        int p = 0, q = 0, o = 0, d = 0, t = 0;
+        if (mv) { p = bk.price[s][i - 1]; q = bk.qty[s][i - 1]; o = bk.owner[s][i - 1]; d = bk.oid[s][i - 1]; t = bk.ts[s][i - 1]; }
+        CDA_WSYNC();
+        if (mv) { bk.price[s][i] = p; bk.qty[s][i] = q; bk.owner[s][i] = o; bk.oid[s][i] = d; bk.ts[s][i] = t; }
+        CDA_WSYNC();
+    }
+    // every lane writes the same values to the same slot (keeps each lane's view coherent)
+    bk.price[s][pos] = price; bk.qty[s][pos] = qty; bk.owner[s][pos] = owner; bk.oid[s][pos] = oid; bk.ts[s][pos] = ts;
+    CDA_WSYNC();
+    n += 1;
+    return true;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+    #pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = __shfl_xor(v, off, WAVE);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+// Trader._get_order_ID (agent/trader.py:254-287): index on the side or -1
+__device__ int find_own_order(const Book& bk, int s, int n, int tr, int type, int price, int lane) {
+    if (type == T_MODIFY) {                 // oldest own order: minimum timestamp (unique)
+        uint64_t best = ~0ull;
+        for (int i = lane; i < n; i += WAVE)
+            if (bk.owner[s][i] == tr) { uint64_t key = ((uint64_t)(uint32_t)bk.ts[s][i] << 32) | (uint32_t)i; best = key < best ? key : best; }
+        best = wave_min_u64(best);
+        return best == ~0ull ? -1 : (int)(uint32_t)best;
+    }
+    // limit / cancel: first own order at that price in order_map insertion order == first in the
+    // level's FIFO, i.e. first hit in queue order
+    for (int base = 0; base < n; base += WAVE) {
+        int i = base + lane;
+        bool c = i < n && bk.owner[s][i] == tr && bk.price[s][i] == price;
+        uint64_t mk = __ballot(c);
+        if (mk) return base + (__ffsll((long long)mk) - 1);
+    }
+    return -1;
+}
+
+// ======================================================================================
+// Ledger (account/account.py, cash_processor.py, calculate.py) - executed by the owning lane
+// ======================================================================================
+__device__ __forceinline__ D cal_profit(bool is_long, D mkt, D raw) { return is_long ? d_sub(mkt, raw) : d_sub(raw, mkt); }
+
+__device__ void process_acc(Acc& a, int32_t q, int32_t price, int own_side, bool counter, uint32_t& flags) {
+    a.num_trades += 1; a.num_trades_step += 1; if (counter) a.num_passive_fills_step += 1;
+    D cash = ld_dec(a.cash), hold = ld_dec(a.hold), posval = ld_dec(a.posval), vwap = ld_dec(a.vwap);
+    D p = d_price(price);
+    D tv = d_mul_u32(p, (uint32_t)q, 0);                 // Decimal(q) * price
+    int32_t pos = a.net_position;
+    uint32_t ap = (uint32_t)(pos < 0 ? -pos : pos);
+    bool is_long = pos > 0;
+    int mode;                                           // 0 neutral, 1 increase, 2 decrease, 3 flip
+    if (pos > 0) mode = own_side == S_BID ? 1 : (pos >= q ? 2 : 3);
+    else if (pos < 0) mode = own_side == S_ASK ? 1 : (ap >= (uint32_t)q ? 2 : 3);
+    else mode = 0;
+    D xi = d_zero(), xd = d_zero();                     // amounts for XFER_INC / XFER_DEC (applied below)
+    bool do_inc = false, do_dec = false;
+    if (mode == 0) { posval = d_add(posval, tv); vwap = p; xi = tv; do_inc = true; }
+    else if (mode == 1 || (mode == 2 && ap > (uint32_t)q)) {
+        uint32_t n = mode == 1 ? ap + (uint32_t)q : ap - (uint32_t)q;
+        D num = d_mul_int(vwap, ap);
+        num = mode == 1 ? d_add(num, tv) : d_sub(num, tv);
+        vwap = d_div_u32(num, n);
+        D raw = d_mul_int(vwap, n), mkt = d_mul_u32(p, n, 0);
+        posval = d_add(raw, cal_profit(is_long, mkt, raw));
+        if (mode == 1) { xi = tv; do_inc = true; } else { xd = tv; do_dec = true; }
+    } else {
+        // _covered (account.py:135-149)
+        D raw = d_mul_int(vwap, ap), mkt = d_mul_u32(p, ap, 0);
+        posval = d_add(raw, cal_profit(is_long, mkt, raw));
+        cash = d_add(cash, d_sub(posval, mkt));
+        posval = d_zero(); vwap = d_zero();
+        if (mode == 2) { xd = tv; do_dec = true; }
+        else {                                           // _covered_side_chg (account.py:163-171)
+            xd = mkt; do_dec = true;
+            uint32_t nw = (uint32_t)q - ap;
+            posval = d_mul_u32(p, nw, 0); vwap = p;
+            xi = posval; do_inc = true;
+        }
+    }
+    if (do_dec) {                                        // size_decrease_cash_transfer (cash_processor.py:38-45)
+        if (!counter) cash = d_add(cash, xd);
+        else { cash = d_add(cash, xd); hold = d_sub(hold, xd); cash = d_add(cash, xd); }
+    }
+    if (do_inc) {                                        // size_increase_cash_transfer (cash_processor.py:31-36)
+        if (!counter) cash = d_sub(cash, xi); else hold = d_sub(hold, xi);
+    }
+    st_dec(a.cash, cash, flags); st_dec(a.hold, hold, flags); st_dec(a.posval, posval, flags); st_dec(a.vwap, vwap, flags);
+    int64_t np = (int64_t)pos + (own_side == S_BID ? (int64_t)q : -(int64_t)q);
+    if (np > 2147483647LL || np < -2147483647LL) flags |= CDA_FLAG_INT_OVERFLOW;
+    a.net_position = (int32_t)np;
+}
+
+// one fill: counter party (passive) and initiator settle in two lanes at once (trader.py:303-345)
+__device__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t price, int init_side, uint32_t& flags, int lane) {
+    uint32_t f = 0;
+    if (counter != tr) {
+        if (lane == tr || lane == counter) process_acc(L.acc[lane], q, price, lane == tr ? init_side : init_side ^ 1, lane == counter, f);
+    } else if (lane == tr) {                             // init_is_counter_cash_transfer (cash_processor.py:55-62)
+        Acc& a = L.acc[lane];
+        D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
+        D hold = d_sub(ld_dec(a.hold), tv), cash = d_add(ld_dec(a.cash), tv);
+        st_dec(a.hold, hold, f); st_dec(a.cash, cash, f);
+    }
+    uint64_t any = __ballot(f != 0);
+    if (any) flags |= CDA_FLAG_DEC_DOMAIN;
+}
+
+// matching loops of OrderBook.process_order_list / process_market_order / process_limit_order
+// (orderbook.py:61-194).  limit < 0 = market order.  Returns the unfilled quantity.
+__device__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, int32_t qty, int32_t limit, int lane) {
+    int opp = own_side ^ 1;
+    int h = 0, nopp = m.n[opp];
+    Book& bk = L.book;
+    while (qty > 0 && h < nopp) {
+        int32_t p = bk.price[opp][h];
+        if (limit >= 0) { if (own_side == S_BID ? !(limit >= p) : !(limit <= p)) break; }
+        int32_t rq = bk.qty[opp][h], c = bk.owner[opp][h], f;
+        if (qty < rq) { f = qty; bk.qty[opp][h] = rq - qty; qty = 0; CDA_WSYNC(); }    // all lanes store the same value
+        else { f = rq; qty -= rq; h++; }
+        m.has_trade = 1; m.last_trade_price = p;
+        settle_fill(L, tr, c, f, p, own_side, m.flags, lane);
+    }
+    if (h) book_remove(bk, opp, m.n[opp], 0, h, lane);
+    return qty;
+}
+
+__device__ __forceinline__ void escrow_rest(Acc& a, int32_t price, int32_t qty, uint32_t& flags) {   // cash_processor.py:15-29
+    D v = d_mul_u32(d_price(price), (uint32_t)qty, 0);
+    D cash = d_sub(ld_dec(a.cash), v), hold = d_add(ld_dec(a.hold), v);
+    st_dec(a.cash, cash, flags); st_dec(a.hold, hold, flags);
+}
+__device__ __forceinline__ void cancel_cash_transfer(Acc& a, int32_t price, int32_t qty, uint32_t& flags) {   // cash_processor.py:85-97
+    D v = d_mul_u32(d_price(price), (uint32_t)qty, 0);
+    D hold = d_sub(ld_dec(a.hold), v), cash = d_add(ld_dec(a.cash), v);
+    st_dec(a.hold, hold, flags); st_dec(a.cash, cash, flags);
+}
+
+// Trader.__modify_limit_order + OrderBook.modify_order (trader.py:219-235, orderbook.py:210-266)
+__device__ void modify_order(Lds& L, Mkt& m, int tr, int side, int idx, int32_t new_price, int32_t new_qty,
+                             int32_t& rest_price, int32_t& rest_qty, int lane) {
+    Book& bk = L.book;
+    int32_t op = bk.price[side][idx], oq = bk.qty[side][idx], ooid = bk.oid[side][idx];
+    uint32_t f = 0;
+    if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
+    m.lob_time += 1;
+    if (new_price == op && new_qty <= oq) {
+        bk.qty[side][idx] = new_qty; bk.ts[side][idx] = m.lob_time;    // in place: priority kept
+        CDA_WSYNC();
+        rest_price = new_price; rest_qty = new_qty;
+    } else {
+        book_remove(bk, side, m.n[side], idx, 1, lane);
+        int32_t left = match(L, m, tr, side, new_qty, new_price, lane);
+        if (left > 0) {
+            if (book_insert(bk, side, m.n[side], new_price, left, tr, ooid, m.lob_time, lane)) { rest_price = new_price; rest_qty = left; }
+            else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
+        }
+    }
+    if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
+}
+
+// Trader._order_approved (agent/trader.py:108-151), evaluated by lane `tr`, result broadcast
+__device__ bool order_approved(Lds& L, const Mkt& m, int tr, int side, int32_t size, int32_t price, int lane) {
+    int ok = 0;
+    if (lane == tr) {
+        const Acc& a = L.acc[lane];
+        D nav = ld_dec(a.nav);
+        if (d_sgn(nav) > 0) {
+            int64_t pos = a.net_position, opening;
+            int64_t apos = pos < 0 ? -pos : pos;
+            if ((side == S_BID && pos >= 0) || (side == S_ASK && pos <= 0)) opening = size;
+            else { opening = (int64_t)size - apos; if (opening < 0) opening = 0; }
+            if (opening <= 0) ok = 1;
+            else {
+                D est;
+                if (price < 0) {
+                    int opp = side ^ 1;
+                    if (m.n[opp] > 0) est = d_price(L.book.price[opp][0]);
+                    else if (m.has_trade) est = d_price(m.last_trade_price);
+                    else est = d_from_u32(1);
+                } else est = d_price(price);
+                D order_val = d_mul_u32(est, (uint32_t)opening, 0);
+                ok = d_cmp(ld_dec(a.cash), order_val) >= 0;
+            }
+        }
+    }
+    return __shfl(ok, tr, WAVE) != 0;
+}
+
+// Trader.place_order (agent/trader.py:49-106)
+__device__ void place_order(Lds& L, Mkt& m, int tr, int type, int side, int32_t size, int32_t price, int lane) {
+    if (side == S_NONE) return;
+    if (!order_approved(L, m, tr, side, size, type == T_MARKET ? -1 : price, lane)) {
+        if (lane == tr) L.acc[lane].num_rejected_step += 1;
+        return;
+    }
+    if ((type == T_MARKET || type == T_LIMIT) && lane == tr) L.acc[lane].order_step_placed = 1;
+    Book& bk = L.book;
+    int32_t rest_price = 0, rest_qty = 0;
+    if (type == T_MARKET) {
+        m.lob_time += 1; m.next_oid += 1;                     // orderbook.py:39-44
+        match(L, m, tr, side, size, -1, lane);
+    } else if (type == T_LIMIT) {
+        int idx = find_own_order(bk, side, m.n[side], tr, T_LIMIT, price, lane);
+        if (idx < 0) {
+            m.lob_time += 1; m.next_oid += 1;
+            int32_t left = match(L, m, tr, side, size, price, lane);
+            if (left > 0) {
+                if (book_insert(bk, side, m.n[side], price, left, tr, m.next_oid, m.lob_time, lane)) { rest_price = price; rest_qty = left; }
+                else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
+            }
+        } else modify_order(L, m, tr, side, idx, price, size, rest_price, rest_qty, lane);
+    } else if (type == T_MODIFY) {
+        int idx = find_own_order(bk, side, m.n[side], tr, T_MODIFY, price, lane);
+        if (idx >= 0) modify_order(L, m, tr, side, idx, price, size, rest_price, rest_qty, lane);
+    } else {                                                  // cancel: trader.py:237-252, orderbook.py:196-208
+        int idx = find_own_order(bk, side, m.n[side], tr, T_CANCEL, price, lane);
+        if (idx >= 0) {
+            int32_t op = bk.price[side][idx], oq = bk.qty[side][idx];
+            m.lob_time += 1;
+            book_remove(bk, side, m.n[side], idx, 1, lane);
+            uint32_t f = 0;
+            if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
+            if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
+        }
+    }
+    if (rest_qty > 0) {
+        uint32_t f = 0;
+        if (lane == tr) escrow_rest(L.acc[lane], rest_price, rest_qty, f);
+        if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
+    }
+}
+
+// Exchg_Helper.mark_to_mkt + Calculate.mark_to_mkt (exchg_helper.py:56-66, calculate.py:35-55)
+__device__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
+    if (!m.has_trade) return;
+    m.last_price = m.last_trade_price;
+    uint32_t f = 0;
+    if (lane < A) {
+        Acc& a = L.acc[lane];
+        D p = d_price(m.last_trade_price), vwap = ld_dec(a.vwap);
+        int32_t pos = a.net_position;
+        uint32_t ap = (uint32_t)(pos < 0 ? -pos : pos);
+        D diff = pos >= 0 ? d_sub(p, vwap) : d_sub(vwap, p);
+        D profit = d_mul_int(diff, ap);
+        D raw = d_mul_int(vwap, ap);
+        D posval = d_add(raw, profit);
+        D nav = d_add(d_add(ld_dec(a.cash), ld_dec(a.hold)), posval);
+        a.prev_nav = a.nav;
+        st_dec(a.posval, posval, f); st_dec(a.nav, nav, f);
+        if (d_cmp(nav, ld_dec(a.max_nav)) > 0) st_dec(a.max_nav, nav, f);
+    }
+    if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
+}
+
+// ======================================================================================
+// Observation (State_Helper.set_agg_LOB, exchg/state_helper.py:113-214)
+// ======================================================================================
+// top-K aggregation per side -> L.lvl_px / L.lvl_sz (integers; 0 = empty level)
+__device__ void aggregate_levels(Lds& L, const Mkt& m, int lane) {
+    if (lane < 2 * CDA_K_ROWS) { (&L.lvl_px[0][0])[lane] = 0; (&L.lvl_sz[0][0])[lane] = 0; }
+    CDA_WSYNC();
+    #pragma unroll
+    for (int s = 0; s < 2; s++) {
+        int carry = 0, n = m.n[s];
+        for (int base = 0; base < n && carry <= CDA_K_ROWS; base += WAVE) {
+            int i = base + lane;
+            bool valid = i < n;
+            int p = valid ? L.book.price[s][i] : 0;
+            int pp = (valid && i > 0) ? L.book.price[s][i - 1] : -1;
+            bool head = valid && (i == 0 || p != pp);
+            uint64_t mk = __ballot(head);
+            uint64_t le = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+            int lvl = carry + __popcll(mk & le) - 1;
+            if (valid && lvl < CDA_K_ROWS) {
+                atomicAdd(&L.lvl_sz[s][lvl], L.book.qty[s][i]);
+                if (head) L.lvl_px[s][lvl] = p;
+            }
+            carry += __popcll(mk);
+        }
+    }
+    CDA_WSYNC();
+}
+// raw f32[40] = agg_LOB_raw (state_helper.py:159-160); empty ask levels stay +0.0
+__device__ __forceinline__ float raw_value(const Lds& L, int j) {
+    int row = j / CDA_K_ROWS, k = j % CDA_K_ROWS;
+    int v = row == 0 ? L.lvl_px[0][k] : row == 1 ? L.lvl_sz[0][k] : row == 2 ? L.lvl_px[1][k] : L.lvl_sz[1][k];
+    float f = (float)v;
+    return (row >= 2 && v != 0) ? -f : f;
+}
+// one normalised snapshot value for lane j in [0,42)
+__device__ float snapshot_value(const Lds& L, const Mkt& m, int tick, int j) {
+    double l1_bid = (double)L.lvl_px[0][0], l1_ask = (double)L.lvl_px[1][0], M;
+    bool two = l1_bid > 0 && l1_ask > 0;
+    if (two) M = (l1_bid + l1_ask) / 2.0;
+    else if (l1_bid > 0) M = l1_bid;
+    else if (l1_ask > 0) M = l1_ask;
+    else { M = (double)m.last_price; if (M <= 0) M = 100.0; }
+    double out;
+    if (j < 40) {
+        int row = j / CDA_K_ROWS, k = j % CDA_K_ROWS;
+        if (row == 0) { double bp = (double)L.lvl_px[0][k]; out = bp > 0 ? (M - bp) / M : 0.0; }
+        else if (row == 1) { double sz = (double)L.lvl_sz[0][k]; out = sz > 0 ? sqrt(sz) : 0.0; }
+        else if (row == 2) { double ap = (double)L.lvl_px[1][k]; out = ap != 0 ? -((ap - M) / M) : 0.0; }
+        else { double sz = (double)L.lvl_sz[1][k]; out = sz != 0 ? -sqrt(sz) : 0.0; }
+    } else if (j == 40) out = log(M);
+    else {
+        if (two) { double st = (l1_ask - l1_bid) / (double)tick; out = glibc_log1p(st > 0.0 ? st : 0.0); }
+        else out = 0.0;
+    }
+    return (float)out;
+}
+
+}  // namespace cda

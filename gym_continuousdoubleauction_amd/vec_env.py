@@ -1,0 +1,186 @@
+"""CDAVecEnv - N independent continuous-double-auction markets stepped in lockstep on one MI355X.
+
+Host-side mirror of the reference env surface (continuousDoubleAuction_env.py:21-309) for a batch:
+`reset()` / `step()` over torch tensors that stay resident in HBM.  All compute happens in the HIP
+kernels behind the C-ABI (include/cda.h); PyTorch is only used for device memory and streams.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi as K
+from ._lib import CDAError, check, lib
+
+_TORCH_OF = {C.c_int32: torch.int32, C.c_double: torch.float64, C.c_uint8: torch.uint8}
+
+DEC_DTYPE = np.dtype([("w", np.uint32, (3,)), ("exp", np.int16), ("sign", np.uint8), ("pad", np.uint8)])
+
+ACTION_KEYS = ("category", "size_mean", "size_sigma", "price", "price_offset")
+
+
+class CDAVecEnv:
+    """Batched env.  Tensors: actions [N,A]; obs f32[N, n_hist*42]; reward f64[N,A];
+    terminated/truncated bool[N] (the reference's "__all__" flags); info = dict of SoA tensors."""
+
+    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True):
+        self.cfg_struct, self.config = K.make_config(config)
+        self.n_markets = int(n_markets)
+        self.num_agents = self.cfg_struct.num_agents
+        self.n_hist = self.cfg_struct.n_hist
+        self.obs_dim = self.n_hist * K.SNAPSHOT_DIM
+        self.max_step = self.cfg_struct.max_step
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise CDAError("CDAVecEnv needs a HIP device (torch device 'cuda:<i>'); there is no CPU fallback")
+        if not torch.cuda.is_available():
+            raise CDAError("no GPU visible to PyTorch-ROCm; the HIP path cannot run and there is no CPU fallback")
+        self.device_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.agents = [f"agent_{i}" for i in range(self.num_agents)]
+        h = C.c_void_p()
+        check(lib().cda_create(C.byref(self.cfg_struct), self.n_markets, self.device_index, C.byref(h)), "cda_create")
+        self._h = h
+        N, A, dev = self.n_markets, self.num_agents, self.device
+        self.obs = torch.zeros((N, self.obs_dim), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros((N, A), dtype=torch.float64, device=dev)
+        self._term = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.with_info = bool(with_info)
+        self.info = {}
+        self._info_ptrs = K.InfoPtrs()
+        if self.with_info:
+            for name, ct, per_agent, dims in K.INFO_FIELDS:
+                shape = ((N, A) if per_agent else (N,)) + tuple(dims)
+                if ct is K.Dec:
+                    t = torch.zeros(shape + (16,), dtype=torch.uint8, device=dev)
+                else:
+                    t = torch.zeros(shape, dtype=_TORCH_OF[ct], device=dev)
+                self.info[name] = t
+                setattr(self._info_ptrs, name, t.data_ptr())
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cda_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self, seed=None, mask=None):
+        """reset(seed=None): every selected market keeps its RNG stream (a never-seeded market is seeded
+        with its index).  seed=int s: market i is seeded SeedSequence(s + i).  seed=array/tensor of N
+        unsigned 64-bit seeds: per market.  mask: bool/uint8 [N] selecting the markets to reset."""
+        seeds_t = None
+        if seed is not None:
+            if isinstance(seed, (int, np.integer)):
+                arr = (np.uint64(int(seed)) + np.arange(self.n_markets, dtype=np.uint64)).astype(np.uint64)
+            elif isinstance(seed, torch.Tensor):
+                arr = seed.detach().cpu().numpy().astype(np.int64).view(np.uint64)
+            else:
+                arr = np.ascontiguousarray(seed, dtype=np.uint64)
+            if arr.shape != (self.n_markets,):
+                raise ValueError(f"need {self.n_markets} seeds, got shape {arr.shape}")
+            seeds_t = torch.from_numpy(arr.view(np.int64).copy()).to(self.device)
+        mask_t = None
+        if mask is not None:
+            mask_t = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask_t.shape != (self.n_markets,):
+                raise ValueError("mask must have shape [n_markets]")
+        with torch.cuda.device(self.device):
+            check(lib().cda_reset(self._h, seeds_t.data_ptr() if seeds_t is not None else None,
+                                  mask_t.data_ptr() if mask_t is not None else None,
+                                  self.obs.data_ptr(), self._stream()), "cda_reset")
+        self._keep = (seeds_t, mask_t)
+        return self.obs
+
+    def _prep(self, x, dtype):
+        t = torch.as_tensor(x)
+        if t.device != self.device or t.dtype != dtype:
+            t = t.to(device=self.device, dtype=dtype)
+        t = t.reshape(self.n_markets, self.num_agents)
+        return t.contiguous()
+
+    def step(self, category, size_mean=None, size_sigma=None, price=None, price_offset=None, present=None):
+        """One env step for all markets.  `category` may also be a dict holding the five action tensors."""
+        if isinstance(category, dict):
+            d = category
+            present = d.get("present", present)
+            category, size_mean, size_sigma, price, price_offset = (d[k] for k in ACTION_KEYS)
+        cat = self._prep(category, torch.int32)
+        sm = self._prep(size_mean, torch.float32)
+        ss = self._prep(size_sigma, torch.float32)
+        pr = self._prep(price, torch.int32)
+        po = self._prep(price_offset, torch.int32)
+        ps = None if present is None else self._prep(present, torch.uint8)
+        with torch.cuda.device(self.device):
+            check(lib().cda_step(self._h, cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
+                                 ps.data_ptr() if ps is not None else None,
+                                 self.obs.data_ptr(), self.reward.data_ptr(), self._term.data_ptr(), self._trunc.data_ptr(),
+                                 C.byref(self._info_ptrs) if self.with_info else None, self._stream()), "cda_step")
+        self._keep = (cat, sm, ss, pr, po, ps)      # keep inputs alive until the async kernel has consumed them
+        return self.obs, self.reward, self._term.bool(), self._trunc.bool(), self.info
+
+    # ------------------------------------------------------------------ diagnostics
+    def place_order(self, market, trader, type_, side, size, price=1):
+        check(lib().cda_place_order(self._h, market, trader, type_, side, size, price), "cda_place_order")
+
+    def mark_to_mkt(self, market=0):
+        check(lib().cda_mark_to_mkt(self._h, market), "cda_mark_to_mkt")
+
+    def get_state(self, market=0):
+        s = K.MarketState()
+        torch.cuda.synchronize(self.device)
+        check(lib().cda_get_state(self._h, market, C.byref(s)), "cda_get_state")
+        return s
+
+    def set_state(self, market, state):
+        torch.cuda.synchronize(self.device)
+        check(lib().cda_set_state(self._h, market, C.byref(state)), "cda_set_state")
+
+    def raw_snapshot(self):
+        raw = torch.zeros((self.n_markets, K.RAW_DIM), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().cda_get_raw_snapshot(self._h, raw.data_ptr(), self._stream()), "cda_get_raw_snapshot")
+        return raw
+
+    def flags(self):
+        f = torch.zeros(self.n_markets, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().cda_last_flags(self._h, f.data_ptr(), self._stream()), "cda_last_flags")
+        return f
+
+    def state_bytes_per_market(self):
+        return int(lib().cda_state_bytes_per_market(self._h))
+
+    def nav_decimals(self):
+        """info['nav'] as exact decimal.Decimal objects, [N][A] nested lists (host copy)."""
+        raw = self.info["nav"].cpu().numpy().view(DEC_DTYPE).reshape(self.n_markets, self.num_agents)
+        return [[K.dec_to_decimal(raw[i, a]) for a in range(self.num_agents)] for i in range(self.n_markets)]
+
+
+def selftest_dec(op, a, b=None, device=0):
+    """Device self-test of the ledger arithmetic: numpy DEC_DTYPE arrays in/out."""
+    a = np.ascontiguousarray(a)
+    out = np.zeros(len(a), DEC_DTYPE)
+    bp = None if b is None else np.ascontiguousarray(b).ctypes.data
+    check(lib().cda_selftest_dec(device, op, len(a), a.ctypes.data, bp, out.ctypes.data), "cda_selftest_dec")
+    return out
+
+
+def selftest_rng(seed, lo, hi, n_steps, n_normals, perm_n, device=0):
+    first = np.zeros(2, np.int32)
+    normals = np.zeros((n_steps, n_normals), np.float64)
+    perms = np.zeros((n_steps, max(perm_n, 1)), np.int32)
+    fs = np.zeros(8, np.uint64)
+    perm_arg = perms[:, :perm_n].copy() if perm_n else perms
+    check(lib().cda_selftest_rng(device, seed, lo, hi, n_steps, n_normals, perm_n, first.ctypes.data,
+                                 normals.ctypes.data, perm_arg.ctypes.data, fs.ctypes.data), "cda_selftest_rng")
+    return int(first[0]), normals, perm_arg[:, :perm_n], fs

@@ -73,8 +73,11 @@ static int big_bits(const big* a) {
     return 0;
 }
 static int big_bit(const big* a, int i) { return (a->w[i >> 5] >> (i & 31)) & 1; }
+static int big_fits_u64(const big* a);
+static void big_divmod_u64(const big* a, uint64_t d, big* q, big* r);
 /* schoolbook bit-serial division: q = a / b, r = a % b (b != 0) */
 static void big_divmod(const big* a, const big* b, big* q, big* r) {
+    if (big_fits_u64(b)) { big_divmod_u64(a, (uint64_t)b->w[0] | ((uint64_t)b->w[1] << 32), q, r); return; }
     big quo, rem; memset(&quo, 0, sizeof quo); memset(&rem, 0, sizeof rem);
     for (int i = big_bits(a) - 1; i >= 0; i--) {
         for (int k = BL - 1; k > 0; k--) rem.w[k] = (rem.w[k] << 1) | (rem.w[k - 1] >> 31);
@@ -82,6 +85,19 @@ static void big_divmod(const big* a, const big* b, big* q, big* r) {
         if (big_cmp(&rem, b) >= 0) { rem = big_sub(&rem, b); quo.w[i >> 5] |= 1u << (i & 31); }
     }
     *q = quo; *r = rem;
+}
+/* a /= d (32-bit divisor), returns the remainder */
+static uint32_t big_div_u32(big* a, uint32_t d) {
+    uint64_t rem = 0;
+    for (int i = BL - 1; i >= 0; i--) { uint64_t cur = (rem << 32) | a->w[i]; a->w[i] = (uint32_t)(cur / d); rem = cur % d; }
+    return (uint32_t)rem;
+}
+static int big_fits_u64(const big* a) { for (int i = 2; i < BL; i++) if (a->w[i]) return 0; return 1; }
+/* q = a / d, r = a % d for a divisor below 2^64 (limb-wise with a 128-bit intermediate) */
+static void big_divmod_u64(const big* a, uint64_t d, big* q, big* r) {
+    u128 rem = 0; big quo;
+    for (int i = BL - 1; i >= 0; i--) { u128 cur = (rem << 32) | a->w[i]; quo.w[i] = (uint32_t)(cur / d); rem = cur % d; }
+    *q = quo; *r = big_from_u64((uint64_t)rem);
 }
 static uint32_t big_mod_u32(const big* a, uint32_t d) {
     uint64_t rem = 0;
@@ -100,9 +116,10 @@ static void oracle_init(void) {
     g_init_done = 1;
 }
 static int big_ndigits(const big* a) { /* len(str(a)); 1 for zero */
-    int n = 1;
-    while (n < NPOW && big_cmp(a, &g_pow10[n]) >= 0) n++;
-    return n;
+    int b = big_bits(a);
+    if (b == 0) return 1;
+    int t = (b * 1233) >> 12;                 /* floor(b*log10(2)) for b <= 256 */
+    return t + (big_cmp(a, &g_pow10[t]) >= 0 ? 1 : 0);
 }
 
 /* ======================================================================================
@@ -125,11 +142,11 @@ static dec dec_fix(dec d) {
     int nd = big_ndigits(&d.c);
     if (nd <= PREC) return d;
     int drop = nd - PREC;
-    big q, r; big_divmod(&d.c, &g_pow10[drop], &q, &r);
-    big half = g_pow10[drop]; /* 10^drop / 2 = 5 * 10^(drop-1) */
-    big five = big_from_u64(5); half = big_mul(&g_pow10[drop - 1], &five);
-    int c = big_cmp(&r, &half);
-    if (c > 0 || (c == 0 && (q.w[0] & 1))) {
+    big q = d.c; int sticky = 0, k = drop - 1;
+    while (k >= 9) { sticky |= big_div_u32(&q, 1000000000u) != 0; k -= 9; }
+    if (k > 0) { static const uint32_t p10[9] = {1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u, 100000000u}; sticky |= big_div_u32(&q, p10[k]) != 0; }
+    uint32_t dg = big_div_u32(&q, 10u);
+    if (dg > 5 || (dg == 5 && (sticky || (q.w[0] & 1)))) {
         big one = big_from_u64(1); q = big_add(&q, &one);
         if (big_cmp(&q, &g_pow10[PREC]) == 0) { q = g_pow10[PREC - 1]; drop += 1; }
     }
@@ -189,7 +206,7 @@ static dec dec_div(dec a, dec b) {
         if (big_mod_u32(&q, 5) == 0) { big one = big_from_u64(1); q = big_add(&q, &one); }
     } else {
         int32_t ideal = a.exp - b.exp;
-        while (exp < ideal && big_mod_u32(&q, 10) == 0) { big t, rr; big_divmod(&q, &g_pow10[1], &t, &rr); q = t; exp++; }
+        while (exp < ideal && big_mod_u32(&q, 10) == 0) { big_div_u32(&q, 10u); exp++; }
     }
     r.c = q; r.exp = exp;
     return dec_fix(r);
@@ -213,7 +230,11 @@ static int dec_sign_cmp0(dec a) { if (big_is_zero(&a.c)) return 0; return a.sign
 static void big_to_digits(const big* a, char* out /* >= 80 */) {
     char tmp[80]; int n = 0; big v = *a;
     if (big_is_zero(&v)) { out[0] = '0'; out[1] = 0; return; }
-    while (!big_is_zero(&v)) { big q, r; big_divmod(&v, &g_pow10[1], &q, &r); tmp[n++] = (char)('0' + r.w[0]); v = q; }
+    while (!big_is_zero(&v)) {
+        uint32_t r = big_div_u32(&v, 1000000000u);
+        int last = big_is_zero(&v);
+        for (int j = 0; j < 9 && (!last || r); j++) { tmp[n++] = (char)('0' + r % 10); r /= 10; }
+    }
     for (int i = 0; i < n; i++) out[i] = tmp[n - 1 - i];
     out[n] = 0;
 }

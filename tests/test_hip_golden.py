@@ -1,0 +1,23 @@
+"""GPU parity, anchored on the reference: the HIP path (through the C-ABI) replays the golden traces
+cut from the real reference and must reproduce every recorded field bit for bit."""
+import json
+
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+GROUPS = G.group_by_config(G.trace_names())
+
+
+@pytest.mark.parametrize("key", sorted(GROUPS), ids=lambda k: "+".join(r["name"] for r in GROUPS[k])[:60])
+def test_hip_matches_reference_goldens(key):
+    from hip_env import HipEnv
+    recs = GROUPS[key]
+    env = HipEnv(json.loads(key), n_markets=len(recs))
+    # full state dump every 8th step (each dump is a synchronous D2H copy), outputs every step
+    steps = G.run_group(env, recs, state_every=8)
+    assert steps > 0
+    assert (env.flags() == 0).all()
+    env.close()

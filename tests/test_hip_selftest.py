@@ -1,0 +1,120 @@
+"""GPU: device ledger arithmetic vs CPython `decimal`, device RNG vs numpy (both live third-party
+implementations of the arithmetic the reference delegates to - SURVEY §8c)."""
+import random
+import struct
+from decimal import Decimal as D
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gym_continuousdoubleauction_amd import _capi as K
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd_dec(rng, maxdig=28, emin=-30, emax=0, allow_zero=True):
+    nd = rng.randint(1, maxdig)
+    if allow_zero and rng.random() < 0.05:
+        c = 0
+    else:
+        c = rng.randint(10 ** (nd - 1) if nd > 1 else 1, 10 ** nd - 1)
+    r = rng.random()
+    if r < 0.2:
+        keep = max(1, nd // 2)
+        c = int(str(c)[:keep] + "0" * (nd - keep))
+    elif r < 0.3:
+        c = int("9" * nd)
+    elif r < 0.4 and nd > 2:
+        c = int("1" + "0" * (nd - 2) + "5")
+    return D((rng.randint(0, 1), tuple(map(int, str(c))), rng.randint(emin, emax)))
+
+
+def make_pairs(rng, n, op):
+    A = [rnd_dec(rng) for _ in range(n)]
+    B = []
+    for a in A:
+        if op in (2, 3):
+            c = rng.randint(1, 2 ** 32 - 1) if rng.random() < 0.5 else rng.randint(1, 5000)
+            e = -1 if (op == 2 and rng.random() < 0.5) else 0
+            B.append(D((0, tuple(map(int, str(c))), e)))
+            continue
+        r = rng.random()
+        if r < 0.3:
+            B.append(rnd_dec(rng))
+        elif r < 0.6:
+            e = a.as_tuple().exponent
+            B.append(rnd_dec(rng, emin=e - 3, emax=min(0, e + 3)))
+        elif r < 0.7:
+            B.append(-a if op == 0 else a)
+        else:
+            B.append(a + D((rng.randint(0, 1), (rng.randint(1, 9),), a.adjusted() - rng.randint(20, 40))))
+    return A, B
+
+
+@pytest.mark.parametrize("op,name", [(0, "add"), (1, "sub"), (2, "mul"), (3, "div"), (4, "cmp"), (5, "float")])
+def test_device_decimal_matches_cpython(op, name):
+    from gym_continuousdoubleauction_amd.vec_env import selftest_dec
+    rng = random.Random(100 + op)
+    n = 20000
+    A, B = make_pairs(rng, n, op)
+    if op == 5:   # the domain of the device conversion: exponent in [-54, 0]
+        A = [a for a in A if -54 <= a.as_tuple().exponent <= 0]
+        B = B[: len(A)]
+    a, b = O.dec_array(A), O.dec_array(B)
+    out = selftest_dec(op, a, b)
+    ref = O.dec_op(op, a, b)            # the CPU oracle must agree as well
+    bad = []
+    for i in range(len(A)):
+        if op == 0:
+            exp = A[i] + B[i]
+        elif op == 1:
+            exp = A[i] - B[i]
+        elif op == 2:
+            exp = A[i] * B[i]
+        elif op == 3:
+            exp = A[i] / B[i]
+        elif op == 4:
+            c = (A[i] > B[i]) - (A[i] < B[i])
+            if int(out[i]["w"][0]) - 1 != c:
+                bad.append((A[i], B[i], c, int(out[i]["w"][0]) - 1))
+            continue
+        else:
+            bits = struct.unpack("<Q", struct.pack("<d", float(A[i])))[0]
+            got = int(out[i]["w"][0]) | (int(out[i]["w"][1]) << 32)
+            if got != bits or int(out[i]["w"][2]) != 0:
+                bad.append((A[i], hex(bits), hex(got)))
+            continue
+        got = K.dec_to_decimal(out[i])
+        if got.as_tuple() != exp.as_tuple():
+            bad.append((A[i], B[i], exp, got))
+    assert not bad, bad[:5]
+    if op < 4:
+        assert np.array_equal(out.view(np.uint8), ref.view(np.uint8))
+
+
+def test_device_rng_matches_numpy():
+    from gym_continuousdoubleauction_amd.vec_env import selftest_rng
+    for seed in [0, 1, 2, 3, 123, 977, 2 ** 32 + 5, 2 ** 63 + 12345, 2 ** 64 - 1]:
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        first, normals, perms, fs = selftest_rng(seed, 10, 100, 400, 8, 8)
+        assert first == int(g.integers(10, 101))
+        for s in range(400):
+            z = np.array([g.standard_normal() for _ in range(8)])
+            p = g.permutation(8)
+            assert np.array_equal(z.view(np.uint64), normals[s].view(np.uint64)), (seed, s)
+            assert np.array_equal(p, perms[s]), (seed, s)
+        st = g.bit_generator.state
+        assert (int(fs[0]) << 64 | int(fs[1])) == st["state"]["state"]
+        assert (int(fs[2]) << 64 | int(fs[3])) == st["state"]["inc"]
+        assert int(fs[4]) == st["has_uint32"]
+
+
+def test_device_normal_slow_paths_match_numpy():
+    """Long stream: exercises the ziggurat wedge and tail branches (log1p / exp on the device)."""
+    from gym_continuousdoubleauction_amd.vec_env import selftest_rng
+    g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(4242)))
+    first, normals, perms, fs = selftest_rng(4242, 0, 0, 1, 200000, 0)
+    g.integers(0, 1)
+    z = g.standard_normal(200000)
+    assert np.array_equal(z.view(np.uint64), normals[0].view(np.uint64))
