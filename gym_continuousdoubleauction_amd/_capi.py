@@ -1,7 +1,6 @@
 """ctypes mirror of include/cda.h (struct layouts and constants).
 
-Kept free of any library loading so that both the product binding (`_lib.py`) and the test-only
-oracle loader (`tests/oracle_lib.py`) can share the struct definitions.
+Kept free of any library loading: pure struct definitions and value conversions, importable anywhere.
 """
 import ctypes as C
 

@@ -126,7 +126,7 @@ class CDAVecEnv:
                                  self.obs.data_ptr(), self.reward.data_ptr(), self._term.data_ptr(), self._trunc.data_ptr(),
                                  C.byref(self._info_ptrs) if self.with_info else None, self._stream()), "cda_step")
         self._keep = (cat, sm, ss, pr, po, ps)      # keep inputs alive until the async kernel has consumed them
-        return self.obs, self.reward, self._term.bool(), self._trunc.bool(), self.info
+        return self.obs, self.reward, self._term.view(torch.bool), self._trunc.view(torch.bool), self.info
 
     # ------------------------------------------------------------------ diagnostics
     def place_order(self, market, trader, type_, side, size, price=1):

@@ -857,6 +857,23 @@ int oracle_step(oracle_env* e,
                              obs_out, reward_out, terminated_out, truncated_out, info_out, trace);
 }
 
+/* cpu_baseline helper: n_steps steps of markets [first, first+count) cycling through T pre-generated
+ * action steps laid out [T,N,A]; one call per worker thread (no per-step FFI overhead). */
+int oracle_run_range(oracle_env* e, int32_t first, int32_t count, int32_t n_steps, int32_t T,
+                     const int32_t* category, const float* size_mean, const float* size_sigma,
+                     const int32_t* price, const int32_t* price_offset,
+                     float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out) {
+    if (!e || T < 1) return CDA_ERR_INVALID;
+    size_t per = (size_t)e->n * (size_t)e->cfg.num_agents;
+    for (int s = 0; s < n_steps; s++) {
+        size_t o = per * (size_t)(s % T);
+        int rc = oracle_step_range(e, first, count, category + o, size_mean + o, size_sigma + o, price + o, price_offset + o, NULL,
+                                   obs_out, reward_out, terminated_out, truncated_out, NULL, NULL);
+        if (rc) return rc;
+    }
+    return CDA_OK;
+}
+
 int oracle_place_order(oracle_env* e, int32_t market, int32_t trader, int32_t type, int32_t side, int32_t size, int32_t price) {
     if (!e || market < 0 || market >= e->n || trader < 0 || trader >= e->cfg.num_agents) return CDA_ERR_INVALID;
     if (type < 0 || type > 3 || side < 0 || side > 1 || size < 1) return CDA_ERR_INVALID;

@@ -38,6 +38,10 @@ int oracle_step_range(oracle_env* env, int32_t first, int32_t count,
                       const int32_t* price, const int32_t* price_offset, const uint8_t* present,
                       float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
                       const cda_info_ptrs* info_out, oracle_trace* trace);
+int oracle_run_range(oracle_env* env, int32_t first, int32_t count, int32_t n_steps, int32_t T,
+                     const int32_t* category, const float* size_mean, const float* size_sigma,
+                     const int32_t* price, const int32_t* price_offset,
+                     float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out);
 int oracle_place_order(oracle_env* env, int32_t market, int32_t trader, int32_t type, int32_t side,
                        int32_t size, int32_t price);
 int oracle_mark_to_mkt(oracle_env* env, int32_t market);

@@ -39,6 +39,7 @@ def lib():
         _lib.oracle_reset.argtypes = [vp, vp, vp, vp]
         _lib.oracle_step.argtypes = [vp] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), vp]
         _lib.oracle_step_range.argtypes = [vp, C.c_int32, C.c_int32] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), vp]
+        _lib.oracle_run_range.argtypes = [vp] + [C.c_int32] * 4 + [vp] * 9
         _lib.oracle_place_order.argtypes = [vp] + [C.c_int32] * 6
         _lib.oracle_mark_to_mkt.argtypes = [vp, C.c_int32]
         _lib.oracle_get_state.argtypes = [vp, C.c_int32, C.POINTER(K.MarketState)]

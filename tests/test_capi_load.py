@@ -1,0 +1,90 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cda.h declares; the ctypes struct
+mirror has the C layout; without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "cda.h")
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cda_[a-z_0-9]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build_hip()
+    from gym_continuousdoubleauction_amd import _lib
+    return _lib.lib(), _lib
+
+
+def test_every_declared_symbol_is_exported(hip_lib):
+    L, _lib = hip_lib
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/cda.h but not exported by libcda_hip.so"
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_ctypes_layout_matches_c(tmp_path):
+    from gym_continuousdoubleauction_amd import _capi as K
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+                   'sizeof(cda_config),sizeof(cda_dec),sizeof(cda_info_ptrs),sizeof(cda_order),sizeof(cda_account_state),'
+                   'sizeof(cda_market_state),offsetof(cda_market_state,acc),offsetof(cda_market_state,hist));return 0;}\n' % HEADER)
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(K.Config), C.sizeof(K.Dec), C.sizeof(K.InfoPtrs), C.sizeof(K.Order), C.sizeof(K.AccountState),
+            C.sizeof(K.MarketState), K.MarketState.acc.offset, K.MarketState.hist.offset]
+    assert got == want
+
+
+def test_default_config_matches_reference_defaults(hip_lib):
+    L, _ = hip_lib
+    from gym_continuousdoubleauction_amd import _capi as K
+    c = K.Config()
+    assert L.cda_default_config(C.byref(c)) == 0
+    d = K.ENV_DEFAULTS     # config/env_defaults.json:8-27 of the reference
+    assert (c.num_agents, c.max_step, c.n_hist, c.tick_size, c.init_cash) == (d["num_of_agents"], d["max_step"], d["n_hist"], 1, d["init_cash"])
+    assert (c.initial_price_min, c.initial_price_max, c.min_size, c.mkt_max_size, c.limit_size_multiple) == (10, 100, 1, 100, 10)
+    assert (c.order_penalty, c.trade_penalty, c.drawdown_penalty, c.passive_bonus, c.loss_multiplier) == (0.1, 0.05, 0.2, 0.1, 1.5)
+    assert L.cda_strerror(-2).decode().startswith("no HIP device")
+
+
+def test_no_gpu_means_loud_failure_not_fallback(hip_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L, _lib = hip_lib
+    from gym_continuousdoubleauction_amd import _capi as K
+    cfg, _ = K.make_config({"num_of_agents": 4})
+    h = C.c_void_p()
+    rc = L.cda_create(C.byref(cfg), 8, 0, C.byref(h))
+    assert rc == K.ERR_NO_DEVICE and not h.value
+    from gym_continuousdoubleauction_amd import CDAVecEnv, CDAEnv
+    with pytest.raises(_lib.CDAError):
+        CDAVecEnv({"num_of_agents": 4}, n_markets=8)
+    with pytest.raises(_lib.CDAError):
+        CDAEnv({"num_of_agents": 4})
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may import, load or mention it."""
+    pkg = os.path.join(ROOT, "gym_continuousdoubleauction_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in txt and "libcda_oracle" not in txt and "cda_oracle" not in txt, f

@@ -1,0 +1,67 @@
+"""CPU: host-side logic of the product (config mapping, Decimal triples, spaces, sharding helpers)."""
+from decimal import Decimal
+
+import numpy as np
+import pytest
+import torch
+
+from gym_continuousdoubleauction_amd import _capi as K
+from gym_continuousdoubleauction_amd import parallel as P
+from gym_continuousdoubleauction_amd import spaces as S
+
+
+def test_make_config_defaults_and_overrides():
+    c, cfg = K.make_config(None)
+    assert c.num_agents == 5 and c.max_step == 64 and c.init_cash == 1000000 and cfg["is_render"] is True
+    c, _ = K.make_config({"num_of_agents": 8, "init_cash": 5000.0, "max_step": 4096, "loss_multiplier": 2.0})
+    assert (c.num_agents, c.init_cash, c.max_step, c.loss_multiplier) == (8, 5000, 4096, 2.0)
+    with pytest.raises(KeyError):
+        K.make_config({"num_agents": 4})            # the env-side spelling is num_of_agents
+    with pytest.raises(ValueError):
+        K.make_config({"tick_size": 0.5})
+    with pytest.raises(ValueError):
+        K.make_config({"init_cash": 10.5})
+
+
+@pytest.mark.parametrize("text", ["1000000", "999525.0", "978412.0000000000000000000002", "-12.50", "0E-27", "0.0",
+                                  "1E+3", "0.000001234", "-0"])
+def test_decimal_triple_roundtrip_and_str(text):
+    d = Decimal(text)
+    s = K.decimal_to_dec(d)
+    back = K.dec_to_decimal(s)
+    assert back.as_tuple() == d.as_tuple()
+    assert K.dec_to_str(s) == str(d)
+
+
+def test_spaces_match_the_reference_contract():
+    obs = S.observation_space(4)
+    assert obs.shape == (168,) and np.dtype(obs.dtype) == np.float32
+    act = S.action_space()
+    assert set(act.spaces.keys()) == {"category", "size_mean", "size_sigma", "price", "price_offset"}
+    assert act["category"].n == 9 and act["price"].n == 10 and act["price_offset"].n == 3
+    assert act["size_mean"].shape == (1,) and float(act["size_mean"].low[0]) == -1.0 and float(act["size_sigma"].low[0]) == 0.0
+    act.seed(3)
+    s = act.sample()
+    assert act.contains(s) and s["size_mean"].dtype == np.float32
+
+
+def test_shard_range_and_seeds():
+    assert P.shard_range(0, 8, 16384) == (0, 2048) and P.shard_range(7, 8, 16384) == (14336, 2048)
+    with pytest.raises(ValueError):
+        P.shard_range(0, 3, 10)
+    s = P.global_seeds(1000, 2048, 4)
+    assert s.tolist() == [3048, 3049, 3050, 3051]
+
+
+def test_pack_unpack_is_bit_preserving():
+    g = torch.Generator().manual_seed(0)
+    obs = torch.randn((5, 168), generator=g)
+    rew = torch.randn((5, 4), generator=g, dtype=torch.float64) * 1e-9
+    term = torch.tensor([0, 1, 0, 0, 1], dtype=torch.bool)
+    trunc = torch.tensor([1, 0, 0, 1, 0], dtype=torch.bool)
+    p = P.pack_outputs(obs, rew, term, trunc)
+    assert p.shape == (5, 168 + 8 + 2)
+    o2, r2, t2, u2 = P.unpack_outputs(p, 168, 4)
+    assert torch.equal(o2.view(torch.int32), obs.view(torch.int32))
+    assert torch.equal(r2.view(torch.int64), rew.view(torch.int64))
+    assert torch.equal(t2, term) and torch.equal(u2, trunc)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): kernel-trace stats + PMC passes for the step kernel.
+# Usage: tools/profile_gpu.sh <tag>   -> writes gpurun_out/prof_<tag>/...
+# PMC passes are separate runs with --kernel-trace only (gpurun refuses --pmc combined with sys traces).
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $R/bench.py --steps 200 --warmup 16 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $BENCH > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -o p -- $BENCH > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INSTS_FLAT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o p -- $BENCH > /dev/null 2> $OUT/pmc_sq2.err
+cd $R
+python tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
