@@ -162,7 +162,12 @@ __device__ __forceinline__ int d_sgn(const D& a) { return d_is_zero(a) ? 0 : (a.
 
 // Decimal._fix (_pydecimal.py:1661): round a wide coefficient to 28 digits, half-even
 __device__ __noinline__ D d_fix(int sign, W x, int exp) {
-    if (w_is_zero(x)) return d_make(0, 0, 0, exp, sign);
+    // common case first: fewer than 29 digits <=> x < 10^28 (three-limb constant, no table access)
+    if ((x.w[3] | x.w[4] | x.w[5] | x.w[6] | x.w[7]) == 0) {
+        const uint32_t P28_0 = 0x10000000u, P28_1 = 0x3e250261u, P28_2 = 0x204fce5eu;   // 10^28
+        bool lt = x.w[2] < P28_2 || (x.w[2] == P28_2 && (x.w[1] < P28_1 || (x.w[1] == P28_1 && x.w[0] < P28_0)));
+        if (lt) return d_make(x.w[0], x.w[1], x.w[2], exp, sign);
+    }
     int nd = w_ndigits(x);
     if (nd > 28) {
         int drop = nd - 28;
@@ -200,10 +205,16 @@ __device__ __noinline__ D d_add(D a, D b) {
     W xt = d_wide(dt), xo = d_wide(dO);
     int et = dt.exp, eo = dO.exp;
     if (et != eo) {
-        int tmp_len = w_ndigits(xt), oth_len = w_ndigits(xo);
-        int m = tmp_len - 30; if (m > -1) m = -1;
-        int e = et + m;
-        if (oth_len + eo - 1 < e) { xo = w_from3(1, 0, 0); eo = e; }
+        // _normalize replaces `other` by 10^e only when other.adjusted() < e = et + min(-1, tmp_len - 30).
+        // e <= et - 1 and other.adjusted() >= eo + floor((bits-1)*log10 2): decide from bit lengths when
+        // that is conclusive (it is for every gap the ledger produces), count digits only otherwise.
+        int lb_adj = eo + (((w_bits(xo) - 1) * 1233) >> 12);
+        if (lb_adj < et - 1) {
+            int tmp_len = w_ndigits(xt), oth_len = w_ndigits(xo);
+            int m = tmp_len - 30; if (m > -1) m = -1;
+            int e = et + m;
+            if (oth_len + eo - 1 < e) { xo = w_from3(1, 0, 0); eo = e; }
+        }
         w_mul_pow10(xt, et - eo);
     }
     W r; int rs;
@@ -253,10 +264,13 @@ __device__ __noinline__ int d_cmp(D a, D b) {
     if (bz) return a.sign ? -1 : 1;
     if (a.sign != b.sign) return a.sign ? -1 : 1;
     int s = a.sign ? -1 : 1;
+    // both non-zero, same sign.  A coefficient is < 10^28, so an exponent gap >= 28 decides on its own;
+    // otherwise scale the larger-exponent operand (<= 10^27 * 2^94 fits 256 bits) and compare exactly.
+    int diff = a.exp - b.exp;
+    if (diff >= 28) return s;
+    if (diff <= -28) return -s;
     W xa = d_wide(a), xb = d_wide(b);
-    int aa = w_ndigits(xa) + a.exp, ba = w_ndigits(xb) + b.exp;
-    if (aa != ba) return aa > ba ? s : -s;
-    if (a.exp > b.exp) w_mul_pow10(xa, a.exp - b.exp); else if (b.exp > a.exp) w_mul_pow10(xb, b.exp - a.exp);
+    if (diff > 0) w_mul_pow10(xa, diff); else if (diff < 0) w_mul_pow10(xb, -diff);
     int c = w_cmp(xa, xb);
     return c == 0 ? 0 : (c > 0 ? s : -s);
 }
@@ -273,6 +287,13 @@ __device__ __noinline__ double d_to_double(D a, uint32_t* domain_err) {
         r = (double)(uint64_t)(c >> 64) * 18446744073709551616.0 + (double)(uint64_t)c;
         r = r * pow(10.0, (double)a.exp);
         return a.sign ? -r : r;
+    }
+    if ((c >> 53) != 0 && k > 0) {
+        // 999525.0000000000000000000000 -> 9995250 * 10^-1: strip factors of 10 (exact), 9 digits at a time
+        W x = w_from3(a.w0, a.w1, a.w2);
+        while (k >= 9) { W t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; k -= 9; }
+        while (k > 0) { W t = x; if (w_divc<10u>(t) != 0) break; x = t; k -= 1; }
+        c = ((u128)x.w[2] << 64) | ((u128)x.w[1] << 32) | x.w[0];
     }
     if ((c >> 53) == 0 && k <= 22) {
         r = (double)(uint64_t)c / POW10_F64[k];          // both exact -> one correctly rounded division

@@ -53,13 +53,17 @@ __device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params&
 // ------------------------------------------------------------------------------------------
 // reset
 // ------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char cda_smem[];
+__device__ __forceinline__ Lds& wave_lds(const Params& P, int wave) {
+    return *reinterpret_cast<Lds*>(cda_smem + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents));
+}
+
 __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out) {
-    __shared__ Lds lds[CDA_WPB];
     int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     if (mi >= P.n_markets) return;
     if (mask && !mask[mi]) return;
-    Lds& L = lds[wave];
+    Lds& L = wave_lds(P, wave);
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     load_header(mp.hdr, m, lane);
@@ -104,12 +108,11 @@ struct StepArgs {
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(64 * CDA_WPB) void k_step(uint8_t* arena, Params P, StepArgs S) {
-    __shared__ Lds lds[CDA_WPB];
+__global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params P, StepArgs S) {
     int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     if (mi >= P.n_markets) return;
-    Lds& L = lds[wave];
+    Lds& L = wave_lds(P, wave);
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(64 * CDA_WPB) void k_step(uint8_t* arena, Params P,
 // test hooks and small kernels
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, int mi, int tr, int type, int side, int size, int price) {
-    __shared__ Lds lds1;
+    Lds& lds1 = wave_lds(P, 0);
     int lane = lane_id();
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, in
     store_market(mp, P, lds1, m, lane);
 }
 __global__ __launch_bounds__(64) void k_mark_to_mkt(uint8_t* arena, Params P, int mi) {
-    __shared__ Lds lds1;
+    Lds& lds1 = wave_lds(P, 0);
     int lane = lane_id();
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
@@ -279,11 +282,10 @@ __global__ __launch_bounds__(64) void k_mark_to_mkt(uint8_t* arena, Params P, in
     store_market(mp, P, lds1, m, lane);
 }
 __global__ __launch_bounds__(64 * CDA_WPB) void k_raw_snapshot(uint8_t* arena, Params P, float* raw_out) {
-    __shared__ Lds lds[CDA_WPB];
     int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     if (mi >= P.n_markets) return;
-    Lds& L = lds[wave];
+    Lds& L = wave_lds(P, wave);
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     load_header(mp.hdr, m, lane);
@@ -389,6 +391,7 @@ static int cfg_ok(const cda_config* c) {
 }
 
 static dim3 grid_for(int n) { return dim3((unsigned)((n + CDA_WPB - 1) / CDA_WPB)); }
+static size_t smem_for(const Params& P, int waves) { return (size_t)waves * (size_t)lds_bytes_per_wave(P.cfg.num_agents); }
 
 int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env** out) {
     if (!cfg || !out || n_markets < 1) return CDA_ERR_INVALID;
@@ -430,7 +433,7 @@ int cda_destroy(cda_env* e) {
 int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs_out, void* stream) {
     if (!e) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_reset, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), 0, (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out);
+    hipLaunchKernelGGL(k_reset, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -446,7 +449,7 @@ int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const 
     S.category = category; S.size_mean = size_mean; S.size_sigma = size_sigma; S.price = price; S.price_offset = price_offset;
     S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
     if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
-    hipLaunchKernelGGL(k_step, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), 0, (hipStream_t)stream, e->arena, e->P, S);
+    hipLaunchKernelGGL(k_step, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, S);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -456,7 +459,7 @@ int cda_place_order(cda_env* e, int32_t market, int32_t trader, int32_t type, in
     if (type < 0 || type > 3 || side < 0 || side > 1 || size < 1) return CDA_ERR_INVALID;
     if (type != 0 && price < 1) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_place_order, dim3(1), dim3(64), 0, 0, e->arena, e->P, market, trader, type, side, size, price);
+    hipLaunchKernelGGL(k_place_order, dim3(1), dim3(64), smem_for(e->P, 1), 0, e->arena, e->P, market, trader, type, side, size, price);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return CDA_OK;
@@ -464,7 +467,7 @@ int cda_place_order(cda_env* e, int32_t market, int32_t trader, int32_t type, in
 int cda_mark_to_mkt(cda_env* e, int32_t market) {
     if (!e || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_mark_to_mkt, dim3(1), dim3(64), 0, 0, e->arena, e->P, market);
+    hipLaunchKernelGGL(k_mark_to_mkt, dim3(1), dim3(64), smem_for(e->P, 1), 0, e->arena, e->P, market);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return CDA_OK;
@@ -493,10 +496,11 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
     const int32_t* bp = (const int32_t*)(rec + P.lay.book_off);
     for (int sd = 0; sd < 2; sd++) {
         int n = sd == 0 ? s->n_bids : s->n_asks;
-        const int32_t* sp = bp + sd * 5 * CAP;
+        const int32_t* sp = bp + sd * BOOK_FIELDS * CAP;
         for (int i = 0; i < n && i < CAP; i++) {
             cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
-            o->price = sp[0 * CAP + i]; o->qty = sp[1 * CAP + i]; o->owner = sp[2 * CAP + i]; o->order_id = sp[3 * CAP + i]; o->timestamp = sp[4 * CAP + i];
+            o->price = sp[0 * CAP + i]; o->qty = sp[1 * CAP + i]; o->owner = sp[2 * CAP + i] & 15;
+            o->order_id = (int32_t)((uint32_t)sp[2 * CAP + i] >> 4); o->timestamp = sp[3 * CAP + i];
         }
     }
     const Acc* ap = (const Acc*)(rec + P.lay.acc_off);
@@ -538,10 +542,11 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
     int32_t* bp = (int32_t*)(rec + P.lay.book_off);
     for (int sd = 0; sd < 2; sd++) {
         int n = sd == 0 ? s->n_bids : s->n_asks;
-        int32_t* sp = bp + sd * 5 * CAP;
+        int32_t* sp = bp + sd * BOOK_FIELDS * CAP;
         for (int i = 0; i < n; i++) {
             const cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
-            sp[0 * CAP + i] = o->price; sp[1 * CAP + i] = o->qty; sp[2 * CAP + i] = o->owner; sp[3 * CAP + i] = o->order_id; sp[4 * CAP + i] = o->timestamp;
+            if (o->owner < 0 || o->owner >= CDA_MAX_AGENTS || o->order_id < 0 || o->order_id >= (1 << 27)) { free(rec); return CDA_ERR_INVALID; }
+            sp[0 * CAP + i] = o->price; sp[1 * CAP + i] = o->qty; sp[2 * CAP + i] = (int32_t)(((uint32_t)o->order_id << 4) | (uint32_t)o->owner); sp[3 * CAP + i] = o->timestamp;
         }
     }
     Acc* ap = (Acc*)(rec + P.lay.acc_off);
@@ -564,7 +569,7 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
 int cda_get_raw_snapshot(cda_env* e, float* raw_out, void* stream) {
     if (!e || !raw_out) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_raw_snapshot, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), 0, (hipStream_t)stream, e->arena, e->P, raw_out);
+    hipLaunchKernelGGL(k_raw_snapshot, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, raw_out);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }

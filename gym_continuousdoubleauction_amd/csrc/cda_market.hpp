@@ -53,18 +53,22 @@ static_assert(sizeof(Acc) == 144, "Acc layout");
 struct Book {                    // LDS image of the two sides, queue order (best first, FIFO in a level)
     int32_t price[2][CAP];
     int32_t qty[2][CAP];
-    int32_t owner[2][CAP];
-    int32_t oid[2][CAP];
+    int32_t oo[2][CAP];          // (order_id << 4) | owner   (owner < 16, order_id < 2^27)
     int32_t ts[2][CAP];
 };
-constexpr int BOOK_BYTES = sizeof(Book);   // 10240
+constexpr int BOOK_BYTES = sizeof(Book);   // 8192
+constexpr int BOOK_FIELDS = 4;
+__device__ __forceinline__ int oo_owner(int32_t oo) { return oo & 15; }
+__device__ __forceinline__ int oo_pack(int32_t oid, int owner) { return (int32_t)(((uint32_t)oid << 4) | (uint32_t)owner); }
 
-struct Lds {                     // per-wave LDS
+struct Lds {                     // per-wave LDS image; `acc` is sized for the env's agent count at launch
     Book book;
-    Acc acc[CDA_MAX_AGENTS];
     int32_t lvl_px[2][CDA_K_ROWS];
     int32_t lvl_sz[2][CDA_K_ROWS];
+    Acc acc[CDA_MAX_AGENTS];     // only the first num_agents records are backed by LDS
 };
+// bytes of LDS one wave needs for `agents` accounts
+__host__ __device__ constexpr int lds_bytes_per_wave(int agents) { return (int)(sizeof(Book) + 2 * 2 * CDA_K_ROWS * 4) + agents * (int)sizeof(Acc); }
 
 struct Layout {                  // byte offsets inside a market record
     int32_t acc_off, hist_off, book_off, stride;
@@ -267,20 +271,18 @@ __device__ void store_header(uint32_t* hp, const Mkt& m, int lane) {
 __device__ void load_book(const int32_t* bp, Book& bk, const Mkt& m, int lane) {
     #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const int32_t* sp = bp + s * 5 * CAP;
+        const int32_t* sp = bp + s * BOOK_FIELDS * CAP;
         for (int i = lane; i < m.n[s]; i += WAVE) {
-            bk.price[s][i] = sp[0 * CAP + i]; bk.qty[s][i] = sp[1 * CAP + i]; bk.owner[s][i] = sp[2 * CAP + i];
-            bk.oid[s][i] = sp[3 * CAP + i]; bk.ts[s][i] = sp[4 * CAP + i];
+            bk.price[s][i] = sp[0 * CAP + i]; bk.qty[s][i] = sp[1 * CAP + i]; bk.oo[s][i] = sp[2 * CAP + i]; bk.ts[s][i] = sp[3 * CAP + i];
         }
     }
 }
 __device__ void store_book(int32_t* bp, const Book& bk, const Mkt& m, int lane) {
     #pragma unroll
     for (int s = 0; s < 2; s++) {
-        int32_t* sp = bp + s * 5 * CAP;
+        int32_t* sp = bp + s * BOOK_FIELDS * CAP;
         for (int i = lane; i < m.n[s]; i += WAVE) {
-            sp[0 * CAP + i] = bk.price[s][i]; sp[1 * CAP + i] = bk.qty[s][i]; sp[2 * CAP + i] = bk.owner[s][i];
-            sp[3 * CAP + i] = bk.oid[s][i]; sp[4 * CAP + i] = bk.ts[s][i];
+            sp[0 * CAP + i] = bk.price[s][i]; sp[1 * CAP + i] = bk.qty[s][i]; sp[2 * CAP + i] = bk.oo[s][i]; sp[3 * CAP + i] = bk.ts[s][i];
         }
     }
 }
@@ -296,10 +298,10 @@ __device__ void book_remove(Book& bk, int s, int& n, int idx, int cnt, int lane)
     for (int base = idx - (idx % WAVE); base < n - cnt; base += WAVE) {
         int i = base + lane;
         bool mv = i >= idx && i < n - cnt;
-        int p = 0, q = 0, o = 0, d = 0, t = 0;
-        if (mv) { p = bk.price[s][i + cnt]; q = bk.qty[s][i + cnt]; o = bk.owner[s][i + cnt]; d = bk.oid[s][i + cnt]; t = bk.ts[s][i + cnt]; }
+        int p = 0, q = 0, o = 0, t = 0;
+        if (mv) { p = bk.price[s][i + cnt]; q = bk.qty[s][i + cnt]; o = bk.oo[s][i + cnt]; t = bk.ts[s][i + cnt]; }
         CDA_WSYNC();
-        if (mv) { bk.price[s][i] = p; bk.qty[s][i] = q; bk.owner[s][i] = o; bk.oid[s][i] = d; bk.ts[s][i] = t; }
+        if (mv) { bk.price[s][i] = p; bk.qty[s][i] = q; bk.oo[s][i] = o; bk.ts[s][i] = t; }
         CDA_WSYNC();
     }
     n -= cnt;
@@ -317,14 +319,14 @@ __device__ bool book_insert(Book& bk, int s, int& n, int price, int qty, int own
     for (int base = n - (n % WAVE); base >= 0; base -= WAVE) {
         int i = base + lane;
         bool mv = i > pos && i <= n;
-        int p = 0, q = 0, o = 0, d = 0, t = 0;
-        if (mv) { p = bk.price[s][i - 1]; q = bk.qty[s][i - 1]; o = bk.owner[s][i - 1]; d = bk.oid[s][i - 1]; t = bk.ts[s][i - 1]; }
+        int p = 0, q = 0, o = 0, t = 0;
+        if (mv) { p = bk.price[s][i - 1]; q = bk.qty[s][i - 1]; o = bk.oo[s][i - 1]; t = bk.ts[s][i - 1]; }
         CDA_WSYNC();
-        if (mv) { bk.price[s][i] = p; bk.qty[s][i] = q; bk.owner[s][i] = o; bk.oid[s][i] = d; bk.ts[s][i] = t; }
+        if (mv) { bk.price[s][i] = p; bk.qty[s][i] = q; bk.oo[s][i] = o; bk.ts[s][i] = t; }
         CDA_WSYNC();
     }
     // every lane writes the same values to the same slot (keeps each lane's view coherent)
-    bk.price[s][pos] = price; bk.qty[s][pos] = qty; bk.owner[s][pos] = owner; bk.oid[s][pos] = oid; bk.ts[s][pos] = ts;
+    bk.price[s][pos] = price; bk.qty[s][pos] = qty; bk.oo[s][pos] = oo_pack(oid, owner); bk.ts[s][pos] = ts;
     CDA_WSYNC();
     n += 1;
     return true;
@@ -342,7 +344,7 @@ __device__ int find_own_order(const Book& bk, int s, int n, int tr, int type, in
     if (type == T_MODIFY) {                 // oldest own order: minimum timestamp (unique)
         uint64_t best = ~0ull;
         for (int i = lane; i < n; i += WAVE)
-            if (bk.owner[s][i] == tr) { uint64_t key = ((uint64_t)(uint32_t)bk.ts[s][i] << 32) | (uint32_t)i; best = key < best ? key : best; }
+            if (oo_owner(bk.oo[s][i]) == tr) { uint64_t key = ((uint64_t)(uint32_t)bk.ts[s][i] << 32) | (uint32_t)i; best = key < best ? key : best; }
         best = wave_min_u64(best);
         return best == ~0ull ? -1 : (int)(uint32_t)best;
     }
@@ -350,7 +352,7 @@ __device__ int find_own_order(const Book& bk, int s, int n, int tr, int type, in
     // level's FIFO, i.e. first hit in queue order
     for (int base = 0; base < n; base += WAVE) {
         int i = base + lane;
-        bool c = i < n && bk.owner[s][i] == tr && bk.price[s][i] == price;
+        bool c = i < n && oo_owner(bk.oo[s][i]) == tr && bk.price[s][i] == price;
         uint64_t mk = __ballot(c);
         if (mk) return base + (__ffsll((long long)mk) - 1);
     }
@@ -436,7 +438,7 @@ __device__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, int32_t qty, int3
     while (qty > 0 && h < nopp) {
         int32_t p = bk.price[opp][h];
         if (limit >= 0) { if (own_side == S_BID ? !(limit >= p) : !(limit <= p)) break; }
-        int32_t rq = bk.qty[opp][h], c = bk.owner[opp][h], f;
+        int32_t rq = bk.qty[opp][h], c = oo_owner(bk.oo[opp][h]), f;
         if (qty < rq) { f = qty; bk.qty[opp][h] = rq - qty; qty = 0; CDA_WSYNC(); }    // all lanes store the same value
         else { f = rq; qty -= rq; h++; }
         m.has_trade = 1; m.last_trade_price = p;
@@ -461,7 +463,7 @@ __device__ __forceinline__ void cancel_cash_transfer(Acc& a, int32_t price, int3
 __device__ void modify_order(Lds& L, Mkt& m, int tr, int side, int idx, int32_t new_price, int32_t new_qty,
                              int32_t& rest_price, int32_t& rest_qty, int lane) {
     Book& bk = L.book;
-    int32_t op = bk.price[side][idx], oq = bk.qty[side][idx], ooid = bk.oid[side][idx];
+    int32_t op = bk.price[side][idx], oq = bk.qty[side][idx], ooid = (int32_t)((uint32_t)bk.oo[side][idx] >> 4);
     uint32_t f = 0;
     if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
     m.lob_time += 1;
@@ -520,6 +522,7 @@ __device__ void place_order(Lds& L, Mkt& m, int tr, int type, int side, int32_t 
     int32_t rest_price = 0, rest_qty = 0;
     if (type == T_MARKET) {
         m.lob_time += 1; m.next_oid += 1;                     // orderbook.py:39-44
+        if (m.next_oid >= (1 << 27)) m.flags |= CDA_FLAG_INT_OVERFLOW;
         match(L, m, tr, side, size, -1, lane);
     } else if (type == T_LIMIT) {
         int idx = find_own_order(bk, side, m.n[side], tr, T_LIMIT, price, lane);
