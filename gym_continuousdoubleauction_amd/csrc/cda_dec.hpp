@@ -188,7 +188,7 @@ __device__ __noinline__ D d_fix(int sign, W x, int exp) {
 }
 
 // Decimal.__add__ (_pydecimal.py:1157) with _normalize (:5640) and _rescale (:2612)
-__device__ __noinline__ D d_add(D a, D b) {
+__device__ __noinline__ D d_add_slow(D a, D b) {
     int exp = a.exp < b.exp ? a.exp : b.exp;
     bool az = d_is_zero(a), bz = d_is_zero(b);
     if (az && bz) return d_make(0, 0, 0, exp, a.sign < b.sign ? a.sign : b.sign);
@@ -225,10 +225,10 @@ __device__ __noinline__ D d_add(D a, D b) {
     } else { r = w_add(xt, xo); rs = dt.sign; }
     return d_fix(rs, r, eo);
 }
-__device__ __forceinline__ D d_sub(D a, D b) { return d_add(a, d_neg(b)); }
+
 
 // Decimal.__mul__ (_pydecimal.py:1267) for b = (+) m * 10^mexp with m < 2^32
-__device__ __noinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
+__device__ __noinline__ D d_mul_u32_slow(D a, uint32_t m, int mexp) {
     int exp = a.exp + mexp;
     if (d_is_zero(a) || m == 0) return d_make(0, 0, 0, exp, a.sign);
     W x = d_wide(a);
@@ -236,7 +236,7 @@ __device__ __noinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
     return d_fix(a.sign, x, exp);
 }
 // int * Decimal: Decimal(n) * a, n >= 0
-__device__ __forceinline__ D d_mul_int(D a, uint32_t n) { return d_mul_u32(a, n, 0); }
+
 
 // Decimal.__truediv__ (_pydecimal.py:1324) for b = Decimal(n), n > 0 an integer < 2^32
 __device__ __noinline__ D d_div_u32(D a, uint32_t n) {
@@ -258,7 +258,7 @@ __device__ __noinline__ D d_div_u32(D a, uint32_t n) {
 }
 
 // Decimal._cmp (_pydecimal.py:817): -1, 0, 1
-__device__ __noinline__ int d_cmp(D a, D b) {
+__device__ __noinline__ int d_cmp_slow(D a, D b) {
     bool az = d_is_zero(a), bz = d_is_zero(b);
     if (az) return bz ? 0 : (b.sign ? 1 : -1);
     if (bz) return a.sign ? -1 : 1;
@@ -277,7 +277,7 @@ __device__ __noinline__ int d_cmp(D a, D b) {
 
 // Decimal.__float__ (_pydecimal.py:1610) = correctly rounded nearest double of coeff * 10^exp.
 // Domain: exp in [-54, 0] (wider sets *domain_err).
-__device__ __noinline__ double d_to_double(D a, uint32_t* domain_err) {
+__device__ __noinline__ double d_to_double_slow(D a, uint32_t* domain_err) {
     if (d_is_zero(a)) return a.sign ? -0.0 : 0.0;
     int k = -a.exp;
     u128 c = ((u128)a.w2 << 64) | ((u128)a.w1 << 32) | a.w0;
@@ -322,6 +322,92 @@ __device__ __noinline__ double d_to_double(D a, uint32_t* domain_err) {
     if (low > half || (low == half && (sticky || (mant & 1)))) mant += 1;
     r = ldexp((double)mant, t - 56 + sh - k);
     return a.sign ? -r : r;
+}
+
+
+// ---- inline fast paths (128-bit, no table access, no call); anything unusual goes to the *_slow versions ----
+__device__ __forceinline__ u128 d_c128(const D& a) { return ((u128)a.w2 << 64) | ((u128)a.w1 << 32) | (u128)a.w0; }
+__device__ __forceinline__ D d_from128(u128 c, int exp, int sign) { return d_make((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)(c >> 64), exp, sign); }
+__device__ __forceinline__ u128 p28_128() { return ((u128)0x204fce5eULL << 64) | 0x3e25026110000000ULL; }   // 10^28
+__device__ __forceinline__ int bits128(u128 c) {
+    uint64_t hi = (uint64_t)(c >> 64), lo = (uint64_t)c;
+    return hi ? 128 - __clzll(hi) : (lo ? 64 - __clzll(lo) : 0);
+}
+__device__ __forceinline__ uint32_t pow10_sel(int r) {   // 10^r, r in 0..9, as a select chain (no memory)
+    uint32_t v = 1u;
+    v = r == 1 ? 10u : v; v = r == 2 ? 100u : v; v = r == 3 ? 1000u : v; v = r == 4 ? 10000u : v; v = r == 5 ? 100000u : v;
+    v = r == 6 ? 1000000u : v; v = r == 7 ? 10000000u : v; v = r == 8 ? 100000000u : v; v = r == 9 ? 1000000000u : v;
+    return v;
+}
+__device__ __forceinline__ u128 mul_pow10_128(u128 x, int k) {   // caller guarantees the result fits
+    while (k >= 9) { x *= (u128)1000000000u; k -= 9; }
+    return x * (u128)pow10_sel(k);
+}
+// does c * 10^k stay below 2^126 ?  (3402/1024 > log2(10))
+__device__ __forceinline__ bool scale_fits128(u128 c, int k) { return bits128(c) + ((k * 3402) >> 10) + 1 <= 126; }
+
+__device__ __forceinline__ D d_add(D a, D b) {
+    bool az = d_is_zero(a), bz = d_is_zero(b);
+    if (!az && !bz) {
+        bool swp = a.exp < b.exp;
+        D t = swp ? b : a, o = swp ? a : b;                 // t: larger exponent (ties: a)
+        int diff = t.exp - o.exp;
+        u128 ct = d_c128(t), co = d_c128(o);
+        bool ok = true;
+        if (diff) {
+            int lb_adj = o.exp + (((bits128(co) - 1) * 1233) >> 12);          // lower bound of other.adjusted()
+            ok = scale_fits128(ct, diff) && lb_adj >= t.exp - 1;               // no _normalize replacement possible
+        }
+        if (ok) {
+            if (diff) ct = mul_pow10_128(ct, diff);
+            u128 r; int rs;
+            if (t.sign != o.sign) {
+                if (ct == co) return d_make(0, 0, 0, o.exp, 0);
+                if (ct > co) { r = ct - co; rs = t.sign; } else { r = co - ct; rs = o.sign; }
+            } else { r = ct + co; rs = t.sign; }
+            if (r < p28_128()) return d_from128(r, o.exp, rs);
+        }
+    } else if (az != bz) {
+        D o = az ? b : a, z = az ? a : b;
+        if (z.exp >= o.exp) return o;                       // rescale by 10^0: the non-zero operand unchanged
+    }
+    return d_add_slow(a, b);
+}
+__device__ __forceinline__ D d_sub(D a, D b) { return d_add(a, d_neg(b)); }
+
+__device__ __forceinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
+    int exp = a.exp + mexp;
+    if (d_is_zero(a) || m == 0) return d_make(0, 0, 0, exp, a.sign);
+    u128 p = d_c128(a) * (u128)m;                           // < 2^94 * 2^32
+    if (p < p28_128()) return d_from128(p, exp, a.sign);
+    return d_mul_u32_slow(a, m, mexp);
+}
+__device__ __forceinline__ D d_mul_int(D a, uint32_t n) { return d_mul_u32(a, n, 0); }
+
+__device__ __forceinline__ int d_cmp(D a, D b) {
+    bool az = d_is_zero(a), bz = d_is_zero(b);
+    if (az) return bz ? 0 : (b.sign ? 1 : -1);
+    if (bz) return a.sign ? -1 : 1;
+    if (a.sign != b.sign) return a.sign ? -1 : 1;
+    int s = a.sign ? -1 : 1;
+    int diff = a.exp - b.exp;
+    u128 ca = d_c128(a), cb = d_c128(b);
+    if (diff > 0) { if (!scale_fits128(ca, diff)) return d_cmp_slow(a, b); ca = mul_pow10_128(ca, diff); }
+    else if (diff < 0) { if (!scale_fits128(cb, -diff)) return d_cmp_slow(a, b); cb = mul_pow10_128(cb, -diff); }
+    return ca == cb ? 0 : (ca > cb ? s : -s);
+}
+
+__device__ __forceinline__ double d_to_double(D a, uint32_t* domain_err) {
+    int k = -a.exp;
+    if (a.w2 == 0 && a.w1 < (1u << 21) && k >= 0 && k <= 22) {   // coefficient < 2^53: one exact division
+        uint64_t c = ((uint64_t)a.w1 << 32) | a.w0;
+        // 10^k (k <= 22) built from exact powers of ten: every partial product is itself an exact double
+        double p = ((k & 1) ? 10.0 : 1.0) * ((k & 2) ? 100.0 : 1.0);
+        p *= (k & 4) ? 1.0e4 : 1.0; p *= (k & 8) ? 1.0e8 : 1.0; p *= (k & 16) ? 1.0e16 : 1.0;
+        double r = (double)c / p;
+        return a.sign ? -r : r;
+    }
+    return d_to_double_slow(a, domain_err);
 }
 
 }  // namespace cda

@@ -431,7 +431,7 @@ __device__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t pric
 
 // matching loops of OrderBook.process_order_list / process_market_order / process_limit_order
 // (orderbook.py:61-194).  limit < 0 = market order.  Returns the unfilled quantity.
-__device__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, int32_t qty, int32_t limit, int lane) {
+__device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, int32_t qty, int32_t limit, int lane) {
     int opp = own_side ^ 1;
     int h = 0, nopp = m.n[opp];
     Book& bk = L.book;
@@ -457,29 +457,6 @@ __device__ __forceinline__ void cancel_cash_transfer(Acc& a, int32_t price, int3
     D v = d_mul_u32(d_price(price), (uint32_t)qty, 0);
     D hold = d_sub(ld_dec(a.hold), v), cash = d_add(ld_dec(a.cash), v);
     st_dec(a.hold, hold, flags); st_dec(a.cash, cash, flags);
-}
-
-// Trader.__modify_limit_order + OrderBook.modify_order (trader.py:219-235, orderbook.py:210-266)
-__device__ void modify_order(Lds& L, Mkt& m, int tr, int side, int idx, int32_t new_price, int32_t new_qty,
-                             int32_t& rest_price, int32_t& rest_qty, int lane) {
-    Book& bk = L.book;
-    int32_t op = bk.price[side][idx], oq = bk.qty[side][idx], ooid = (int32_t)((uint32_t)bk.oo[side][idx] >> 4);
-    uint32_t f = 0;
-    if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
-    m.lob_time += 1;
-    if (new_price == op && new_qty <= oq) {
-        bk.qty[side][idx] = new_qty; bk.ts[side][idx] = m.lob_time;    // in place: priority kept
-        CDA_WSYNC();
-        rest_price = new_price; rest_qty = new_qty;
-    } else {
-        book_remove(bk, side, m.n[side], idx, 1, lane);
-        int32_t left = match(L, m, tr, side, new_qty, new_price, lane);
-        if (left > 0) {
-            if (book_insert(bk, side, m.n[side], new_price, left, tr, ooid, m.lob_time, lane)) { rest_price = new_price; rest_qty = left; }
-            else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
-        }
-    }
-    if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
 }
 
 // Trader._order_approved (agent/trader.py:108-151), evaluated by lane `tr`, result broadcast
@@ -510,7 +487,10 @@ __device__ bool order_approved(Lds& L, const Mkt& m, int tr, int side, int32_t s
     return __shfl(ok, tr, WAVE) != 0;
 }
 
-// Trader.place_order (agent/trader.py:49-106)
+// Trader.place_order (agent/trader.py:49-106) with Trader._place_limit_order / _modify_limit_order /
+// __modify_limit_order / _cancel_limit_order (:189-252) and OrderBook.process_order / modify_order /
+// cancel_order (orderbook/orderbook.py:33-59, :196-266).  Structured so that the matching loop has ONE
+// call site: the type-specific part only decides what (if anything) is matched and what may rest.
 __device__ void place_order(Lds& L, Mkt& m, int tr, int type, int side, int32_t size, int32_t price, int lane) {
     if (side == S_NONE) return;
     if (!order_approved(L, m, tr, side, size, type == T_MARKET ? -1 : price, lane)) {
@@ -520,39 +500,47 @@ __device__ void place_order(Lds& L, Mkt& m, int tr, int type, int side, int32_t 
     if ((type == T_MARKET || type == T_LIMIT) && lane == tr) L.acc[lane].order_step_placed = 1;
     Book& bk = L.book;
     int32_t rest_price = 0, rest_qty = 0;
+    bool do_match = false, can_rest = false;
+    int32_t m_limit = -1, rest_oid = 0;
+    uint32_t f = 0;
     if (type == T_MARKET) {
         m.lob_time += 1; m.next_oid += 1;                     // orderbook.py:39-44
-        if (m.next_oid >= (1 << 27)) m.flags |= CDA_FLAG_INT_OVERFLOW;
-        match(L, m, tr, side, size, -1, lane);
-    } else if (type == T_LIMIT) {
-        int idx = find_own_order(bk, side, m.n[side], tr, T_LIMIT, price, lane);
-        if (idx < 0) {
+        do_match = true;
+    } else {
+        int idx = find_own_order(bk, side, m.n[side], tr, type, price, lane);
+        if (type == T_LIMIT && idx < 0) {                     // a new order
             m.lob_time += 1; m.next_oid += 1;
-            int32_t left = match(L, m, tr, side, size, price, lane);
-            if (left > 0) {
-                if (book_insert(bk, side, m.n[side], price, left, tr, m.next_oid, m.lob_time, lane)) { rest_price = price; rest_qty = left; }
-                else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
-            }
-        } else modify_order(L, m, tr, side, idx, price, size, rest_price, rest_qty, lane);
-    } else if (type == T_MODIFY) {
-        int idx = find_own_order(bk, side, m.n[side], tr, T_MODIFY, price, lane);
-        if (idx >= 0) modify_order(L, m, tr, side, idx, price, size, rest_price, rest_qty, lane);
-    } else {                                                  // cancel: trader.py:237-252, orderbook.py:196-208
-        int idx = find_own_order(bk, side, m.n[side], tr, T_CANCEL, price, lane);
-        if (idx >= 0) {
+            do_match = true; can_rest = true; m_limit = price; rest_oid = m.next_oid;
+        } else if (idx >= 0) {
             int32_t op = bk.price[side][idx], oq = bk.qty[side][idx];
+            int32_t ooid = (int32_t)((uint32_t)bk.oo[side][idx] >> 4);
             m.lob_time += 1;
-            book_remove(bk, side, m.n[side], idx, 1, lane);
-            uint32_t f = 0;
-            if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
-            if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
+            if (type == T_CANCEL) {                           // trader.py:237-252: cancel, then release the escrow
+                book_remove(bk, side, m.n[side], idx, 1, lane);
+                if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
+            } else {                                          // upsert / modify: release, then modify_order
+                if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
+                if (price == op && size <= oq) {              // in place: priority kept, timestamp := now
+                    bk.qty[side][idx] = size; bk.ts[side][idx] = m.lob_time;
+                    CDA_WSYNC();
+                    rest_price = price; rest_qty = size;
+                } else {                                      // remove and re-process with the same order id
+                    book_remove(bk, side, m.n[side], idx, 1, lane);
+                    do_match = true; can_rest = true; m_limit = price; rest_oid = ooid;
+                }
+            }
         }
     }
-    if (rest_qty > 0) {
-        uint32_t f = 0;
-        if (lane == tr) escrow_rest(L.acc[lane], rest_price, rest_qty, f);
-        if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
+    if (m.next_oid >= (1 << 27)) m.flags |= CDA_FLAG_INT_OVERFLOW;
+    if (do_match) {
+        int32_t left = match(L, m, tr, side, size, m_limit, lane);
+        if (left > 0 && can_rest) {
+            if (book_insert(bk, side, m.n[side], price, left, tr, rest_oid, m.lob_time, lane)) { rest_price = price; rest_qty = left; }
+            else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
+        }
     }
+    if (rest_qty > 0 && lane == tr) escrow_rest(L.acc[lane], rest_price, rest_qty, f);
+    if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
 }
 
 // Exchg_Helper.mark_to_mkt + Calculate.mark_to_mkt (exchg_helper.py:56-66, calculate.py:35-55)
