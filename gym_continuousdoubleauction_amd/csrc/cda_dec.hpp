@@ -3,9 +3,14 @@
 // The reference keeps every account in Python `decimal.Decimal` (default context: prec 28,
 // ROUND_HALF_EVEN; account/account.py:12-53).  Rewards, NAV strings and observations' downstream
 // consumers see the 28-digit rounding noise, so the device ledger reproduces the General Decimal
-// Arithmetic operations exactly: a value is (sign, coefficient < 10^28 < 2^94, exponent); wide
-// intermediates (<= 58 digits) live in 8 x u32 limbs held in VGPRs.  There is no MFMA-shaped work
-// here: it is carry chains, compares and constant-divisor divisions.
+// Arithmetic operations exactly: a value is (sign, coefficient < 10^28 < 2^94, exponent).
+// There is no MFMA-shaped work here: it is carry chains, compares and constant-divisor divisions.
+//
+// Three tiers, chosen per operation from the operands' bit lengths:
+//   1. inline, 128-bit, exact result already < 10^28: a handful of VALU instructions, no memory;
+//   2. `*_mid` leaf helpers on 4 x u32 limbs (intermediates < 2^126): rounding to 28 digits with
+//      compile-time-constant divisors and a power-of-ten table held in LDS;
+//   3. `*_wide` helpers on 8 x u32 limbs (<= 58 digits): the fully general path, rarely taken.
 //
 // Call-site facts this file exploits: every multiplication has one operand that is a
 // plain integer (< 2^32) or a tick price, and every division is by an integer position size.
@@ -17,7 +22,9 @@ typedef unsigned __int128 u128;
 
 namespace cda {
 
-struct W { uint32_t w[8]; };          // 256-bit unsigned, little endian
+template <int NL> struct WN { uint32_t w[NL]; };   // unsigned, NL x 32 bits, little endian
+typedef WN<8> W;
+typedef WN<4> W4;
 
 struct D {                            // a Decimal in registers
     uint32_t w0, w1, w2;
@@ -43,67 +50,82 @@ constexpr Pow5Tab make_pow5() {
     for (int k = 0; k < 56; k++) { t.lo[k] = (uint64_t)v; t.hi[k] = (uint64_t)(v >> 64); v *= 5; }
     return t;
 }
-__device__ const Pow10Tab POW10 = make_pow10();
+__device__ const Pow10Tab POW10 = make_pow10();     // global memory: only the wide path reads it
 __device__ const Pow5Tab POW5 = make_pow5();
-__device__ const uint32_t POW10_U32[10] = {1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u, 100000000u, 1000000000u};
-__device__ const double POW10_F64[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
-                                         1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
 
-// ---- wide integer helpers ----------------------------------------------------------------
-__device__ __forceinline__ W w_zero() {
-    W r;
+// LDS copy of 10^0 .. 10^38 as 4 limbs, at the start of the workgroup's dynamic LDS; filled by
+// dec_tables_init() at kernel entry.
+constexpr int DEC_LDS_POW = 39;
+constexpr int DEC_TABLE_BYTES = 640;                // 39 * 16 = 624, padded
+extern __shared__ __attribute__((aligned(16))) unsigned char cda_smem[];
+__device__ __forceinline__ const uint32_t* lds_pow10(int k) { return reinterpret_cast<const uint32_t*>(cda_smem) + 4 * k; }
+// every thread of the workgroup must call this once, before any decimal operation
+__device__ __forceinline__ void dec_tables_init() {
+    uint32_t* t = reinterpret_cast<uint32_t*>(cda_smem);
+    for (int i = (int)threadIdx.x; i < DEC_LDS_POW * 4; i += (int)blockDim.x) t[i] = POW10.v[i >> 2][i & 3];
+    __syncthreads();
+}
+
+// ---- wide integer helpers (templated on the limb count) ------------------------------------
+template <int NL> __device__ __forceinline__ WN<NL> w_from3(uint32_t a, uint32_t b, uint32_t c) {
+    WN<NL> r;
     #pragma unroll
-    for (int i = 0; i < 8; i++) r.w[i] = 0;
+    for (int i = 0; i < NL; i++) r.w[i] = 0;
+    r.w[0] = a; r.w[1] = b; r.w[2] = c;
     return r;
 }
-__device__ __forceinline__ W w_from3(uint32_t a, uint32_t b, uint32_t c) { W r = w_zero(); r.w[0] = a; r.w[1] = b; r.w[2] = c; return r; }
-__device__ __forceinline__ bool w_is_zero(const W& a) {
+template <int NL> __device__ __forceinline__ bool w_is_zero(const WN<NL>& a) {
     uint32_t o = 0;
     #pragma unroll
-    for (int i = 0; i < 8; i++) o |= a.w[i];
+    for (int i = 0; i < NL; i++) o |= a.w[i];
     return o == 0;
 }
-__device__ __forceinline__ int w_cmp(const W& a, const W& b) {
+template <int NL> __device__ __forceinline__ int w_cmp(const WN<NL>& a, const WN<NL>& b) {
     int r = 0;
     #pragma unroll
-    for (int i = 0; i < 8; i++) { if (a.w[i] != b.w[i]) r = a.w[i] < b.w[i] ? -1 : 1; }   // highest differing limb wins
+    for (int i = 0; i < NL; i++) { if (a.w[i] != b.w[i]) r = a.w[i] < b.w[i] ? -1 : 1; }   // highest differing limb wins
     return r;
 }
-__device__ __forceinline__ W w_add(const W& a, const W& b) {
-    W r; uint64_t c = 0;
+template <int NL> __device__ __forceinline__ WN<NL> w_add(const WN<NL>& a, const WN<NL>& b) {
+    WN<NL> r; uint64_t c = 0;
     #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (uint64_t)a.w[i] + b.w[i]; r.w[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < NL; i++) { c += (uint64_t)a.w[i] + b.w[i]; r.w[i] = (uint32_t)c; c >>= 32; }
     return r;
 }
-__device__ __forceinline__ W w_sub(const W& a, const W& b) {   // a >= b
-    W r; int64_t c = 0;
+template <int NL> __device__ __forceinline__ WN<NL> w_sub(const WN<NL>& a, const WN<NL>& b) {   // a >= b
+    WN<NL> r; int64_t c = 0;
     #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (int64_t)a.w[i] - (int64_t)b.w[i]; r.w[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < NL; i++) { c += (int64_t)a.w[i] - (int64_t)b.w[i]; r.w[i] = (uint32_t)c; c >>= 32; }
     return r;
 }
-__device__ __forceinline__ void w_mul_small(W& x, uint32_t m) {
+template <int NL> __device__ __forceinline__ void w_mul_small(WN<NL>& x, uint32_t m) {
     uint64_t c = 0;
     #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (uint64_t)x.w[i] * m; x.w[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < NL; i++) { c += (uint64_t)x.w[i] * m; x.w[i] = (uint32_t)c; c >>= 32; }
 }
-__device__ __forceinline__ void w_mul_pow10(W& x, int k) {
+__device__ __forceinline__ uint32_t pow10_sel(int r) {   // 10^r, r in 0..9, as a select chain (no memory)
+    uint32_t v = 1u;
+    v = r == 1 ? 10u : v; v = r == 2 ? 100u : v; v = r == 3 ? 1000u : v; v = r == 4 ? 10000u : v; v = r == 5 ? 100000u : v;
+    v = r == 6 ? 1000000u : v; v = r == 7 ? 10000000u : v; v = r == 8 ? 100000000u : v; v = r == 9 ? 1000000000u : v;
+    return v;
+}
+template <int NL> __device__ __forceinline__ void w_mul_pow10(WN<NL>& x, int k) {
     while (k >= 9) { w_mul_small(x, 1000000000u); k -= 9; }
-    if (k > 0) w_mul_small(x, POW10_U32[k]);
+    if (k > 0) w_mul_small(x, pow10_sel(k));
 }
-__device__ __forceinline__ void w_inc(W& x) {
+template <int NL> __device__ __forceinline__ void w_inc(WN<NL>& x) {
     uint64_t c = 1;
     #pragma unroll
-    for (int i = 0; i < 8; i++) { c += x.w[i]; x.w[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < NL; i++) { c += x.w[i]; x.w[i] = (uint32_t)c; c >>= 32; }
 }
 // x /= DV (compile-time divisor -> multiply-high sequences), returns the remainder
-template <uint32_t DV>
-__device__ __forceinline__ uint32_t w_divc(W& x) {
+template <uint32_t DV, int NL> __device__ __forceinline__ uint32_t w_divc(WN<NL>& x) {
     uint64_t rem = 0;
     #pragma unroll
-    for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | x.w[i]; uint64_t q = cur / DV; x.w[i] = (uint32_t)q; rem = cur - q * DV; }
+    for (int i = NL - 1; i >= 0; i--) { uint64_t cur = (rem << 32) | x.w[i]; uint64_t q = cur / DV; x.w[i] = (uint32_t)q; rem = cur - q * DV; }
     return (uint32_t)rem;
 }
-__device__ __noinline__ uint32_t w_div_pow10_small(W& x, int r) {   // r in 1..9
+template <int NL> __device__ __forceinline__ uint32_t w_div_pow10_small(WN<NL>& x, int r) {   // r in 1..9
     switch (r) {
         case 1: return w_divc<10u>(x);
         case 2: return w_divc<100u>(x);
@@ -117,30 +139,36 @@ __device__ __noinline__ uint32_t w_div_pow10_small(W& x, int r) {   // r in 1..9
     }
 }
 // x /= d for a run-time 32-bit divisor, returns the remainder
-__device__ __forceinline__ uint32_t w_div_u32(W& x, uint32_t d) {
+template <int NL> __device__ __forceinline__ uint32_t w_div_u32(WN<NL>& x, uint32_t d) {
     uint64_t rem = 0;
     #pragma unroll
-    for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | x.w[i]; uint64_t q = cur / d; x.w[i] = (uint32_t)q; rem = cur - q * d; }
+    for (int i = NL - 1; i >= 0; i--) { uint64_t cur = (rem << 32) | x.w[i]; uint64_t q = cur / d; x.w[i] = (uint32_t)q; rem = cur - q * d; }
     return (uint32_t)rem;
 }
-__device__ __forceinline__ int w_bits(const W& a) {
+template <int NL> __device__ __forceinline__ int w_bits(const WN<NL>& a) {
     int b = 0;
     #pragma unroll
-    for (int i = 0; i < 8; i++) if (a.w[i]) b = 32 * i + 32 - __clz(a.w[i]);
+    for (int i = 0; i < NL; i++) if (a.w[i]) b = 32 * i + 32 - __clz(a.w[i]);
     return b;
 }
-__device__ __forceinline__ W w_pow10(int k) {
+template <int NL> __device__ __forceinline__ WN<NL> w_pow10(int k);
+template <> __device__ __forceinline__ W w_pow10<8>(int k) {        // global table (wide path only)
     W r;
     #pragma unroll
     for (int i = 0; i < 8; i++) r.w[i] = POW10.v[k][i];
     return r;
 }
+template <> __device__ __forceinline__ W4 w_pow10<4>(int k) {       // LDS table, k <= 38
+    const uint32_t* p = lds_pow10(k);
+    W4 r; r.w[0] = p[0]; r.w[1] = p[1]; r.w[2] = p[2]; r.w[3] = p[3];
+    return r;
+}
 // len(str(x)) (1 for zero): floor(bits*log10(2)) then one table compare
-__device__ __forceinline__ int w_ndigits(const W& x) {
+template <int NL> __device__ __forceinline__ int w_ndigits(const WN<NL>& x) {
     int b = w_bits(x);
     if (b == 0) return 1;
     int t = (b * 1233) >> 12;
-    W p = w_pow10(t);
+    WN<NL> p = w_pow10<NL>(t);
     return t + (w_cmp(x, p) >= 0 ? 1 : 0);
 }
 
@@ -155,19 +183,14 @@ __device__ __forceinline__ D d_from_u32(uint32_t v) { return d_make(v, 0, 0, 0, 
 // a tick price as the book holds it: Decimal(str(float(p))) = Decimal('p.0') (orderbook.py:52,239)
 __device__ __forceinline__ D d_price(int32_t p) { uint64_t a = (uint64_t)(uint32_t)p * 10u; return d_make((uint32_t)a, (uint32_t)(a >> 32), 0, -1, 0); }
 __device__ __forceinline__ bool d_is_zero(const D& a) { return (a.w0 | a.w1 | a.w2) == 0; }
-__device__ __forceinline__ W d_wide(const D& a) { return w_from3(a.w0, a.w1, a.w2); }
+template <int NL> __device__ __forceinline__ WN<NL> d_wide(const D& a) { return w_from3<NL>(a.w0, a.w1, a.w2); }
 __device__ __forceinline__ D d_neg(D a) { a.sign ^= 1; return a; }
 // sign of a compared with 0: -1, 0, 1
 __device__ __forceinline__ int d_sgn(const D& a) { return d_is_zero(a) ? 0 : (a.sign ? -1 : 1); }
 
 // Decimal._fix (_pydecimal.py:1661): round a wide coefficient to 28 digits, half-even
-__device__ __noinline__ D d_fix(int sign, W x, int exp) {
-    // common case first: fewer than 29 digits <=> x < 10^28 (three-limb constant, no table access)
-    if ((x.w[3] | x.w[4] | x.w[5] | x.w[6] | x.w[7]) == 0) {
-        const uint32_t P28_0 = 0x10000000u, P28_1 = 0x3e250261u, P28_2 = 0x204fce5eu;   // 10^28
-        bool lt = x.w[2] < P28_2 || (x.w[2] == P28_2 && (x.w[1] < P28_1 || (x.w[1] == P28_1 && x.w[0] < P28_0)));
-        if (lt) return d_make(x.w[0], x.w[1], x.w[2], exp, sign);
-    }
+template <int NL> __device__ __forceinline__ D d_fix_impl(int sign, WN<NL> x, int exp) {
+    if (w_is_zero(x)) return d_make(0, 0, 0, exp, sign);
     int nd = w_ndigits(x);
     if (nd > 28) {
         int drop = nd - 28;
@@ -179,42 +202,55 @@ __device__ __noinline__ D d_fix(int sign, W x, int exp) {
         bool up = dg > 5 || (dg == 5 && (sticky || (x.w[0] & 1u)));
         if (up) {
             w_inc(x);
-            W p28 = w_pow10(28);
-            if (w_cmp(x, p28) == 0) { x = w_pow10(27); drop += 1; }
+            // 10^28 = 0x204fce5e_3e250261_10000000
+            if (x.w[0] == 0x10000000u && x.w[1] == 0x3e250261u && x.w[2] == 0x204fce5eu) {
+                x.w[0] = 0xe8000000u; x.w[1] = 0x9fd0803cu; x.w[2] = 0x033b2e3cu; drop += 1;   // 10^27
+            }
         }
         exp += drop;
     }
     return d_make(x.w[0], x.w[1], x.w[2], exp, sign);
 }
+__device__ __noinline__ D d_fix_mid(int sign, W4 x, int exp) { return d_fix_impl<4>(sign, x, exp); }
+__device__ __noinline__ D d_fix_wide(int sign, W x, int exp) { return d_fix_impl<8>(sign, x, exp); }
 
-// Decimal.__add__ (_pydecimal.py:1157) with _normalize (:5640) and _rescale (:2612)
-__device__ __noinline__ D d_add_slow(D a, D b) {
+// ---- 128-bit helpers -----------------------------------------------------------------------
+__device__ __forceinline__ u128 d_c128(const D& a) { return ((u128)a.w2 << 64) | ((u128)a.w1 << 32) | (u128)a.w0; }
+__device__ __forceinline__ D d_from128(u128 c, int exp, int sign) { return d_make((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)(c >> 64), exp, sign); }
+__device__ __forceinline__ W4 w4_from128(u128 c) { W4 r; r.w[0] = (uint32_t)c; r.w[1] = (uint32_t)(c >> 32); r.w[2] = (uint32_t)(c >> 64); r.w[3] = (uint32_t)(c >> 96); return r; }
+__device__ __forceinline__ u128 p28_128() { return ((u128)0x204fce5eULL << 64) | 0x3e25026110000000ULL; }   // 10^28
+__device__ __forceinline__ int bits128(u128 c) {
+    uint64_t hi = (uint64_t)(c >> 64), lo = (uint64_t)c;
+    return hi ? 128 - __clzll(hi) : (lo ? 64 - __clzll(lo) : 0);
+}
+__device__ __forceinline__ u128 mul_pow10_128(u128 x, int k) {   // caller guarantees the result fits
+    while (k >= 9) { x *= (u128)1000000000u; k -= 9; }
+    return x * (u128)pow10_sel(k);
+}
+// does c * 10^k stay below 2^126 ?  (3402/1024 > log2(10))
+__device__ __forceinline__ bool scale_fits128(u128 c, int k) { return bits128(c) + ((k * 3402) >> 10) + 1 <= 126; }
+
+// ---- addition: Decimal.__add__ (_pydecimal.py:1157) with _normalize (:5640) and _rescale (:2612) ----
+__device__ __noinline__ D d_add_wide(D a, D b) {
     int exp = a.exp < b.exp ? a.exp : b.exp;
     bool az = d_is_zero(a), bz = d_is_zero(b);
     if (az && bz) return d_make(0, 0, 0, exp, a.sign < b.sign ? a.sign : b.sign);
     if (az || bz) {
         D o = az ? b : a;
         int e = exp > o.exp - 29 ? exp : o.exp - 29;
-        W x = d_wide(o);
+        W x = d_wide<8>(o);
         w_mul_pow10(x, o.exp - e);
-        return d_fix(o.sign, x, e);
+        return d_fix_wide(o.sign, x, e);
     }
-    // t = the operand with the larger exponent (ties: a), o = the other one
     bool swp = a.exp < b.exp;
-    D dt = swp ? b : a, dO = swp ? a : b;
-    W xt = d_wide(dt), xo = d_wide(dO);
+    D dt = swp ? b : a, dO = swp ? a : b;            // dt: larger exponent (ties: a)
+    W xt = d_wide<8>(dt), xo = d_wide<8>(dO);
     int et = dt.exp, eo = dO.exp;
     if (et != eo) {
-        // _normalize replaces `other` by 10^e only when other.adjusted() < e = et + min(-1, tmp_len - 30).
-        // e <= et - 1 and other.adjusted() >= eo + floor((bits-1)*log10 2): decide from bit lengths when
-        // that is conclusive (it is for every gap the ledger produces), count digits only otherwise.
-        int lb_adj = eo + (((w_bits(xo) - 1) * 1233) >> 12);
-        if (lb_adj < et - 1) {
-            int tmp_len = w_ndigits(xt), oth_len = w_ndigits(xo);
-            int m = tmp_len - 30; if (m > -1) m = -1;
-            int e = et + m;
-            if (oth_len + eo - 1 < e) { xo = w_from3(1, 0, 0); eo = e; }
-        }
+        int tmp_len = w_ndigits(xt), oth_len = w_ndigits(xo);
+        int m = tmp_len - 30; if (m > -1) m = -1;
+        int e = et + m;
+        if (oth_len + eo - 1 < e) { xo = w_from3<8>(1, 0, 0); eo = e; }
         w_mul_pow10(xt, et - eo);
     }
     W r; int rs;
@@ -223,86 +259,128 @@ __device__ __noinline__ D d_add_slow(D a, D b) {
         if (c == 0) return d_make(0, 0, 0, exp, 0);
         if (c > 0) { r = w_sub(xt, xo); rs = dt.sign; } else { r = w_sub(xo, xt); rs = dO.sign; }
     } else { r = w_add(xt, xo); rs = dt.sign; }
-    return d_fix(rs, r, eo);
+    return d_fix_wide(rs, r, eo);
 }
+__device__ __forceinline__ D d_add(D a, D b) {
+    bool az = d_is_zero(a), bz = d_is_zero(b);
+    if (!az && !bz) {
+        bool swp = a.exp < b.exp;
+        D t = swp ? b : a, o = swp ? a : b;                 // t: larger exponent (ties: a)
+        int diff = t.exp - o.exp;
+        u128 ct = d_c128(t), co = d_c128(o);
+        bool ok = true;
+        if (diff) {
+            // _normalize replaces `other` by 10^e only when other.adjusted() < e = t.exp + min(-1, len-30) <= t.exp-1;
+            // other.adjusted() >= o.exp + floor((bits-1)*log10 2) decides that from bit lengths alone.
+            int lb_adj = o.exp + (((bits128(co) - 1) * 1233) >> 12);
+            ok = scale_fits128(ct, diff) && lb_adj >= t.exp - 1;
+        }
+        if (ok) {
+            if (diff) ct = mul_pow10_128(ct, diff);
+            u128 r; int rs;
+            if (t.sign != o.sign) {
+                if (ct == co) return d_make(0, 0, 0, o.exp, 0);
+                if (ct > co) { r = ct - co; rs = t.sign; } else { r = co - ct; rs = o.sign; }
+            } else { r = ct + co; rs = t.sign; }
+            if (r < p28_128()) return d_from128(r, o.exp, rs);
+            return d_fix_mid(rs, w4_from128(r), o.exp);     // < 2^127: round on 4 limbs
+        }
+    } else if (az != bz) {
+        D o = az ? b : a, z = az ? a : b;
+        if (z.exp >= o.exp) return o;                       // rescale by 10^0: the non-zero operand unchanged
+    }
+    return d_add_wide(a, b);
+}
+__device__ __forceinline__ D d_sub(D a, D b) { return d_add(a, d_neg(b)); }
 
-
-// Decimal.__mul__ (_pydecimal.py:1267) for b = (+) m * 10^mexp with m < 2^32
-__device__ __noinline__ D d_mul_u32_slow(D a, uint32_t m, int mexp) {
+// ---- multiplication: Decimal.__mul__ (_pydecimal.py:1267) for b = (+) m * 10^mexp with m < 2^32 ----
+__device__ __forceinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
     int exp = a.exp + mexp;
     if (d_is_zero(a) || m == 0) return d_make(0, 0, 0, exp, a.sign);
-    W x = d_wide(a);
-    w_mul_small(x, m);
-    return d_fix(a.sign, x, exp);
+    u128 p = d_c128(a) * (u128)m;                           // < 2^94 * 2^32 = 2^126
+    if (p < p28_128()) return d_from128(p, exp, a.sign);
+    return d_fix_mid(a.sign, w4_from128(p), exp);
 }
-// int * Decimal: Decimal(n) * a, n >= 0
+__device__ __forceinline__ D d_mul_int(D a, uint32_t n) { return d_mul_u32(a, n, 0); }   // int * Decimal
 
-
-// Decimal.__truediv__ (_pydecimal.py:1324) for b = Decimal(n), n > 0 an integer < 2^32
-__device__ __noinline__ D d_div_u32(D a, uint32_t n) {
-    if (d_is_zero(a)) return d_make(0, 0, 0, a.exp, a.sign);
-    W x = d_wide(a);
-    W nn = w_from3(n, 0, 0);
-    int shift = w_ndigits(nn) - w_ndigits(x) + 29;      // >= 2
+// ---- division: Decimal.__truediv__ (_pydecimal.py:1324) for b = Decimal(n), n > 0 an integer < 2^32 ----
+template <int NL> __device__ __forceinline__ D d_div_impl(D a, uint32_t n, int shift) {
+    WN<NL> x = d_wide<NL>(a);
     int exp = a.exp - shift;
     w_mul_pow10(x, shift);
     uint32_t rem = w_div_u32(x, n);
     if (rem != 0) {
-        W t = x; if (w_divc<5u>(t) == 0) w_inc(x);
+        WN<NL> t = x; if (w_divc<5u>(t) == 0) w_inc(x);
     } else {
         int ideal = a.exp;
-        while (exp + 9 <= ideal) { W t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; exp += 9; }
-        while (exp < ideal) { W t = x; if (w_divc<10u>(t) != 0) break; x = t; exp += 1; }
+        while (exp + 9 <= ideal) { WN<NL> t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; exp += 9; }
+        while (exp < ideal) { WN<NL> t = x; if (w_divc<10u>(t) != 0) break; x = t; exp += 1; }
     }
-    return d_fix(a.sign, x, exp);
+    return d_fix_impl<NL>(a.sign, x, exp);
+}
+__device__ __noinline__ D d_div_u32(D a, uint32_t n) {
+    if (d_is_zero(a)) return d_make(0, 0, 0, a.exp, a.sign);
+    W4 xa = d_wide<4>(a), xn = w_from3<4>(n, 0, 0);
+    int ln = w_ndigits(xn);
+    int shift = ln - w_ndigits(xa) + 29;                    // >= 2; a * 10^shift has ln + 28 or ln + 29 digits
+    if (ln <= 9) return d_div_impl<4>(a, n, shift);         // <= 38 digits < 2^127
+    return d_div_impl<8>(a, n, shift);
 }
 
-// Decimal._cmp (_pydecimal.py:817): -1, 0, 1
-__device__ __noinline__ int d_cmp_slow(D a, D b) {
+// ---- comparison: Decimal._cmp (_pydecimal.py:817): -1, 0, 1 ----
+__device__ __noinline__ int d_cmp_wide(D a, D b) {          // both non-zero, same sign
+    int s = a.sign ? -1 : 1;
+    // a coefficient is < 10^28, so an exponent gap >= 28 decides on its own; otherwise scale and compare
+    int diff = a.exp - b.exp;
+    if (diff >= 28) return s;
+    if (diff <= -28) return -s;
+    W xa = d_wide<8>(a), xb = d_wide<8>(b);
+    if (diff > 0) w_mul_pow10(xa, diff); else if (diff < 0) w_mul_pow10(xb, -diff);
+    int c = w_cmp(xa, xb);
+    return c == 0 ? 0 : (c > 0 ? s : -s);
+}
+__device__ __forceinline__ int d_cmp(D a, D b) {
     bool az = d_is_zero(a), bz = d_is_zero(b);
     if (az) return bz ? 0 : (b.sign ? 1 : -1);
     if (bz) return a.sign ? -1 : 1;
     if (a.sign != b.sign) return a.sign ? -1 : 1;
     int s = a.sign ? -1 : 1;
-    // both non-zero, same sign.  A coefficient is < 10^28, so an exponent gap >= 28 decides on its own;
-    // otherwise scale the larger-exponent operand (<= 10^27 * 2^94 fits 256 bits) and compare exactly.
     int diff = a.exp - b.exp;
-    if (diff >= 28) return s;
-    if (diff <= -28) return -s;
-    W xa = d_wide(a), xb = d_wide(b);
-    if (diff > 0) w_mul_pow10(xa, diff); else if (diff < 0) w_mul_pow10(xb, -diff);
-    int c = w_cmp(xa, xb);
-    return c == 0 ? 0 : (c > 0 ? s : -s);
+    u128 ca = d_c128(a), cb = d_c128(b);
+    if (diff > 0) { if (!scale_fits128(ca, diff)) return d_cmp_wide(a, b); ca = mul_pow10_128(ca, diff); }
+    else if (diff < 0) { if (!scale_fits128(cb, -diff)) return d_cmp_wide(a, b); cb = mul_pow10_128(cb, -diff); }
+    return ca == cb ? 0 : (ca > cb ? s : -s);
 }
 
-// Decimal.__float__ (_pydecimal.py:1610) = correctly rounded nearest double of coeff * 10^exp.
-// Domain: exp in [-54, 0] (wider sets *domain_err).
+// ---- Decimal.__float__ (_pydecimal.py:1610) = correctly rounded nearest double of coeff * 10^exp ----
+// Domain of the exact path: exp in [-54, 0] (anything else sets *domain_err).
 __device__ __noinline__ double d_to_double_slow(D a, uint32_t* domain_err) {
     if (d_is_zero(a)) return a.sign ? -0.0 : 0.0;
     int k = -a.exp;
-    u128 c = ((u128)a.w2 << 64) | ((u128)a.w1 << 32) | a.w0;
     double r;
     if (k < 0 || k > 54) {
         if (domain_err) *domain_err |= 0x4u;
-        r = (double)(uint64_t)(c >> 64) * 18446744073709551616.0 + (double)(uint64_t)c;
+        u128 c0 = d_c128(a);
+        r = (double)(uint64_t)(c0 >> 64) * 18446744073709551616.0 + (double)(uint64_t)c0;
         r = r * pow(10.0, (double)a.exp);
         return a.sign ? -r : r;
     }
-    if ((c >> 53) != 0 && k > 0) {
-        // 999525.0000000000000000000000 -> 9995250 * 10^-1: strip factors of 10 (exact), 9 digits at a time
-        W x = w_from3(a.w0, a.w1, a.w2);
-        while (k >= 9) { W t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; k -= 9; }
-        while (k > 0) { W t = x; if (w_divc<10u>(t) != 0) break; x = t; k -= 1; }
-        c = ((u128)x.w[2] << 64) | ((u128)x.w[1] << 32) | x.w[0];
+    // 999525.0000000000000000000000 -> 9995250 * 10^-1: strip factors of 10 (exact), 9 digits at a time
+    WN<3> x; x.w[0] = a.w0; x.w[1] = a.w1; x.w[2] = a.w2;
+    if (a.w2 != 0 || a.w1 >= (1u << 21)) {
+        while (k >= 9) { WN<3> t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; k -= 9; }
+        while (k > 0) { WN<3> t = x; if (w_divc<10u>(t) != 0) break; x = t; k -= 1; }
     }
+    u128 c = ((u128)x.w[2] << 64) | ((u128)x.w[1] << 32) | x.w[0];
     if ((c >> 53) == 0 && k <= 22) {
-        r = (double)(uint64_t)c / POW10_F64[k];          // both exact -> one correctly rounded division
+        double p = ((k & 1) ? 10.0 : 1.0) * ((k & 2) ? 100.0 : 1.0);
+        p *= (k & 4) ? 1.0e4 : 1.0; p *= (k & 8) ? 1.0e8 : 1.0; p *= (k & 16) ? 1.0e16 : 1.0;
+        r = (double)(uint64_t)c / p;                     // both exact -> one correctly rounded division
         return a.sign ? -r : r;
     }
     // exact path: value = c / (5^k * 2^k); restoring division for 57 quotient bits + sticky
     u128 dv = ((u128)POW5.hi[k] << 64) | POW5.lo[k];
-    int bn = 128 - ((uint64_t)(c >> 64) ? __clzll((uint64_t)(c >> 64)) : 64 + __clzll((uint64_t)c));
-    int bd = 128 - ((uint64_t)(dv >> 64) ? __clzll((uint64_t)(dv >> 64)) : 64 + __clzll((uint64_t)dv));
+    int bn = bits128(c), bd = bits128(dv);
     int t = bn - bd;
     u128 rr = c, dn = dv;
     if (t >= 0) dn <<= t; else rr <<= (-t);
@@ -323,80 +401,6 @@ __device__ __noinline__ double d_to_double_slow(D a, uint32_t* domain_err) {
     r = ldexp((double)mant, t - 56 + sh - k);
     return a.sign ? -r : r;
 }
-
-
-// ---- inline fast paths (128-bit, no table access, no call); anything unusual goes to the *_slow versions ----
-__device__ __forceinline__ u128 d_c128(const D& a) { return ((u128)a.w2 << 64) | ((u128)a.w1 << 32) | (u128)a.w0; }
-__device__ __forceinline__ D d_from128(u128 c, int exp, int sign) { return d_make((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)(c >> 64), exp, sign); }
-__device__ __forceinline__ u128 p28_128() { return ((u128)0x204fce5eULL << 64) | 0x3e25026110000000ULL; }   // 10^28
-__device__ __forceinline__ int bits128(u128 c) {
-    uint64_t hi = (uint64_t)(c >> 64), lo = (uint64_t)c;
-    return hi ? 128 - __clzll(hi) : (lo ? 64 - __clzll(lo) : 0);
-}
-__device__ __forceinline__ uint32_t pow10_sel(int r) {   // 10^r, r in 0..9, as a select chain (no memory)
-    uint32_t v = 1u;
-    v = r == 1 ? 10u : v; v = r == 2 ? 100u : v; v = r == 3 ? 1000u : v; v = r == 4 ? 10000u : v; v = r == 5 ? 100000u : v;
-    v = r == 6 ? 1000000u : v; v = r == 7 ? 10000000u : v; v = r == 8 ? 100000000u : v; v = r == 9 ? 1000000000u : v;
-    return v;
-}
-__device__ __forceinline__ u128 mul_pow10_128(u128 x, int k) {   // caller guarantees the result fits
-    while (k >= 9) { x *= (u128)1000000000u; k -= 9; }
-    return x * (u128)pow10_sel(k);
-}
-// does c * 10^k stay below 2^126 ?  (3402/1024 > log2(10))
-__device__ __forceinline__ bool scale_fits128(u128 c, int k) { return bits128(c) + ((k * 3402) >> 10) + 1 <= 126; }
-
-__device__ __forceinline__ D d_add(D a, D b) {
-    bool az = d_is_zero(a), bz = d_is_zero(b);
-    if (!az && !bz) {
-        bool swp = a.exp < b.exp;
-        D t = swp ? b : a, o = swp ? a : b;                 // t: larger exponent (ties: a)
-        int diff = t.exp - o.exp;
-        u128 ct = d_c128(t), co = d_c128(o);
-        bool ok = true;
-        if (diff) {
-            int lb_adj = o.exp + (((bits128(co) - 1) * 1233) >> 12);          // lower bound of other.adjusted()
-            ok = scale_fits128(ct, diff) && lb_adj >= t.exp - 1;               // no _normalize replacement possible
-        }
-        if (ok) {
-            if (diff) ct = mul_pow10_128(ct, diff);
-            u128 r; int rs;
-            if (t.sign != o.sign) {
-                if (ct == co) return d_make(0, 0, 0, o.exp, 0);
-                if (ct > co) { r = ct - co; rs = t.sign; } else { r = co - ct; rs = o.sign; }
-            } else { r = ct + co; rs = t.sign; }
-            if (r < p28_128()) return d_from128(r, o.exp, rs);
-        }
-    } else if (az != bz) {
-        D o = az ? b : a, z = az ? a : b;
-        if (z.exp >= o.exp) return o;                       // rescale by 10^0: the non-zero operand unchanged
-    }
-    return d_add_slow(a, b);
-}
-__device__ __forceinline__ D d_sub(D a, D b) { return d_add(a, d_neg(b)); }
-
-__device__ __forceinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
-    int exp = a.exp + mexp;
-    if (d_is_zero(a) || m == 0) return d_make(0, 0, 0, exp, a.sign);
-    u128 p = d_c128(a) * (u128)m;                           // < 2^94 * 2^32
-    if (p < p28_128()) return d_from128(p, exp, a.sign);
-    return d_mul_u32_slow(a, m, mexp);
-}
-__device__ __forceinline__ D d_mul_int(D a, uint32_t n) { return d_mul_u32(a, n, 0); }
-
-__device__ __forceinline__ int d_cmp(D a, D b) {
-    bool az = d_is_zero(a), bz = d_is_zero(b);
-    if (az) return bz ? 0 : (b.sign ? 1 : -1);
-    if (bz) return a.sign ? -1 : 1;
-    if (a.sign != b.sign) return a.sign ? -1 : 1;
-    int s = a.sign ? -1 : 1;
-    int diff = a.exp - b.exp;
-    u128 ca = d_c128(a), cb = d_c128(b);
-    if (diff > 0) { if (!scale_fits128(ca, diff)) return d_cmp_slow(a, b); ca = mul_pow10_128(ca, diff); }
-    else if (diff < 0) { if (!scale_fits128(cb, -diff)) return d_cmp_slow(a, b); cb = mul_pow10_128(cb, -diff); }
-    return ca == cb ? 0 : (ca > cb ? s : -s);
-}
-
 __device__ __forceinline__ double d_to_double(D a, uint32_t* domain_err) {
     int k = -a.exp;
     if (a.w2 == 0 && a.w1 < (1u << 21) && k >= 0 && k <= 22) {   // coefficient < 2^53: one exact division

@@ -53,9 +53,9 @@ __device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params&
 // ------------------------------------------------------------------------------------------
 // reset
 // ------------------------------------------------------------------------------------------
-extern __shared__ __attribute__((aligned(16))) unsigned char cda_smem[];
+// dynamic LDS of a workgroup: [decimal power-of-ten table (640 B)] [wave 0 image] [wave 1 image] ...
 __device__ __forceinline__ Lds& wave_lds(const Params& P, int wave) {
-    return *reinterpret_cast<Lds*>(cda_smem + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents));
+    return *reinterpret_cast<Lds*>(cda_smem + DEC_TABLE_BYTES + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents));
 }
 
 __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out) {
@@ -98,11 +98,18 @@ __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P
 // ------------------------------------------------------------------------------------------
 // step - the hot kernel
 // ------------------------------------------------------------------------------------------
+#ifdef CDA_PHASE_TIMING
+#define PHASE_MARK(i) do { unsigned long long _t = __builtin_readcyclecounter(); if (S.phase_cycles && lane == 0) S.phase_cycles[(size_t)mi * 16 + (i)] = _t; } while (0)
+#else
+#define PHASE_MARK(i) do {} while (0)
+#endif
+
 struct StepArgs {
     const int32_t* category; const float* size_mean; const float* size_sigma;
     const int32_t* price; const int32_t* price_offset; const uint8_t* present;
     float* obs_out; double* reward_out; uint8_t* terminated_out; uint8_t* truncated_out;
     cda_info_ptrs info; int has_info;
+    unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,16] cycle stamps
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
@@ -111,12 +118,15 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 __global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params P, StepArgs S) {
     int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     int mi = (int)blockIdx.x * CDA_WPB + wave;
+    dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit
     if (mi >= P.n_markets) return;
     Lds& L = wave_lds(P, wave);
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
+    PHASE_MARK(0);
     load_market(mp, P, L, m, lane);
+    PHASE_MARK(1);
 
     // my action (lane a = agent a) - coalesced loads
     size_t ao = (size_t)mi * (size_t)A + (size_t)(lane < A ? lane : 0);
@@ -128,6 +138,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params
     }
     // 1. pre-step snapshot (continuousDoubleAuction_env.py:274): prices of ALL orders resolve against it
     aggregate_levels(L, m, lane);
+    PHASE_MARK(2);
     // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order
     uint32_t present_mask = (uint32_t)__ballot(my_present != 0);
     uint32_t act_mask = 0, pass_mask = 0;
@@ -163,6 +174,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params
         if (lane == a) { my_type = type; my_side = side; my_size = size; my_price = pr; }
         if (side != S_NONE) act_mask |= 1u << a; else pass_mask |= 1u << a;
     }
+    PHASE_MARK(3);
     // 3. rand_exec_seq (action_helper.py:174-199): Fisher-Yates over the n non-pass orders, nibble-packed
     int n_acts = __popc(act_mask);
     uint64_t perm = 0xFEDCBA9876543210ull;
@@ -172,6 +184,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params
         perm &= ~((0xFull << (4 * i)) | (0xFull << (4 * j)));
         perm |= (vj << (4 * i)) | (vi << (4 * j));
     }
+    PHASE_MARK(4);
     // 4. do_actions (action_helper.py:201-239): sequential, order dependent
     for (int i = 0; i < n_acts; i++) {
         int k = (int)((perm >> (4 * i)) & 0xFull);
@@ -182,8 +195,10 @@ __global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params
         int32_t size = __shfl(my_size, tr, WAVE), pr = __shfl(my_price, tr, WAVE);
         place_order(L, m, tr, type, side, size, pr, lane);
     }
+    PHASE_MARK(5);
     // 5. mark_to_mkt
     mark_to_mkt(L, m, A, lane);
+    PHASE_MARK(6);
     // 6. prep_next_state (state_helper.py:80-92): new frame, history ring, stacked observation
     aggregate_levels(L, m, lane);
     {
@@ -200,6 +215,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params
         }
         m.hist_head = m.hist_head + 1 >= H ? 0 : m.hist_head + 1;
     }
+    PHASE_MARK(7);
     // 7. set_step_outputs (exchg_helper.py:93-124)
     uint32_t ferr = 0;
     bool bankrupt = false;
@@ -257,7 +273,9 @@ __global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params
         S.truncated_out[mi] = (uint8_t)(m.t_step + 1 >= P.cfg.max_step);
     }
     m.t_step += 1;
+    PHASE_MARK(8);
     store_market(mp, P, L, m, lane);
+    PHASE_MARK(9);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -266,6 +284,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params
 __global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, int mi, int tr, int type, int side, int size, int price) {
     Lds& lds1 = wave_lds(P, 0);
     int lane = lane_id();
+    dec_tables_init();
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     load_market(mp, P, lds1, m, lane);
@@ -275,6 +294,7 @@ __global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, in
 __global__ __launch_bounds__(64) void k_mark_to_mkt(uint8_t* arena, Params P, int mi) {
     Lds& lds1 = wave_lds(P, 0);
     int lane = lane_id();
+    dec_tables_init();
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     load_market(mp, P, lds1, m, lane);
@@ -308,6 +328,7 @@ __global__ void k_init_arena(uint8_t* arena, Params P) {
 
 __global__ void k_selftest_dec(int op, int n, const cda_dec* a, const cda_dec* b, cda_dec* out) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    dec_tables_init();
     if (i >= n) return;
     D x = ld_dec(a[i]);
     D y = b ? ld_dec(b[i]) : d_zero();
@@ -351,6 +372,7 @@ struct cda_env {
 };
 
 static thread_local char g_err[256] = "";
+static unsigned long long* g_phase_cycles = NULL;   // debug (CDA_PHASE_TIMING builds): device buffer [N,16]
 static int hip_fail(hipError_t e, const char* what) {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
     return CDA_ERR_HIP;
@@ -391,7 +413,7 @@ static int cfg_ok(const cda_config* c) {
 }
 
 static dim3 grid_for(int n) { return dim3((unsigned)((n + CDA_WPB - 1) / CDA_WPB)); }
-static size_t smem_for(const Params& P, int waves) { return (size_t)waves * (size_t)lds_bytes_per_wave(P.cfg.num_agents); }
+static size_t smem_for(const Params& P, int waves) { return (size_t)DEC_TABLE_BYTES + (size_t)waves * (size_t)lds_bytes_per_wave(P.cfg.num_agents); }
 
 int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env** out) {
     if (!cfg || !out || n_markets < 1) return CDA_ERR_INVALID;
@@ -449,6 +471,7 @@ int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const 
     S.category = category; S.size_mean = size_mean; S.size_sigma = size_sigma; S.price = price; S.price_offset = price_offset;
     S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
     if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
+    S.phase_cycles = g_phase_cycles;
     hipLaunchKernelGGL(k_step, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, S);
     HIPCHK(hipGetLastError());
     return CDA_OK;
@@ -592,7 +615,7 @@ int cda_selftest_dec(int32_t device, int32_t op, int32_t n, const cda_dec* a_hos
     HIPCHK(hipMalloc((void**)&da, bytes)); HIPCHK(hipMalloc((void**)&dout, bytes));
     HIPCHK(hipMemcpy(da, a_host, bytes, hipMemcpyHostToDevice));
     if (b_host) { HIPCHK(hipMalloc((void**)&db, bytes)); HIPCHK(hipMemcpy(db, b_host, bytes, hipMemcpyHostToDevice)); }
-    hipLaunchKernelGGL(k_selftest_dec, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, n, da, db, dout);
+    hipLaunchKernelGGL(k_selftest_dec, dim3((unsigned)((n + 63) / 64)), dim3(64), DEC_TABLE_BYTES, 0, op, n, da, db, dout);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out_host, dout, bytes, hipMemcpyDeviceToHost));
@@ -619,6 +642,9 @@ int cda_selftest_rng(int32_t device, uint64_t seed, int32_t lo, int32_t hi, int3
     (void)hipFree(dfi); (void)hipFree(dn); (void)hipFree(dp); (void)hipFree(dfs);
     return CDA_OK;
 }
+
+/* debug hook (not in include/cda.h): device buffer [N,16] of cycle stamps, used by tools/phase_timing.py */
+void cda_debug_set_phase_buffer(unsigned long long* dev_buf) { g_phase_cycles = dev_buf; }
 
 int32_t cda_num_markets(const cda_env* e) { return e ? e->P.n_markets : 0; }
 int32_t cda_obs_dim(const cda_env* e) { return e ? e->P.cfg.n_hist * CDA_SNAPSHOT_DIM : 0; }

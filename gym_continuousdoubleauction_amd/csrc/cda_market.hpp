@@ -491,7 +491,7 @@ __device__ bool order_approved(Lds& L, const Mkt& m, int tr, int side, int32_t s
 // __modify_limit_order / _cancel_limit_order (:189-252) and OrderBook.process_order / modify_order /
 // cancel_order (orderbook/orderbook.py:33-59, :196-266).  Structured so that the matching loop has ONE
 // call site: the type-specific part only decides what (if anything) is matched and what may rest.
-__device__ void place_order(Lds& L, Mkt& m, int tr, int type, int side, int32_t size, int32_t price, int lane) {
+__device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, int side, int32_t size, int32_t price, int lane) {
     if (side == S_NONE) return;
     if (!order_approved(L, m, tr, side, size, type == T_MARKET ? -1 : price, lane)) {
         if (lane == tr) L.acc[lane].num_rejected_step += 1;

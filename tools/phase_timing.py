@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Debug: per-phase cycle breakdown of k_step (needs a -DCDA_PHASE_TIMING build of the library).
+Run on the GPU box: python tools/phase_timing.py"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+so = os.path.join(ROOT, "gpurun_out", "libcda_hip_timing.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                       "-DCDA_PHASE_TIMING", "-o", so, os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_hip.hip")])
+from gym_continuousdoubleauction_amd import _lib
+_lib.LIB_PATH = so
+from gym_continuousdoubleauction_amd import CDAVecEnv
+
+N, A = 4096, 4
+env = CDAVecEnv({"num_of_agents": A, "init_cash": 1000000, "max_step": 100000, "is_render": False}, n_markets=N, with_info=False)
+env.reset(seed=np.arange(1000, 1000 + N, dtype=np.uint64))
+buf = torch.zeros((N, 16), dtype=torch.int64, device="cuda:0")
+L = _lib.lib()
+L.cda_debug_set_phase_buffer.argtypes = [C.c_void_p]
+L.cda_debug_set_phase_buffer(C.c_void_p(buf.data_ptr()))
+g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+names = ["load", "snapshot_pre", "decode+rng", "shuffle", "orders", "mtm", "snapshot_post+obs", "reward/info", "store"]
+acc = np.zeros(9); span = 0.0
+T, W = 300, 200
+for t in range(W + T):
+    cat = torch.randint(0, 9, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
+    price = torch.randint(0, 10, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
+    off = torch.randint(0, 3, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
+    mean = torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1
+    sigma = torch.rand((N, A), generator=g, device="cuda:0")
+    env.step(cat, mean, sigma, price, off)
+    if t >= W:
+        b = buf.cpu().numpy().astype(np.float64)
+        d = b[:, 1:10] - b[:, 0:9]
+        acc += d.mean(axis=0)
+        span += (b[:, 9].max() - b[:, 0].min())
+acc /= T
+tot = acc.sum()
+print(f"mean cycles per wave per step: {tot:.0f}; kernel span (first start -> last end) {span / T:.0f} cycles")
+for n, v in zip(names, acc):
+    print(f"  {n:20s} {v:10.0f} cycles  {100 * v / tot:5.1f} %")
