@@ -353,12 +353,48 @@ __device__ __forceinline__ int d_cmp(D a, D b) {
 }
 
 // ---- Decimal.__float__ (_pydecimal.py:1610) = correctly rounded nearest double of coeff * 10^exp ----
-// Domain of the exact path: exp in [-54, 0] (anything else sets *domain_err).
+// Domain of the exact paths: exp in [-109, 0] (anything else sets *domain_err).
+// round a quotient q (top set bit at position 55 or 56, weights 2^t..2^(t-56)) + sticky to a double * 2^-k
+__device__ __forceinline__ double round_quotient(uint64_t q, bool sticky, int t, int k) {
+    int nb = 64 - __clzll(q);
+    int sh = nb - 53;
+    uint64_t mant = q >> sh;
+    uint64_t low = q & (((uint64_t)1 << sh) - 1);
+    uint64_t half = (uint64_t)1 << (sh - 1);
+    if (low > half || (low == half && (sticky || (mant & 1)))) mant += 1;
+    return ldexp((double)mant, t - 56 + sh - k);
+}
+__device__ __forceinline__ void w_shl(W& x, int n) {          // x <<= n, 0 <= n < 256
+    int ws = n >> 5, bs = n & 31;
+    W r;
+    #pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        uint32_t lo = (i - ws >= 0) ? x.w[(i - ws) & 7] : 0u, lo2 = (i - ws - 1 >= 0) ? x.w[(i - ws - 1) & 7] : 0u;
+        r.w[i] = bs ? ((lo << bs) | (lo2 >> (32 - bs))) : lo;
+    }
+    x = r;
+}
+// deep exponents (55 <= k <= 109): the same restoring division on 256-bit integers, 5^k built on the fly
+__device__ __noinline__ double d_to_double_deep(u128 c, int k) {
+    W dv = w_from3<8>(1, 0, 0);
+    for (int i = k; i > 0;) { int st = i >= 13 ? 13 : i; uint32_t f = 1; for (int j = 0; j < st; j++) f *= 5u; w_mul_small(dv, f); i -= st; }
+    W rr = w_from3<8>((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)(c >> 64)); rr.w[3] = (uint32_t)(c >> 96);
+    int t = w_bits(rr) - w_bits(dv);
+    if (t >= 0) w_shl(dv, t); else w_shl(rr, -t);
+    uint64_t q = 0;
+    for (int i = 0; i < 57; i++) {
+        q <<= 1;
+        if (w_cmp(rr, dv) >= 0) { rr = w_sub(rr, dv); q |= 1; }
+        w_shl(rr, 1);
+    }
+    return round_quotient(q, !w_is_zero(rr), t, k);
+}
 __device__ __noinline__ double d_to_double_slow(D a, uint32_t* domain_err) {
     if (d_is_zero(a)) return a.sign ? -0.0 : 0.0;
     int k = -a.exp;
     double r;
-    if (k < 0 || k > 54) {
+    if (k > 54 && k <= 109) { r = d_to_double_deep(d_c128(a), k); return a.sign ? -r : r; }
+    if (k < 0 || k > 109) {
         if (domain_err) *domain_err |= 0x4u;
         u128 c0 = d_c128(a);
         r = (double)(uint64_t)(c0 >> 64) * 18446744073709551616.0 + (double)(uint64_t)c0;
@@ -391,14 +427,7 @@ __device__ __noinline__ double d_to_double_slow(D a, uint32_t* domain_err) {
         rr <<= 1;
     }
     // q holds quotient bits of weights 2^t .. 2^(t-56); its top set bit is bit 56 or 55
-    int nb = 64 - __clzll(q);
-    int sh = nb - 53;
-    uint64_t mant = q >> sh;
-    uint64_t low = q & (((uint64_t)1 << sh) - 1);
-    uint64_t half = (uint64_t)1 << (sh - 1);
-    bool sticky = rr != 0;
-    if (low > half || (low == half && (sticky || (mant & 1)))) mant += 1;
-    r = ldexp((double)mant, t - 56 + sh - k);
+    r = round_quotient(q, rr != 0, t, k);
     return a.sign ? -r : r;
 }
 __device__ __forceinline__ double d_to_double(D a, uint32_t* domain_err) {
