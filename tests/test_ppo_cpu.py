@@ -1,0 +1,54 @@
+"""CPU: the PPO loop's math and plumbing on a stand-in env (the CPU oracle behind the CDAVecEnv surface)."""
+import numpy as np
+import torch
+
+from gym_continuousdoubleauction_amd import ppo
+
+
+class _CpuEnv:
+    """CDAVecEnv-shaped stand-in over the CPU oracle (test infrastructure only)."""
+
+    def __init__(self, n, a, max_step):
+        import oracle_lib as O
+        self.o = O.OracleEnv({"num_of_agents": a, "init_cash": 1000000, "max_step": max_step, "is_render": False}, n)
+        self.n_markets, self.num_agents, self.obs_dim = n, a, self.o.obs_dim
+        self.obs = torch.zeros((n, self.obs_dim))
+
+    def reset(self, seed=None, mask=None):
+        seeds = None if seed is None else (np.arange(self.n_markets, dtype=np.uint64) + np.uint64(seed))
+        m = None if mask is None else mask.numpy().astype(np.uint8)
+        self.obs.copy_(torch.from_numpy(self.o.reset(seeds=seeds, mask=m)))
+        return self.obs
+
+    def step(self, cat, mean, sigma, price, off):
+        obs, rew, term, trunc, _ = self.o.step(cat.numpy(), mean.numpy(), sigma.numpy(), price.numpy(), off.numpy())
+        self.obs.copy_(torch.from_numpy(obs))
+        return self.obs, torch.from_numpy(rew.copy()), torch.from_numpy(term.astype(bool)), torch.from_numpy(trunc.astype(bool)), {}
+
+
+def test_gae_matches_the_textbook_recursion():
+    rew = torch.tensor([[1.0], [0.0], [2.0]]); val = torch.tensor([[0.5], [0.4], [0.3]]); done = torch.tensor([[0.0], [0.0], [1.0]])
+    adv, ret = ppo.gae(rew, val, torch.tensor([9.0]), done, gamma=0.9, lam=0.8)
+    d2 = 2.0 - 0.3
+    d1 = 0.0 + 0.9 * 0.3 - 0.4
+    d0 = 1.0 + 0.9 * 0.4 - 0.5
+    a2 = d2; a1 = d1 + 0.9 * 0.8 * a2; a0 = d0 + 0.9 * 0.8 * a1
+    assert torch.allclose(adv.squeeze(), torch.tensor([a0, a1, a2]), atol=1e-6)
+    assert torch.allclose(ret, adv + val)
+
+
+def test_action_mapping_respects_the_space_bounds():
+    torch.manual_seed(0)
+    m = ppo.ActorCritic(168)
+    acts, logp, val = m.act(torch.randn(40, 168))
+    cat, mean, sigma, price, off = ppo.to_env_actions(acts, 10, 4)
+    assert cat.shape == (10, 4) and cat.dtype == torch.int32 and 0 <= int(cat.min()) and int(cat.max()) <= 8
+    assert float(mean.min()) >= -1 and float(mean.max()) <= 1 and float(sigma.min()) >= 0 and float(sigma.max()) <= 1
+    assert int(price.max()) <= 9 and int(off.max()) <= 2 and logp.shape == (40,) and val.shape == (40,)
+
+
+def test_ppo_loop_runs_and_resets_truncated_markets():
+    env = _CpuEnv(6, 3, max_step=5)
+    model, hist = ppo.train(env, iters=2, horizon=12, log=lambda s: None)
+    assert len(hist) == 2 and all(np.isfinite(h["pg_loss"]) and np.isfinite(h["v_loss"]) for h in hist)
+    assert hist[0]["agent_steps"] == 6 * 3 * 12
