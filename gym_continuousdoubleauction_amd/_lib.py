@@ -7,7 +7,8 @@ import os
 from . import _capi as K
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcda_hip.so")
+# CDA_HIP_LIB lets the tuning scripts load an experimental build of the SAME HIP library (never a CPU path)
+LIB_PATH = os.environ.get("CDA_HIP_LIB") or os.path.join(_HERE, "libcda_hip.so")
 
 _lib = None
 

@@ -320,6 +320,11 @@ template <int NL> __device__ __forceinline__ D d_div_impl(D a, uint32_t n, int s
 }
 __device__ __noinline__ D d_div_u32(D a, uint32_t n) {
     if (d_is_zero(a)) return d_make(0, 0, 0, a.exp, a.sign);
+    {   // exact integer quotient (e.g. adding to a position at its own VWAP): the result is coefficient / n at the
+        // ideal exponent a.exp - no scaling, no trailing-zero stripping, and it already has <= 28 digits
+        WN<3> x; x.w[0] = a.w0; x.w[1] = a.w1; x.w[2] = a.w2;
+        if (w_div_u32(x, n) == 0) return d_make(x.w[0], x.w[1], x.w[2], a.exp, a.sign);
+    }
     W4 xa = d_wide<4>(a), xn = w_from3<4>(n, 0, 0);
     int ln = w_ndigits(xn);
     int shift = ln - w_ndigits(xa) + 29;                    // >= 2; a * 10^shift has ln + 28 or ln + 29 digits

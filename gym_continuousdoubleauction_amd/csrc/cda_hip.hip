@@ -23,6 +23,9 @@ using namespace cda;
 #ifndef CDA_WPB
 #define CDA_WPB 4            // markets (waves) per workgroup
 #endif
+#ifndef CDA_MIN_WAVES
+#define CDA_MIN_WAVES 4      // waves per SIMD the step kernel is register-budgeted for (LDS allows 4)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // device helpers shared by the kernels
@@ -38,9 +41,11 @@ __device__ __forceinline__ MarketPtrs market_ptrs(uint8_t* arena, const Params& 
     return r;
 }
 __device__ __forceinline__ void load_market(const MarketPtrs& mp, const Params& P, Lds& L, Mkt& m, int lane) {
-    load_header(mp.hdr, m, lane);
-    load_book(mp.book, L.book, m, lane);
+    uint32_t hv = load_header_word(mp.hdr, lane);          // all three requests are in flight together
+    BookPrefetch pre = prefetch_book(mp.book, lane);
     copy_words((uint32_t*)&L.acc[0], mp.acc, P.cfg.num_agents * (int)(sizeof(Acc) / 4), lane);
+    decode_header(hv, m);
+    finish_book_load(mp.book, pre, L.book, m, lane);
     CDA_WSYNC();
 }
 __device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params& P, Lds& L, const Mkt& m, int lane) {
@@ -115,7 +120,7 @@ struct StepArgs {
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(64 * CDA_WPB, 4) void k_step(uint8_t* arena, Params P, StepArgs S) {
+__global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
     int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit

@@ -237,8 +237,10 @@ __device__ double rng_std_normal(Mkt& m) {
 // ======================================================================================
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 
-__device__ void load_header(const uint32_t* hp, Mkt& m, int lane) {
-    uint32_t v = lane < H_WORDS ? hp[lane] : 0u;
+__device__ __forceinline__ uint32_t load_header_word(const uint32_t* hp, int lane) { return lane < H_WORDS ? hp[lane] : 0u; }
+__device__ void decode_header(uint32_t v, Mkt& m);
+__device__ void load_header(const uint32_t* hp, Mkt& m, int lane) { decode_header(load_header_word(hp, lane), m); }
+__device__ void decode_header(uint32_t v, Mkt& m) {
     #define RL(i) ((uint32_t)__builtin_amdgcn_readlane((int)v, (i)))
     uint64_t slo = (uint64_t)RL(H_RNG_STATE_LO) | ((uint64_t)RL(H_RNG_STATE_LO + 1) << 32);
     uint64_t shi = (uint64_t)RL(H_RNG_STATE_HI) | ((uint64_t)RL(H_RNG_STATE_HI + 1) << 32);
@@ -267,7 +269,29 @@ __device__ void store_header(uint32_t* hp, const Mkt& m, int lane) {
         hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head;
     }
 }
-// book record in HBM: [side][field][CAP] int32 ; only the live prefix of each side moves
+// book record in HBM: [side][field][CAP] int32 ; only the live prefix of each side moves.
+// Prefetch form: the first 64 entries of every array are requested BEFORE the header (which holds the
+// counts) has arrived, so the two HBM round trips of a naive load overlap into one.
+struct BookPrefetch { int32_t v[2][BOOK_FIELDS]; };
+__device__ __forceinline__ BookPrefetch prefetch_book(const int32_t* bp, int lane) {
+    BookPrefetch r;
+    #pragma unroll
+    for (int s = 0; s < 2; s++) {
+        #pragma unroll
+        for (int f = 0; f < BOOK_FIELDS; f++) r.v[s][f] = bp[(s * BOOK_FIELDS + f) * CAP + lane];
+    }
+    return r;
+}
+__device__ __forceinline__ void finish_book_load(const int32_t* bp, const BookPrefetch& pre, Book& bk, const Mkt& m, int lane) {
+    #pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int32_t* sp = bp + s * BOOK_FIELDS * CAP;
+        if (lane < m.n[s]) { bk.price[s][lane] = pre.v[s][0]; bk.qty[s][lane] = pre.v[s][1]; bk.oo[s][lane] = pre.v[s][2]; bk.ts[s][lane] = pre.v[s][3]; }
+        for (int i = lane + WAVE; i < m.n[s]; i += WAVE) {
+            bk.price[s][i] = sp[0 * CAP + i]; bk.qty[s][i] = sp[1 * CAP + i]; bk.oo[s][i] = sp[2 * CAP + i]; bk.ts[s][i] = sp[3 * CAP + i];
+        }
+    }
+}
 __device__ void load_book(const int32_t* bp, Book& bk, const Mkt& m, int lane) {
     #pragma unroll
     for (int s = 0; s < 2; s++) {

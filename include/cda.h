@@ -35,7 +35,9 @@ extern "C" {
 #define CDA_RAW_DIM       40            /* agg_LOB_raw: state_helper.py:159-160 */
 #define CDA_MAX_HIST      16            /* n_hist upper bound of this build (reference default 4) */
 #define CDA_MAX_AGENTS    16            /* agents per market upper bound of this build */
+#ifndef CDA_BOOK_CAP
 #define CDA_BOOK_CAP      256           /* resting orders per side per market (reference: unbounded) */
+#endif
 #define CDA_NUM_REWARD_TERMS 5          /* reward_helper.py:75-81 */
 
 typedef enum cda_status {
