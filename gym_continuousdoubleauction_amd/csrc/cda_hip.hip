@@ -64,7 +64,7 @@ __device__ __forceinline__ Lds& wave_lds(const Params& P, int wave) {
 }
 
 __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out) {
-    int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     if (mi >= P.n_markets) return;
     if (mask && !mask[mi]) return;
@@ -121,7 +121,7 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
-    int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit
     if (mi >= P.n_markets) return;
@@ -133,51 +133,47 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     load_market(mp, P, L, m, lane);
     PHASE_MARK(1);
 
-    // my action (lane a = agent a) - coalesced loads
-    size_t ao = (size_t)mi * (size_t)A + (size_t)(lane < A ? lane : 0);
-    int my_cat = 0, my_level = 0, my_off = 1, my_present = 0; float my_mean = 0.f, my_sigma = 0.f;
-    if (lane < A) {
-        my_cat = clampi(S.category[ao], 0, 8); my_mean = clampf(S.size_mean[ao], -1.0f, 1.0f); my_sigma = clampf(S.size_sigma[ao], 0.0f, 1.0f);
-        my_level = clampi(S.price[ao], 0, CDA_K_ROWS - 1); my_off = clampi(S.price_offset[ao], 0, 2);
-        my_present = S.present ? (S.present[ao] != 0) : 1;
-    }
     // 1. pre-step snapshot (continuousDoubleAuction_env.py:274): prices of ALL orders resolve against it
     aggregate_levels(L, m, lane);
     PHASE_MARK(2);
-    // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order
-    uint32_t present_mask = (uint32_t)__ballot(my_present != 0);
+    // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order.
+    //    The action words are read at wave-uniform addresses (scalar loads); decoded orders go to LDS.
     uint32_t act_mask = 0, pass_mask = 0;
-    int my_type = 0, my_side = S_NONE; int32_t my_size = 0, my_price = -1;
-    for (int a = 0; a < A; a++) {
-        if (!((present_mask >> a) & 1u)) continue;
-        int cat = __shfl(my_cat, a, WAVE);
-        float mean = __shfl(my_mean, a, WAVE), sigma = __shfl(my_sigma, a, WAVE);
-        int level = __shfl(my_level, a, WAVE), off = __shfl(my_off, a, WAVE) - 1;
-        int side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
-        int type = cat == 0 ? T_MARKET : ((cat - 1) & 3);
-        float locf = (type == T_MARKET ? P.mkt_mul : P.lim_mul) * mean;      // float32 product (numpy NEP 50)
-        double z = rng_std_normal(m);
-        double prod = (double)sigma * z;
-        double sample = (double)locf + prod;                                   // built with -ffp-contract=off
-        double rs = rint(fabs(sample));
-        if (rs > 1.0e9) { rs = 1.0e9; m.flags |= CDA_FLAG_INT_OVERFLOW; }
-        int32_t size = (int32_t)rs + P.cfg.min_size;
-        int32_t pr = -1;
-        if (type != T_MARKET) {                                                // _set_price (action_helper.py:341-397)
-            if (side == S_BID) {
-                int32_t p = L.lvl_px[0][level];
-                int32_t base = p == 0 ? m.last_price - (level + 1) * tick : p;
-                pr = base + off * tick;
-            } else {
-                int32_t p = L.lvl_px[1][level];
-                int32_t base = p == 0 ? m.last_price + (level + 1) * tick : p;
-                pr = base - off * tick;
+    {
+        const size_t ab = (size_t)mi * (size_t)A;
+        for (int a = 0; a < A; a++) {
+            if (S.present && !S.present[ab + a]) continue;
+            int cat = clampi(S.category[ab + a], 0, 8);
+            float mean = clampf(S.size_mean[ab + a], -1.0f, 1.0f), sigma = clampf(S.size_sigma[ab + a], 0.0f, 1.0f);
+            int level = clampi(S.price[ab + a], 0, CDA_K_ROWS - 1), off = clampi(S.price_offset[ab + a], 0, 2) - 1;
+            int side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
+            int type = cat == 0 ? T_MARKET : ((cat - 1) & 3);
+            float locf = (type == T_MARKET ? P.mkt_mul : P.lim_mul) * mean;      // float32 product (numpy NEP 50)
+            double z = rng_std_normal(m);
+            double prod = (double)sigma * z;
+            double sample = (double)locf + prod;                                   // built with -ffp-contract=off
+            double rs = rint(fabs(sample));
+            if (rs > 1.0e9) { rs = 1.0e9; m.flags |= CDA_FLAG_INT_OVERFLOW; }
+            int32_t size = (int32_t)rs + P.cfg.min_size;
+            int32_t pr = -1;
+            if (type != T_MARKET) {                                                // _set_price (action_helper.py:341-397)
+                if (side == S_BID) {
+                    int32_t p = L.lvl_px[0][level];
+                    int32_t base = p == 0 ? m.last_price - (level + 1) * tick : p;
+                    pr = base + off * tick;
+                } else {
+                    int32_t p = L.lvl_px[1][level];
+                    int32_t base = p == 0 ? m.last_price + (level + 1) * tick : p;
+                    pr = base - off * tick;
+                }
+                if (pr < tick) pr = tick;
+                if (pr >= (1 << 24)) { pr = (1 << 24) - 1; m.flags |= CDA_FLAG_INT_OVERFLOW; }
             }
-            if (pr < tick) pr = tick;
-            if (pr >= (1 << 24)) m.flags |= CDA_FLAG_INT_OVERFLOW;
+            L.act_tsp[a] = type | (side << 2) | ((pr + 1) << 4);                   // every lane stores the same words
+            L.act_size[a] = size;
+            if (side != S_NONE) act_mask |= 1u << a; else pass_mask |= 1u << a;
         }
-        if (lane == a) { my_type = type; my_side = side; my_size = size; my_price = pr; }
-        if (side != S_NONE) act_mask |= 1u << a; else pass_mask |= 1u << a;
+        CDA_WSYNC();
     }
     PHASE_MARK(3);
     // 3. rand_exec_seq (action_helper.py:174-199): Fisher-Yates over the n non-pass orders, nibble-packed
@@ -196,9 +192,8 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
         uint32_t mk = act_mask;
         for (int s = 0; s < k; s++) mk &= mk - 1;                             // drop k lowest set bits
         int tr = __ffs((int)mk) - 1;
-        int type = __shfl(my_type, tr, WAVE), side = __shfl(my_side, tr, WAVE);
-        int32_t size = __shfl(my_size, tr, WAVE), pr = __shfl(my_price, tr, WAVE);
-        place_order(L, m, tr, type, side, size, pr, lane);
+        int32_t tsp = L.act_tsp[tr], size = L.act_size[tr];
+        place_order(L, m, tr, tsp & 3, (tsp >> 2) & 3, size, (tsp >> 4) - 1, lane);
     }
     PHASE_MARK(5);
     // 5. mark_to_mkt
@@ -307,7 +302,7 @@ __global__ __launch_bounds__(64) void k_mark_to_mkt(uint8_t* arena, Params P, in
     store_market(mp, P, lds1, m, lane);
 }
 __global__ __launch_bounds__(64 * CDA_WPB) void k_raw_snapshot(uint8_t* arena, Params P, float* raw_out) {
-    int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     if (mi >= P.n_markets) return;
     Lds& L = wave_lds(P, wave);

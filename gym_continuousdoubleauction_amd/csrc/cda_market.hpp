@@ -65,10 +65,12 @@ struct Lds {                     // per-wave LDS image; `acc` is sized for the e
     Book book;
     int32_t lvl_px[2][CDA_K_ROWS];
     int32_t lvl_sz[2][CDA_K_ROWS];
+    int32_t act_tsp[CDA_MAX_AGENTS];   // decoded order of agent a: type | side << 2 | (price + 1) << 4   (price < 2^24)
+    int32_t act_size[CDA_MAX_AGENTS];
     Acc acc[CDA_MAX_AGENTS];     // only the first num_agents records are backed by LDS
 };
 // bytes of LDS one wave needs for `agents` accounts
-__host__ __device__ constexpr int lds_bytes_per_wave(int agents) { return (int)(sizeof(Book) + 2 * 2 * CDA_K_ROWS * 4) + agents * (int)sizeof(Acc); }
+__host__ __device__ constexpr int lds_bytes_per_wave(int agents) { return (int)(sizeof(Book) + 2 * 2 * CDA_K_ROWS * 4 + 2 * CDA_MAX_AGENTS * 4) + agents * (int)sizeof(Acc); }
 
 struct Layout {                  // byte offsets inside a market record
     int32_t acc_off, hist_off, book_off, stride;
