@@ -394,13 +394,12 @@ __device__ __noinline__ double d_to_double_deep(u128 c, int k) {
     }
     return round_quotient(q, !w_is_zero(rr), t, k);
 }
-__device__ __noinline__ double d_to_double_slow(D a, uint32_t* domain_err) {
+__device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no caller state is forced to memory
     if (d_is_zero(a)) return a.sign ? -0.0 : 0.0;
     int k = -a.exp;
     double r;
     if (k > 54 && k <= 109) { r = d_to_double_deep(d_c128(a), k); return a.sign ? -r : r; }
-    if (k < 0 || k > 109) {
-        if (domain_err) *domain_err |= 0x4u;
+    if (k < 0 || k > 109) {                                  // outside the exact domain (flagged by the inline wrapper)
         u128 c0 = d_c128(a);
         r = (double)(uint64_t)(c0 >> 64) * 18446744073709551616.0 + (double)(uint64_t)c0;
         r = r * pow(10.0, (double)a.exp);
@@ -445,7 +444,8 @@ __device__ __forceinline__ double d_to_double(D a, uint32_t* domain_err) {
         double r = (double)c / p;
         return a.sign ? -r : r;
     }
-    return d_to_double_slow(a, domain_err);
+    if ((k < 0 || k > 109) && !d_is_zero(a) && domain_err) *domain_err |= 0x4u;
+    return d_to_double_slow(a);
 }
 
 }  // namespace cda

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P
     load_header(mp.hdr, m, lane);
     if (seeds) { rng_seed(m, seeds[mi]); m.seeded = 1; }
     else if (!m.seeded) { rng_seed(m, (uint64_t)mi); m.seeded = 1; }
-    m.n[0] = 0; m.n[1] = 0;
+    m.nb = 0; m.na = 0;
     m.t_step = 0; m.lob_time = 0; m.next_oid = 0; m.has_trade = 0; m.last_trade_price = 0; m.done_mask = 0; m.flags = 0;
     m.last_price = rng_integers(m, P.cfg.initial_price_min, P.cfg.initial_price_max);
     int A = P.cfg.num_agents;
@@ -261,12 +261,12 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     if (lane == 0) {
         if (S.has_info) {
             const cda_info_ptrs& I = S.info;
-            double bb = m.n[0] ? (double)L.book.price[0][0] : __longlong_as_double(0x7ff8000000000000LL);
-            double ba = m.n[1] ? (double)L.book.price[1][0] : __longlong_as_double(0x7ff8000000000000LL);
+            double bb = m.nb ? (double)L.book.price[0][0] : __longlong_as_double(0x7ff8000000000000LL);
+            double ba = m.na ? (double)L.book.price[1][0] : __longlong_as_double(0x7ff8000000000000LL);
             if (I.last_price) I.last_price[mi] = (double)m.last_price;
             if (I.best_bid) I.best_bid[mi] = bb;
             if (I.best_ask) I.best_ask[mi] = ba;
-            if (I.spread) I.spread[mi] = (m.n[0] && m.n[1]) ? ba - bb : __longlong_as_double(0x7ff8000000000000LL);
+            if (I.spread) I.spread[mi] = (m.nb && m.na) ? ba - bb : __longlong_as_double(0x7ff8000000000000LL);
         }
         // Done_Helper.set_all_done (done_helper.py:20-54)
         S.terminated_out[mi] = (uint8_t)(__popc(m.done_mask) == A);
@@ -324,6 +324,19 @@ __global__ void k_init_arena(uint8_t* arena, Params P) {
         uint32_t* h = (uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride);
         for (int k = 0; k < H_WORDS; k++) h[k] = 0;
     }
+}
+
+// PMC calibration (tools/profile_gpu.sh): known byte counts in THIS library's access pattern (4 B per lane,
+// coalesced) so that FETCH_SIZE / WRITE_SIZE can be converted to bytes (MI355X_MICROARCH.md, HBM section).
+__global__ void k_calib_read(const uint32_t* p, size_t n, uint32_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i < n; i += stride) acc ^= p[i];
+    if (acc == 0x12345679u) out[0] = acc;
+}
+__global__ void k_calib_write(uint32_t* p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = (uint32_t)i;
 }
 
 __global__ void k_selftest_dec(int op, int n, const cda_dec* a, const cda_dec* b, cda_dec* out) {
@@ -641,6 +654,14 @@ int cda_selftest_rng(int32_t device, uint64_t seed, int32_t lo, int32_t hi, int3
     HIPCHK(hipMemcpy(final_state_host, dfs, 48, hipMemcpyDeviceToHost));
     (void)hipFree(dfi); (void)hipFree(dn); (void)hipFree(dp); (void)hipFree(dfs);
     return CDA_OK;
+}
+
+/* debug hook (not in include/cda.h): read (mode 0) or write (mode 1) n_bytes of a device buffer, 4 B per lane */
+int cda_debug_calib(void* dev_buf, size_t n_bytes, int mode, void* stream) {
+    size_t n = n_bytes / 4;
+    if (mode == 0) hipLaunchKernelGGL(k_calib_read, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)dev_buf, n, (uint32_t*)dev_buf);
+    else hipLaunchKernelGGL(k_calib_write, dim3(2048), dim3(256), 0, (hipStream_t)stream, (uint32_t*)dev_buf, n);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
 /* debug hook (not in include/cda.h): device buffer [N,16] of cycle stamps, used by tools/phase_timing.py */

@@ -89,9 +89,11 @@ struct Mkt {
     uint32_t has_u32, uinteger;
     int32_t t_step, lob_time, next_oid, last_price, has_trade, last_trade_price;
     uint32_t done_mask, flags;
-    int32_t n[2];
+    int32_t nb, na;              // resting orders per side (two scalars: a dynamically indexed array would force Mkt into scratch)
     int32_t seeded, hist_head;
 };
+__device__ __forceinline__ int mkt_n(const Mkt& m, int s) { return s == 0 ? m.nb : m.na; }
+__device__ __forceinline__ void mkt_set_n(Mkt& m, int s, int v) { if (s == 0) m.nb = v; else m.na = v; }
 
 __device__ __forceinline__ D ld_dec(const cda_dec& p) { return d_make(p.w[0], p.w[1], p.w[2], (int)p.exp, (int)p.sign); }
 __device__ __forceinline__ void st_dec(cda_dec& p, const D& d, uint32_t& flags) {
@@ -122,7 +124,7 @@ __device__ __forceinline__ double rng_double(Mkt& m) { return (double)(rng_next6
 __device__ __forceinline__ uint32_t ss_hashmix(uint32_t value, uint32_t& hc) { value ^= hc; hc *= 0x931e8875u; value *= hc; value ^= value >> 16; return value; }
 __device__ __forceinline__ uint32_t ss_mix(uint32_t x, uint32_t y) { uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y; r ^= r >> 16; return r; }
 // Generator(PCG64(SeedSequence(seed))) for an integer seed < 2^64
-__device__ void rng_seed(Mkt& m, uint64_t seed) {
+__device__ __forceinline__ void rng_seed(Mkt& m, uint64_t seed) {
     uint32_t e0 = (uint32_t)seed, e1 = (uint32_t)(seed >> 32);
     uint32_t pool[4], hc = 0x43b0d7e5u;
     pool[0] = ss_hashmix(e0, hc);
@@ -146,7 +148,7 @@ __device__ void rng_seed(Mkt& m, uint64_t seed) {
     m.rng_state = m.rng_state * pcg_mult() + m.rng_inc;
     m.has_u32 = 0; m.uinteger = 0;
 }
-__device__ int32_t rng_integers(Mkt& m, int32_t lo, int32_t hi_incl) {
+__device__ __forceinline__ int32_t rng_integers(Mkt& m, int32_t lo, int32_t hi_incl) {
     uint32_t rng = (uint32_t)(hi_incl - lo);
     if (rng == 0) return lo;
     uint32_t rng_excl = rng + 1u;
@@ -174,7 +176,7 @@ __device__ __forceinline__ double f64_set_hi(double x, int32_t h) {
     b = (b & 0xffffffffull) | ((unsigned long long)(uint32_t)h << 32);
     return __longlong_as_double((long long)b);
 }
-__device__ double glibc_log1p(double x) {
+__device__ __forceinline__ double glibc_log1p(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                  Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
@@ -210,7 +212,7 @@ __device__ double glibc_log1p(double x) {
     if (k == 0) return f - (hfsq - s * (hfsq + R));
     return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
 }
-__device__ double rng_std_normal(Mkt& m) {
+__device__ __forceinline__ double rng_std_normal(Mkt& m) {
     const double zr = 3.6541528853610087963519472518, inv_r = 0.27366123732975827203338247596;
     for (;;) {
         uint64_t u = rng_next64(m);
@@ -240,9 +242,9 @@ __device__ double rng_std_normal(Mkt& m) {
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 
 __device__ __forceinline__ uint32_t load_header_word(const uint32_t* hp, int lane) { return lane < H_WORDS ? hp[lane] : 0u; }
-__device__ void decode_header(uint32_t v, Mkt& m);
-__device__ void load_header(const uint32_t* hp, Mkt& m, int lane) { decode_header(load_header_word(hp, lane), m); }
-__device__ void decode_header(uint32_t v, Mkt& m) {
+__device__ __forceinline__ void decode_header(uint32_t v, Mkt& m);
+__device__ __forceinline__ void load_header(const uint32_t* hp, Mkt& m, int lane) { decode_header(load_header_word(hp, lane), m); }
+__device__ __forceinline__ void decode_header(uint32_t v, Mkt& m) {
     #define RL(i) ((uint32_t)__builtin_amdgcn_readlane((int)v, (i)))
     uint64_t slo = (uint64_t)RL(H_RNG_STATE_LO) | ((uint64_t)RL(H_RNG_STATE_LO + 1) << 32);
     uint64_t shi = (uint64_t)RL(H_RNG_STATE_HI) | ((uint64_t)RL(H_RNG_STATE_HI + 1) << 32);
@@ -253,11 +255,11 @@ __device__ void decode_header(uint32_t v, Mkt& m) {
     m.t_step = (int32_t)RL(H_T_STEP); m.lob_time = (int32_t)RL(H_LOB_TIME); m.next_oid = (int32_t)RL(H_NEXT_OID);
     m.last_price = (int32_t)RL(H_LAST_PRICE); m.has_trade = (int32_t)RL(H_HAS_TRADE); m.last_trade_price = (int32_t)RL(H_LAST_TRADE_PRICE);
     m.done_mask = RL(H_DONE_MASK); m.flags = RL(H_FLAGS);
-    m.n[0] = (int32_t)RL(H_N_BIDS); m.n[1] = (int32_t)RL(H_N_ASKS);
+    m.nb = (int32_t)RL(H_N_BIDS); m.na = (int32_t)RL(H_N_ASKS);
     m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD);
     #undef RL
 }
-__device__ void store_header(uint32_t* hp, const Mkt& m, int lane) {
+__device__ __forceinline__ void store_header(uint32_t* hp, const Mkt& m, int lane) {
     if (lane == 0) {
         hp[H_RNG_STATE_LO] = (uint32_t)m.rng_state; hp[H_RNG_STATE_LO + 1] = (uint32_t)(m.rng_state >> 32);
         hp[H_RNG_STATE_HI] = (uint32_t)(m.rng_state >> 64); hp[H_RNG_STATE_HI + 1] = (uint32_t)(m.rng_state >> 96);
@@ -267,7 +269,7 @@ __device__ void store_header(uint32_t* hp, const Mkt& m, int lane) {
         hp[H_T_STEP] = (uint32_t)m.t_step; hp[H_LOB_TIME] = (uint32_t)m.lob_time; hp[H_NEXT_OID] = (uint32_t)m.next_oid;
         hp[H_LAST_PRICE] = (uint32_t)m.last_price; hp[H_HAS_TRADE] = (uint32_t)m.has_trade; hp[H_LAST_TRADE_PRICE] = (uint32_t)m.last_trade_price;
         hp[H_DONE_MASK] = m.done_mask; hp[H_FLAGS] = m.flags;
-        hp[H_N_BIDS] = (uint32_t)m.n[0]; hp[H_N_ASKS] = (uint32_t)m.n[1];
+        hp[H_N_BIDS] = (uint32_t)m.nb; hp[H_N_ASKS] = (uint32_t)m.na;
         hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head;
     }
 }
@@ -288,31 +290,32 @@ __device__ __forceinline__ void finish_book_load(const int32_t* bp, const BookPr
     #pragma unroll
     for (int s = 0; s < 2; s++) {
         const int32_t* sp = bp + s * BOOK_FIELDS * CAP;
-        if (lane < m.n[s]) { bk.price[s][lane] = pre.v[s][0]; bk.qty[s][lane] = pre.v[s][1]; bk.oo[s][lane] = pre.v[s][2]; bk.ts[s][lane] = pre.v[s][3]; }
-        for (int i = lane + WAVE; i < m.n[s]; i += WAVE) {
+        const int ns = mkt_n(m, s);
+        if (lane < ns) { bk.price[s][lane] = pre.v[s][0]; bk.qty[s][lane] = pre.v[s][1]; bk.oo[s][lane] = pre.v[s][2]; bk.ts[s][lane] = pre.v[s][3]; }
+        for (int i = lane + WAVE; i < ns; i += WAVE) {
             bk.price[s][i] = sp[0 * CAP + i]; bk.qty[s][i] = sp[1 * CAP + i]; bk.oo[s][i] = sp[2 * CAP + i]; bk.ts[s][i] = sp[3 * CAP + i];
         }
     }
 }
-__device__ void load_book(const int32_t* bp, Book& bk, const Mkt& m, int lane) {
+__device__ __forceinline__ void load_book(const int32_t* bp, Book& bk, const Mkt& m, int lane) {
     #pragma unroll
     for (int s = 0; s < 2; s++) {
         const int32_t* sp = bp + s * BOOK_FIELDS * CAP;
-        for (int i = lane; i < m.n[s]; i += WAVE) {
+        for (int i = lane; i < mkt_n(m, s); i += WAVE) {
             bk.price[s][i] = sp[0 * CAP + i]; bk.qty[s][i] = sp[1 * CAP + i]; bk.oo[s][i] = sp[2 * CAP + i]; bk.ts[s][i] = sp[3 * CAP + i];
         }
     }
 }
-__device__ void store_book(int32_t* bp, const Book& bk, const Mkt& m, int lane) {
+__device__ __forceinline__ void store_book(int32_t* bp, const Book& bk, const Mkt& m, int lane) {
     #pragma unroll
     for (int s = 0; s < 2; s++) {
         int32_t* sp = bp + s * BOOK_FIELDS * CAP;
-        for (int i = lane; i < m.n[s]; i += WAVE) {
+        for (int i = lane; i < mkt_n(m, s); i += WAVE) {
             sp[0 * CAP + i] = bk.price[s][i]; sp[1 * CAP + i] = bk.qty[s][i]; sp[2 * CAP + i] = bk.oo[s][i]; sp[3 * CAP + i] = bk.ts[s][i];
         }
     }
 }
-__device__ void copy_words(uint32_t* dst, const uint32_t* src, int nwords, int lane) {
+__device__ __forceinline__ void copy_words(uint32_t* dst, const uint32_t* src, int nwords, int lane) {
     for (int i = lane; i < nwords; i += WAVE) dst[i] = src[i];
 }
 
@@ -320,7 +323,7 @@ __device__ void copy_words(uint32_t* dst, const uint32_t* src, int nwords, int l
 // Order book primitives (OrderTree / OrderList, orderbook/ordertree.py, orderlist.py)
 // ======================================================================================
 // remove `cnt` entries starting at `idx` (shift the tail down)
-__device__ void book_remove(Book& bk, int s, int& n, int idx, int cnt, int lane) {
+__device__ __forceinline__ void book_remove(Book& bk, int s, int n, int idx, int cnt, int lane) {
     for (int base = idx - (idx % WAVE); base < n - cnt; base += WAVE) {
         int i = base + lane;
         bool mv = i >= idx && i < n - cnt;
@@ -330,10 +333,9 @@ __device__ void book_remove(Book& bk, int s, int& n, int idx, int cnt, int lane)
         if (mv) { bk.price[s][i] = p; bk.qty[s][i] = q; bk.oo[s][i] = o; bk.ts[s][i] = t; }
         CDA_WSYNC();
     }
-    n -= cnt;
 }
 // OrderTree.insert_order (ordertree.py:44-58): tail of its price level.  false = side full.
-__device__ bool book_insert(Book& bk, int s, int& n, int price, int qty, int owner, int oid, int ts, int lane) {
+__device__ __forceinline__ bool book_insert(Book& bk, int s, int n, int price, int qty, int owner, int oid, int ts, int lane) {
     if (n >= CAP) return false;
     int pos = 0;
     for (int base = 0; base < n; base += WAVE) {
@@ -354,7 +356,6 @@ __device__ bool book_insert(Book& bk, int s, int& n, int price, int qty, int own
     // every lane writes the same values to the same slot (keeps each lane's view coherent)
     bk.price[s][pos] = price; bk.qty[s][pos] = qty; bk.oo[s][pos] = oo_pack(oid, owner); bk.ts[s][pos] = ts;
     CDA_WSYNC();
-    n += 1;
     return true;
 }
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
@@ -366,7 +367,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
     return v;
 }
 // Trader._get_order_ID (agent/trader.py:254-287): index on the side or -1
-__device__ int find_own_order(const Book& bk, int s, int n, int tr, int type, int price, int lane) {
+__device__ __forceinline__ int find_own_order(const Book& bk, int s, int n, int tr, int type, int price, int lane) {
     if (type == T_MODIFY) {                 // oldest own order: minimum timestamp (unique)
         uint64_t best = ~0ull;
         for (int i = lane; i < n; i += WAVE)
@@ -390,7 +391,7 @@ __device__ int find_own_order(const Book& bk, int s, int n, int tr, int type, in
 // ======================================================================================
 __device__ __forceinline__ D cal_profit(bool is_long, D mkt, D raw) { return is_long ? d_sub(mkt, raw) : d_sub(raw, mkt); }
 
-__device__ void process_acc(Acc& a, int32_t q, int32_t price, int own_side, bool counter, uint32_t& flags) {
+__device__ __forceinline__ void process_acc(Acc& a, int32_t q, int32_t price, int own_side, bool counter, uint32_t& flags) {
     a.num_trades += 1; a.num_trades_step += 1; if (counter) a.num_passive_fills_step += 1;
     D cash = ld_dec(a.cash), hold = ld_dec(a.hold), posval = ld_dec(a.posval), vwap = ld_dec(a.vwap);
     D p = d_price(price);
@@ -441,7 +442,7 @@ __device__ void process_acc(Acc& a, int32_t q, int32_t price, int own_side, bool
 }
 
 // one fill: counter party (passive) and initiator settle in two lanes at once (trader.py:303-345)
-__device__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t price, int init_side, uint32_t& flags, int lane) {
+__device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t price, int init_side, uint32_t& flags, int lane) {
     uint32_t f = 0;
     if (counter != tr) {
         if (lane == tr || lane == counter) process_acc(L.acc[lane], q, price, lane == tr ? init_side : init_side ^ 1, lane == counter, f);
@@ -459,7 +460,7 @@ __device__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t pric
 // (orderbook.py:61-194).  limit < 0 = market order.  Returns the unfilled quantity.
 __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, int32_t qty, int32_t limit, int lane) {
     int opp = own_side ^ 1;
-    int h = 0, nopp = m.n[opp];
+    int h = 0, nopp = mkt_n(m, opp);
     Book& bk = L.book;
     while (qty > 0 && h < nopp) {
         int32_t p = bk.price[opp][h];
@@ -470,7 +471,7 @@ __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, i
         m.has_trade = 1; m.last_trade_price = p;
         settle_fill(L, tr, c, f, p, own_side, m.flags, lane);
     }
-    if (h) book_remove(bk, opp, m.n[opp], 0, h, lane);
+    if (h) { book_remove(bk, opp, nopp, 0, h, lane); mkt_set_n(m, opp, nopp - h); }
     return qty;
 }
 
@@ -486,7 +487,7 @@ __device__ __forceinline__ void cancel_cash_transfer(Acc& a, int32_t price, int3
 }
 
 // Trader._order_approved (agent/trader.py:108-151), evaluated by lane `tr`, result broadcast
-__device__ bool order_approved(Lds& L, const Mkt& m, int tr, int side, int32_t size, int32_t price, int lane) {
+__device__ __forceinline__ bool order_approved(Lds& L, const Mkt& m, int tr, int side, int32_t size, int32_t price, int lane) {
     int ok = 0;
     if (lane == tr) {
         const Acc& a = L.acc[lane];
@@ -501,7 +502,7 @@ __device__ bool order_approved(Lds& L, const Mkt& m, int tr, int side, int32_t s
                 D est;
                 if (price < 0) {
                     int opp = side ^ 1;
-                    if (m.n[opp] > 0) est = d_price(L.book.price[opp][0]);
+                    if (mkt_n(m, opp) > 0) est = d_price(L.book.price[opp][0]);
                     else if (m.has_trade) est = d_price(m.last_trade_price);
                     else est = d_from_u32(1);
                 } else est = d_price(price);
@@ -533,7 +534,8 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
         m.lob_time += 1; m.next_oid += 1;                     // orderbook.py:39-44
         do_match = true;
     } else {
-        int idx = find_own_order(bk, side, m.n[side], tr, type, price, lane);
+        const int nside = mkt_n(m, side);
+        int idx = find_own_order(bk, side, nside, tr, type, price, lane);
         if (type == T_LIMIT && idx < 0) {                     // a new order
             m.lob_time += 1; m.next_oid += 1;
             do_match = true; can_rest = true; m_limit = price; rest_oid = m.next_oid;
@@ -542,7 +544,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
             int32_t ooid = (int32_t)((uint32_t)bk.oo[side][idx] >> 4);
             m.lob_time += 1;
             if (type == T_CANCEL) {                           // trader.py:237-252: cancel, then release the escrow
-                book_remove(bk, side, m.n[side], idx, 1, lane);
+                book_remove(bk, side, nside, idx, 1, lane); mkt_set_n(m, side, nside - 1);
                 if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
             } else {                                          // upsert / modify: release, then modify_order
                 if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
@@ -551,7 +553,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
                     CDA_WSYNC();
                     rest_price = price; rest_qty = size;
                 } else {                                      // remove and re-process with the same order id
-                    book_remove(bk, side, m.n[side], idx, 1, lane);
+                    book_remove(bk, side, nside, idx, 1, lane); mkt_set_n(m, side, nside - 1);
                     do_match = true; can_rest = true; m_limit = price; rest_oid = ooid;
                 }
             }
@@ -561,7 +563,8 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
     if (do_match) {
         int32_t left = match(L, m, tr, side, size, m_limit, lane);
         if (left > 0 && can_rest) {
-            if (book_insert(bk, side, m.n[side], price, left, tr, rest_oid, m.lob_time, lane)) { rest_price = price; rest_qty = left; }
+            const int nown = mkt_n(m, side);
+            if (book_insert(bk, side, nown, price, left, tr, rest_oid, m.lob_time, lane)) { mkt_set_n(m, side, nown + 1); rest_price = price; rest_qty = left; }
             else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
         }
     }
@@ -570,7 +573,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
 }
 
 // Exchg_Helper.mark_to_mkt + Calculate.mark_to_mkt (exchg_helper.py:56-66, calculate.py:35-55)
-__device__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
+__device__ __forceinline__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
     if (!m.has_trade) return;
     m.last_price = m.last_trade_price;
     uint32_t f = 0;
@@ -595,12 +598,12 @@ __device__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
 // Observation (State_Helper.set_agg_LOB, exchg/state_helper.py:113-214)
 // ======================================================================================
 // top-K aggregation per side -> L.lvl_px / L.lvl_sz (integers; 0 = empty level)
-__device__ void aggregate_levels(Lds& L, const Mkt& m, int lane) {
+__device__ __forceinline__ void aggregate_levels(Lds& L, const Mkt& m, int lane) {
     if (lane < 2 * CDA_K_ROWS) { (&L.lvl_px[0][0])[lane] = 0; (&L.lvl_sz[0][0])[lane] = 0; }
     CDA_WSYNC();
     #pragma unroll
     for (int s = 0; s < 2; s++) {
-        int carry = 0, n = m.n[s];
+        int carry = 0, n = mkt_n(m, s);
         for (int base = 0; base < n && carry <= CDA_K_ROWS; base += WAVE) {
             int i = base + lane;
             bool valid = i < n;
@@ -627,7 +630,7 @@ __device__ __forceinline__ float raw_value(const Lds& L, int j) {
     return (row >= 2 && v != 0) ? -f : f;
 }
 // one normalised snapshot value for lane j in [0,42)
-__device__ float snapshot_value(const Lds& L, const Mkt& m, int tick, int j) {
+__device__ __forceinline__ float snapshot_value(const Lds& L, const Mkt& m, int tick, int j) {
     double l1_bid = (double)L.lvl_px[0][0], l1_ask = (double)L.lvl_px[1][0], M;
     bool two = l1_bid > 0 && l1_ask > 0;
     if (two) M = (l1_bid + l1_ask) / 2.0;

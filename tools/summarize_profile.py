@@ -41,3 +41,37 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
                 cnt[row["Counter_Name"]] += 1
         for k in sorted(acc):
             print(f"{sub}: {k} avg/dispatch = {acc[k]/cnt[k]:.1f}  (n={cnt[k]})")
+
+print("== PMC calibration: 1 GiB per launch, 4 B per lane coalesced (tools/pmc_calib.py) ==")
+calib = {}
+for sub, kern, ctr in (("calib_fetch", "k_calib_read", "FETCH_SIZE"), ("calib_write", "k_calib_write", "WRITE_SIZE")):
+    for f in find(sub, "*counter_collection.csv"):
+        vals = []
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if kern in row.get("Kernel_Name", "") and row["Counter_Name"] == ctr:
+                    vals.append(float(row["Counter_Value"]))
+        if vals:
+            avg = sum(vals) / len(vals)
+            calib[ctr] = (1 << 30) / avg
+            print(f"{ctr}: avg counter per 1 GiB launch = {avg:.1f} -> {calib[ctr]:.1f} bytes per counter unit (n={len(vals)})")
+import json
+res = {}
+for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    for f in find(sub, "*counter_collection.csv"):
+        vals = []
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "k_step" in row.get("Kernel_Name", "") and row["Counter_Name"] == ctr:
+                    vals.append(float(row["Counter_Value"]))
+        if vals:
+            res[ctr] = sum(vals) / len(vals)
+if res and calib:
+    fetch_b = res.get("FETCH_SIZE", 0) * calib.get("FETCH_SIZE", 1024)
+    write_b = res.get("WRITE_SIZE", 0) * calib.get("WRITE_SIZE", 1024)
+    out_json = {"kernel": "k_step", "workload": "bench.py default (4096 markets x 4 agents)", "fetch_counter": res.get("FETCH_SIZE"),
+                "write_counter": res.get("WRITE_SIZE"), "bytes_per_fetch_unit": calib.get("FETCH_SIZE"), "bytes_per_write_unit": calib.get("WRITE_SIZE"),
+                "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b, "hbm_bytes_per_launch": fetch_b + write_b}
+    print("k_step HBM traffic per launch (calibrated):", json.dumps(out_json))
+    with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+        json.dump(out_json, fh, indent=1)
