@@ -195,6 +195,16 @@ def main():
         value = total_agent_steps / elapsed
         alg_bytes = (ALG_BYTES_CONST + ALG_BYTES_PER_AGENT * A) * N            # per launch (one rank)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, calibrated on a known byte count in
+        # this library's access pattern by tools/profile_gpu.sh); a committed measurement of THIS workload, not live
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as fh:
+                pmc = json.load(fh)
+            if N == 4096 and A == 4 and not args.info:
+                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc, calibrated)"
+        except Exception:  # noqa: BLE001
+            pass
         out = {
             "metric": "agent-steps/sec (whole node), 4 agents x N parallel markets",
             "value": value, "unit": "agent-steps/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
@@ -206,7 +216,7 @@ def main():
                        "collective": "all_gather(obs,reward)" if gather else "none",
                        "flagged_markets": n_flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_step", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -30,8 +30,15 @@ enum { S_BID = 0, S_ASK = 1, S_NONE = 2 };
 
 // Cross-lane visibility of LDS written by other lanes of the same wave: the hardware executes a
 // wave's LDS operations in order, so only the compiler has to be stopped from forwarding values.
+#ifdef CDA_WSYNC_FENCE
 #define CDA_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+// A compiler-only barrier is enough: LDS instructions of one wave are issued and executed in program order, so a
+// later ds_read always sees an earlier ds_write of ANY lane; nothing has to be drained (a fence would also wait for
+// the unrelated global loads/stores in flight).
+#define CDA_WSYNC() do { __asm__ volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); __asm__ volatile("" ::: "memory"); } while (0)
+#endif
 
 // ---- HBM record of one market (see DESIGN.md "Data layout") --------------------------------
 // header words (u32)
