@@ -1,49 +1,91 @@
-"""Random-agent driver - the build's counterpart of the reference's `CDA_rand.run_random`
-(gym_continuousDoubleAuction/CDA_rand.py:40-85): build the env, reset(seed), sample every agent's action
-from its action space each step, step to the horizon or until an `__all__` flag is raised.
+"""Random-agent driver for the MI355X env (the role `CDA_rand.run_random` plays in the reference,
+gym_continuousDoubleAuction/CDA_rand.py:40-85: reset with a seed, draw every agent's action from its action
+space, step until the horizon or an `__all__` flag).
 
-    python -m gym_continuousdoubleauction_amd.cda_rand --agents 4 --steps 1000 --seed 123
+Two modes:
+  * `run_random(...)`   one market through the dict-shaped `CDAEnv` facade (BASELINE config #1 plumbing);
+  * `run_random_batched(...)`  N markets through `CDAVecEnv` with the same uniform action law sampled on the GPU.
+
+    python -m gym_continuousdoubleauction_amd.cda_rand --agents 4 --steps 1000 --seed 123 [--markets 4096]
 """
 import argparse
 import sys
+import time
 
 # config/cli_defaults.json:9-14 of the reference
-CLI_DEFAULTS = {"num_agents": 4, "max_step": 1000, "init_cash": 1000000, "is_render": False, "seed": None}
+DEFAULT_AGENTS, DEFAULT_STEPS, DEFAULT_CASH = 4, 1000, 1000000
+
+
+def _env_config(num_agents, max_step, init_cash):
+    return {"num_of_agents": DEFAULT_AGENTS if num_agents is None else num_agents,
+            "max_step": DEFAULT_STEPS if max_step is None else max_step,
+            "init_cash": DEFAULT_CASH if init_cash is None else init_cash, "is_render": False}
 
 
 def run_random(num_agents=None, max_step=None, init_cash=None, is_render=None, seed=None, device="cuda:0"):
-    """Returns the number of steps actually taken (same contract as the reference)."""
+    """Single market, dict API.  Returns the number of steps taken (the reference's contract)."""
     from .env import CDAEnv
-    num_agents = CLI_DEFAULTS["num_agents"] if num_agents is None else num_agents
-    max_step = CLI_DEFAULTS["max_step"] if max_step is None else max_step
-    init_cash = CLI_DEFAULTS["init_cash"] if init_cash is None else init_cash
-    is_render = CLI_DEFAULTS["is_render"] if is_render is None else is_render
-    env = CDAEnv({"num_of_agents": num_agents, "init_cash": init_cash, "max_step": max_step, "is_render": is_render},
-                 device=device)
+    cfg = _env_config(num_agents, max_step, init_cash)
+    env = CDAEnv(cfg, device=device)
+    try:
+        env.reset(seed=seed)
+        space = env.action_spaces[env.agents[0]]            # one shared Dict space for every agent
+        if seed is not None:
+            space.seed(seed)
+        taken = 0
+        while taken < cfg["max_step"]:
+            _, _, terminateds, truncateds, _ = env.step({aid: space.sample() for aid in env.agents})
+            taken += 1
+            if terminateds["__all__"] or truncateds["__all__"]:
+                break
+        return taken
+    finally:
+        env.close()
+
+
+def run_random_batched(n_markets, num_agents=None, max_step=None, init_cash=None, seed=0, device="cuda:0"):
+    """N markets in lockstep; actions ~ the RandomRLModule law (train/model/model_handler.py:38-53) drawn on the device.
+    Returns (steps, agent_steps_per_second)."""
+    import torch
+    from .vec_env import CDAVecEnv
+    cfg = _env_config(num_agents, max_step, init_cash)
+    env = CDAVecEnv(cfg, n_markets=n_markets, device=device, with_info=False)
+    n, a = env.n_markets, env.num_agents
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
     env.reset(seed=seed)
-    if seed is not None:
-        for agent_id in env.agents:
-            env.action_spaces[agent_id].seed(seed)
-    steps = 0
-    for _ in range(max_step):
-        actions = {agent_id: env.action_spaces[agent_id].sample() for agent_id in env.agents}
-        _obs, _rewards, terminateds, truncateds, _infos = env.step(actions)
+    torch.cuda.synchronize()
+    t0, steps = time.perf_counter(), 0
+    for _ in range(cfg["max_step"]):
+        _, _, term, trunc, _ = env.step(
+            torch.randint(0, 9, (n, a), generator=gen, device=device, dtype=torch.int32),
+            torch.rand((n, a), generator=gen, device=device) * 2.0 - 1.0,
+            torch.rand((n, a), generator=gen, device=device),
+            torch.randint(0, 10, (n, a), generator=gen, device=device, dtype=torch.int32),
+            torch.randint(0, 3, (n, a), generator=gen, device=device, dtype=torch.int32))
         steps += 1
-        if terminateds.get("__all__", False) or truncateds.get("__all__", False):
-            break
+        if steps == cfg["max_step"] and not bool(trunc.all()):
+            raise RuntimeError("every market must truncate exactly on max_step")
+    torch.cuda.synchronize()
+    rate = n * a * steps / (time.perf_counter() - t0)
     env.close()
-    return steps
+    return steps, rate
 
 
 def main(argv=None):
-    p = argparse.ArgumentParser(description="Random-agent CDA simulation on one MI355X.")
-    p.add_argument("--agents", type=int, default=CLI_DEFAULTS["num_agents"])
-    p.add_argument("--steps", type=int, default=CLI_DEFAULTS["max_step"])
-    p.add_argument("--init-cash", type=int, default=CLI_DEFAULTS["init_cash"])
-    p.add_argument("--seed", type=int, default=CLI_DEFAULTS["seed"])
-    args = p.parse_args(argv)
-    steps = run_random(args.agents, args.steps, args.init_cash, False, args.seed)
-    print(f"completed {steps} steps with {args.agents} random agents.")
+    ap = argparse.ArgumentParser(description="Random-agent CDA simulation on one MI355X.")
+    ap.add_argument("--agents", type=int, default=DEFAULT_AGENTS)
+    ap.add_argument("--steps", type=int, default=DEFAULT_STEPS)
+    ap.add_argument("--init-cash", type=int, default=DEFAULT_CASH)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--markets", type=int, default=1, help="> 1 runs the batched env")
+    args = ap.parse_args(argv)
+    if args.markets > 1:
+        steps, rate = run_random_batched(args.markets, args.agents, args.steps, args.init_cash, seed=args.seed or 0)
+        print(f"{args.markets} markets x {args.agents} random agents: {steps} steps, {rate / 1e6:.1f} M agent-steps/s")
+    else:
+        steps = run_random(args.agents, args.steps, args.init_cash, seed=args.seed)
+        print(f"completed {steps} steps with {args.agents} random agents.")
     return 0
 
 
