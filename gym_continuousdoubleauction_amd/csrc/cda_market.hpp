@@ -398,11 +398,26 @@ __device__ __forceinline__ int find_own_order(const Book& bk, int s, int n, int 
 // ======================================================================================
 __device__ __forceinline__ D cal_profit(bool is_long, D mkt, D raw) { return is_long ? d_sub(mkt, raw) : d_sub(raw, mkt); }
 
+// Memory-to-memory style on purpose: every statement loads its operands from the account record in LDS and
+// stores its result back, so that almost nothing is live across the (rare) calls into the rounding helpers.
+// Keeping the whole account in registers made this function need 165 VGPRs (callee-saved registers are sparse
+// in the AMDGPU calling convention) and capped the kernel at 3-4 waves per SIMD.
+#define ACC_UPD(field, expr) do { D _r = (expr); st_dec(a.field, _r, flags); } while (0)
+__device__ __forceinline__ void xfer_inc(Acc& a, bool counter, D v, uint32_t& flags) {   // size_increase_cash_transfer (cash_processor.py:31-36)
+    if (!counter) ACC_UPD(cash, d_sub(ld_dec(a.cash), v)); else ACC_UPD(hold, d_sub(ld_dec(a.hold), v));
+}
+__device__ __forceinline__ void xfer_dec(Acc& a, bool counter, D v, uint32_t& flags) {   // size_decrease_cash_transfer (cash_processor.py:38-45)
+    ACC_UPD(cash, d_add(ld_dec(a.cash), v));
+    if (counter) { ACC_UPD(hold, d_sub(ld_dec(a.hold), v)); ACC_UPD(cash, d_add(ld_dec(a.cash), v)); }
+}
+// position_val = raw + profit with raw = n * VWAP, mkt = n * price (account.py:128-131, :141-143, :155-157)
+__device__ __forceinline__ D posval_from(Acc& a, uint32_t n, int32_t price, bool is_long, D* mkt_out) {
+    D raw = d_mul_int(ld_dec(a.vwap), n), mkt = d_mul_u32(d_price(price), n, 0);
+    if (mkt_out) *mkt_out = mkt;
+    return d_add(raw, cal_profit(is_long, mkt, raw));
+}
 __device__ __forceinline__ void process_acc(Acc& a, int32_t q, int32_t price, int own_side, bool counter, uint32_t& flags) {
     a.num_trades += 1; a.num_trades_step += 1; if (counter) a.num_passive_fills_step += 1;
-    D cash = ld_dec(a.cash), hold = ld_dec(a.hold), posval = ld_dec(a.posval), vwap = ld_dec(a.vwap);
-    D p = d_price(price);
-    D tv = d_mul_u32(p, (uint32_t)q, 0);                 // Decimal(q) * price
     int32_t pos = a.net_position;
     uint32_t ap = (uint32_t)(pos < 0 ? -pos : pos);
     bool is_long = pos > 0;
@@ -410,39 +425,36 @@ __device__ __forceinline__ void process_acc(Acc& a, int32_t q, int32_t price, in
     if (pos > 0) mode = own_side == S_BID ? 1 : (pos >= q ? 2 : 3);
     else if (pos < 0) mode = own_side == S_ASK ? 1 : (ap >= (uint32_t)q ? 2 : 3);
     else mode = 0;
-    D xi = d_zero(), xd = d_zero();                     // amounts for XFER_INC / XFER_DEC (applied below)
-    bool do_inc = false, do_dec = false;
-    if (mode == 0) { posval = d_add(posval, tv); vwap = p; xi = tv; do_inc = true; }
-    else if (mode == 1 || (mode == 2 && ap > (uint32_t)q)) {
+    if (mode == 0) {                                     // _neutral (account.py:173-176)
+        D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
+        ACC_UPD(posval, d_add(ld_dec(a.posval), tv));
+        st_dec(a.vwap, d_price(price), flags);
+        xfer_inc(a, counter, tv, flags);
+    } else if (mode == 1 || (mode == 2 && ap > (uint32_t)q)) {   // _size_increase / _size_decrease (account.py:124-133, :151-161)
         uint32_t n = mode == 1 ? ap + (uint32_t)q : ap - (uint32_t)q;
-        D num = d_mul_int(vwap, ap);
-        num = mode == 1 ? d_add(num, tv) : d_sub(num, tv);
-        vwap = d_div_u32(num, n);
-        D raw = d_mul_int(vwap, n), mkt = d_mul_u32(p, n, 0);
-        posval = d_add(raw, cal_profit(is_long, mkt, raw));
-        if (mode == 1) { xi = tv; do_inc = true; } else { xd = tv; do_dec = true; }
+        {
+            D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
+            D num = d_mul_int(ld_dec(a.vwap), ap);
+            num = mode == 1 ? d_add(num, tv) : d_sub(num, tv);
+            ACC_UPD(vwap, d_div_u32(num, n));
+        }
+        ACC_UPD(posval, posval_from(a, n, price, is_long, nullptr));
+        D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
+        if (mode == 1) xfer_inc(a, counter, tv, flags); else xfer_dec(a, counter, tv, flags);
     } else {
         // _covered (account.py:135-149)
-        D raw = d_mul_int(vwap, ap), mkt = d_mul_u32(p, ap, 0);
-        posval = d_add(raw, cal_profit(is_long, mkt, raw));
-        cash = d_add(cash, d_sub(posval, mkt));
-        posval = d_zero(); vwap = d_zero();
-        if (mode == 2) { xd = tv; do_dec = true; }
+        D mkt;
+        D pv = posval_from(a, ap, price, is_long, &mkt);
+        ACC_UPD(cash, d_add(ld_dec(a.cash), d_sub(pv, mkt)));      // size_zero_cash_transfer (cash_processor.py:47-53)
+        st_dec(a.posval, d_zero(), flags); st_dec(a.vwap, d_zero(), flags);
+        if (mode == 2) xfer_dec(a, counter, d_mul_u32(d_price(price), (uint32_t)q, 0), flags);
         else {                                           // _covered_side_chg (account.py:163-171)
-            xd = mkt; do_dec = true;
-            uint32_t nw = (uint32_t)q - ap;
-            posval = d_mul_u32(p, nw, 0); vwap = p;
-            xi = posval; do_inc = true;
+            xfer_dec(a, counter, mkt, flags);
+            D npv = d_mul_u32(d_price(price), (uint32_t)q - ap, 0);
+            st_dec(a.posval, npv, flags); st_dec(a.vwap, d_price(price), flags);
+            xfer_inc(a, counter, npv, flags);
         }
     }
-    if (do_dec) {                                        // size_decrease_cash_transfer (cash_processor.py:38-45)
-        if (!counter) cash = d_add(cash, xd);
-        else { cash = d_add(cash, xd); hold = d_sub(hold, xd); cash = d_add(cash, xd); }
-    }
-    if (do_inc) {                                        // size_increase_cash_transfer (cash_processor.py:31-36)
-        if (!counter) cash = d_sub(cash, xi); else hold = d_sub(hold, xi);
-    }
-    st_dec(a.cash, cash, flags); st_dec(a.hold, hold, flags); st_dec(a.posval, posval, flags); st_dec(a.vwap, vwap, flags);
     int64_t np = (int64_t)pos + (own_side == S_BID ? (int64_t)q : -(int64_t)q);
     if (np > 2147483647LL || np < -2147483647LL) flags |= CDA_FLAG_INT_OVERFLOW;
     a.net_position = (int32_t)np;
