@@ -23,8 +23,14 @@ using namespace cda;
 #ifndef CDA_WPB
 #define CDA_WPB 4            // markets (waves) per workgroup
 #endif
+// The step kernel is built twice: register-budgeted for 4 waves per SIMD (128 VGPRs, no spills: fastest while
+// every market-wave of the launch is resident at once, i.e. up to 256 CUs x 16 = 4096 markets) and for 6 waves per
+// SIMD (80 VGPRs, a few spills: +15..22 % throughput once the batch no longer fits at 4 per SIMD).
 #ifndef CDA_MIN_WAVES
-#define CDA_MIN_WAVES 4      // waves per SIMD the step kernel is register-budgeted for (LDS allows 4)
+#define CDA_MIN_WAVES 4
+#endif
+#ifndef CDA_MIN_WAVES_LARGE
+#define CDA_MIN_WAVES_LARGE 6
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -120,7 +126,8 @@ struct StepArgs {
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
+template <int MINW>
+__global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Params P, StepArgs S) {
     int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit
@@ -380,6 +387,7 @@ __global__ void k_selftest_rng(uint64_t seed, int lo, int hi, int n_steps, int n
 struct cda_env {
     Params P;
     int device;
+    int resident_markets_at_min_waves;   // CUs x 4 SIMDs x CDA_MIN_WAVES: batches up to this size use the 128-VGPR build
     uint8_t* arena;
     size_t arena_bytes;
 };
@@ -438,6 +446,12 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     cda_env* e = (cda_env*)calloc(1, sizeof *e);
     if (!e) return CDA_ERR_NOMEM;
     e->device = device;
+    {
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        e->resident_markets_at_min_waves = cus * 4 * CDA_MIN_WAVES;
+    }
     Params& P = e->P;
     P.cfg = *cfg; P.n_markets = n_markets;
     P.mkt_mul = (float)((double)(cfg->mkt_max_size - cfg->min_size) / 2.0);
@@ -485,7 +499,10 @@ int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const 
     S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
     if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
     S.phase_cycles = g_phase_cycles;
-    hipLaunchKernelGGL(k_step, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, S);
+    if (e->P.n_markets <= e->resident_markets_at_min_waves)
+        hipLaunchKernelGGL(k_step<CDA_MIN_WAVES>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, S);
+    else
+        hipLaunchKernelGGL(k_step<CDA_MIN_WAVES_LARGE>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, S);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -532,11 +549,11 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
     const int32_t* bp = (const int32_t*)(rec + P.lay.book_off);
     for (int sd = 0; sd < 2; sd++) {
         int n = sd == 0 ? s->n_bids : s->n_asks;
-        const int32_t* sp = bp + sd * BOOK_FIELDS * CAP;
         for (int i = 0; i < n && i < CAP; i++) {
             cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
-            o->price = sp[0 * CAP + i]; o->qty = sp[1 * CAP + i]; o->owner = sp[2 * CAP + i] & 15;
-            o->order_id = (int32_t)((uint32_t)sp[2 * CAP + i] >> 4); o->timestamp = sp[3 * CAP + i];
+            const int ph = book_phys(sd, i);
+            o->price = bp[0 * CAP + ph]; o->qty = bp[1 * CAP + ph]; o->owner = bp[2 * CAP + ph] & 15;
+            o->order_id = (int32_t)((uint32_t)bp[2 * CAP + ph] >> 4); o->timestamp = bp[3 * CAP + ph];
         }
     }
     const Acc* ap = (const Acc*)(rec + P.lay.acc_off);
@@ -560,7 +577,7 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
 
 int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
-    if (s->n_bids < 0 || s->n_bids > CAP || s->n_asks < 0 || s->n_asks > CAP) return CDA_ERR_INVALID;
+    if (s->n_bids < 0 || s->n_asks < 0 || s->n_bids + s->n_asks > CAP) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     const Params& P = e->P;
     uint8_t* rec = (uint8_t*)calloc(1, (size_t)P.lay.stride);
@@ -578,11 +595,11 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
     int32_t* bp = (int32_t*)(rec + P.lay.book_off);
     for (int sd = 0; sd < 2; sd++) {
         int n = sd == 0 ? s->n_bids : s->n_asks;
-        int32_t* sp = bp + sd * BOOK_FIELDS * CAP;
         for (int i = 0; i < n; i++) {
             const cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
             if (o->owner < 0 || o->owner >= CDA_MAX_AGENTS || o->order_id < 0 || o->order_id >= (1 << 27)) { free(rec); return CDA_ERR_INVALID; }
-            sp[0 * CAP + i] = o->price; sp[1 * CAP + i] = o->qty; sp[2 * CAP + i] = (int32_t)(((uint32_t)o->order_id << 4) | (uint32_t)o->owner); sp[3 * CAP + i] = o->timestamp;
+            const int ph = book_phys(sd, i);
+            bp[0 * CAP + ph] = o->price; bp[1 * CAP + ph] = o->qty; bp[2 * CAP + ph] = (int32_t)(((uint32_t)o->order_id << 4) | (uint32_t)o->owner); bp[3 * CAP + ph] = o->timestamp;
         }
     }
     Acc* ap = (Acc*)(rec + P.lay.acc_off);

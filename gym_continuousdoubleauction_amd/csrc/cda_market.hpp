@@ -57,13 +57,23 @@ struct Acc {                     // 144 B, 16-byte aligned; lane a owns account 
 };
 static_assert(sizeof(Acc) == 144, "Acc layout");
 
-struct Book {                    // LDS image of the two sides, queue order (best first, FIFO in a level)
-    int32_t price[2][CAP];
-    int32_t qty[2][CAP];
-    int32_t oo[2][CAP];          // (order_id << 4) | owner   (owner < 16, order_id < 2^27)
-    int32_t ts[2][CAP];
+// The two sides share ONE pool of CAP slots per field: bids grow up from slot 0, asks grow down from slot CAP-1
+// (logical index i of the ask side lives in physical slot CAP-1-i).  Halves the LDS footprint of a market
+// (4 KB), which is what lets more than 4 waves per SIMD be resident; capacity is CAP resting orders per market.
+__host__ __device__ constexpr int book_phys(int s, int i) { return s == 0 ? i : CAP - 1 - i; }
+struct BookField {
+    int32_t v[CAP];
+    struct Row { int32_t* base; int s; __device__ __forceinline__ int32_t& operator[](int i) const { return base[book_phys(s, i)]; } };
+    struct CRow { const int32_t* base; int s; __device__ __forceinline__ const int32_t& operator[](int i) const { return base[book_phys(s, i)]; } };
+    __device__ __forceinline__ Row operator[](int s) { return Row{v, s}; }
+    __device__ __forceinline__ CRow operator[](int s) const { return CRow{v, s}; }
 };
-constexpr int BOOK_BYTES = sizeof(Book);   // 8192
+struct Book {                    // LDS image of the book, queue order per side (best first, FIFO in a level)
+    BookField price, qty;
+    BookField oo;                // (order_id << 4) | owner   (owner < 16, order_id < 2^27)
+    BookField ts;
+};
+constexpr int BOOK_BYTES = sizeof(Book);   // 4096
 constexpr int BOOK_FIELDS = 4;
 __device__ __forceinline__ int oo_owner(int32_t oo) { return oo & 15; }
 __device__ __forceinline__ int oo_pack(int32_t oid, int owner) { return (int32_t)(((uint32_t)oid << 4) | (uint32_t)owner); }
@@ -280,7 +290,7 @@ __device__ __forceinline__ void store_header(uint32_t* hp, const Mkt& m, int lan
         hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head;
     }
 }
-// book record in HBM: [side][field][CAP] int32 ; only the live prefix of each side moves.
+// book record in HBM: [field][CAP] int32, pooled like the LDS image; only the live prefix of each side moves.
 // Prefetch form: the first 64 entries of every array are requested BEFORE the header (which holds the
 // counts) has arrived, so the two HBM round trips of a naive load overlap into one.
 struct BookPrefetch { int32_t v[2][BOOK_FIELDS]; };
@@ -289,36 +299,36 @@ __device__ __forceinline__ BookPrefetch prefetch_book(const int32_t* bp, int lan
     #pragma unroll
     for (int s = 0; s < 2; s++) {
         #pragma unroll
-        for (int f = 0; f < BOOK_FIELDS; f++) r.v[s][f] = bp[(s * BOOK_FIELDS + f) * CAP + lane];
+        for (int f = 0; f < BOOK_FIELDS; f++) r.v[s][f] = bp[f * CAP + book_phys(s, lane)];
     }
     return r;
 }
 __device__ __forceinline__ void finish_book_load(const int32_t* bp, const BookPrefetch& pre, Book& bk, const Mkt& m, int lane) {
     #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const int32_t* sp = bp + s * BOOK_FIELDS * CAP;
         const int ns = mkt_n(m, s);
         if (lane < ns) { bk.price[s][lane] = pre.v[s][0]; bk.qty[s][lane] = pre.v[s][1]; bk.oo[s][lane] = pre.v[s][2]; bk.ts[s][lane] = pre.v[s][3]; }
         for (int i = lane + WAVE; i < ns; i += WAVE) {
-            bk.price[s][i] = sp[0 * CAP + i]; bk.qty[s][i] = sp[1 * CAP + i]; bk.oo[s][i] = sp[2 * CAP + i]; bk.ts[s][i] = sp[3 * CAP + i];
+            const int ph = book_phys(s, i);
+            bk.price[s][i] = bp[0 * CAP + ph]; bk.qty[s][i] = bp[1 * CAP + ph]; bk.oo[s][i] = bp[2 * CAP + ph]; bk.ts[s][i] = bp[3 * CAP + ph];
         }
     }
 }
 __device__ __forceinline__ void load_book(const int32_t* bp, Book& bk, const Mkt& m, int lane) {
     #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const int32_t* sp = bp + s * BOOK_FIELDS * CAP;
         for (int i = lane; i < mkt_n(m, s); i += WAVE) {
-            bk.price[s][i] = sp[0 * CAP + i]; bk.qty[s][i] = sp[1 * CAP + i]; bk.oo[s][i] = sp[2 * CAP + i]; bk.ts[s][i] = sp[3 * CAP + i];
+            const int ph = book_phys(s, i);
+            bk.price[s][i] = bp[0 * CAP + ph]; bk.qty[s][i] = bp[1 * CAP + ph]; bk.oo[s][i] = bp[2 * CAP + ph]; bk.ts[s][i] = bp[3 * CAP + ph];
         }
     }
 }
 __device__ __forceinline__ void store_book(int32_t* bp, const Book& bk, const Mkt& m, int lane) {
     #pragma unroll
     for (int s = 0; s < 2; s++) {
-        int32_t* sp = bp + s * BOOK_FIELDS * CAP;
         for (int i = lane; i < mkt_n(m, s); i += WAVE) {
-            sp[0 * CAP + i] = bk.price[s][i]; sp[1 * CAP + i] = bk.qty[s][i]; sp[2 * CAP + i] = bk.oo[s][i]; sp[3 * CAP + i] = bk.ts[s][i];
+            const int ph = book_phys(s, i);
+            bp[0 * CAP + ph] = bk.price[s][i]; bp[1 * CAP + ph] = bk.qty[s][i]; bp[2 * CAP + ph] = bk.oo[s][i]; bp[3 * CAP + ph] = bk.ts[s][i];
         }
     }
 }
@@ -342,8 +352,8 @@ __device__ __forceinline__ void book_remove(Book& bk, int s, int n, int idx, int
     }
 }
 // OrderTree.insert_order (ordertree.py:44-58): tail of its price level.  false = side full.
-__device__ __forceinline__ bool book_insert(Book& bk, int s, int n, int price, int qty, int owner, int oid, int ts, int lane) {
-    if (n >= CAP) return false;
+__device__ __forceinline__ bool book_insert(Book& bk, int s, int n, int n_other, int price, int qty, int owner, int oid, int ts, int lane) {
+    if (n + n_other >= CAP) return false;             // the pool is shared by both sides
     int pos = 0;
     for (int base = 0; base < n; base += WAVE) {
         int i = base + lane;
@@ -583,7 +593,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
         int32_t left = match(L, m, tr, side, size, m_limit, lane);
         if (left > 0 && can_rest) {
             const int nown = mkt_n(m, side);
-            if (book_insert(bk, side, nown, price, left, tr, rest_oid, m.lob_time, lane)) { mkt_set_n(m, side, nown + 1); rest_price = price; rest_qty = left; }
+            if (book_insert(bk, side, nown, mkt_n(m, side ^ 1), price, left, tr, rest_oid, m.lob_time, lane)) { mkt_set_n(m, side, nown + 1); rest_price = price; rest_qty = left; }
             else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
         }
     }

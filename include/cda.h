@@ -36,7 +36,7 @@ extern "C" {
 #define CDA_MAX_HIST      16            /* n_hist upper bound of this build (reference default 4) */
 #define CDA_MAX_AGENTS    16            /* agents per market upper bound of this build */
 #ifndef CDA_BOOK_CAP
-#define CDA_BOOK_CAP      256           /* resting orders per side per market (reference: unbounded) */
+#define CDA_BOOK_CAP      256           /* resting orders per market, both sides together (reference: unbounded) */
 #endif
 #define CDA_NUM_REWARD_TERMS 5          /* reward_helper.py:75-81 */
 
@@ -50,7 +50,7 @@ typedef enum cda_status {
 } cda_status;
 
 /* Per-market sticky flag bits reported by cda_last_flags. */
-#define CDA_FLAG_BOOK_OVERFLOW   0x1u   /* a rest was dropped: side already held CDA_BOOK_CAP orders */
+#define CDA_FLAG_BOOK_OVERFLOW   0x1u   /* a rest was dropped: the market already held CDA_BOOK_CAP orders */
 #define CDA_FLAG_INT_OVERFLOW    0x2u   /* a size/position/price left the int32 / 2^24 domain */
 #define CDA_FLAG_DEC_DOMAIN      0x4u   /* a ledger value left the 28-digit / exponent domain */
 

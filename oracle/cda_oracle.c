@@ -411,8 +411,8 @@ static void side_remove(side_t* sd, int idx) {
     sd->n--;
 }
 /* OrderTree.insert_order (orderbook/ordertree.py:44-58): tail of its price level */
-static int side_insert(side_t* sd, int s, order_t o) {
-    if (sd->n >= CDA_BOOK_CAP) return 0;
+static int side_insert(side_t* sd, const side_t* other, int s, order_t o) {
+    if (sd->n + other->n >= CDA_BOOK_CAP) return 0;       /* the build's capacity: CDA_BOOK_CAP resting orders per market */
     int pos = 0;
     while (pos < sd->n && better_or_equal(s, sd->o[pos].price, o.price)) pos++;
     for (int i = sd->n; i > pos; i--) sd->o[i] = sd->o[i - 1];
@@ -560,7 +560,7 @@ static void modify_order(market_t* m, int tr, int side, int idx, int32_t new_pri
     int32_t left = match(m, side, new_qty, new_price, fills, nf);
     if (left > 0) {
         order_t o; o.price = new_price; o.qty = left; o.owner = old.owner; o.order_id = old.order_id; o.timestamp = m->lob_time;
-        if (side_insert(sd, side, o)) { *rest_price = new_price; *rest_qty = left; }
+        if (side_insert(sd, &m->side[side ^ 1], side, o)) { *rest_price = new_price; *rest_qty = left; }
         else m->flags |= CDA_FLAG_BOOK_OVERFLOW;
     }
 }
@@ -583,7 +583,7 @@ static void place_order(market_t* m, int tr, int type, int side, int32_t size, i
             int32_t left = match(m, side, size, price, fills, &nf);
             if (left > 0) {
                 order_t o; o.price = price; o.qty = left; o.owner = tr; o.order_id = m->next_order_id; o.timestamp = m->lob_time;
-                if (side_insert(&m->side[side], side, o)) { rest_price = price; rest_qty = left; }
+                if (side_insert(&m->side[side], &m->side[side ^ 1], side, o)) { rest_price = price; rest_qty = left; }
                 else m->flags |= CDA_FLAG_BOOK_OVERFLOW;
             }
         } else modify_order(m, tr, side, idx, price, size, fills, &nf, &rest_price, &rest_qty);
@@ -914,7 +914,7 @@ int oracle_get_state(oracle_env* e, int32_t market, cda_market_state* s) {
 }
 int oracle_set_state(oracle_env* e, int32_t market, const cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->n) return CDA_ERR_INVALID;
-    if (s->n_bids < 0 || s->n_bids > CDA_BOOK_CAP || s->n_asks < 0 || s->n_asks > CDA_BOOK_CAP) return CDA_ERR_INVALID;
+    if (s->n_bids < 0 || s->n_asks < 0 || s->n_bids + s->n_asks > CDA_BOOK_CAP) return CDA_ERR_INVALID;
     market_t* m = &e->m[market];
     m->rng.state = ((u128)s->rng_state_hi << 64) | s->rng_state_lo; m->rng.inc = ((u128)s->rng_inc_hi << 64) | s->rng_inc_lo;
     m->rng.has_uint32 = s->rng_has_uint32; m->rng.uinteger = s->rng_uinteger; m->seeded = 1;

@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $BENCH > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -o p -- $BENCH > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INSTS_FLAT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o p -- $BENCH > /dev/null 2> $OUT/pmc_sq2.err
+rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq3 -o p -- $BENCH > /dev/null 2> $OUT/pmc_sq3.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -o p -- python $R/tools/pmc_calib.py > /dev/null 2> $OUT/calib_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -o p -- python $R/tools/pmc_calib.py > /dev/null 2> $OUT/calib_write.err
 cd $R

@@ -30,7 +30,7 @@ for f in find("trace", "*kernel_trace.csv"):
         d = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows]
         print(f"k_step dispatches={len(d)} avg_ns={sum(d)/len(d):.0f} min_ns={min(d)} max_ns={max(d)}")
 print("== PMC (per k_step dispatch averages) ==")
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
     for f in find(sub, "*counter_collection.csv"):
         acc, cnt = defaultdict(float), defaultdict(int)
         with open(f) as fh:
