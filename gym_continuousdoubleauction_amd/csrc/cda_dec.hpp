@@ -138,11 +138,23 @@ template <int NL> __device__ __forceinline__ uint32_t w_div_pow10_small(WN<NL>& 
         default: return w_divc<1000000000u>(x);
     }
 }
-// x /= d for a run-time 32-bit divisor, returns the remainder
+// x /= d for a run-time 32-bit divisor, returns the remainder.  One f64 reciprocal per call, then per limb a
+// floating estimate of the 64/32 quotient corrected by an exact remainder test (the estimate is off by at most
+// one: cur < d * 2^32 < 2^64 converts to f64 with relative error 2^-53, and so does the reciprocal).  The
+// generic 64-bit integer division the compiler would emit costs ~70 instructions per limb.
 template <int NL> __device__ __forceinline__ uint32_t w_div_u32(WN<NL>& x, uint32_t d) {
+    const double rd = 1.0 / (double)d;
     uint64_t rem = 0;
     #pragma unroll
-    for (int i = NL - 1; i >= 0; i--) { uint64_t cur = (rem << 32) | x.w[i]; uint64_t q = cur / d; x.w[i] = (uint32_t)q; rem = cur - q * d; }
+    for (int i = NL - 1; i >= 0; i--) {
+        uint64_t cur = (rem << 32) | x.w[i];              // rem < d  =>  cur / d < 2^32
+        uint64_t q = (uint64_t)((double)cur * rd);
+        q = q > 0xffffffffull ? 0xffffffffull : q;
+        int64_t r = (int64_t)(cur - q * d);
+        if (r < 0) { q -= 1; r += d; }
+        if (r >= (int64_t)d) { q += 1; r -= d; }
+        x.w[i] = (uint32_t)q; rem = (uint64_t)r;
+    }
     return (uint32_t)rem;
 }
 template <int NL> __device__ __forceinline__ int w_bits(const WN<NL>& a) {
@@ -194,12 +206,14 @@ template <int NL> __device__ __forceinline__ D d_fix_impl(int sign, WN<NL> x, in
     int nd = w_ndigits(x);
     if (nd > 28) {
         int drop = nd - 28;
+        // one division by 10^drop when drop <= 9 (the usual case): the remainder decides half-even directly;
+        // larger drops first peel 10^9 chunks whose remainders only feed the sticky bit
         bool sticky = false;
-        int k = drop - 1;
-        while (k >= 9) { sticky |= (w_divc<1000000000u>(x) != 0); k -= 9; }
-        if (k > 0) sticky |= (w_div_pow10_small(x, k) != 0);
-        uint32_t dg = w_divc<10u>(x);
-        bool up = dg > 5 || (dg == 5 && (sticky || (x.w[0] & 1u)));
+        int k = drop;
+        while (k > 9) { sticky |= (w_divc<1000000000u>(x) != 0); k -= 9; }
+        uint32_t rem = w_div_pow10_small(x, k);
+        uint32_t half = 5u * pow10_sel(k - 1);
+        bool up = rem > half || (rem == half && (sticky || (x.w[0] & 1u)));
         if (up) {
             w_inc(x);
             // 10^28 = 0x204fce5e_3e250261_10000000
@@ -261,32 +275,64 @@ __device__ __noinline__ D d_add_wide(D a, D b) {
     } else { r = w_add(xt, xo); rs = dt.sign; }
     return d_fix_wide(rs, r, eo);
 }
+// 128-bit tier, out of line: any exponent gap whose scaled operand still fits 128 bits, with rounding
+__device__ __noinline__ D d_add_mid(D a, D b) {
+    bool swp = a.exp < b.exp;
+    D t = swp ? b : a, o = swp ? a : b;                     // t: larger exponent (ties: a); both non-zero
+    int diff = t.exp - o.exp;
+    u128 ct = d_c128(t), co = d_c128(o);
+    bool ok = true;
+    if (diff) {
+        // _normalize replaces `other` by 10^e only when other.adjusted() < e = t.exp + min(-1, len-30) <= t.exp-1;
+        // other.adjusted() >= o.exp + floor((bits-1)*log10 2) decides that from bit lengths alone.
+        int lb_adj = o.exp + (((bits128(co) - 1) * 1233) >> 12);
+        ok = scale_fits128(ct, diff) && lb_adj >= t.exp - 1;
+    }
+    if (!ok) return d_add_wide(a, b);
+    if (diff) ct = mul_pow10_128(ct, diff);
+    u128 r; int rs;
+    if (t.sign != o.sign) {
+        if (ct == co) return d_make(0, 0, 0, o.exp, 0);
+        if (ct > co) { r = ct - co; rs = t.sign; } else { r = co - ct; rs = o.sign; }
+    } else { r = ct + co; rs = t.sign; }
+    if (r < p28_128()) return d_from128(r, o.exp, rs);
+    return d_fix_mid(rs, w4_from128(r), o.exp);             // < 2^127: round on 4 limbs
+}
+// u32 * 10^k (k <= 28) from the LDS table: < 2^32 * 10^28 < 2^126
+__device__ __forceinline__ u128 mul_u32_pow10_lds(uint32_t c, int k) {
+    const uint32_t* p = lds_pow10(k);
+    u128 pw = ((u128)p[2] << 64) | ((u128)p[1] << 32) | (u128)p[0];      // 10^28 < 2^94: three limbs
+    return pw * (u128)c;
+}
+// Inline tier: the two shapes the ledger produces almost always - equal exponents, or a short coefficient
+// (an order value, a price: < 2^32) on the larger-exponent side that is scaled with ONE table multiply.
 __device__ __forceinline__ D d_add(D a, D b) {
-    bool az = d_is_zero(a), bz = d_is_zero(b);
+    const bool az = d_is_zero(a), bz = d_is_zero(b);
     if (!az && !bz) {
-        bool swp = a.exp < b.exp;
-        D t = swp ? b : a, o = swp ? a : b;                 // t: larger exponent (ties: a)
-        int diff = t.exp - o.exp;
-        u128 ct = d_c128(t), co = d_c128(o);
-        bool ok = true;
-        if (diff) {
-            // _normalize replaces `other` by 10^e only when other.adjusted() < e = t.exp + min(-1, len-30) <= t.exp-1;
-            // other.adjusted() >= o.exp + floor((bits-1)*log10 2) decides that from bit lengths alone.
-            int lb_adj = o.exp + (((bits128(co) - 1) * 1233) >> 12);
-            ok = scale_fits128(ct, diff) && lb_adj >= t.exp - 1;
-        }
+        const bool swp = a.exp < b.exp;
+        const D t = swp ? b : a, o = swp ? a : b;           // t: larger exponent (ties: a)
+        const int diff = t.exp - o.exp;
+        const u128 co = d_c128(o);
+        u128 ct;
+        bool ok;
+        if (diff == 0) { ct = d_c128(t); ok = true; }
+        else if ((t.w1 | t.w2) == 0 && diff <= 28) {
+            ok = (((bits128(co) - 1) * 1233) >> 12) >= diff - 1;   // no _normalize replacement (see d_add_mid)
+            ct = mul_u32_pow10_lds(t.w0, diff);
+        } else { ok = false; ct = 0; }
         if (ok) {
-            if (diff) ct = mul_pow10_128(ct, diff);
             u128 r; int rs;
             if (t.sign != o.sign) {
                 if (ct == co) return d_make(0, 0, 0, o.exp, 0);
                 if (ct > co) { r = ct - co; rs = t.sign; } else { r = co - ct; rs = o.sign; }
             } else { r = ct + co; rs = t.sign; }
             if (r < p28_128()) return d_from128(r, o.exp, rs);
-            return d_fix_mid(rs, w4_from128(r), o.exp);     // < 2^127: round on 4 limbs
+            return d_fix_mid(rs, w4_from128(r), o.exp);
         }
-    } else if (az != bz) {
-        D o = az ? b : a, z = az ? a : b;
+        return d_add_mid(a, b);
+    }
+    if (az != bz) {
+        const D o = az ? b : a, z = az ? a : b;
         if (z.exp >= o.exp) return o;                       // rescale by 10^0: the non-zero operand unchanged
     }
     return d_add_wide(a, b);
@@ -344,16 +390,26 @@ __device__ __noinline__ int d_cmp_wide(D a, D b) {          // both non-zero, sa
     int c = w_cmp(xa, xb);
     return c == 0 ? 0 : (c > 0 ? s : -s);
 }
-__device__ __forceinline__ int d_cmp(D a, D b) {
-    bool az = d_is_zero(a), bz = d_is_zero(b);
-    if (az) return bz ? 0 : (b.sign ? 1 : -1);
-    if (bz) return a.sign ? -1 : 1;
-    if (a.sign != b.sign) return a.sign ? -1 : 1;
+__device__ __noinline__ int d_cmp_mid(D a, D b) {           // both non-zero, same sign, any exponents
     int s = a.sign ? -1 : 1;
     int diff = a.exp - b.exp;
     u128 ca = d_c128(a), cb = d_c128(b);
     if (diff > 0) { if (!scale_fits128(ca, diff)) return d_cmp_wide(a, b); ca = mul_pow10_128(ca, diff); }
     else if (diff < 0) { if (!scale_fits128(cb, -diff)) return d_cmp_wide(a, b); cb = mul_pow10_128(cb, -diff); }
+    return ca == cb ? 0 : (ca > cb ? s : -s);
+}
+__device__ __forceinline__ int d_cmp(D a, D b) {
+    const bool az = d_is_zero(a), bz = d_is_zero(b);
+    if (az) return bz ? 0 : (b.sign ? 1 : -1);
+    if (bz) return a.sign ? -1 : 1;
+    if (a.sign != b.sign) return a.sign ? -1 : 1;
+    const int s = a.sign ? -1 : 1;
+    const int diff = a.exp - b.exp;
+    u128 ca, cb;
+    if (diff == 0) { ca = d_c128(a); cb = d_c128(b); }
+    else if (diff > 0 && (a.w1 | a.w2) == 0 && diff <= 28) { ca = mul_u32_pow10_lds(a.w0, diff); cb = d_c128(b); }
+    else if (diff < 0 && (b.w1 | b.w2) == 0 && diff >= -28) { ca = d_c128(a); cb = mul_u32_pow10_lds(b.w0, -diff); }
+    else return d_cmp_mid(a, b);
     return ca == cb ? 0 : (ca > cb ? s : -s);
 }
 
@@ -409,7 +465,14 @@ __device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no
     WN<3> x; x.w[0] = a.w0; x.w[1] = a.w1; x.w[2] = a.w2;
     if (a.w2 != 0 || a.w1 >= (1u << 21)) {
         while (k >= 9) { WN<3> t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; k -= 9; }
-        while (k > 0) { WN<3> t = x; if (w_divc<10u>(t) != 0) break; x = t; k -= 1; }
+        // what is left has fewer than 9 strippable zeros: peel 4, 2, 1 (then 4, 2, 1 once more covers up to 8... a second
+        // pass of the three tests handles 8 = 4+2+1+1) instead of one digit at a time
+        #pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            if (k >= 4) { WN<3> t = x; if (w_divc<10000u>(t) == 0) { x = t; k -= 4; } }
+            if (k >= 2) { WN<3> t = x; if (w_divc<100u>(t) == 0) { x = t; k -= 2; } }
+            if (k >= 1) { WN<3> t = x; if (w_divc<10u>(t) == 0) { x = t; k -= 1; } }
+        }
     }
     u128 c = ((u128)x.w[2] << 64) | ((u128)x.w[1] << 32) | x.w[0];
     if ((c >> 53) == 0 && k <= 22) {

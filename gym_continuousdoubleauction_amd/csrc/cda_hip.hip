@@ -52,7 +52,12 @@ __device__ __forceinline__ void load_market(const MarketPtrs& mp, const Params& 
     copy_words((uint32_t*)&L.acc[0], mp.acc, P.cfg.num_agents * (int)(sizeof(Acc) / 4), lane);
     decode_header(hv, m);
     finish_book_load(mp.book, pre, L.book, m, lane);
+    if (m.levels_valid && lane >= H_LEVELS && lane < H_LEVELS + 4 * CDA_K_ROWS) (&L.lvl_px[0][0])[lane - H_LEVELS] = (int32_t)hv;
     CDA_WSYNC();
+}
+// the level aggregation currently in LDS describes the book as it is being stored: keep it for the next step
+__device__ __forceinline__ void store_levels(const MarketPtrs& mp, const Lds& L, int lane) {
+    if (lane >= H_LEVELS && lane < H_LEVELS + 4 * CDA_K_ROWS) mp.hdr[lane] = (uint32_t)(&L.lvl_px[0][0])[lane - H_LEVELS];
 }
 __device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params& P, Lds& L, const Mkt& m, int lane) {
     CDA_WSYNC();
@@ -103,7 +108,9 @@ __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P
         }
     }
     m.hist_head = 0;
+    m.levels_valid = 1;                                   // aggregate_levels above ran on the (empty) book
     store_market(mp, P, L, m, lane);
+    store_levels(mp, L, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -136,12 +143,17 @@ __global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Par
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
+#ifdef CDA_PHASE_TIMING
+    for (int i = 0; i < 6; i++) m.tacc[i] = 0;
+#endif
     PHASE_MARK(0);
     load_market(mp, P, L, m, lane);
     PHASE_MARK(1);
 
-    // 1. pre-step snapshot (continuousDoubleAuction_env.py:274): prices of ALL orders resolve against it
-    aggregate_levels(L, m, lane);
+    // 1. pre-step snapshot (continuousDoubleAuction_env.py:274): prices of ALL orders resolve against it.  It equals the
+    //    post-step aggregation of the previous step, which travels in the header; recomputed only when a test hook,
+    //    set_state or reset touched the book in between.
+    if (!m.levels_valid) aggregate_levels(L, m, lane);
     PHASE_MARK(2);
     // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order.
     //    The action words are read at wave-uniform addresses (scalar loads); decoded orders go to LDS.
@@ -280,9 +292,14 @@ __global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Par
         S.truncated_out[mi] = (uint8_t)(m.t_step + 1 >= P.cfg.max_step);
     }
     m.t_step += 1;
+    m.levels_valid = 1;                                   // lvl_px/lvl_sz hold the post-step aggregation (phase 6)
     PHASE_MARK(8);
     store_market(mp, P, L, m, lane);
+    store_levels(mp, L, lane);
     PHASE_MARK(9);
+#ifdef CDA_PHASE_TIMING
+    if (S.phase_cycles && lane == 0) for (int i = 0; i < 6; i++) S.phase_cycles[(size_t)mi * 16 + 10 + i] = m.tacc[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -296,6 +313,7 @@ __global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, in
     Mkt m;
     load_market(mp, P, lds1, m, lane);
     place_order(lds1, m, tr, type, side, size, price, lane);
+    m.levels_valid = 0;                                   // the cached aggregation no longer describes the book
     store_market(mp, P, lds1, m, lane);
 }
 __global__ __launch_bounds__(64) void k_mark_to_mkt(uint8_t* arena, Params P, int mi) {
@@ -591,7 +609,7 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
     h[H_T_STEP] = (uint32_t)s->t_step; h[H_LOB_TIME] = (uint32_t)s->lob_time; h[H_NEXT_OID] = (uint32_t)s->next_order_id;
     h[H_LAST_PRICE] = (uint32_t)s->last_price; h[H_HAS_TRADE] = (uint32_t)s->has_trade; h[H_LAST_TRADE_PRICE] = (uint32_t)s->last_trade_price;
     h[H_DONE_MASK] = s->done_mask; h[H_FLAGS] = s->flags; h[H_N_BIDS] = (uint32_t)s->n_bids; h[H_N_ASKS] = (uint32_t)s->n_asks;
-    h[H_SEEDED] = 1; h[H_HIST_HEAD] = 0;
+    h[H_SEEDED] = 1; h[H_HIST_HEAD] = 0; h[H_LEVELS_VALID] = 0;
     int32_t* bp = (int32_t*)(rec + P.lay.book_off);
     for (int sd = 0; sd < 2; sd++) {
         int n = sd == 0 ? s->n_bids : s->n_asks;

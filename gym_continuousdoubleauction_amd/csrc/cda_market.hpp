@@ -45,9 +45,12 @@ enum { S_BID = 0, S_ASK = 1, S_NONE = 2 };
 enum {
     H_RNG_STATE_LO = 0, H_RNG_STATE_HI = 2, H_RNG_INC_LO = 4, H_RNG_INC_HI = 6, H_HAS_U32 = 8, H_UINTEGER = 9,
     H_T_STEP = 10, H_LOB_TIME = 11, H_NEXT_OID = 12, H_LAST_PRICE = 13, H_HAS_TRADE = 14, H_LAST_TRADE_PRICE = 15,
-    H_DONE_MASK = 16, H_FLAGS = 17, H_N_BIDS = 18, H_N_ASKS = 19, H_SEEDED = 20, H_HIST_HEAD = 21, H_WORDS = 32
+    H_DONE_MASK = 16, H_FLAGS = 17, H_N_BIDS = 18, H_N_ASKS = 19, H_SEEDED = 20, H_HIST_HEAD = 21, H_LEVELS_VALID = 22,
+    H_LEVELS = 24,            // 40 words: the top-10 aggregation (lvl_px[2][10], lvl_sz[2][10]) of the book as stored,
+                              // so that the next step's pre-step snapshot is a copy instead of a scan (valid flag above)
+    H_WORDS = 64
 };
-constexpr int HEADER_BYTES = H_WORDS * 4;   // 128
+constexpr int HEADER_BYTES = H_WORDS * 4;   // 256: one coalesced load per wave
 
 struct Acc {                     // 144 B, 16-byte aligned; lane a owns account a
     cda_dec cash, hold, posval, vwap, nav, prev_nav, max_nav;     // 7 x 16 B
@@ -107,8 +110,20 @@ struct Mkt {
     int32_t t_step, lob_time, next_oid, last_price, has_trade, last_trade_price;
     uint32_t done_mask, flags;
     int32_t nb, na;              // resting orders per side (two scalars: a dynamically indexed array would force Mkt into scratch)
-    int32_t seeded, hist_head;
+    int32_t seeded, hist_head, levels_valid;
+#ifdef CDA_PHASE_TIMING
+    unsigned long long tacc[6];     // debug: cycles in approval / find / match+settle / insert+remove / escrow+cancel, fills
+#endif
 };
+#ifdef CDA_PHASE_TIMING
+#define TACC_BEGIN() unsigned long long _tb = __builtin_readcyclecounter()
+#define TACC_END(m, i) do { unsigned long long _te = __builtin_readcyclecounter(); (m).tacc[i] += _te - _tb; _tb = _te; } while (0)
+#define TACC_COUNT(m, i, n) do { (m).tacc[i] += (n); } while (0)
+#else
+#define TACC_BEGIN() do {} while (0)
+#define TACC_END(m, i) do {} while (0)
+#define TACC_COUNT(m, i, n) do {} while (0)
+#endif
 __device__ __forceinline__ int mkt_n(const Mkt& m, int s) { return s == 0 ? m.nb : m.na; }
 __device__ __forceinline__ void mkt_set_n(Mkt& m, int s, int v) { if (s == 0) m.nb = v; else m.na = v; }
 
@@ -273,7 +288,7 @@ __device__ __forceinline__ void decode_header(uint32_t v, Mkt& m) {
     m.last_price = (int32_t)RL(H_LAST_PRICE); m.has_trade = (int32_t)RL(H_HAS_TRADE); m.last_trade_price = (int32_t)RL(H_LAST_TRADE_PRICE);
     m.done_mask = RL(H_DONE_MASK); m.flags = RL(H_FLAGS);
     m.nb = (int32_t)RL(H_N_BIDS); m.na = (int32_t)RL(H_N_ASKS);
-    m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD);
+    m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD); m.levels_valid = (int32_t)RL(H_LEVELS_VALID);
     #undef RL
 }
 __device__ __forceinline__ void store_header(uint32_t* hp, const Mkt& m, int lane) {
@@ -287,7 +302,7 @@ __device__ __forceinline__ void store_header(uint32_t* hp, const Mkt& m, int lan
         hp[H_LAST_PRICE] = (uint32_t)m.last_price; hp[H_HAS_TRADE] = (uint32_t)m.has_trade; hp[H_LAST_TRADE_PRICE] = (uint32_t)m.last_trade_price;
         hp[H_DONE_MASK] = m.done_mask; hp[H_FLAGS] = m.flags;
         hp[H_N_BIDS] = (uint32_t)m.nb; hp[H_N_ASKS] = (uint32_t)m.na;
-        hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head;
+        hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head; hp[H_LEVELS_VALID] = (uint32_t)m.levels_valid;
     }
 }
 // book record in HBM: [field][CAP] int32, pooled like the LDS image; only the live prefix of each side moves.
@@ -498,6 +513,7 @@ __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, i
         if (qty < rq) { f = qty; bk.qty[opp][h] = rq - qty; qty = 0; CDA_WSYNC(); }    // all lanes store the same value
         else { f = rq; qty -= rq; h++; }
         m.has_trade = 1; m.last_trade_price = p;
+        TACC_COUNT(m, 5, 1);
         settle_fill(L, tr, c, f, p, own_side, m.flags, lane);
     }
     if (h) { book_remove(bk, opp, nopp, 0, h, lane); mkt_set_n(m, opp, nopp - h); }
@@ -549,7 +565,10 @@ __device__ __forceinline__ bool order_approved(Lds& L, const Mkt& m, int tr, int
 // call site: the type-specific part only decides what (if anything) is matched and what may rest.
 __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, int side, int32_t size, int32_t price, int lane) {
     if (side == S_NONE) return;
-    if (!order_approved(L, m, tr, side, size, type == T_MARKET ? -1 : price, lane)) {
+    TACC_BEGIN();
+    bool approved_ = order_approved(L, m, tr, side, size, type == T_MARKET ? -1 : price, lane);
+    TACC_END(m, 0);
+    if (!approved_) {
         if (lane == tr) L.acc[lane].num_rejected_step += 1;
         return;
     }
@@ -565,6 +584,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
     } else {
         const int nside = mkt_n(m, side);
         int idx = find_own_order(bk, side, nside, tr, type, price, lane);
+        TACC_END(m, 1);
         if (type == T_LIMIT && idx < 0) {                     // a new order
             m.lob_time += 1; m.next_oid += 1;
             do_match = true; can_rest = true; m_limit = price; rest_oid = m.next_oid;
@@ -589,15 +609,19 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
         }
     }
     if (m.next_oid >= (1 << 27)) m.flags |= CDA_FLAG_INT_OVERFLOW;
+    TACC_END(m, 4);
     if (do_match) {
         int32_t left = match(L, m, tr, side, size, m_limit, lane);
+        TACC_END(m, 2);
         if (left > 0 && can_rest) {
             const int nown = mkt_n(m, side);
             if (book_insert(bk, side, nown, mkt_n(m, side ^ 1), price, left, tr, rest_oid, m.lob_time, lane)) { mkt_set_n(m, side, nown + 1); rest_price = price; rest_qty = left; }
             else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
         }
+        TACC_END(m, 3);
     }
     if (rest_qty > 0 && lane == tr) escrow_rest(L.acc[lane], rest_price, rest_qty, f);
+    TACC_END(m, 4);
     if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
 }
 

@@ -13,7 +13,7 @@ import torch
 
 so = os.path.join(ROOT, "gpurun_out", "libcda_hip_timing.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                        "-DCDA_PHASE_TIMING", "-o", so, os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_hip.hip")])
 from gym_continuousdoubleauction_amd import _lib
 _lib.LIB_PATH = so
@@ -29,6 +29,7 @@ L.cda_debug_set_phase_buffer(C.c_void_p(buf.data_ptr()))
 g = torch.Generator(device="cuda:0"); g.manual_seed(1)
 names = ["load", "snapshot_pre", "decode+rng", "shuffle", "orders", "mtm", "snapshot_post+obs", "reward/info", "store"]
 acc = np.zeros(9); span = 0.0
+tot_all = []; worst = None; sub = np.zeros(6); sub_worst = None
 T, W = 300, 200
 for t in range(W + T):
     cat = torch.randint(0, 9, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
@@ -42,8 +43,24 @@ for t in range(W + T):
         d = b[:, 1:10] - b[:, 0:9]
         acc += d.mean(axis=0)
         span += (b[:, 9].max() - b[:, 0].min())
+        sub += b[:, 10:16].mean(axis=0)
+        tw = d.sum(axis=1)
+        tot_all.append(tw)
+        i = int(tw.argmax())
+        if worst is None or tw[i] > worst[0]:
+            worst = (tw[i], d[i].copy(), t, i); sub_worst = b[i, 10:16].copy()
 acc /= T
 tot = acc.sum()
 print(f"mean cycles per wave per step: {tot:.0f}; kernel span (first start -> last end) {span / T:.0f} cycles")
 for n, v in zip(names, acc):
     print(f"  {n:20s} {v:10.0f} cycles  {100 * v / tot:5.1f} %")
+
+tw = np.concatenate(tot_all)
+print("per-wave total cycles: mean %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f" % (tw.mean(), *np.percentile(tw, [50, 90, 99, 99.9]), tw.max()))
+per_step_max = np.array([x.max() for x in tot_all])
+print("max over the 4096 waves of one step: mean %.0f  (min %.0f, max %.0f)" % (per_step_max.mean(), per_step_max.min(), per_step_max.max()))
+print("slowest wave seen: %.0f cycles at step %d market %d; phases:" % (worst[0], worst[2], worst[3]), dict(zip(names, worst[1].astype(int).tolist())))
+
+subn = ["approval", "find_own", "match+settle", "insert/remove(after match)", "cancel/escrow/other", "fills"]
+print("orders phase breakdown, mean per wave per step:", {n: round(v / T, 1) for n, v in zip(subn, sub)})
+print("orders phase breakdown, slowest wave:", dict(zip(subn, sub_worst.astype(int).tolist())))
