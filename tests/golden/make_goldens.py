@@ -99,7 +99,7 @@ def book_rows(lob):
     return out, len(rows_b), len(rows_a)
 
 
-def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None, reseed_at=None):
+def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None, reseed_at=None, presets=None):
     env = continuousDoubleAuctionEnv(dict(config))
     A = env.num_of_agents
     obs0, _ = env.reset(seed=seed)
@@ -121,7 +121,16 @@ def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None,
     netpos_l, ntr_l, cnt_l, pass_l, terms_l, inff_l, mkt_l, rng_l = [], [], [], [], [], [], [], []
     book_all, book_off = [], []
     resets = []
+    preset_rows = []
     for t in range(T):
+        for (pt, tr, fields) in (presets or []):
+            if pt == t:   # overwrite account fields directly, as the reference's own unit tests do (test_accounting.py:143-150)
+                acc = env.traders[tr].acc
+                for f, v in fields.items():
+                    setattr(acc, f, int(v) if f == "net_position" else Decimal(v))
+                acc.cal_nav()
+                preset_rows.append((t, tr, int(fields.get("cash", -1)), int(fields.get("position_val", -1)), int(fields.get("VWAP", -1)),
+                                    int(fields.get("net_position", 0))))
         if reseed_at and t in reseed_at:       # mid-trace reset: seed=None keeps the stream
             o, _ = env.reset(seed=reseed_at[t])
             resets.append((t, -1 if reseed_at[t] is None else reseed_at[t]))
@@ -213,6 +222,7 @@ def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None,
         reward_terms=np.array(terms_l), info_floats=np.array(inff_l), market=np.array(mkt_l), rng=np.array(rng_l),
         book=np.array(book_all, np.int32).reshape(-1, 5), book_off=np.array(book_off, np.int64),
         resets=np.array(resets, np.int64).reshape(-1, 2),
+        presets=np.array(preset_rows, np.int64).reshape(-1, 6),
     )
     nonint = sum(1 for s in acc_exp for v in s[:, 4] if v < -1)
     print(f"{name}: T={T} A={A} tape={L['tape_len'][-1]} max_orders={max(b[1] + b[2] for b in book_off)} "
@@ -244,6 +254,11 @@ def main():
                                                     limit_size_multiple=3), 43, 128, 7043)
     traces["reset_s51"] = run_trace("reset_s51", dict(base4, max_step=40), 51, 120, 7051, reseed_at={40: None, 80: 977})
     traces["big_seed"] = run_trace("big_seed", dict(base4), 2 ** 63 + 12345, 64, 7061)
+    # bankruptcies: heavily short accounts are marked against a much higher price -> NAV <= 0 -> done_set, rejections,
+    # and finally terminateds["__all__"]
+    short = lambda v: {"cash": 100, "position_val": 10 * v, "VWAP": 10, "net_position": -v}   # noqa: E731
+    traces["bankrupt_s61"] = run_trace("bankrupt_s61", dict(base4, max_step=96), 61, 96, 7161,
+                                       presets=[(3, 0, short(60000)), (20, 1, short(80000)), (40, 2, short(90000)), (60, 3, short(70000))])
     traces["long_s100"] = run_trace("long_s100", dict(base4, max_step=2048), 100, 2048, 7100)
     for name, rec in traces.items():
         np.savez_compressed(os.path.join(out_dir, f"trace_{name}.npz"), **rec)

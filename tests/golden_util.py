@@ -96,6 +96,21 @@ def check_state(state, rec, t, A, ctx, n_hist):
     _eq("hist", f32_bits(hist), f32_bits(rec["obs"][t]), ctx)
 
 
+def _apply_preset(env, i, row):
+    """(t, trader, cash, position_val, VWAP, net_position): overwrite the fields, then nav = cash + hold + position_val."""
+    from decimal import Decimal
+    _, tr, cash, pv, vw, pos = (int(x) for x in row)
+    s = env.get_state(i)
+    acc = s.acc[tr]
+    acc.cash = K.decimal_to_dec(Decimal(cash)); acc.position_val = K.decimal_to_dec(Decimal(pv)); acc.vwap = K.decimal_to_dec(Decimal(vw))
+    acc.net_position = pos
+    nav = Decimal(cash) + K.dec_to_decimal(acc.cash_on_hold) + Decimal(pv)
+    acc.nav = K.decimal_to_dec(nav)
+    if nav > K.dec_to_decimal(acc.max_nav):
+        acc.max_nav = K.decimal_to_dec(nav)
+    env.set_state(i, s)
+
+
 def run_group(env, recs, state_every=1, trace_getter=None, max_steps=None):
     """Drive `env` (N == len(recs) markets, one golden trace per market) and compare everything."""
     N = len(recs)
@@ -126,6 +141,10 @@ def run_group(env, recs, state_every=1, trace_getter=None, max_steps=None):
                         sd[i] = rs
                         o = env.reset(seeds=sd, mask=mask)
                     _eq("reset obs", f32_bits(o[i]), f32_bits(r[f"reset_obs_{t}"]), f"{r['name']} reset@{t}")
+        for i, r in enumerate(recs):      # account presets recorded by the generator (applied through set_state)
+            for row in r.get("presets", np.zeros((0, 6), np.int64)):
+                if row[0] == t:
+                    _apply_preset(env, i, row)
         cat = np.zeros((N, A), np.int32)
         mean = np.zeros((N, A), np.float32)
         sigma = np.zeros((N, A), np.float32)
