@@ -481,7 +481,45 @@ __device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no
         r = (double)(uint64_t)c / p;                     // both exact -> one correctly rounded division
         return a.sign ? -r : r;
     }
-    // exact path: value = c / (5^k * 2^k); restoring division for 57 quotient bits + sticky
+    // exact path: value = c / (5^k * 2^k)
+    if (k <= 27) {
+        // 5^k < 2^63: base-2^32 long division of (c << 64) by the 64-bit divisor.  Each quotient digit is estimated in
+        // f64 (relative error 2^-52, i.e. off by at most one) and corrected with an exact 128-bit remainder test.
+        // The 158-bit numerator guarantees >= 64 quotient bits below the leading one; the rest folds into `sticky`.
+        const uint64_t dv = POW5.lo[k];
+        const double rdv = 1.0 / (double)dv;
+        const int nshift = 96 - bits128(c);                              // normalise: top bit of the coefficient to bit 95
+        const u128 cn = c << nshift;                                     // >= 2^95 > dv  =>  quotient >= 2^96
+        uint32_t num[5] = {0u, 0u, (uint32_t)cn, (uint32_t)(cn >> 32), (uint32_t)(cn >> 64)};   // (cn << 64), little endian
+        uint32_t ql[5];
+        uint64_t rem = 0;                                                // < dv
+        #pragma unroll
+        for (int i = 4; i >= 0; i--) {
+            u128 cur = ((u128)rem << 32) | num[i];                       // < dv * 2^32
+            double curd = (double)(uint64_t)(cur >> 32) * 4294967296.0 + (double)(uint32_t)cur;
+            uint64_t q = (uint64_t)(curd * rdv);
+            q = q > 0xffffffffull ? 0xffffffffull : q;
+            u128 prod = (u128)q * dv;
+            while (prod > cur) { q -= 1; prod -= dv; }
+            u128 r128 = cur - prod;
+            while (r128 >= (u128)dv) { q += 1; r128 -= dv; }
+            ql[i] = (uint32_t)q; rem = (uint64_t)r128;
+        }
+        // quotient = ql[4..0] (160 bits, top limbs mostly zero); take 57 bits from its top set bit
+        u128 qhi = ((u128)ql[4] << 64) | ((u128)ql[3] << 32) | ql[2];    // bits 64..159
+        uint64_t qlo = ((uint64_t)ql[1] << 32) | ql[0];                  // bits 0..63
+        int hb = bits128(qhi);                                           // cn >= 2^95, dv < 2^63  =>  hb >= 33
+        // top 57 bits of the 160-bit quotient Q = qhi * 2^64 + qlo
+        uint64_t q57; bool sticky = rem != 0;
+        int sh = hb + 64 - 57;                                           // right shift of Q, >= 9
+        if (sh >= 64) { int s2 = sh - 64; q57 = (uint64_t)(qhi >> s2); sticky |= qlo != 0 || (s2 && (qhi & (((u128)1 << s2) - 1)) != 0); }
+        else { q57 = (uint64_t)(qhi << (64 - sh)) | (qlo >> sh); sticky |= (qlo & (((uint64_t)1 << sh) - 1)) != 0; }
+        // Q * 2^-64 * 2^-k = value; q57 = floor(Q / 2^sh): weights 2^(sh-64-k) per unit; round_quotient expects the top bit
+        // at position 56 with weight 2^t, i.e. unit weight 2^(t-56)  =>  t = sh - 64 + 56
+        r = round_quotient(q57, sticky, sh - 8 - nshift, k);
+        return a.sign ? -r : r;
+    }
+    // 28 <= k <= 54: restoring division for 57 quotient bits + sticky
     u128 dv = ((u128)POW5.hi[k] << 64) | POW5.lo[k];
     int bn = bits128(c), bd = bits128(dv);
     int t = bn - bd;
@@ -493,7 +531,6 @@ __device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no
         if (rr >= dn) { rr -= dn; q |= 1; }
         rr <<= 1;
     }
-    // q holds quotient bits of weights 2^t .. 2^(t-56); its top set bit is bit 56 or 55
     r = round_quotient(q, rr != 0, t, k);
     return a.sign ? -r : r;
 }

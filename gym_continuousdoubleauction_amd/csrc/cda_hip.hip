@@ -351,6 +351,29 @@ __global__ void k_init_arena(uint8_t* arena, Params P) {
     }
 }
 
+// debug micro-benchmark (tools/opbench.py): cycles of one decimal operation on representative ledger operands,
+// measured on a single wave (one active lane) as a dependent chain of `iters` operations
+__global__ void k_opbench(int op, int iters, const cda_dec* a, const cda_dec* b, unsigned long long* out, cda_dec* sink) {
+    dec_tables_init();
+    if (threadIdx.x != 0) return;
+    D x = ld_dec(a[0]), y = ld_dec(b[0]);
+    uint32_t f = 0; double dacc = 0.0; int iacc = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) {
+        switch (op) {
+            case 0: x = d_add(x, y); y.sign ^= 1; break;                       // add / sub alternating: value stays bounded
+            case 1: { D r = d_mul_u32(x, y.w0, 0); x.w0 = (x.w0 ^ r.w0) | 1u; break; }
+            case 2: { D r = d_div_u32(x, y.w0); x.w0 = (x.w0 ^ r.w0) | 1u; break; }
+            case 3: iacc += d_cmp(x, y); x.w0 ^= (uint32_t)iacc; break;
+            case 4: dacc += d_to_double(x, &f); x.w0 ^= (uint32_t)__double_as_longlong(dacc); break;
+            default: { uint32_t z = 0; process_acc(*(Acc*)(cda_smem + DEC_TABLE_BYTES), (int32_t)y.w0, 57, (i & 1), (i & 2) != 0, z); f |= z; break; }
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[0] = t1 - t0;
+    st_dec(sink[0], x, f); sink[1].w[0] = (uint32_t)iacc + (uint32_t)__double_as_longlong(dacc);
+}
+
 // PMC calibration (tools/profile_gpu.sh): known byte counts in THIS library's access pattern (4 B per lane,
 // coalesced) so that FETCH_SIZE / WRITE_SIZE can be converted to bytes (MI355X_MICROARCH.md, HBM section).
 __global__ void k_calib_read(const uint32_t* p, size_t n, uint32_t* out) {
@@ -689,6 +712,20 @@ int cda_selftest_rng(int32_t device, uint64_t seed, int32_t lo, int32_t hi, int3
     HIPCHK(hipMemcpy(final_state_host, dfs, 48, hipMemcpyDeviceToHost));
     (void)hipFree(dfi); (void)hipFree(dn); (void)hipFree(dp); (void)hipFree(dfs);
     return CDA_OK;
+}
+
+/* debug hook (not in include/cda.h): cycles of `iters` dependent decimal operations of kind `op` (see k_opbench) */
+long long cda_debug_opbench(int op, int iters, const cda_dec* a_host, const cda_dec* b_host, const void* acc_host /* 144 B or NULL */) {
+    cda_dec *da = NULL, *db = NULL, *ds = NULL; unsigned long long* dout = NULL; unsigned long long cyc = 0;
+    if (hipMalloc((void**)&da, 16) != hipSuccess || hipMalloc((void**)&db, 16) != hipSuccess || hipMalloc((void**)&ds, 32) != hipSuccess ||
+        hipMalloc((void**)&dout, 8) != hipSuccess) return -1;
+    (void)hipMemcpy(da, a_host, 16, hipMemcpyHostToDevice); (void)hipMemcpy(db, b_host, 16, hipMemcpyHostToDevice);
+    (void)acc_host;
+    hipLaunchKernelGGL(k_opbench, dim3(1), dim3(64), DEC_TABLE_BYTES + 256, 0, op, iters, da, db, dout, ds);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    (void)hipMemcpy(&cyc, dout, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dout);
+    return (long long)cyc;
 }
 
 /* debug hook (not in include/cda.h): read (mode 0) or write (mode 1) n_bytes of a device buffer, 4 B per lane */
