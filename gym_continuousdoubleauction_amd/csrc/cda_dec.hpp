@@ -483,18 +483,17 @@ __device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no
     }
     // exact path: value = c / (5^k * 2^k)
     if (k <= 27) {
-        // 5^k < 2^63: base-2^32 long division of (c << 64) by the 64-bit divisor.  Each quotient digit is estimated in
-        // f64 (relative error 2^-52, i.e. off by at most one) and corrected with an exact 128-bit remainder test.
-        // The 158-bit numerator guarantees >= 64 quotient bits below the leading one; the rest folds into `sticky`.
+        // 5^k < 2^63: base-2^32 long division of the normalised coefficient (shifted up one limb) by the 64-bit divisor.
+        // Each quotient digit is estimated in f64 (relative error 2^-52) and corrected with an exact 128-bit remainder test.
         const uint64_t dv = POW5.lo[k];
         const double rdv = 1.0 / (double)dv;
         const int nshift = 96 - bits128(c);                              // normalise: top bit of the coefficient to bit 95
         const u128 cn = c << nshift;                                     // >= 2^95 > dv  =>  quotient >= 2^96
-        uint32_t num[5] = {0u, 0u, (uint32_t)cn, (uint32_t)(cn >> 32), (uint32_t)(cn >> 64)};   // (cn << 64), little endian
-        uint32_t ql[5];
+        uint32_t num[4] = {0u, (uint32_t)cn, (uint32_t)(cn >> 32), (uint32_t)(cn >> 64)};   // (cn << 32), little endian
+        uint32_t ql[4];
         uint64_t rem = 0;                                                // < dv
         #pragma unroll
-        for (int i = 4; i >= 0; i--) {
+        for (int i = 3; i >= 0; i--) {
             u128 cur = ((u128)rem << 32) | num[i];                       // < dv * 2^32
             double curd = (double)(uint64_t)(cur >> 32) * 4294967296.0 + (double)(uint32_t)cur;
             uint64_t q = (uint64_t)(curd * rdv);
@@ -505,18 +504,14 @@ __device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no
             while (r128 >= (u128)dv) { q += 1; r128 -= dv; }
             ql[i] = (uint32_t)q; rem = (uint64_t)r128;
         }
-        // quotient = ql[4..0] (160 bits, top limbs mostly zero); take 57 bits from its top set bit
-        u128 qhi = ((u128)ql[4] << 64) | ((u128)ql[3] << 32) | ql[2];    // bits 64..159
-        uint64_t qlo = ((uint64_t)ql[1] << 32) | ql[0];                  // bits 0..63
-        int hb = bits128(qhi);                                           // cn >= 2^95, dv < 2^63  =>  hb >= 33
-        // top 57 bits of the 160-bit quotient Q = qhi * 2^64 + qlo
-        uint64_t q57; bool sticky = rem != 0;
-        int sh = hb + 64 - 57;                                           // right shift of Q, >= 9
-        if (sh >= 64) { int s2 = sh - 64; q57 = (uint64_t)(qhi >> s2); sticky |= qlo != 0 || (s2 && (qhi & (((u128)1 << s2) - 1)) != 0); }
-        else { q57 = (uint64_t)(qhi << (64 - sh)) | (qlo >> sh); sticky |= (qlo & (((uint64_t)1 << sh) - 1)) != 0; }
-        // Q * 2^-64 * 2^-k = value; q57 = floor(Q / 2^sh): weights 2^(sh-64-k) per unit; round_quotient expects the top bit
-        // at position 56 with weight 2^t, i.e. unit weight 2^(t-56)  =>  t = sh - 64 + 56
-        r = round_quotient(q57, sticky, sh - 8 - nshift, k);
+        // Q = floor(cn * 2^32 / dv) >= 2^(127-63): at least 65 bits, so its top 57 bits + sticky decide the rounding
+        u128 Q = ((u128)ql[3] << 96) | ((u128)ql[2] << 64) | ((u128)ql[1] << 32) | ql[0];
+        int sh = bits128(Q) - 57;                                        // >= 8
+        uint64_t q57 = (uint64_t)(Q >> sh);
+        bool sticky = rem != 0 || (Q & (((u128)1 << sh) - 1)) != 0;
+        // value = Q * 2^-32 * 2^-nshift * 2^-k, so one unit of q57 weighs 2^(sh - 32 - nshift - k); round_quotient wants the
+        // unit weight as 2^(t - 56 - k)
+        r = round_quotient(q57, sticky, sh + 24 - nshift, k);
         return a.sign ? -r : r;
     }
     // 28 <= k <= 54: restoring division for 57 quotient bits + sticky
