@@ -210,7 +210,7 @@ def main():
             "value": value, "unit": "agent-steps/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+dec28+f64", "data": "synthetic",
-            "config": {"workload": f"{N} markets x {A} random agents per GPU, book capacity {256} orders/side "
+            "config": {"workload": f"{N} markets x {A} random agents per GPU, book capacity {256} resting orders per market "
                                    f"(BASELINE configs[2]); global {world * N} markets",
                        "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info),
                        "collective": "all_gather(obs,reward)" if gather else "none",
