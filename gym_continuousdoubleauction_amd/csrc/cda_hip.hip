@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Par
         for (int s = 0; s < k; s++) mk &= mk - 1;                             // drop k lowest set bits
         int tr = __ffs((int)mk) - 1;
         int32_t tsp = L.act_tsp[tr], size = L.act_size[tr];
-        place_order(L, m, tr, tsp & 3, (tsp >> 2) & 3, size, (tsp >> 4) - 1, lane);
+        place_order<true>(L, m, tr, tsp & 3, (tsp >> 2) & 3, size, (tsp >> 4) - 1, lane);     // mark_to_mkt below rewrites position_val
     }
     PHASE_MARK(5);
     // 5. mark_to_mkt
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, in
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     load_market(mp, P, lds1, m, lane);
-    place_order(lds1, m, tr, type, side, size, price, lane);
+    place_order<false>(lds1, m, tr, type, side, size, price, lane);
     m.levels_valid = 0;                                   // the cached aggregation no longer describes the book
     store_market(mp, P, lds1, m, lane);
 }
@@ -366,7 +366,7 @@ __global__ void k_opbench(int op, int iters, const cda_dec* a, const cda_dec* b,
             case 2: { D r = d_div_u32(x, y.w0); x.w0 = (x.w0 ^ r.w0) | 1u; break; }
             case 3: iacc += d_cmp(x, y); x.w0 ^= (uint32_t)iacc; break;
             case 4: dacc += d_to_double(x, &f); x.w0 ^= (uint32_t)__double_as_longlong(dacc); break;
-            default: { uint32_t z = 0; process_acc(*(Acc*)(cda_smem + DEC_TABLE_BYTES), (int32_t)y.w0, 57, (i & 1), (i & 2) != 0, z); f |= z; break; }
+            default: { uint32_t z = 0; process_acc<false>(*(Acc*)(cda_smem + DEC_TABLE_BYTES), (int32_t)y.w0, 57, (i & 1), (i & 2) != 0, z); f |= z; break; }
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();

@@ -441,6 +441,11 @@ __device__ __forceinline__ D posval_from(Acc& a, uint32_t n, int32_t price, bool
     if (mkt_out) *mkt_out = mkt;
     return d_add(raw, cal_profit(is_long, mkt, raw));
 }
+// LAZY_POSVAL: inside k_step every fill is followed, before anything can read it, by Calculate.mark_to_mkt (it runs
+// whenever the tape is non-empty), which recomputes position_val from (net_position, VWAP, price) alone.  The value
+// _size_increase/_size_decrease store is therefore dead there and its four decimal operations are skipped; the paths
+// that READ position_val (_neutral, _covered) are untouched.  The one-order test hook keeps the full semantics.
+template <bool LAZY_POSVAL>
 __device__ __forceinline__ void process_acc(Acc& a, int32_t q, int32_t price, int own_side, bool counter, uint32_t& flags) {
     a.num_trades += 1; a.num_trades_step += 1; if (counter) a.num_passive_fills_step += 1;
     int32_t pos = a.net_position;
@@ -463,7 +468,7 @@ __device__ __forceinline__ void process_acc(Acc& a, int32_t q, int32_t price, in
             num = mode == 1 ? d_add(num, tv) : d_sub(num, tv);
             ACC_UPD(vwap, d_div_u32(num, n));
         }
-        ACC_UPD(posval, posval_from(a, n, price, is_long, nullptr));
+        if (!LAZY_POSVAL) ACC_UPD(posval, posval_from(a, n, price, is_long, nullptr));
         D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
         if (mode == 1) xfer_inc(a, counter, tv, flags); else xfer_dec(a, counter, tv, flags);
     } else {
@@ -486,10 +491,11 @@ __device__ __forceinline__ void process_acc(Acc& a, int32_t q, int32_t price, in
 }
 
 // one fill: counter party (passive) and initiator settle in two lanes at once (trader.py:303-345)
+template <bool LAZY_POSVAL>
 __device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t price, int init_side, uint32_t& flags, int lane) {
     uint32_t f = 0;
     if (counter != tr) {
-        if (lane == tr || lane == counter) process_acc(L.acc[lane], q, price, lane == tr ? init_side : init_side ^ 1, lane == counter, f);
+        if (lane == tr || lane == counter) process_acc<LAZY_POSVAL>(L.acc[lane], q, price, lane == tr ? init_side : init_side ^ 1, lane == counter, f);
     } else if (lane == tr) {                             // init_is_counter_cash_transfer (cash_processor.py:55-62)
         Acc& a = L.acc[lane];
         D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
@@ -502,6 +508,7 @@ __device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t
 
 // matching loops of OrderBook.process_order_list / process_market_order / process_limit_order
 // (orderbook.py:61-194).  limit < 0 = market order.  Returns the unfilled quantity.
+template <bool LAZY_POSVAL>
 __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, int32_t qty, int32_t limit, int lane) {
     int opp = own_side ^ 1;
     int h = 0, nopp = mkt_n(m, opp);
@@ -514,7 +521,7 @@ __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, i
         else { f = rq; qty -= rq; h++; }
         m.has_trade = 1; m.last_trade_price = p;
         TACC_COUNT(m, 5, 1);
-        settle_fill(L, tr, c, f, p, own_side, m.flags, lane);
+        settle_fill<LAZY_POSVAL>(L, tr, c, f, p, own_side, m.flags, lane);
     }
     if (h) { book_remove(bk, opp, nopp, 0, h, lane); mkt_set_n(m, opp, nopp - h); }
     return qty;
@@ -563,6 +570,7 @@ __device__ __forceinline__ bool order_approved(Lds& L, const Mkt& m, int tr, int
 // __modify_limit_order / _cancel_limit_order (:189-252) and OrderBook.process_order / modify_order /
 // cancel_order (orderbook/orderbook.py:33-59, :196-266).  Structured so that the matching loop has ONE
 // call site: the type-specific part only decides what (if anything) is matched and what may rest.
+template <bool LAZY_POSVAL>
 __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, int side, int32_t size, int32_t price, int lane) {
     if (side == S_NONE) return;
     TACC_BEGIN();
@@ -611,7 +619,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
     if (m.next_oid >= (1 << 27)) m.flags |= CDA_FLAG_INT_OVERFLOW;
     TACC_END(m, 4);
     if (do_match) {
-        int32_t left = match(L, m, tr, side, size, m_limit, lane);
+        int32_t left = match<LAZY_POSVAL>(L, m, tr, side, size, m_limit, lane);
         TACC_END(m, 2);
         if (left > 0 && can_rest) {
             const int nown = mkt_n(m, side);
