@@ -350,18 +350,36 @@ __device__ __forceinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
 __device__ __forceinline__ D d_mul_int(D a, uint32_t n) { return d_mul_u32(a, n, 0); }   // int * Decimal
 
 // ---- division: Decimal.__truediv__ (_pydecimal.py:1324) for b = Decimal(n), n > 0 an integer < 2^32 ----
+template <int NL> __device__ __forceinline__ uint32_t w_mod5(const WN<NL>& x) {     // 2^32 = 1 (mod 5): the limb sum decides
+    uint64_t sacc = 0;
+    #pragma unroll
+    for (int i = 0; i < NL; i++) sacc += x.w[i];
+    return (uint32_t)(sacc % 5u);
+}
 template <int NL> __device__ __forceinline__ D d_div_impl(D a, uint32_t n, int shift) {
     WN<NL> x = d_wide<NL>(a);
     int exp = a.exp - shift;
     w_mul_pow10(x, shift);
     uint32_t rem = w_div_u32(x, n);
     if (rem != 0) {
-        WN<NL> t = x; if (w_divc<5u>(t) == 0) w_inc(x);
-    } else {
-        int ideal = a.exp;
-        while (exp + 9 <= ideal) { WN<NL> t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; exp += 9; }
-        while (exp < ideal) { WN<NL> t = x; if (w_divc<10u>(t) != 0) break; x = t; exp += 1; }
+        // inexact: the quotient has 29 or 30 digits (the dividend was scaled to len(n) + 29 digits); `coeff % 5 == 0 -> += 1`
+        // folds the lost remainder into the last digit, then _fix drops one or two digits half-even (_pydecimal.py:1362-1376)
+        if (w_mod5(x) == 0) w_inc(x);
+        WN<NL> p29 = w_pow10<NL>(29);
+        const bool d30 = w_cmp(x, p29) >= 0;
+        uint32_t dg, half;
+        if (d30) { dg = w_divc<100u>(x); half = 50u; exp += 2; } else { dg = w_divc<10u>(x); half = 5u; exp += 1; }
+        if (dg > half || (dg == half && (x.w[0] & 1u))) {
+            w_inc(x);
+            if (x.w[0] == 0x10000000u && x.w[1] == 0x3e250261u && x.w[2] == 0x204fce5eu) {    // reached 10^28
+                x.w[0] = 0xe8000000u; x.w[1] = 0x9fd0803cu; x.w[2] = 0x033b2e3cu; exp += 1;   // 10^27
+            }
+        }
+        return d_make(x.w[0], x.w[1], x.w[2], exp, a.sign);
     }
+    int ideal = a.exp;
+    while (exp + 9 <= ideal) { WN<NL> t = x; if (w_divc<1000000000u>(t) != 0) break; x = t; exp += 9; }
+    while (exp < ideal) { WN<NL> t = x; if (w_divc<10u>(t) != 0) break; x = t; exp += 1; }
     return d_fix_impl<NL>(a.sign, x, exp);
 }
 __device__ __noinline__ D d_div_u32(D a, uint32_t n) {
