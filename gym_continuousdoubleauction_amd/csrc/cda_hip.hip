@@ -69,9 +69,14 @@ __device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params&
 // ------------------------------------------------------------------------------------------
 // reset
 // ------------------------------------------------------------------------------------------
-// dynamic LDS of a workgroup: [decimal power-of-ten table (640 B)] [wave 0 image] [wave 1 image] ...
-__device__ __forceinline__ Lds& wave_lds(const Params& P, int wave) {
-    return *reinterpret_cast<Lds*>(cda_smem + DEC_TABLE_BYTES + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents));
+// dynamic LDS of a workgroup: [decimal power-of-ten table (640 B)] [k_step only: ziggurat wi, ki (4 KB)] [wave 0 image] ...
+constexpr int ZIG_LDS_BYTES = 2 * 256 * 8;
+__device__ __forceinline__ Lds& wave_lds(const Params& P, int wave, int extra = 0) {
+    return *reinterpret_cast<Lds*>(cda_smem + DEC_TABLE_BYTES + extra + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents));
+}
+__device__ __forceinline__ void zig_tables_init() {       // every thread of the workgroup, before the first __syncthreads
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
+    for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) { t[i] = cda_zig_wi_bits[i]; t[256 + i] = cda_zig_ki[i]; }
 }
 
 __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out) {
@@ -137,9 +142,12 @@ template <int MINW>
 __global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Params P, StepArgs S) {
     int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
     int mi = (int)blockIdx.x * CDA_WPB + wave;
+    zig_tables_init();
     dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit
     if (mi >= P.n_markets) return;
-    Lds& L = wave_lds(P, wave);
+    Lds& L = wave_lds(P, wave, ZIG_LDS_BYTES);
+    const unsigned long long* zig_wi = reinterpret_cast<const unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
+    const unsigned long long* zig_ki = zig_wi + 256;
     MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Par
             int side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
             int type = cat == 0 ? T_MARKET : ((cat - 1) & 3);
             float locf = (type == T_MARKET ? P.mkt_mul : P.lim_mul) * mean;      // float32 product (numpy NEP 50)
-            double z = rng_std_normal(m);
+            double z = rng_std_normal(m, zig_wi, zig_ki);
             double prod = (double)sigma * z;
             double sample = (double)locf + prod;                                   // built with -ffp-contract=off
             double rs = rint(fabs(sample));
@@ -541,9 +549,9 @@ int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const 
     if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
     S.phase_cycles = g_phase_cycles;
     if (e->P.n_markets <= e->resident_markets_at_min_waves)
-        hipLaunchKernelGGL(k_step<CDA_MIN_WAVES>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, S);
+        hipLaunchKernelGGL(k_step<CDA_MIN_WAVES>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, S);
     else
-        hipLaunchKernelGGL(k_step<CDA_MIN_WAVES_LARGE>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, S);
+        hipLaunchKernelGGL(k_step<CDA_MIN_WAVES_LARGE>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, S);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }

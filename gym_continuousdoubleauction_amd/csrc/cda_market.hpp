@@ -244,16 +244,19 @@ __device__ __forceinline__ double glibc_log1p(double x) {
     if (k == 0) return f - (hfsq - s * (hfsq + R));
     return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
 }
-__device__ __forceinline__ double rng_std_normal(Mkt& m) {
+// wi / ki: the two tables every draw reads (numpy's wi_double, ki_double).  k_step passes LDS copies (the index is data
+// dependent, so each draw pays the table latency in full: ~100 cycles from LDS instead of a scalar-cache / L2 round
+// trip); fi is only read on the rare wedge path and stays in global memory.
+__device__ __forceinline__ double rng_std_normal(Mkt& m, const unsigned long long* wi = cda_zig_wi_bits, const unsigned long long* ki = cda_zig_ki) {
     const double zr = 3.6541528853610087963519472518, inv_r = 0.27366123732975827203338247596;
     for (;;) {
         uint64_t u = rng_next64(m);
         int idx = (int)(u & 0xff); u >>= 8;
         int sign = (int)(u & 1);
         uint64_t rabs = (u >> 1) & 0x000fffffffffffffULL;
-        double x = (double)rabs * __longlong_as_double((long long)cda_zig_wi_bits[idx]);
+        double x = (double)rabs * __longlong_as_double((long long)wi[idx]);
         if (sign) x = -x;
-        if (rabs < cda_zig_ki[idx]) return x;
+        if (rabs < ki[idx]) return x;
         if (idx == 0) {
             for (;;) {
                 double xx = -inv_r * glibc_log1p(-rng_double(m));
@@ -558,8 +561,14 @@ __device__ __forceinline__ bool order_approved(Lds& L, const Mkt& m, int tr, int
                     else if (m.has_trade) est = d_price(m.last_trade_price);
                     else est = d_from_u32(1);
                 } else est = d_price(price);
-                D order_val = d_mul_u32(est, (uint32_t)opening, 0);
-                ok = d_cmp(ld_dec(a.cash), order_val) >= 0;
+                // order_val = opening * est = ov * 10^-1 with ov < 2^63 (est is a tick price or 1: coefficient < 2^28).  When the
+                // bit lengths alone prove cash > order_val the exact decimal compare is skipped (cash of 1e6 vs orders of 1e2..1e5).
+                D cash = ld_dec(a.cash);
+                uint64_t ov = (uint64_t)((uint32_t)est.w0) * (uint64_t)opening;          // exact: est.w1 == est.w2 == 0
+                int kdig = est.exp - cash.exp;                                            // cash coefficient is compared with ov * 10^kdig
+                int bc = bits128(d_c128(cash)), bo = 64 - __clzll(ov | 1ull);
+                if (!cash.sign && kdig >= 0 && kdig <= 30 && opening < (1LL << 31) && bc - 1 >= bo + ((kdig * 3402) >> 10) + 1) ok = 1;
+                else ok = d_cmp(cash, d_mul_u32(est, (uint32_t)opening, 0)) >= 0;
             }
         }
     }
