@@ -39,6 +39,9 @@ def parse():
     p.add_argument("--agents", type=int, default=4)
     p.add_argument("--info", action="store_true", help="also emit the info tensors every step")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the obs/reward all-gather")
+    p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each step's all-gather before the next launch")
+    p.add_argument("--force-gather", action="store_true",
+                   help="run the N>1 code path (process group + all-gather) even with one rank; diagnostics")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline sample")
     return p.parse_args()
@@ -111,11 +114,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     n_gpus = world
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -125,40 +130,59 @@ def main():
     N, A, K, W = args.markets, args.agents, args.steps, args.warmup
     max_step = max(4096, K + W + 1)                   # no truncation inside the run
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
-    env = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=args.info)
+    gather = use_dist and not args.no_gather
+    # N > 1: the per-step outputs (obs | reward | flags: one contiguous slab written by k_step itself) are
+    # all-gathered over xGMI with ONE collective per step and no packing pass.  The env rotates two slabs, so
+    # the gather of step t runs on RCCL's stream underneath the kernel of step t+1.
+    env = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=args.info, out_buffers=2 if gather else 1)
     first_market = rank * N                           # global market index -> seed, independent of the GPU count
     seeds = (1000 + first_market + torch.arange(N, dtype=torch.int64)).numpy().astype("uint64")
     env.reset(seed=seeds)
     # action stream: chunks of <= 256 steps keep the resident set small (20 B per agent-step)
     chunk = min(256, K + W)
     acts = gen_actions(torch, N, A, chunk, device, 2024 + rank)
-    gather = world > 1 and not args.no_gather
     if gather:
-        packed = torch.empty((N, env.obs_dim + 2 * A), dtype=torch.float32, device=device)   # obs + reward(f64 as 2 x f32)
-        gathered = torch.empty((world * N, env.obs_dim + 2 * A), dtype=torch.float32, device=device)
+        gathered = [torch.empty(world * env.slab_layout["bytes"], dtype=torch.uint8, device=device) for _ in range(2)]
+    in_flight = [None]
+
+    def do_gather(t):
+        if args.no_overlap:
+            dist.all_gather_into_tensor(gathered[t & 1], env.out_slab)
+            return
+        work = dist.all_gather_into_tensor(gathered[t & 1], env.out_slab, async_op=True)
+        if in_flight[0] is not None:
+            in_flight[0].wait()             # stream-level: step t+1 may overwrite the slab gather t-1 read
+        in_flight[0] = work
 
     def one_step(t):
         i = t % chunk
-        obs, rew, term, trunc, _ = env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+        env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
         if gather:
-            packed[:, : env.obs_dim].copy_(obs)
-            packed[:, env.obs_dim:].copy_(rew.view(torch.float32))
-            dist.all_gather_into_tensor(gathered, packed)
+            do_gather(t)
+
+    def drain():
+        if in_flight[0] is not None:
+            in_flight[0].wait()
+            in_flight[0] = None
 
     for t in range(W):
         one_step(t)
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     # HIP events on the stream the kernel is launched on (torch's current stream == the stream handed
     # to cda_step).  N == 1: one pair brackets the K back-to-back launches (nothing else is enqueued in
-    # between), so kernel_ms = span / K.  N > 1: the pack/all-gather work sits between launches, so each
-    # launch gets its own pair.
+    # between), so kernel_ms = span / K.  N > 1: the all-gather's stream dependencies sit between launches, so
+    # single launches get their own pair - every EV_STRIDE-th one only, a timing event pair costs ~8 us of
+    # stream time (tools/host_overhead.py).
     per_launch = gather
+    EV_STRIDE = 16
     if per_launch:
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+        timed_steps = list(range(0, K, EV_STRIDE))
+        ev0 = {t: torch.cuda.Event(enable_timing=True) for t in timed_steps}
+        ev1 = {t: torch.cuda.Event(enable_timing=True) for t in timed_steps}
     else:
         ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -166,27 +190,26 @@ def main():
         ev_a.record()
     for t in range(K):
         i = (W + t) % chunk
-        if per_launch:
+        if per_launch and t in ev0:
             ev0[t].record()
         env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
-        if per_launch:
+        if per_launch and t in ev1:
             ev1[t].record()
         if gather:
-            packed[:, : env.obs_dim].copy_(env.obs)
-            packed[:, env.obs_dim:].copy_(env.reward.view(torch.float32))
-            dist.all_gather_into_tensor(gathered, packed)
+            do_gather(W + t)
+    drain()
     if not per_launch:
         ev_b.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kernel_ms = (sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / K) if per_launch else ev_a.elapsed_time(ev_b) / K
+    kernel_ms = (sum(ev0[t].elapsed_time(ev1[t]) for t in ev0) / len(ev0)) if per_launch else ev_a.elapsed_time(ev_b) / K
     flags = env.flags()
     n_flagged = int((flags != 0).sum().item())
 
@@ -213,7 +236,7 @@ def main():
             "config": {"workload": f"{N} markets x {A} random agents per GPU, book capacity {256} resting orders per market "
                                    f"(BASELINE configs[2]); global {world * N} markets",
                        "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info),
-                       "collective": "all_gather(obs,reward)" if gather else "none",
+                       "collective": ("all_gather(obs|reward|flags slab), " + ("serial" if args.no_overlap else "overlapped with the next step")) if gather else "none",
                        "flagged_markets": n_flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -226,7 +249,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out))
     env.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -4,9 +4,12 @@ RCCL on ROCm, "gloo" in the CPU tests).
 Markets are fully independent (each owns its book, accounts and RNG - SURVEY §8e), so the simulation
 needs NO collective: rank r steps the contiguous block [r*N/G, (r+1)*N/G).  Seeds derive from the GLOBAL
 market index, so results do not depend on the GPU count.  The only exchange is the hand-back of the
-per-market outputs to a central learner: one all-gather per step of a packed [n_local, obs_dim + 2A + 2]
-float32 buffer (obs | reward f64 as 2 x f32 | terminated | truncated).  On the fully connected xGMI node
-each rank pushes its shard directly to its 7 peers, so the gather is per-link bound.
+per-market outputs to a central learner: ONE all-gather per step of the env's output slab
+(obs f32[n,obs_dim] | reward f64[n,A] | terminated u8[n] | truncated u8[n], the bytes `k_step` itself
+wrote - no packing pass).  On the fully connected xGMI node each rank pushes its shard directly to its 7
+peers, so the gather is per-link bound (2.9 MB per rank at 4096 x 4: ~50 us at ~55 GB/s per link); it
+is issued asynchronously (`gather_async`) and overlaps the NEXT step's kernel, whose outputs go to the
+other slab of a double-buffered env.  `gather()` is the simple synchronous packed variant for any env.
 """
 import torch
 
@@ -22,6 +25,46 @@ def shard_range(rank, world, n_total):
 def global_seeds(seed_base, first, count):
     """Seed of global market i = seed_base + i (uint64 bit pattern carried in an int64 tensor)."""
     return (torch.arange(first, first + count, dtype=torch.int64) + int(seed_base))
+
+
+def slab_layout(n, obs_dim, num_agents):
+    """Byte offsets of one rank's per-step outputs inside its output slab (16-byte padded)."""
+    o_obs = 0
+    o_rew = o_obs + n * obs_dim * 4
+    o_rew = (o_rew + 7) // 8 * 8
+    o_term = o_rew + n * num_agents * 8
+    o_trunc = o_term + n
+    total = (o_trunc + n + 15) // 16 * 16
+    return {"n": n, "obs_dim": obs_dim, "num_agents": num_agents,
+            "obs": o_obs, "reward": o_rew, "terminated": o_term, "truncated": o_trunc, "bytes": total}
+
+
+def slab_views(slab, lay):
+    """Typed views (no copies) into uint8 slab(s) of shape [..., bytes]:
+    obs f32[..., n, obs_dim], reward f64[..., n, A], terminated u8[..., n], truncated u8[..., n]."""
+    n, od, a = lay["n"], lay["obs_dim"], lay["num_agents"]
+    lead = slab.shape[:-1]
+    obs = slab[..., lay["obs"]:lay["obs"] + n * od * 4].view(torch.float32).view(*lead, n, od)
+    rew = slab[..., lay["reward"]:lay["reward"] + n * a * 8].view(torch.float64).view(*lead, n, a)
+    term = slab[..., lay["terminated"]:lay["terminated"] + n]
+    trunc = slab[..., lay["truncated"]:lay["truncated"] + n]
+    return obs, rew, term, trunc
+
+
+class GatherHandle:
+    """An all-gather in flight.  wait() orders the caller's CURRENT stream after it (no host sync on a
+    GPU) and returns per-rank views [world, n_local, ...] into the gathered buffer: obs, reward,
+    terminated (bool), truncated (bool).  `.reshape(world * n_local, ...)` flattens them (one copy)."""
+
+    def __init__(self, work, gathered, lay):
+        self.work, self.gathered, self.lay = work, gathered, lay
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        obs, rew, term, trunc = slab_views(self.gathered, self.lay)
+        return obs, rew, term != 0, trunc != 0
 
 
 def pack_outputs(obs, reward, terminated, truncated, out=None):
@@ -61,12 +104,14 @@ class ShardedVecEnv:
         self.first, self.n_local = shard_range(self.rank, self.world, self.n_total)
         if env_factory is None:
             from .vec_env import CDAVecEnv
-            env_factory = lambda cfg, n, dev: CDAVecEnv(cfg, n_markets=n, device=dev, with_info=False)   # noqa: E731
+            env_factory = lambda cfg, n, dev: CDAVecEnv(cfg, n_markets=n, device=dev, with_info=False, out_buffers=2)   # noqa: E731
         self.env = env_factory(config, self.n_local, device)
         self.obs_dim = self.env.obs_dim
         self.num_agents = self.env.num_agents
         self._packed = None
         self._gathered = None
+        self.layout = slab_layout(self.n_local, self.obs_dim, self.num_agents)
+        self._gbufs, self._gnext = [None, None], 0
 
     def reset(self, seed_base=0):
         seeds = global_seeds(seed_base, self.first, self.n_local)
@@ -85,6 +130,30 @@ class ShardedVecEnv:
             self._gathered = torch.empty((self.n_total, self._packed.shape[1]), dtype=torch.float32, device=self._packed.device)
         self.dist.all_gather_into_tensor(self._gathered, self._packed)
         return unpack_outputs(self._gathered, self.obs_dim, self.num_agents)
+
+    def gather_async(self, outputs=None):
+        """Start the all-gather of this rank's output slab (the env's current one, i.e. the outputs of the
+        step just enqueued; or a slab built from `outputs` for an env without one) and return a GatherHandle.  Two gathered buffers rotate, so at most two
+        handles may be outstanding; with a double-buffered env the caller's loop is
+            step(t); h = gather_async(); prev.wait(); prev = h
+        which lets gather(t) run under the kernel of step t+1."""
+        slab = getattr(self.env, "out_slab", None) if outputs is None else None
+        if slab is None:                    # an env without slab-backed outputs: build the slab (copies)
+            if outputs is None:
+                raise ValueError("this env has no output slab: pass outputs=(obs, reward, terminated, truncated)")
+            slab = torch.zeros(self.layout["bytes"], dtype=torch.uint8, device=outputs[0].device)
+            for dst, src in zip(slab_views(slab, self.layout), outputs):
+                dst.copy_(src.to(dst.dtype))
+        b = self._gnext
+        self._gnext ^= 1
+        if self._gbufs[b] is None:
+            self._gbufs[b] = torch.zeros((self.world, self.layout["bytes"]), dtype=torch.uint8, device=slab.device)
+        g = self._gbufs[b]
+        if self.world == 1:
+            g[0].copy_(slab)
+            return GatherHandle(None, g, self.layout)
+        work = self.dist.all_gather_into_tensor(g.view(-1), slab, async_op=True)
+        return GatherHandle(work, g, self.layout)
 
     def close(self):
         self.env.close()

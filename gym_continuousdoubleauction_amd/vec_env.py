@@ -23,7 +23,7 @@ class CDAVecEnv:
     """Batched env.  Tensors: actions [N,A]; obs f32[N, n_hist*42]; reward f64[N,A];
     terminated/truncated bool[N] (the reference's "__all__" flags); info = dict of SoA tensors."""
 
-    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True):
+    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True, out_buffers=1):
         self.cfg_struct, self.config = K.make_config(config)
         self.n_markets = int(n_markets)
         self.num_agents = self.cfg_struct.num_agents
@@ -41,10 +41,18 @@ class CDAVecEnv:
         check(lib().cda_create(C.byref(self.cfg_struct), self.n_markets, self.device_index, C.byref(h)), "cda_create")
         self._h = h
         N, A, dev = self.n_markets, self.num_agents, self.device
-        self.obs = torch.zeros((N, self.obs_dim), dtype=torch.float32, device=dev)
-        self.reward = torch.zeros((N, A), dtype=torch.float64, device=dev)
-        self._term = torch.zeros(N, dtype=torch.uint8, device=dev)
-        self._trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
+        # The per-step outputs of one launch live in ONE contiguous slab (obs | reward | terminated | truncated),
+        # so a multi-GPU caller hands them to its peers with a single collective and no packing pass
+        # (parallel.slab_layout describes the byte offsets).  out_buffers > 1 rotates the slab every step:
+        # step t+1 writes a different slab while step t's is still being read by an all-gather in flight.
+        from .parallel import slab_layout, slab_views
+        self.slab_layout = slab_layout(N, self.obs_dim, A)
+        self._slabs = torch.zeros((max(1, int(out_buffers)), self.slab_layout["bytes"]), dtype=torch.uint8, device=dev)
+        self._views = [slab_views(self._slabs[b], self.slab_layout) for b in range(self._slabs.shape[0])]
+        self._out_ptrs = [tuple(t.data_ptr() for t in v) for v in self._views]
+        self._step_call = lib().cda_step
+        self._cur = 0
+        self._bind_outputs()
         self.with_info = bool(with_info)
         self.info = {}
         self._info_ptrs = K.InfoPtrs()
@@ -57,6 +65,11 @@ class CDAVecEnv:
                     t = torch.zeros(shape, dtype=_TORCH_OF[ct], device=dev)
                 self.info[name] = t
                 setattr(self._info_ptrs, name, t.data_ptr())
+        self._info_ref = C.byref(self._info_ptrs) if self.with_info else None
+
+    def _bind_outputs(self):
+        self.out_slab = self._slabs[self._cur]
+        self.obs, self.reward, self._term, self._trunc = self._views[self._cur]
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -102,6 +115,9 @@ class CDAVecEnv:
         return self.obs
 
     def _prep(self, x, dtype):
+        if (isinstance(x, torch.Tensor) and x.dtype == dtype and x.device == self.device and x.is_contiguous()
+                and x.numel() == self.n_markets * self.num_agents):
+            return x                        # the hot loop's case: already a resident tensor of the ABI's layout
         t = torch.as_tensor(x)
         if t.device != self.device or t.dtype != dtype:
             t = t.to(device=self.device, dtype=dtype)
@@ -120,11 +136,19 @@ class CDAVecEnv:
         pr = self._prep(price, torch.int32)
         po = self._prep(price_offset, torch.int32)
         ps = None if present is None else self._prep(present, torch.uint8)
-        with torch.cuda.device(self.device):
-            check(lib().cda_step(self._h, cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
-                                 ps.data_ptr() if ps is not None else None,
-                                 self.obs.data_ptr(), self.reward.data_ptr(), self._term.data_ptr(), self._trunc.data_ptr(),
-                                 C.byref(self._info_ptrs) if self.with_info else None, self._stream()), "cda_step")
+        if len(self._views) > 1:
+            self._cur = (self._cur + 1) % len(self._views)
+            self._bind_outputs()
+        call = (self._h, cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
+                ps.data_ptr() if ps is not None else None, *self._out_ptrs[self._cur],
+                self._info_ref, torch.cuda.current_stream(self.device).cuda_stream)
+        if torch.cuda.current_device() == self.device_index:
+            rc = self._step_call(*call)
+        else:                               # the library selects its own device; keep the caller's current one intact
+            with torch.cuda.device(self.device):
+                rc = self._step_call(*call)
+        if rc != 0:
+            check(rc, "cda_step")
         self._keep = (cat, sm, ss, pr, po, ps)      # keep inputs alive until the async kernel has consumed them
         return self.obs, self.reward, self._term.view(torch.bool), self._trunc.view(torch.bool), self.info
 

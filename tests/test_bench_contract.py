@@ -28,3 +28,19 @@ def test_bench_json_contract():
     assert "traffic" in r and r["kernel"] == "k_step" and r["kernel_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "agent-steps/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+
+
+def test_bench_multi_gpu_code_path_on_one_rank():
+    """The N>1 path of bench.py (RCCL process group, double-buffered output slabs, asynchronous all-gather
+    overlapped with the next launch) with a single rank - what the driver launches under torchrun at N>1."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    for extra in ([], ["--no-overlap"]):
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--markets",
+                                       "512", "--no-cpu-baseline", "--force-gather"] + extra, cwd=ROOT, env=env,
+                                      stderr=subprocess.STDOUT, text=True, timeout=600)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["value"] > 1e6 and "all_gather" in d["config"]["collective"]
+        assert d["config"]["flagged_markets"] == 0 and d["roofline"]["kernel_ms"] > 0

@@ -55,12 +55,26 @@ def _worker(rank, world, port, outdir):
     env = ShardedVecEnv(CFG, N_TOTAL, device=None, env_factory=lambda c, n, d: _OracleStepper(c, n, d))
     assert (env.first, env.n_local) == (rank * N_TOTAL // world, N_TOTAL // world)
     env.reset(seed_base=1000)
-    rec = []
+    rec, rec_async, prev = [], [], None
+
+    def _drain(h):
+        o, r, te, tr = h.wait()            # per-rank views [world, n_local, ...]
+        rec_async.append([o.reshape(N_TOTAL, -1).clone().numpy(), r.reshape(N_TOTAL, -1).clone().numpy(),
+                          te.reshape(-1).clone().numpy(), tr.reshape(-1).clone().numpy()])
+
     for t in range(T):
         acts = [x[env.first:env.first + env.n_local] for x in _actions(t)]
         obs, rew, term, trunc, _ = env.step(*acts)
         g = env.gather(obs, rew, term, trunc)
         rec.append([x.clone().numpy() for x in g])
+        h = env.gather_async(outputs=(obs, rew, term, trunc))     # the pipelined loop of bench.py: <= 2 in flight
+        if prev is not None:
+            _drain(prev)
+        prev = h
+    _drain(prev)
+    for a, b in zip(rec, rec_async):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and np.array_equal(x.view(np.uint8), y.view(np.uint8))
     if rank == 0:
         np.savez(os.path.join(outdir, "gathered.npz"), obs=np.stack([r[0] for r in rec]), rew=np.stack([r[1] for r in rec]),
                  term=np.stack([r[2] for r in rec]), trunc=np.stack([r[3] for r in rec]))

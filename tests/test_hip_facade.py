@@ -191,3 +191,39 @@ def test_bad_inputs_raise_like_the_reference():
 def test_random_agent_driver_runs_to_the_horizon():                  # CDA_rand.run_random / BASELINE config #1
     from gym_continuousdoubleauction_amd import run_random
     assert run_random(num_agents=4, max_step=200, seed=123) == 200
+
+
+def test_double_buffered_output_slabs_and_async_gather():
+    """out_buffers=2: step t+1 must not touch step t's slab; ShardedVecEnv.gather_async hands back the slab contents."""
+    import numpy as np
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv
+    cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 64, "is_render": False}
+    n, a = 96, 4
+    ref = CDAVecEnv(cfg, n_markets=n, with_info=False)
+    sh = ShardedVecEnv(cfg, n, device="cuda:0")                 # world 1, HIP env with two slabs
+    seeds = np.arange(300, 300 + n, dtype=np.uint64)
+    o0 = ref.reset(seed=seeds).clone()
+    assert torch.equal(sh.reset(seed_base=300), o0)
+    rng = np.random.default_rng(3)
+    prev = prev_ref = held = None
+    for t in range(40):
+        acts = (torch.from_numpy(rng.integers(0, 9, (n, a)).astype(np.int32)), torch.from_numpy(rng.uniform(-1, 1, (n, a)).astype(np.float32)),
+                torch.from_numpy(rng.uniform(0, 1, (n, a)).astype(np.float32)), torch.from_numpy(rng.integers(0, 10, (n, a)).astype(np.int32)),
+                torch.from_numpy(rng.integers(0, 3, (n, a)).astype(np.int32)))
+        ro, rr, rt, ru, _ = ref.step(*acts)
+        so, sr, st, su, _ = sh.step(*acts)
+        assert torch.equal(so.view(torch.int32), ro.view(torch.int32)) and torch.equal(sr.view(torch.int64), rr.view(torch.int64))
+        assert torch.equal(st, rt) and torch.equal(su, ru)
+        if held is not None:                                    # last step's tensors still hold last step's values
+            assert torch.equal(held[0].view(torch.int32), held[1].view(torch.int32))
+        held = (so, ro.clone())
+        h = sh.gather_async()
+        if prev is not None:
+            go, gr, gt, gu = prev.wait()
+            assert go.shape == (1, n, 168) and torch.equal(go[0].view(torch.int32), prev_ref[0].view(torch.int32))
+            assert torch.equal(gr[0].view(torch.int64), prev_ref[1].view(torch.int64)) and torch.equal(gt[0], prev_ref[2])
+        prev, prev_ref = h, (ro.clone(), rr.clone(), rt.clone(), ru.clone())
+    ref.close()
+    sh.close()
