@@ -246,15 +246,26 @@ __global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Par
     // 7. set_step_outputs (exchg_helper.py:93-124)
     uint32_t ferr = 0;
     bool bankrupt = false;
+    // The two float(Decimal) conversions of the reward are independent: the owner lane converts nav - prev_nav while its
+    // helper lane (a + 16) converts max_nav - nav, in the same instruction stream.
+    double conv = 0.0;
+    if (lane_acc(lane) < A && lane_grp(lane) < 2) {
+        const Acc& a = L.acc[lane_acc(lane)];
+        const bool own = lane_grp(lane) == 0;
+        D nav = ld_dec(a.nav);
+        D x = own ? nav : ld_dec(a.max_nav), y = own ? ld_dec(a.prev_nav) : nav;
+        D df = d_sub(x, y);                                  // ONE call site each, so owner and helper stay converged
+        if (own || d_sgn(df) > 0) conv = d_to_double(df, &ferr);
+    }
+    const double conv_helper = __shfl(conv, (lane + 16) & 63, WAVE);
     if (lane < A) {
         Acc& a = L.acc[lane];
         size_t ix = (size_t)mi * (size_t)A + (size_t)lane;
-        D nav = ld_dec(a.nav), prev = ld_dec(a.prev_nav), mx = ld_dec(a.max_nav);
+        D nav = ld_dec(a.nav), mx = ld_dec(a.max_nav);
         // Reward_Helper.set_reward (exchg/reward_helper.py:35-102)
-        double nav_change = d_to_double(d_sub(nav, prev), &ferr);
+        double nav_change = conv;
         double nav_term = nav_change * (nav_change < 0 ? P.cfg.loss_multiplier : 1.0);
-        D dd = d_sub(mx, nav);
-        double drawdown = d_sgn(dd) > 0 ? d_to_double(dd, &ferr) : 0.0;
+        double drawdown = conv_helper;
         double t0 = nav_term;
         double t1 = -(P.cfg.order_penalty * (double)a.order_step_placed);
         double t2 = -(P.cfg.trade_penalty * (double)a.num_trades_step);

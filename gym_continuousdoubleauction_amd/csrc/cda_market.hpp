@@ -530,15 +530,31 @@ __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, i
     return qty;
 }
 
-__device__ __forceinline__ void escrow_rest(Acc& a, int32_t price, int32_t qty, uint32_t& flags) {   // cash_processor.py:15-29
-    D v = d_mul_u32(d_price(price), (uint32_t)qty, 0);
-    D cash = d_sub(ld_dec(a.cash), v), hold = d_add(ld_dec(a.hold), v);
-    st_dec(a.cash, cash, flags); st_dec(a.hold, hold, flags);
+// Account a is owned by lane a; lanes a+16 and a+32 are its HELPERS: independent decimal operations on one account are
+// issued on the owner and its helpers in the same instruction stream (CDA_MAX_AGENTS = 16 <= 16 lanes per group), e.g.
+// cash -= v on lane a while hold += v on lane a+16.  All addressing is by (lane & 15); every helper sees the same LDS.
+__device__ __forceinline__ int lane_acc(int lane) { return lane & 15; }
+__device__ __forceinline__ int lane_grp(int lane) { return lane >> 4; }
+__device__ __forceinline__ D d_shfl(const D& v, int src) {
+    D r;
+    r.w0 = (uint32_t)__shfl((int)v.w0, src, WAVE); r.w1 = (uint32_t)__shfl((int)v.w1, src, WAVE); r.w2 = (uint32_t)__shfl((int)v.w2, src, WAVE);
+    int es = __shfl((v.exp << 1) | (v.sign & 1), src, WAVE);
+    r.exp = es >> 1; r.sign = es & 1;
+    return r;
 }
-__device__ __forceinline__ void cancel_cash_transfer(Acc& a, int32_t price, int32_t qty, uint32_t& flags) {   // cash_processor.py:85-97
-    D v = d_mul_u32(d_price(price), (uint32_t)qty, 0);
-    D hold = d_sub(ld_dec(a.hold), v), cash = d_add(ld_dec(a.cash), v);
-    st_dec(a.hold, hold, flags); st_dec(a.cash, cash, flags);
+// cash -+= v and hold +-= v of account `tr` (cash_processor.py:15-29 order_in_book_passive_party with dir = -1: escrow a
+// resting order; :85-97 cancel_cash_transfer with dir = +1: release it).  Group 0 updates cash, group 1 cash_on_hold.
+__device__ __forceinline__ void cash_hold_transfer(Lds& L, int tr, int32_t price, int32_t qty, int cash_dir, uint32_t& flags, int lane) {
+    const int g = lane_grp(lane);
+    if (lane_acc(lane) == tr && g < 2) {
+        Acc& a = L.acc[tr];
+        D v = d_mul_u32(d_price(price), (uint32_t)qty, 0);
+        cda_dec& fld = g == 0 ? a.cash : a.hold;
+        v.sign = (g == 0) == (cash_dir > 0) ? 0 : 1;
+        D r = d_add(ld_dec(fld), v);
+        st_dec(fld, r, flags);
+    }
+    CDA_WSYNC();
 }
 
 // Trader._order_approved (agent/trader.py:108-151), evaluated by lane `tr`, result broadcast
@@ -611,9 +627,9 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
             m.lob_time += 1;
             if (type == T_CANCEL) {                           // trader.py:237-252: cancel, then release the escrow
                 book_remove(bk, side, nside, idx, 1, lane); mkt_set_n(m, side, nside - 1);
-                if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
+                cash_hold_transfer(L, tr, op, oq, +1, f, lane);
             } else {                                          // upsert / modify: release, then modify_order
-                if (lane == tr) cancel_cash_transfer(L.acc[lane], op, oq, f);
+                cash_hold_transfer(L, tr, op, oq, +1, f, lane);
                 if (price == op && size <= oq) {              // in place: priority kept, timestamp := now
                     bk.qty[side][idx] = size; bk.ts[side][idx] = m.lob_time;
                     CDA_WSYNC();
@@ -637,7 +653,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
         }
         TACC_END(m, 3);
     }
-    if (rest_qty > 0 && lane == tr) escrow_rest(L.acc[lane], rest_price, rest_qty, f);
+    if (rest_qty > 0) cash_hold_transfer(L, tr, rest_price, rest_qty, -1, f, lane);
     TACC_END(m, 4);
     if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
 }
@@ -647,20 +663,36 @@ __device__ __forceinline__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
     if (!m.has_trade) return;
     m.last_price = m.last_trade_price;
     uint32_t f = 0;
-    if (lane < A) {
-        Acc& a = L.acc[lane];
-        D p = d_price(m.last_trade_price), vwap = ld_dec(a.vwap);
+    // Three independent chains per account run on the owner lane and its two helpers in the same instruction stream:
+    //   group 0: diff = +-(p - VWAP), profit = diff * |pos|      group 1: raw = VWAP * |pos|      group 2: cash + cash_on_hold
+    // then the owner finishes position_val = raw + profit, nav = (cash + hold) + position_val: 4 dependent operations, not 6.
+    const int g = lane_grp(lane), al = lane_acc(lane);
+    const bool act = al < A && g < 3;
+    D r1 = d_zero(), r2 = d_zero();
+    uint32_t ap = 0;
+    if (act) {
+        const Acc& a = L.acc[al];
         int32_t pos = a.net_position;
-        uint32_t ap = (uint32_t)(pos < 0 ? -pos : pos);
-        D diff = pos >= 0 ? d_sub(p, vwap) : d_sub(vwap, p);
-        D profit = d_mul_int(diff, ap);
-        D raw = d_mul_int(vwap, ap);
-        D posval = d_add(raw, profit);
-        D nav = d_add(d_add(ld_dec(a.cash), ld_dec(a.hold)), posval);
+        ap = (uint32_t)(pos < 0 ? -pos : pos);
+        D vwap = ld_dec(a.vwap);
+        if (g != 1) {                                         // stage 1, one addition: g0 p - VWAP (or VWAP - p), g2 cash + hold
+            D x, y;
+            if (g == 0) { D p = d_price(m.last_trade_price); x = pos >= 0 ? p : vwap; y = d_neg(pos >= 0 ? vwap : p); }
+            else { x = ld_dec(a.cash); y = ld_dec(a.hold); }
+            r1 = d_add(x, y);
+        }
+        if (g != 2) r2 = d_mul_int(g == 0 ? r1 : vwap, ap);   // stage 2, one multiplication: g0 profit, g1 raw
+    }
+    D raw = d_shfl(r2, (lane + 16) & 63), ssum = d_shfl(r1, (lane + 32) & 63);
+    if (act && g == 0) {
+        Acc& a = L.acc[al];
+        D posval = d_add(raw, r2);
+        D nav = d_add(ssum, posval);
         a.prev_nav = a.nav;
         st_dec(a.posval, posval, f); st_dec(a.nav, nav, f);
         if (d_cmp(nav, ld_dec(a.max_nav)) > 0) st_dec(a.max_nav, nav, f);
     }
+    CDA_WSYNC();
     if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
 }
 
