@@ -23,14 +23,11 @@ using namespace cda;
 #ifndef CDA_WPB
 #define CDA_WPB 4            // markets (waves) per workgroup
 #endif
-// The step kernel is built twice: register-budgeted for 4 waves per SIMD (128 VGPRs, no spills: fastest while
-// every market-wave of the launch is resident at once, i.e. up to 256 CUs x 16 = 4096 markets) and for 6 waves per
-// SIMD (80 VGPRs, a few spills: +15..22 % throughput once the batch no longer fits at 4 per SIMD).
+// The step kernel is register-budgeted for 4 waves per SIMD (128 VGPRs, no spills).  A second build for 6 waves per
+// SIMD (80 VGPRs) used to serve batches beyond 4096 markets; as the ledger code grew it needed > 100 spilled VGPRs
+// and measured 20-27 % SLOWER than this build at 8 k..64 k markets, so it is gone.
 #ifndef CDA_MIN_WAVES
 #define CDA_MIN_WAVES 4
-#endif
-#ifndef CDA_MIN_WAVES_LARGE
-#define CDA_MIN_WAVES_LARGE 6
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -69,14 +66,15 @@ __device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params&
 // ------------------------------------------------------------------------------------------
 // reset
 // ------------------------------------------------------------------------------------------
-// dynamic LDS of a workgroup: [decimal power-of-ten table (640 B)] [k_step only: ziggurat wi, ki (4 KB)] [wave 0 image] ...
-constexpr int ZIG_LDS_BYTES = 2 * 256 * 8;
+// dynamic LDS of a workgroup: [decimal power-of-ten table (640 B)] [k_step only: ziggurat wi, ki (4 KB), PCG jump table (512 B)] [wave 0 image] ...
+constexpr int ZIG_LDS_BYTES = (2 * 256 + PCG_JUMP_WORDS64) * 8;
 __device__ __forceinline__ Lds& wave_lds(const Params& P, int wave, int extra = 0) {
     return *reinterpret_cast<Lds*>(cda_smem + DEC_TABLE_BYTES + extra + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents));
 }
 __device__ __forceinline__ void zig_tables_init() {       // every thread of the workgroup, before the first __syncthreads
     unsigned long long* t = reinterpret_cast<unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
     for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) { t[i] = cda_zig_wi_bits[i]; t[256 + i] = cda_zig_ki[i]; }
+    for (int i = (int)threadIdx.x; i < PCG_JUMP_WORDS64; i += (int)blockDim.x) t[512 + i] = reinterpret_cast<const unsigned long long*>(&PCG_JUMP)[i];
 }
 
 __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out) {
@@ -138,8 +136,7 @@ struct StepArgs {
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <int MINW>
-__global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Params P, StepArgs S) {
+__global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
     int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
     int mi = (int)blockIdx.x * CDA_WPB + wave;
     zig_tables_init();
@@ -163,42 +160,63 @@ __global__ __launch_bounds__(64 * CDA_WPB, MINW) void k_step(uint8_t* arena, Par
     //    set_state or reset touched the book in between.
     if (!m.levels_valid) aggregate_levels(L, m, lane);
     PHASE_MARK(2);
-    // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order.
-    //    The action words are read at wave-uniform addresses (scalar loads); decoded orders go to LDS.
+    // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order; lane a
+    //    decodes agent a.  Every agent's normal is first computed SPECULATIVELY in its own lane: the k-th present agent
+    //    jumps the LCG ahead by k + 1 and takes the ziggurat's first candidate.  If every lane accepted (95 % of the steps at
+    //    4 agents) those ARE the sequential draws; otherwise the draws are redone one after the other, wave-uniform.
     uint32_t act_mask = 0, pass_mask = 0;
     {
         const size_t ab = (size_t)mi * (size_t)A;
-        for (int a = 0; a < A; a++) {
-            if (S.present && !S.present[ab + a]) continue;
-            int cat = clampi(S.category[ab + a], 0, 8);
-            float mean = clampf(S.size_mean[ab + a], -1.0f, 1.0f), sigma = clampf(S.size_sigma[ab + a], 0.0f, 1.0f);
-            int level = clampi(S.price[ab + a], 0, CDA_K_ROWS - 1), off = clampi(S.price_offset[ab + a], 0, 2) - 1;
-            int side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
-            int type = cat == 0 ? T_MARKET : ((cat - 1) & 3);
-            float locf = (type == T_MARKET ? P.mkt_mul : P.lim_mul) * mean;      // float32 product (numpy NEP 50)
-            double z = rng_std_normal(m, zig_wi, zig_ki);
-            double prod = (double)sigma * z;
-            double sample = (double)locf + prod;                                   // built with -ffp-contract=off
-            double rs = rint(fabs(sample));
-            if (rs > 1.0e9) { rs = 1.0e9; m.flags |= CDA_FLAG_INT_OVERFLOW; }
-            int32_t size = (int32_t)rs + P.cfg.min_size;
-            int32_t pr = -1;
-            if (type != T_MARKET) {                                                // _set_price (action_helper.py:341-397)
-                if (side == S_BID) {
-                    int32_t p = L.lvl_px[0][level];
-                    int32_t base = p == 0 ? m.last_price - (level + 1) * tick : p;
-                    pr = base + off * tick;
+        const bool pres = lane < A && (!S.present || S.present[ab + lane]);
+        const uint64_t pm = __ballot(pres);
+        if (pm) {
+            double z = 0.0;
+            {
+                const int k = __popcll(pm & ((1ull << lane) - 1ull));             // draws that precede this agent's
+                const u128 sj = pcg_jump_state(zig_ki + 256, k & (CDA_MAX_AGENTS - 1), m.rng_state, m.rng_inc);
+                const bool ok = zig_first_candidate(pcg_output(sj), zig_wi, zig_ki, &z);
+                if (__ballot(pres && !ok) == 0) {
+                    const int last = 63 - __clzll(pm);                             // its state is the stream's state after all draws
+                    uint32_t w0 = (uint32_t)sj, w1 = (uint32_t)(sj >> 32), w2 = (uint32_t)(sj >> 64), w3 = (uint32_t)(sj >> 96);
+                    w0 = (uint32_t)__builtin_amdgcn_readlane((int)w0, last); w1 = (uint32_t)__builtin_amdgcn_readlane((int)w1, last);
+                    w2 = (uint32_t)__builtin_amdgcn_readlane((int)w2, last); w3 = (uint32_t)__builtin_amdgcn_readlane((int)w3, last);
+                    m.rng_state = ((u128)w3 << 96) | ((u128)w2 << 64) | ((u128)w1 << 32) | (u128)w0;
                 } else {
-                    int32_t p = L.lvl_px[1][level];
-                    int32_t base = p == 0 ? m.last_price + (level + 1) * tick : p;
-                    pr = base - off * tick;
+                    for (int a = 0; a < A; a++) {
+                        if (!((pm >> a) & 1ull)) continue;
+                        double za = rng_std_normal(m, zig_wi, zig_ki);
+                        if (lane == a) z = za;
+                    }
                 }
-                if (pr < tick) pr = tick;
-                if (pr >= (1 << 24)) { pr = (1 << 24) - 1; m.flags |= CDA_FLAG_INT_OVERFLOW; }
             }
-            L.act_tsp[a] = type | (side << 2) | ((pr + 1) << 4);                   // every lane stores the same words
-            L.act_size[a] = size;
-            if (side != S_NONE) act_mask |= 1u << a; else pass_mask |= 1u << a;
+            bool ovf = false;
+            int side = S_NONE;
+            if (pres) {
+                int cat = clampi(S.category[ab + lane], 0, 8);
+                float mean = clampf(S.size_mean[ab + lane], -1.0f, 1.0f), sigma = clampf(S.size_sigma[ab + lane], 0.0f, 1.0f);
+                int level = clampi(S.price[ab + lane], 0, CDA_K_ROWS - 1), off = clampi(S.price_offset[ab + lane], 0, 2) - 1;
+                side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
+                int type = cat == 0 ? T_MARKET : ((cat - 1) & 3);
+                float locf = (type == T_MARKET ? P.mkt_mul : P.lim_mul) * mean;      // float32 product (numpy NEP 50)
+                double prod = (double)sigma * z;
+                double sample = (double)locf + prod;                                   // built with -ffp-contract=off
+                double rs = rint(fabs(sample));
+                if (rs > 1.0e9) { rs = 1.0e9; ovf = true; }
+                int32_t size = (int32_t)rs + P.cfg.min_size;
+                int32_t pr = -1;
+                if (type != T_MARKET) {                                                // _set_price (action_helper.py:341-397)
+                    int32_t p = L.lvl_px[side == S_BID ? 0 : 1][level];
+                    if (side == S_BID) pr = (p == 0 ? m.last_price - (level + 1) * tick : p) + off * tick;
+                    else pr = (p == 0 ? m.last_price + (level + 1) * tick : p) - off * tick;
+                    if (pr < tick) pr = tick;
+                    if (pr >= (1 << 24)) { pr = (1 << 24) - 1; ovf = true; }
+                }
+                L.act_tsp[lane] = type | (side << 2) | ((pr + 1) << 4);
+                L.act_size[lane] = size;
+            }
+            act_mask = (uint32_t)__ballot(pres && side != S_NONE);
+            pass_mask = (uint32_t)__ballot(pres && side == S_NONE);
+            if (__ballot(ovf)) m.flags |= CDA_FLAG_INT_OVERFLOW;
         }
         CDA_WSYNC();
     }
@@ -447,7 +465,6 @@ __global__ void k_selftest_rng(uint64_t seed, int lo, int hi, int n_steps, int n
 struct cda_env {
     Params P;
     int device;
-    int resident_markets_at_min_waves;   // CUs x 4 SIMDs x CDA_MIN_WAVES: batches up to this size use the 128-VGPR build
     uint8_t* arena;
     size_t arena_bytes;
 };
@@ -506,12 +523,6 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     cda_env* e = (cda_env*)calloc(1, sizeof *e);
     if (!e) return CDA_ERR_NOMEM;
     e->device = device;
-    {
-        hipDeviceProp_t prop;
-        int cus = 256;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        e->resident_markets_at_min_waves = cus * 4 * CDA_MIN_WAVES;
-    }
     Params& P = e->P;
     P.cfg = *cfg; P.n_markets = n_markets;
     P.mkt_mul = (float)((double)(cfg->mkt_max_size - cfg->min_size) / 2.0);
@@ -559,10 +570,7 @@ int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const 
     S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
     if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
     S.phase_cycles = g_phase_cycles;
-    if (e->P.n_markets <= e->resident_markets_at_min_waves)
-        hipLaunchKernelGGL(k_step<CDA_MIN_WAVES>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, S);
-    else
-        hipLaunchKernelGGL(k_step<CDA_MIN_WAVES_LARGE>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, S);
+    hipLaunchKernelGGL(k_step, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, S);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }

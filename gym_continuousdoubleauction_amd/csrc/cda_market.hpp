@@ -145,6 +145,30 @@ __device__ __forceinline__ uint64_t rng_next64(Mkt& m) {
     unsigned rot = (unsigned)(hi >> 58);
     return (x >> rot) | (x << ((64u - rot) & 63u));
 }
+__device__ __forceinline__ uint64_t pcg_output(u128 state) {
+    uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state, x = hi ^ lo;
+    unsigned rot = (unsigned)(hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+// Jump-ahead of the LCG: after k + 1 advances state = M^(k+1) * s + G_(k+1) * inc with G_n = 1 + M + ... + M^(n-1).
+// Lets the k-th present agent of a market compute ITS draw without waiting for the k draws before it.
+struct PcgJump { uint64_t mlo[CDA_MAX_AGENTS], mhi[CDA_MAX_AGENTS], glo[CDA_MAX_AGENTS], ghi[CDA_MAX_AGENTS]; };
+constexpr PcgJump make_pcg_jump() {
+    PcgJump t{};
+    const u128 M = ((u128)0x2360ed051fc65da4ULL << 64) | 0x4385df649fccf645ULL;
+    u128 mk = 1, gk = 0;
+    for (int k = 0; k < CDA_MAX_AGENTS; k++) {
+        gk = gk * M + 1; mk = mk * M;
+        t.mlo[k] = (uint64_t)mk; t.mhi[k] = (uint64_t)(mk >> 64); t.glo[k] = (uint64_t)gk; t.ghi[k] = (uint64_t)(gk >> 64);
+    }
+    return t;
+}
+__device__ const PcgJump PCG_JUMP = make_pcg_jump();
+constexpr int PCG_JUMP_WORDS64 = 4 * CDA_MAX_AGENTS;
+__device__ __forceinline__ u128 pcg_jump_state(const unsigned long long* jt, int k, u128 state, u128 inc) {   // jt: LDS copy of PCG_JUMP
+    u128 mk = ((u128)jt[CDA_MAX_AGENTS + k] << 64) | jt[k], gk = ((u128)jt[3 * CDA_MAX_AGENTS + k] << 64) | jt[2 * CDA_MAX_AGENTS + k];
+    return mk * state + gk * inc;
+}
 __device__ __forceinline__ uint32_t rng_next32(Mkt& m) {
     if (m.has_u32) { m.has_u32 = 0; return m.uinteger; }
     uint64_t v = rng_next64(m);
@@ -247,6 +271,15 @@ __device__ __forceinline__ double glibc_log1p(double x) {
 // wi / ki: the two tables every draw reads (numpy's wi_double, ki_double).  k_step passes LDS copies (the index is data
 // dependent, so each draw pays the table latency in full: ~100 cycles from LDS instead of a scalar-cache / L2 round
 // trip); fi is only read on the rare wedge path and stays in global memory.
+// first candidate of the ziggurat from one 64-bit draw; true = accepted (98.8 % of the draws)
+__device__ __forceinline__ bool zig_first_candidate(uint64_t u, const unsigned long long* wi, const unsigned long long* ki, double* x_out) {
+    int idx = (int)(u & 0xff); u >>= 8;
+    int sign = (int)(u & 1);
+    uint64_t rabs = (u >> 1) & 0x000fffffffffffffULL;
+    double x = (double)rabs * __longlong_as_double((long long)wi[idx]);
+    *x_out = sign ? -x : x;
+    return rabs < ki[idx];
+}
 __device__ __forceinline__ double rng_std_normal(Mkt& m, const unsigned long long* wi = cda_zig_wi_bits, const unsigned long long* ki = cda_zig_ki) {
     const double zr = 3.6541528853610087963519472518, inv_r = 0.27366123732975827203338247596;
     for (;;) {

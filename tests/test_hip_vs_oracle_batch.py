@@ -18,7 +18,7 @@ def _actions(rng, n, a):
             rng.integers(0, 3, (n, a)).astype(np.int32))
 
 
-# 6000 markets exceed what is resident at 4 waves per SIMD, so that case runs the 6-waves-per-SIMD build of k_step
+# 6000 markets exceed what is resident at 4 waves per SIMD: workgroups of that case run in two rounds
 @pytest.mark.parametrize("n,a,steps", [(1024, 4, 256), (512, 8, 128), (64, 16, 64), (37, 5, 96), (6000, 4, 48)])
 def test_hip_equals_oracle_every_step(n, a, steps):
     from hip_env import HipEnv
