@@ -244,6 +244,41 @@ __device__ __forceinline__ u128 mul_pow10_128(u128 x, int k) {   // caller guara
 // does c * 10^k stay below 2^126 ?  (3402/1024 > log2(10))
 __device__ __forceinline__ bool scale_fits128(u128 c, int k) { return bits128(c) + ((k * 3402) >> 10) + 1 <= 126; }
 
+// Decimal._fix for a 128-bit coefficient r >= 10^28 (the caller has checked), r < 2^127: ONE division by 10^D where
+// D = (upper estimate of the digit count) - 28 comes from the bit length alone.  The quotient shows whether the
+// estimate was one too high (27 digits instead of 28); then the dropped digit is restored from the remainder with
+// 32-bit arithmetic.  No table, no digit count, no second long division; the remainder decides half-even exactly.
+__device__ __noinline__ D d_round_mid(int sign, u128 r, int exp) {
+    const int nd_hi = ((bits128(r) * 1233) >> 12) + 1;          // len(str(r)) is nd_hi or nd_hi - 1
+    int drop = nd_hi - 28;                                      // >= 1
+    if (drop > 9) return d_fix_mid(sign, w4_from128(r), exp);
+    uint32_t pw = pow10_sel(drop);
+    W4 x = w4_from128(r);
+    uint32_t rem = w_div_u32(x, pw);
+    // 10^27 = 0x033b2e3c_9fd0803c_e8000000
+    const bool full = x.w[2] > 0x033b2e3cu || (x.w[2] == 0x033b2e3cu && (x.w[1] > 0x9fd0803cu || (x.w[1] == 0x9fd0803cu && x.w[0] >= 0xe8000000u)));
+    if (!full) {                                                // r has nd_hi - 1 digits: one digit fewer to drop
+        drop -= 1;
+        pw = pow10_sel(drop);
+        uint32_t dg = (uint32_t)((double)rem * (1.0 / (double)pw));          // 0..9, off by at most one
+        int32_t rr = (int32_t)(rem - dg * pw);
+        if (rr < 0) { dg -= 1; rr += (int32_t)pw; }
+        if (rr >= (int32_t)pw) { dg += 1; rr -= (int32_t)pw; }
+        rem = (uint32_t)rr;
+        w_mul_small(x, 10u);
+        x.w[0] += dg;                                           // x * 10 ends in 0: no carry
+    }
+    exp += drop;
+    const uint32_t half = pw >> 1;                              // 5 * 10^(drop-1); drop == 0 cannot round (rem == 0, half == 0)
+    if (rem > half || (rem == half && drop > 0 && (x.w[0] & 1u))) {
+        w_inc(x);
+        if (x.w[0] == 0x10000000u && x.w[1] == 0x3e250261u && x.w[2] == 0x204fce5eu) {    // reached 10^28
+            x.w[0] = 0xe8000000u; x.w[1] = 0x9fd0803cu; x.w[2] = 0x033b2e3cu; exp += 1;   // 10^27
+        }
+    }
+    return d_make(x.w[0], x.w[1], x.w[2], exp, sign);
+}
+
 // ---- addition: Decimal.__add__ (_pydecimal.py:1157) with _normalize (:5640) and _rescale (:2612) ----
 __device__ __noinline__ D d_add_wide(D a, D b) {
     int exp = a.exp < b.exp ? a.exp : b.exp;
@@ -296,7 +331,7 @@ __device__ __noinline__ D d_add_mid(D a, D b) {
         if (ct > co) { r = ct - co; rs = t.sign; } else { r = co - ct; rs = o.sign; }
     } else { r = ct + co; rs = t.sign; }
     if (r < p28_128()) return d_from128(r, o.exp, rs);
-    return d_fix_mid(rs, w4_from128(r), o.exp);             // < 2^127: round on 4 limbs
+    return d_round_mid(rs, r, o.exp);                       // < 2^127
 }
 // u32 * 10^k (k <= 28) from the LDS table: < 2^32 * 10^28 < 2^126
 __device__ __forceinline__ u128 mul_u32_pow10_lds(uint32_t c, int k) {
@@ -304,8 +339,9 @@ __device__ __forceinline__ u128 mul_u32_pow10_lds(uint32_t c, int k) {
     u128 pw = ((u128)p[2] << 64) | ((u128)p[1] << 32) | (u128)p[0];      // 10^28 < 2^94: three limbs
     return pw * (u128)c;
 }
-// Inline tier: the two shapes the ledger produces almost always - equal exponents, or a short coefficient
-// (an order value, a price: < 2^32) on the larger-exponent side that is scaled with ONE table multiply.
+// Inline tier: the shapes the ledger produces almost always - equal exponents; a short coefficient (an order value,
+// a price: < 2^32) on the larger-exponent side that is scaled with ONE table multiply; or two long coefficients a few
+// digits apart (position_val = raw + profit, nav = cash + position_val) scaled by a power of ten below 2^32.
 __device__ __forceinline__ D d_add(D a, D b) {
     const bool az = d_is_zero(a), bz = d_is_zero(b);
     if (!az && !bz) {
@@ -316,10 +352,12 @@ __device__ __forceinline__ D d_add(D a, D b) {
         u128 ct;
         bool ok;
         if (diff == 0) { ct = d_c128(t); ok = true; }
-        else if ((t.w1 | t.w2) == 0 && diff <= 28) {
+        else {
             ok = (((bits128(co) - 1) * 1233) >> 12) >= diff - 1;   // no _normalize replacement (see d_add_mid)
-            ct = mul_u32_pow10_lds(t.w0, diff);
-        } else { ok = false; ct = 0; }
+            if ((t.w1 | t.w2) == 0 && diff <= 28) ct = mul_u32_pow10_lds(t.w0, diff);
+            else if (diff <= 9) ct = d_c128(t) * (u128)pow10_sel(diff);          // < 2^94 * 2^30
+            else { ok = false; ct = 0; }
+        }
         if (ok) {
             u128 r; int rs;
             if (t.sign != o.sign) {
@@ -327,7 +365,7 @@ __device__ __forceinline__ D d_add(D a, D b) {
                 if (ct > co) { r = ct - co; rs = t.sign; } else { r = co - ct; rs = o.sign; }
             } else { r = ct + co; rs = t.sign; }
             if (r < p28_128()) return d_from128(r, o.exp, rs);
-            return d_fix_mid(rs, w4_from128(r), o.exp);
+            return d_round_mid(rs, r, o.exp);
         }
         return d_add_mid(a, b);
     }
@@ -345,7 +383,7 @@ __device__ __forceinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
     if (d_is_zero(a) || m == 0) return d_make(0, 0, 0, exp, a.sign);
     u128 p = d_c128(a) * (u128)m;                           // < 2^94 * 2^32 = 2^126
     if (p < p28_128()) return d_from128(p, exp, a.sign);
-    return d_fix_mid(a.sign, w4_from128(p), exp);
+    return d_round_mid(a.sign, p, exp);
 }
 __device__ __forceinline__ D d_mul_int(D a, uint32_t n) { return d_mul_u32(a, n, 0); }   // int * Decimal
 

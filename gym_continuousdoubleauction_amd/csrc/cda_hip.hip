@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P
 // step - the hot kernel
 // ------------------------------------------------------------------------------------------
 #ifdef CDA_PHASE_TIMING
-#define PHASE_MARK(i) do { unsigned long long _t = __builtin_readcyclecounter(); if (S.phase_cycles && lane == 0) S.phase_cycles[(size_t)mi * 16 + (i)] = _t; } while (0)
+#define PHASE_MARK(i) do { unsigned long long _t = __builtin_readcyclecounter(); if (S.phase_cycles && lane == 0) S.phase_cycles[(size_t)mi * 24 + (i)] = _t; } while (0)
 #else
 #define PHASE_MARK(i) do {} while (0)
 #endif
@@ -130,7 +130,7 @@ struct StepArgs {
     const int32_t* price; const int32_t* price_offset; const uint8_t* present;
     float* obs_out; double* reward_out; uint8_t* terminated_out; uint8_t* truncated_out;
     cda_info_ptrs info; int has_info;
-    unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,16] cycle stamps
+    unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,24] cycle stamps
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     Mkt m;
     const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
 #ifdef CDA_PHASE_TIMING
-    for (int i = 0; i < 6; i++) m.tacc[i] = 0;
+    for (int i = 0; i < 14; i++) m.tacc[i] = 0;
 #endif
     PHASE_MARK(0);
     load_market(mp, P, L, m, lane);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     store_levels(mp, L, lane);
     PHASE_MARK(9);
 #ifdef CDA_PHASE_TIMING
-    if (S.phase_cycles && lane == 0) for (int i = 0; i < 6; i++) S.phase_cycles[(size_t)mi * 16 + 10 + i] = m.tacc[i];
+    if (S.phase_cycles && lane == 0) for (int i = 0; i < 14; i++) S.phase_cycles[(size_t)mi * 24 + 10 + i] = m.tacc[i];
 #endif
 }
 
@@ -470,7 +470,7 @@ struct cda_env {
 };
 
 static thread_local char g_err[256] = "";
-static unsigned long long* g_phase_cycles = NULL;   // debug (CDA_PHASE_TIMING builds): device buffer [N,16]
+static unsigned long long* g_phase_cycles = NULL;   // debug (CDA_PHASE_TIMING builds): device buffer [N,24]
 static int hip_fail(hipError_t e, const char* what) {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
     return CDA_ERR_HIP;
@@ -763,7 +763,7 @@ int cda_debug_calib(void* dev_buf, size_t n_bytes, int mode, void* stream) {
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
-/* debug hook (not in include/cda.h): device buffer [N,16] of cycle stamps, used by tools/phase_timing.py */
+/* debug hook (not in include/cda.h): device buffer [N,24] of cycle stamps, used by tools/phase_timing.py */
 void cda_debug_set_phase_buffer(unsigned long long* dev_buf) { g_phase_cycles = dev_buf; }
 
 int32_t cda_num_markets(const cda_env* e) { return e ? e->P.n_markets : 0; }

@@ -112,7 +112,7 @@ struct Mkt {
     int32_t nb, na;              // resting orders per side (two scalars: a dynamically indexed array would force Mkt into scratch)
     int32_t seeded, hist_head, levels_valid;
 #ifdef CDA_PHASE_TIMING
-    unsigned long long tacc[6];     // debug: cycles in approval / find / match+settle / insert+remove / escrow+cancel, fills
+    unsigned long long tacc[14];    // debug: cycles in approval / find / match+settle / insert+remove / escrow+cancel, fills, 8 free slots
 #endif
 };
 #ifdef CDA_PHASE_TIMING
@@ -703,6 +703,7 @@ __device__ __forceinline__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
     const bool act = al < A && g < 3;
     D r1 = d_zero(), r2 = d_zero();
     uint32_t ap = 0;
+    TACC_BEGIN();
     if (act) {
         const Acc& a = L.acc[al];
         int32_t pos = a.net_position;
@@ -714,16 +715,22 @@ __device__ __forceinline__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
             else { x = ld_dec(a.cash); y = ld_dec(a.hold); }
             r1 = d_add(x, y);
         }
+        TACC_END(m, 6);
         if (g != 2) r2 = d_mul_int(g == 0 ? r1 : vwap, ap);   // stage 2, one multiplication: g0 profit, g1 raw
+        TACC_END(m, 7);
     }
     D raw = d_shfl(r2, (lane + 16) & 63), ssum = d_shfl(r1, (lane + 32) & 63);
+    TACC_END(m, 8);
     if (act && g == 0) {
         Acc& a = L.acc[al];
         D posval = d_add(raw, r2);
+        TACC_END(m, 9);
         D nav = d_add(ssum, posval);
+        TACC_END(m, 10);
         a.prev_nav = a.nav;
         st_dec(a.posval, posval, f); st_dec(a.nav, nav, f);
         if (d_cmp(nav, ld_dec(a.max_nav)) > 0) st_dec(a.max_nav, nav, f);
+        TACC_END(m, 11);
     }
     CDA_WSYNC();
     if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
