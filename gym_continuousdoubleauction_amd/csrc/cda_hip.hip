@@ -403,7 +403,7 @@ __global__ void k_opbench(int op, int iters, const cda_dec* a, const cda_dec* b,
             case 2: { D r = d_div_u32(x, y.w0); x.w0 = (x.w0 ^ r.w0) | 1u; break; }
             case 3: iacc += d_cmp(x, y); x.w0 ^= (uint32_t)iacc; break;
             case 4: dacc += d_to_double(x, &f); x.w0 ^= (uint32_t)__double_as_longlong(dacc); break;
-            default: { uint32_t z = 0; process_acc<false>(*(Acc*)(cda_smem + DEC_TABLE_BYTES), (int32_t)y.w0, 57, (i & 1), (i & 2) != 0, z); f |= z; break; }
+            default: break;
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();

@@ -457,6 +457,18 @@ __device__ __forceinline__ int find_own_order(const Book& bk, int s, int n, int 
 // ======================================================================================
 // Ledger (account/account.py, cash_processor.py, calculate.py) - executed by the owning lane
 // ======================================================================================
+// Account a is owned by lane a; lanes a+16 and a+32 are its HELPERS: independent decimal operations on one account are
+// issued on the owner and its helpers in the same instruction stream (CDA_MAX_AGENTS = 16 <= 16 lanes per group), e.g.
+// cash -= v on lane a while hold += v on lane a+16.  All addressing is by (lane & 15); every helper sees the same LDS.
+__device__ __forceinline__ int lane_acc(int lane) { return lane & 15; }
+__device__ __forceinline__ int lane_grp(int lane) { return lane >> 4; }
+__device__ __forceinline__ D d_shfl(const D& v, int src) {
+    D r;
+    r.w0 = (uint32_t)__shfl((int)v.w0, src, WAVE); r.w1 = (uint32_t)__shfl((int)v.w1, src, WAVE); r.w2 = (uint32_t)__shfl((int)v.w2, src, WAVE);
+    int es = __shfl((v.exp << 1) | (v.sign & 1), src, WAVE);
+    r.exp = es >> 1; r.sign = es & 1;
+    return r;
+}
 __device__ __forceinline__ D cal_profit(bool is_long, D mkt, D raw) { return is_long ? d_sub(mkt, raw) : d_sub(raw, mkt); }
 
 // Memory-to-memory style on purpose: every statement loads its operands from the account record in LDS and
@@ -465,81 +477,106 @@ __device__ __forceinline__ D cal_profit(bool is_long, D mkt, D raw) { return is_
 // in the AMDGPU calling convention) and capped the kernel at 3-4 waves per SIMD.
 #define ACC_UPD(field, expr) do { D _r = (expr); st_dec(a.field, _r, flags); } while (0)
 __device__ __forceinline__ void xfer_inc(Acc& a, bool counter, D v, uint32_t& flags) {   // size_increase_cash_transfer (cash_processor.py:31-36)
-    if (!counter) ACC_UPD(cash, d_sub(ld_dec(a.cash), v)); else ACC_UPD(hold, d_sub(ld_dec(a.hold), v));
+    cda_dec& fld = counter ? a.hold : a.cash;
+    D r = d_sub(ld_dec(fld), v);
+    st_dec(fld, r, flags);
 }
 __device__ __forceinline__ void xfer_dec(Acc& a, bool counter, D v, uint32_t& flags) {   // size_decrease_cash_transfer (cash_processor.py:38-45)
     ACC_UPD(cash, d_add(ld_dec(a.cash), v));
     if (counter) { ACC_UPD(hold, d_sub(ld_dec(a.hold), v)); ACC_UPD(cash, d_add(ld_dec(a.cash), v)); }
 }
 // position_val = raw + profit with raw = n * VWAP, mkt = n * price (account.py:128-131, :141-143, :155-157)
-__device__ __forceinline__ D posval_from(Acc& a, uint32_t n, int32_t price, bool is_long, D* mkt_out) {
+__device__ __forceinline__ D posval_from(Acc& a, uint32_t n, int32_t price, bool is_long) {
     D raw = d_mul_int(ld_dec(a.vwap), n), mkt = d_mul_u32(d_price(price), n, 0);
-    if (mkt_out) *mkt_out = mkt;
     return d_add(raw, cal_profit(is_long, mkt, raw));
 }
+// One fill (trader.py:303-345 _process_trades / _process_counter_party, account.py:215-231 process_acc): the passive
+// party and the initiator settle at the same time, each on its owner lane plus helper lanes (+16, +32).  The ledger
+// update of every mode is laid out as the SAME sequence of generic operations so that both parties - whatever their
+// modes - run them in one instruction stream:
+//   stage 1  one multiplication   owner: VWAP * |pos|  (numerator term of _size_increase/_size_decrease, `raw` of _covered)
+//   stage 2  one addition         owner: numerator +- trade value | profit = +-(mkt - raw) | position_val += trade value (_neutral)
+//                                 helpers: the cash / cash_on_hold transfers that do not depend on the owner's chain
+//   stage 3  owner only           VWAP = numerator / n   or the rest of _covered / _covered_side_chg
+// Operations on ONE field keep the reference's order; different fields of an account are independent.
+//
 // LAZY_POSVAL: inside k_step every fill is followed, before anything can read it, by Calculate.mark_to_mkt (it runs
 // whenever the tape is non-empty), which recomputes position_val from (net_position, VWAP, price) alone.  The value
 // _size_increase/_size_decrease store is therefore dead there and its four decimal operations are skipped; the paths
 // that READ position_val (_neutral, _covered) are untouched.  The one-order test hook keeps the full semantics.
 template <bool LAZY_POSVAL>
-__device__ __forceinline__ void process_acc(Acc& a, int32_t q, int32_t price, int own_side, bool counter, uint32_t& flags) {
-    a.num_trades += 1; a.num_trades_step += 1; if (counter) a.num_passive_fills_step += 1;
-    int32_t pos = a.net_position;
-    uint32_t ap = (uint32_t)(pos < 0 ? -pos : pos);
-    bool is_long = pos > 0;
-    int mode;                                           // 0 neutral, 1 increase, 2 decrease, 3 flip
-    if (pos > 0) mode = own_side == S_BID ? 1 : (pos >= q ? 2 : 3);
-    else if (pos < 0) mode = own_side == S_ASK ? 1 : (ap >= (uint32_t)q ? 2 : 3);
-    else mode = 0;
-    if (mode == 0) {                                     // _neutral (account.py:173-176)
-        D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
-        ACC_UPD(posval, d_add(ld_dec(a.posval), tv));
-        st_dec(a.vwap, d_price(price), flags);
-        xfer_inc(a, counter, tv, flags);
-    } else if (mode == 1 || (mode == 2 && ap > (uint32_t)q)) {   // _size_increase / _size_decrease (account.py:124-133, :151-161)
-        uint32_t n = mode == 1 ? ap + (uint32_t)q : ap - (uint32_t)q;
-        {
-            D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
-            D num = d_mul_int(ld_dec(a.vwap), ap);
-            num = mode == 1 ? d_add(num, tv) : d_sub(num, tv);
-            ACC_UPD(vwap, d_div_u32(num, n));
-        }
-        if (!LAZY_POSVAL) ACC_UPD(posval, posval_from(a, n, price, is_long, nullptr));
-        D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
-        if (mode == 1) xfer_inc(a, counter, tv, flags); else xfer_dec(a, counter, tv, flags);
-    } else {
-        // _covered (account.py:135-149)
-        D mkt;
-        D pv = posval_from(a, ap, price, is_long, &mkt);
-        ACC_UPD(cash, d_add(ld_dec(a.cash), d_sub(pv, mkt)));      // size_zero_cash_transfer (cash_processor.py:47-53)
-        st_dec(a.posval, d_zero(), flags); st_dec(a.vwap, d_zero(), flags);
-        if (mode == 2) xfer_dec(a, counter, d_mul_u32(d_price(price), (uint32_t)q, 0), flags);
-        else {                                           // _covered_side_chg (account.py:163-171)
-            xfer_dec(a, counter, mkt, flags);
-            D npv = d_mul_u32(d_price(price), (uint32_t)q - ap, 0);
-            st_dec(a.posval, npv, flags); st_dec(a.vwap, d_price(price), flags);
-            xfer_inc(a, counter, npv, flags);
-        }
-    }
-    int64_t np = (int64_t)pos + (own_side == S_BID ? (int64_t)q : -(int64_t)q);
-    if (np > 2147483647LL || np < -2147483647LL) flags |= CDA_FLAG_INT_OVERFLOW;
-    a.net_position = (int32_t)np;
-}
-
-// one fill: counter party (passive) and initiator settle in two lanes at once (trader.py:303-345)
-template <bool LAZY_POSVAL>
 __device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t price, int init_side, uint32_t& flags, int lane) {
     uint32_t f = 0;
+    const int al = lane_acc(lane), g = lane_grp(lane);
     if (counter != tr) {
-        if (lane == tr || lane == counter) process_acc<LAZY_POSVAL>(L.acc[lane], q, price, lane == tr ? init_side : init_side ^ 1, lane == counter, f);
+        if ((al == tr || al == counter) && g < 3) {
+            Acc& a = L.acc[al];
+            const bool is_counter = al == counter;
+            const int own_side = is_counter ? init_side ^ 1 : init_side;
+            const int32_t pos = a.net_position;
+            const uint32_t ap = (uint32_t)(pos < 0 ? -pos : pos);
+            const bool is_long = pos > 0;
+            int mode;                                       // 0 _neutral, 1 _size_increase, 2 _size_decrease, 3 _covered, 4 _covered_side_chg
+            if (pos == 0) mode = 0;
+            else if (is_long == (own_side == S_BID)) mode = 1;
+            else mode = ap > (uint32_t)q ? 2 : (ap == (uint32_t)q ? 3 : 4);
+            const D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);             // trade value
+            D X = d_zero(), mkt = d_zero();
+            if (g == 0 && mode != 0) X = d_mul_int(ld_dec(a.vwap), ap);         // stage 1
+            D x2 = d_zero(), y2 = d_zero();
+            cda_dec* dst = nullptr;
+            bool s2 = false;
+            if (g == 0) {
+                s2 = true;
+                if (mode == 0) { x2 = ld_dec(a.posval); y2 = tv; dst = &a.posval; }                 // account.py:173-176
+                else if (mode <= 2) { x2 = X; y2 = tv; y2.sign = mode == 2 ? 1 : 0; }               // account.py:124-133, :151-161
+                else { mkt = d_mul_u32(d_price(price), ap, 0); x2 = is_long ? mkt : X; y2 = d_neg(is_long ? X : mkt); }   // calculate.py cal_profit
+            } else if (mode <= 2) {
+                if (g == 1) {                               // first statement of size_increase / size_decrease_cash_transfer (cash_processor.py:31-45)
+                    s2 = true;
+                    dst = (mode != 2 && is_counter) ? &a.hold : &a.cash;
+                    x2 = ld_dec(*dst); y2 = tv; y2.sign = mode != 2 ? 1 : 0;
+                } else if (mode == 2 && is_counter) {       // the passive party's escrow release
+                    s2 = true;
+                    dst = &a.hold; x2 = ld_dec(a.hold); y2 = d_neg(tv);
+                }
+            }
+            D Y = d_zero();
+            if (s2) { Y = d_add(x2, y2); if (dst) st_dec(*dst, Y, f); }        // stage 2
+            if (g == 0) {                                    // stage 3
+                a.num_trades += 1; a.num_trades_step += 1; if (is_counter) a.num_passive_fills_step += 1;
+                if (mode == 0) st_dec(a.vwap, d_price(price), f);
+                else if (mode <= 2) {
+                    const uint32_t n = mode == 1 ? ap + (uint32_t)q : ap - (uint32_t)q;
+                    ACC_UPD(vwap, d_div_u32(Y, n));
+                    if (!LAZY_POSVAL) ACC_UPD(posval, posval_from(a, n, price, is_long));
+                    if (mode == 2 && is_counter) ACC_UPD(cash, d_add(ld_dec(a.cash), tv));       // third statement of size_decrease_cash_transfer
+                } else {                                     // _covered (account.py:135-149)
+                    D pv = d_add(X, Y);
+                    ACC_UPD(cash, d_add(ld_dec(a.cash), d_sub(pv, mkt)));                        // size_zero_cash_transfer (cash_processor.py:47-53)
+                    st_dec(a.posval, d_zero(), f); st_dec(a.vwap, d_zero(), f);
+                    if (mode == 3) xfer_dec(a, is_counter, tv, f);
+                    else {                                   // _covered_side_chg (account.py:163-171)
+                        xfer_dec(a, is_counter, mkt, f);
+                        D npv = d_mul_u32(d_price(price), (uint32_t)q - ap, 0);
+                        st_dec(a.posval, npv, f); st_dec(a.vwap, d_price(price), f);
+                        xfer_inc(a, is_counter, npv, f);
+                    }
+                }
+                int64_t np = (int64_t)pos + (own_side == S_BID ? (int64_t)q : -(int64_t)q);
+                if (np > 2147483647LL || np < -2147483647LL) f |= CDA_FLAG_INT_OVERFLOW << 8;
+                a.net_position = (int32_t)np;
+            }
+        }
+        CDA_WSYNC();
     } else if (lane == tr) {                             // init_is_counter_cash_transfer (cash_processor.py:55-62)
         Acc& a = L.acc[lane];
         D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
         D hold = d_sub(ld_dec(a.hold), tv), cash = d_add(ld_dec(a.cash), tv);
         st_dec(a.hold, hold, f); st_dec(a.cash, cash, f);
     }
-    uint64_t any = __ballot(f != 0);
-    if (any) flags |= CDA_FLAG_DEC_DOMAIN;
+    if (__ballot((f & 0xffu) != 0)) flags |= CDA_FLAG_DEC_DOMAIN;
+    if (__ballot((f >> 8) != 0)) flags |= CDA_FLAG_INT_OVERFLOW;
 }
 
 // matching loops of OrderBook.process_order_list / process_market_order / process_limit_order
@@ -563,18 +600,6 @@ __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, i
     return qty;
 }
 
-// Account a is owned by lane a; lanes a+16 and a+32 are its HELPERS: independent decimal operations on one account are
-// issued on the owner and its helpers in the same instruction stream (CDA_MAX_AGENTS = 16 <= 16 lanes per group), e.g.
-// cash -= v on lane a while hold += v on lane a+16.  All addressing is by (lane & 15); every helper sees the same LDS.
-__device__ __forceinline__ int lane_acc(int lane) { return lane & 15; }
-__device__ __forceinline__ int lane_grp(int lane) { return lane >> 4; }
-__device__ __forceinline__ D d_shfl(const D& v, int src) {
-    D r;
-    r.w0 = (uint32_t)__shfl((int)v.w0, src, WAVE); r.w1 = (uint32_t)__shfl((int)v.w1, src, WAVE); r.w2 = (uint32_t)__shfl((int)v.w2, src, WAVE);
-    int es = __shfl((v.exp << 1) | (v.sign & 1), src, WAVE);
-    r.exp = es >> 1; r.sign = es & 1;
-    return r;
-}
 // cash -+= v and hold +-= v of account `tr` (cash_processor.py:15-29 order_in_book_passive_party with dir = -1: escrow a
 // resting order; :85-97 cancel_cash_transfer with dir = +1: release it).  Group 0 updates cash, group 1 cash_on_hold.
 __device__ __forceinline__ void cash_hold_transfer(Lds& L, int tr, int32_t price, int32_t qty, int cash_dir, uint32_t& flags, int lane) {

@@ -26,7 +26,6 @@ cases = [
     ("f64  3.0000000000000000000000 (strip)", 4, D("3.0000000000000000000000"), D(1)),
     ("f64  56.99999999999999999999999999 (exact path)", 4, D("56.99999999999999999999999999"), D(1)),
     ("f64  12.5 (fast)", 4, D("12.5"), D(1)),
-    ("process_acc (alternating modes, q=1234)", 9, D(1), D(1234)),
 ]
 for name, op, a, b in cases:
     da, db = K.decimal_to_dec(a), K.decimal_to_dec(b)
