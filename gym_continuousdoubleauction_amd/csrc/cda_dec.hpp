@@ -465,6 +465,8 @@ __device__ __forceinline__ int d_cmp(D a, D b) {
     if (diff == 0) { ca = d_c128(a); cb = d_c128(b); }
     else if (diff > 0 && (a.w1 | a.w2) == 0 && diff <= 28) { ca = mul_u32_pow10_lds(a.w0, diff); cb = d_c128(b); }
     else if (diff < 0 && (b.w1 | b.w2) == 0 && diff >= -28) { ca = d_c128(a); cb = mul_u32_pow10_lds(b.w0, -diff); }
+    else if (diff > 0 && diff <= 9) { ca = d_c128(a) * (u128)pow10_sel(diff); cb = d_c128(b); }     // nav vs max_nav: two long
+    else if (diff < 0 && diff >= -9) { ca = d_c128(a); cb = d_c128(b) * (u128)pow10_sel(-diff); }    // coefficients, a few digits apart
     else return d_cmp_mid(a, b);
     return ca == cb ? 0 : (ca > cb ? s : -s);
 }

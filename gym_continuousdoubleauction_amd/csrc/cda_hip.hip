@@ -43,10 +43,13 @@ __device__ __forceinline__ MarketPtrs market_ptrs(uint8_t* arena, const Params& 
     r.hist = (float*)(rec + P.lay.hist_off); r.book = (int32_t*)(rec + P.lay.book_off);
     return r;
 }
+template <bool WITH_HIST = false>
 __device__ __forceinline__ void load_market(const MarketPtrs& mp, const Params& P, Lds& L, Mkt& m, int lane) {
-    uint32_t hv = load_header_word(mp.hdr, lane);          // all three requests are in flight together
+    uint32_t hv = load_header_word(mp.hdr, lane);          // all the requests are in flight together
     BookPrefetch pre = prefetch_book(mp.book, lane);
     copy_words((uint32_t*)&L.acc[0], mp.acc, P.cfg.num_agents * (int)(sizeof(Acc) / 4), lane);
+    // k_step: the observation's history ring rides along, so that phase 6 does not pay an HBM round trip of its own
+    if (WITH_HIST) copy_words((uint32_t*)lds_hist(L, P.cfg.num_agents), (const uint32_t*)mp.hist, P.cfg.n_hist * CDA_SNAPSHOT_DIM, lane);
     decode_header(hv, m);
     finish_book_load(mp.book, pre, L.book, m, lane);
     if (m.levels_valid && lane >= H_LEVELS && lane < H_LEVELS + 4 * CDA_K_ROWS) (&L.lvl_px[0][0])[lane - H_LEVELS] = (int32_t)hv;
@@ -69,7 +72,7 @@ __device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params&
 // dynamic LDS of a workgroup: [decimal power-of-ten table (640 B)] [k_step only: ziggurat wi, ki (4 KB), PCG jump table (512 B)] [wave 0 image] ...
 constexpr int ZIG_LDS_BYTES = (2 * 256 + PCG_JUMP_WORDS64) * 8;
 __device__ __forceinline__ Lds& wave_lds(const Params& P, int wave, int extra = 0) {
-    return *reinterpret_cast<Lds*>(cda_smem + DEC_TABLE_BYTES + extra + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents));
+    return *reinterpret_cast<Lds*>(cda_smem + DEC_TABLE_BYTES + extra + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents, P.cfg.n_hist));
 }
 __device__ __forceinline__ void zig_tables_init() {       // every thread of the workgroup, before the first __syncthreads
     unsigned long long* t = reinterpret_cast<unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     for (int i = 0; i < 14; i++) m.tacc[i] = 0;
 #endif
     PHASE_MARK(0);
-    load_market(mp, P, L, m, lane);
+    load_market<true>(mp, P, L, m, lane);
     PHASE_MARK(1);
 
     // 1. pre-step snapshot (continuousDoubleAuction_env.py:274): prices of ALL orders resolve against it.  It equals the
@@ -251,9 +254,10 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
         if (lane < CDA_SNAPSHOT_DIM) {
             float v = snapshot_value(L, m, tick, lane);
             int head = m.hist_head;                       // slot of the oldest frame = the one to overwrite
+            const float* hist = lds_hist(L, A);           // staged by load_market
             for (int j = 0; j < H - 1; j++) {
                 int slot = head + 1 + j; if (slot >= H) slot -= H;
-                S.obs_out[ob + (size_t)(j * CDA_SNAPSHOT_DIM + lane)] = mp.hist[slot * CDA_SNAPSHOT_DIM + lane];
+                S.obs_out[ob + (size_t)(j * CDA_SNAPSHOT_DIM + lane)] = hist[slot * CDA_SNAPSHOT_DIM + lane];
             }
             S.obs_out[ob + (size_t)((H - 1) * CDA_SNAPSHOT_DIM + lane)] = v;
             mp.hist[head * CDA_SNAPSHOT_DIM + lane] = v;
@@ -511,7 +515,7 @@ static int cfg_ok(const cda_config* c) {
 }
 
 static dim3 grid_for(int n) { return dim3((unsigned)((n + CDA_WPB - 1) / CDA_WPB)); }
-static size_t smem_for(const Params& P, int waves) { return (size_t)DEC_TABLE_BYTES + (size_t)waves * (size_t)lds_bytes_per_wave(P.cfg.num_agents); }
+static size_t smem_for(const Params& P, int waves) { return (size_t)DEC_TABLE_BYTES + (size_t)waves * (size_t)lds_bytes_per_wave(P.cfg.num_agents, P.cfg.n_hist); }
 
 int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env** out) {
     if (!cfg || !out || n_markets < 1) return CDA_ERR_INVALID;

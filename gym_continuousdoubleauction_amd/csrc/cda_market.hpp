@@ -90,7 +90,12 @@ struct Lds {                     // per-wave LDS image; `acc` is sized for the e
     Acc acc[CDA_MAX_AGENTS];     // only the first num_agents records are backed by LDS
 };
 // bytes of LDS one wave needs for `agents` accounts
-__host__ __device__ constexpr int lds_bytes_per_wave(int agents) { return (int)(sizeof(Book) + 2 * 2 * CDA_K_ROWS * 4 + 2 * CDA_MAX_AGENTS * 4) + agents * (int)sizeof(Acc); }
+// (the history ring of the observation, n_hist x 42 floats, is staged behind the accounts: lds_hist())
+__host__ __device__ constexpr int lds_bytes_per_wave(int agents, int n_hist) {
+    return (int)(sizeof(Book) + 2 * 2 * CDA_K_ROWS * 4 + 2 * CDA_MAX_AGENTS * 4) + agents * (int)sizeof(Acc) + ((n_hist * CDA_SNAPSHOT_DIM * 4 + 15) & ~15);
+}
+
+__device__ __forceinline__ float* lds_hist(Lds& L, int agents) { return reinterpret_cast<float*>(&L.acc[agents]); }
 
 struct Layout {                  // byte offsets inside a market record
     int32_t acc_off, hist_off, book_off, stride;
