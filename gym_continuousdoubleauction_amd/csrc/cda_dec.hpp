@@ -508,10 +508,51 @@ __device__ __noinline__ double d_to_double_deep(u128 c, int k) {
     }
     return round_quotient(q, !w_is_zero(rr), t, k);
 }
+__device__ __forceinline__ double pow10_exact(int k) {       // 10^k, 0 <= k <= 22: every partial product is itself an exact double
+    double p = ((k & 1) ? 10.0 : 1.0) * ((k & 2) ? 100.0 : 1.0);
+    p *= (k & 4) ? 1.0e4 : 1.0; p *= (k & 8) ? 1.0e8 : 1.0; p *= (k & 16) ? 1.0e16 : 1.0;
+    return p;
+}
+// Certified floating path for c * 10^-k, c >= 2^53, 0 <= k <= 44: the quotient is formed in double-double
+// arithmetic (c = ch + cl exactly with a 53-bit ch; q1 = RN(ch / p); the remainder ch - q1 * p is exact in one fma;
+// q2 = RN((r1 + cl) / p); a second such division by 10^(k-22) when k > 22), which approximates the true value to
+// better than 2^-48 ulp.  s = RN(q1 + q2) with the exact error term t (Fast2Sum) is the correctly rounded double
+// unless the true value lies within that bound of a rounding boundary; the test below rejects everything within
+// 2^-30 of half an ulp (and exact powers of two, whose lower neighbour is half as far), and the caller then takes
+// the exact integer path.  Built with -ffp-contract=off; `/` on doubles is the correctly rounded IEEE division.
+__device__ __forceinline__ bool d_to_double_dd(u128 c, int k, double* out) {
+    const int sft = bits128(c) - 53;                          // 0 <= sft <= 41
+    const uint64_t hi = (uint64_t)(c >> sft);
+    const uint64_t lo = (uint64_t)(c & ((((u128)1) << sft) - 1));
+    const double ch = __builtin_ldexp((double)hi, sft), cl = (double)lo;     // both exact
+    const double p = pow10_exact(k > 22 ? 22 : k);
+    double q1 = ch / p;
+    double r1 = __builtin_fma(-q1, p, ch);
+    double q2 = (r1 + cl) / p;
+    if (k > 22) {
+        const double p2 = pow10_exact(k - 22);
+        const double Q1 = q1 / p2;
+        const double R1 = __builtin_fma(-Q1, p2, q1);
+        q2 = (R1 + q2) / p2;
+        q1 = Q1;
+    }
+    const double s = q1 + q2;
+    const double t = (q1 - s) + q2;                           // s + t == q1 + q2 exactly (|q1| >= |q2|)
+    const uint64_t sb = (uint64_t)__double_as_longlong(s);
+    const uint32_t e = (uint32_t)(sb >> 52) & 0x7ffu;
+    if ((sb & 0xfffffffffffffull) == 0 || e < 64u) return false;
+    const double hu = __longlong_as_double((long long)((uint64_t)(e - 53u) << 52));   // half an ulp of s
+    if (!(__builtin_fabs(t) < hu * (1.0 - 9.313225746154785e-10))) return false;      // 2^-30 short of the boundary
+    *out = s;
+    return true;
+}
 __device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no caller state is forced to memory
     if (d_is_zero(a)) return a.sign ? -0.0 : 0.0;
     int k = -a.exp;
     double r;
+    if (k >= 0 && k <= 44 && (a.w2 != 0 || a.w1 >= (1u << 21))) {
+        if (d_to_double_dd(d_c128(a), k, &r)) return a.sign ? -r : r;
+    }
     if (k > 54 && k <= 109) { r = d_to_double_deep(d_c128(a), k); return a.sign ? -r : r; }
     if (k < 0 || k > 109) {                                  // outside the exact domain (flagged by the inline wrapper)
         u128 c0 = d_c128(a);

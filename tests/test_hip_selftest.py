@@ -118,3 +118,37 @@ def test_device_normal_slow_paths_match_numpy():
     g.integers(0, 1)
     z = g.standard_normal(200000)
     assert np.array_equal(z.view(np.uint64), normals[0].view(np.uint64))
+
+
+def test_device_float_conversion_near_rounding_boundaries():
+    """float(Decimal) on the device has a certified double-double path and an exact integer path behind it.
+    28-digit decimals that sit ON, next to and at graded distances from the midpoint of two adjacent doubles
+    exercise the certificate (reject -> exact path) and the accepted side of it."""
+    from gym_continuousdoubleauction_amd.vec_env import selftest_dec
+    import decimal
+    rng = random.Random(77)
+    ctx = decimal.Context(prec=28, rounding=decimal.ROUND_HALF_EVEN)
+    vals = []
+    while len(vals) < 30000:
+        mag = rng.choice([1e-9, 1e-3, 1.0, 57.0, 1e3, 999999.0, 1e6, 1.2345e7, 1e12])
+        x = abs(rng.gauss(0, 1)) * mag + mag * 1e-3
+        m = D(x) + D(np.spacing(x)) / 2                     # the exact midpoint above x (a long decimal)
+        base = ctx.plus(m)                                  # its nearest 28-digit decimal: 1e-28 relative ~ 2^-93 of the boundary
+        e = base.as_tuple().exponent
+        if e > 0 or e < -44:
+            continue
+        step = D((0, (1,), e))
+        for dlt in (0, 1, -1, 2, -3, 10 ** rng.randint(1, 12), -(10 ** rng.randint(1, 12))):
+            v = base + dlt * step
+            if len(v.as_tuple().digits) <= 28 and v > 0:
+                vals.append(v if rng.random() < 0.5 else -v)
+    vals += [D(2) ** 60, D(2) ** 70 + 1, D("9007199254740993"), D("9007199254740992.000000000001"), D("1.000000000000000055511151231")]
+    a = O.dec_array(vals)
+    out = selftest_dec(5, a, a)
+    bad = []
+    for i, v in enumerate(vals):
+        bits = struct.unpack("<Q", struct.pack("<d", float(v)))[0]
+        got = int(out[i]["w"][0]) | (int(out[i]["w"][1]) << 32)
+        if got != bits or int(out[i]["w"][2]) != 0:
+            bad.append((v, hex(bits), hex(got)))
+    assert not bad, (len(bad), bad[:5])
