@@ -4,6 +4,8 @@ Kept free of any library loading: pure struct definitions and value conversions,
 """
 import ctypes as C
 
+import numpy as np
+
 K_ROWS = 10
 SNAPSHOT_DIM = 42
 RAW_DIM = 40
@@ -36,6 +38,9 @@ class Config(C.Structure):
 class Dec(C.Structure):
     _fields_ = [("w", C.c_uint32 * 3), ("exp", C.c_int16), ("sign", C.c_uint8), ("pad", C.c_uint8)]
 
+
+# numpy view of cda_dec (include/cda.h): 96-bit coefficient, int16 exponent, sign
+DEC_DTYPE = np.dtype([("w", np.uint32, (3,)), ("exp", np.int16), ("sign", np.uint8), ("pad", np.uint8)])
 
 INFO_FIELDS = [
     # name, element ctype, per-agent?, trailing dims

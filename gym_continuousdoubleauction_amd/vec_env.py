@@ -14,7 +14,7 @@ from ._lib import CDAError, check, lib
 
 _TORCH_OF = {C.c_int32: torch.int32, C.c_double: torch.float64, C.c_uint8: torch.uint8}
 
-DEC_DTYPE = np.dtype([("w", np.uint32, (3,)), ("exp", np.int16), ("sign", np.uint8), ("pad", np.uint8)])
+DEC_DTYPE = K.DEC_DTYPE
 
 ACTION_KEYS = ("category", "size_mean", "size_sigma", "price", "price_offset")
 

@@ -1,0 +1,68 @@
+"""The per-step episode record (gym_continuousdoubleauction_amd/episode_record.py) against the Parquet file the
+reference's own recorder wrote for the same episode.  CPU: the oracle is the stepper; GPU: the HIP env."""
+import os
+
+import numpy as np
+import pytest
+
+import record_util as R
+
+
+def test_schema_is_the_reference_schema():
+    import pyarrow.parquet as pq
+    from gym_continuousdoubleauction_amd.episode_record import schema
+    ref = pq.read_schema(os.path.join(R.HERE, "golden", "episode_record_ref.parquet"))
+    assert schema().equals(ref)
+
+
+def test_record_from_oracle_stepper_equals_reference_file(tmp_path):
+    import oracle_lib as O
+    path = R.replay_and_record(lambda cfg, n: O.OracleEnv(cfg, n_markets=n), str(tmp_path))
+    R.assert_same_as_reference(path)
+
+
+def test_incomplete_flag_and_file_rotation(tmp_path):
+    import pyarrow.parquet as pq
+    from gym_continuousdoubleauction_amd.episode_record import BatchedEpisodeRecorder
+    import oracle_lib as O
+    cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 64, "is_render": False}
+    env = O.OracleEnv(cfg, n_markets=5)
+    env.reset(np.arange(5, dtype=np.uint64))
+    rec = BatchedEpisodeRecorder(str(tmp_path), num_agents=4, markets=[0, 4], rows_per_file=40)
+    rng = np.random.default_rng(0)
+    for ep in range(3):
+        rec.begin_episodes([f"e{ep}-m0", f"e{ep}-m4"])
+        for t in range(4):
+            acts = (rng.integers(0, 9, (5, 4)).astype(np.int32), rng.uniform(-1, 1, (5, 4)).astype(np.float32), rng.uniform(0, 1, (5, 4)).astype(np.float32),
+                    rng.integers(0, 10, (5, 4)).astype(np.int32), rng.integers(0, 3, (5, 4)).astype(np.int32))
+            obs, rew, term, trunc, info = env.step(*acts)
+            rec.record_step(obs, rew, info, acts)
+        if ep < 2:
+            rec.finish(complete=True)
+    rec.close()                                             # the third pair of episodes never ended
+    assert len(rec.files) == 2 and rec.written_rows == 3 * 2 * 4 * 4
+    t = pq.read_table(rec.files).to_pandas()
+    assert set(t["episode_id"]) == {f"e{e}-m{m}" for e in range(3) for m in (0, 4)}
+    assert t[t.episode_id.str.startswith("e2")]["episode_complete"].eq(False).all()
+    assert t[~t.episode_id.str.startswith("e2")]["episode_complete"].all()
+    assert t["module_id"].isna().all() and t["info_extra"].isna().all()
+    one = t[(t.episode_id == "e1-m4") & (t.agent_id == "agent_2")]
+    assert list(one["step"]) == [0, 1, 2, 3] and all(len(o) == 168 for o in one["obs"]) and all(len(a) == 5 for a in one["action"])
+
+
+@pytest.mark.gpu
+def test_record_from_hip_env_equals_reference_file(tmp_path):
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+
+    class TensorStepper:                                     # device tensors go straight into the recorder
+        def __init__(self, cfg, n):
+            self.env = CDAVecEnv(cfg, n_markets=n, with_info=True)
+
+        def reset(self, seeds):
+            return self.env.reset(seed=seeds)
+
+        def step(self, *acts):
+            return self.env.step(*acts)
+
+    path = R.replay_and_record(TensorStepper, str(tmp_path))
+    R.assert_same_as_reference(path)
