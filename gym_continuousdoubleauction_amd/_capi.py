@@ -29,7 +29,7 @@ class Config(C.Structure):
         ("init_cash", C.c_int64),
         ("initial_price_min", C.c_int32), ("initial_price_max", C.c_int32),
         ("min_size", C.c_int32), ("mkt_max_size", C.c_int32), ("limit_size_multiple", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("auto_reset", C.c_int32),
         ("order_penalty", C.c_double), ("trade_penalty", C.c_double), ("drawdown_penalty", C.c_double),
         ("passive_bonus", C.c_double), ("loss_multiplier", C.c_double),
     ]
@@ -125,6 +125,7 @@ def make_config(config=None):
 
     Unknown keys raise; missing keys take the reference's standalone defaults."""
     cfg = dict(ENV_DEFAULTS)
+    cfg["auto_reset"] = False            # extension of this build (include/cda.h), not a reference key
     for k, v in (config or {}).items():
         if k not in cfg:
             raise KeyError(f"unknown env config key {k!r}; known: {sorted(cfg)}")
@@ -145,6 +146,7 @@ def make_config(config=None):
     c.min_size = int(cfg["min_size"])
     c.mkt_max_size = int(cfg["mkt_max_size"])
     c.limit_size_multiple = int(cfg["limit_size_multiple"])
+    c.auto_reset = 1 if cfg["auto_reset"] else 0
     c.order_penalty = float(cfg["order_penalty"])
     c.trade_penalty = float(cfg["trade_penalty"])
     c.drawdown_penalty = float(cfg["drawdown_penalty"])

@@ -132,6 +132,7 @@ struct StepArgs {
     const int32_t* category; const float* size_mean; const float* size_sigma;
     const int32_t* price; const int32_t* price_offset; const uint8_t* present;
     float* obs_out; double* reward_out; uint8_t* terminated_out; uint8_t* truncated_out;
+    uint8_t* done_out;                  // auto_reset only: terminated | truncated, the mask of the k_reset launch that follows
     cda_info_ptrs info; int has_info;
     unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,24] cycle stamps
 };
@@ -329,8 +330,10 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
             if (I.spread) I.spread[mi] = (m.nb && m.na) ? ba - bb : __longlong_as_double(0x7ff8000000000000LL);
         }
         // Done_Helper.set_all_done (done_helper.py:20-54)
-        S.terminated_out[mi] = (uint8_t)(__popc(m.done_mask) == A);
-        S.truncated_out[mi] = (uint8_t)(m.t_step + 1 >= P.cfg.max_step);
+        const bool term = __popc(m.done_mask) == A, trunc = m.t_step + 1 >= P.cfg.max_step;
+        S.terminated_out[mi] = (uint8_t)term;
+        S.truncated_out[mi] = (uint8_t)trunc;
+        if (S.done_out) S.done_out[mi] = (uint8_t)(term || trunc);
     }
     m.t_step += 1;
     m.levels_valid = 1;                                   // lvl_px/lvl_sz hold the post-step aggregation (phase 6)
@@ -471,6 +474,7 @@ struct cda_env {
     int device;
     uint8_t* arena;
     size_t arena_bytes;
+    uint8_t* done_buf;       // auto_reset: u8[N] behind the market records - terminated | truncated of the last step
 };
 
 static thread_local char g_err[256] = "";
@@ -511,6 +515,7 @@ static int cfg_ok(const cda_config* c) {
     if (c->initial_price_max < c->initial_price_min || c->initial_price_min < 0) return CDA_ERR_INVALID;
     if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;
     if (c->init_cash > (1LL << 62) || c->init_cash < -(1LL << 62)) return CDA_ERR_INVALID;
+    if (c->auto_reset != 0 && c->auto_reset != 1) return CDA_ERR_INVALID;
     return CDA_OK;
 }
 
@@ -536,9 +541,11 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     P.lay.hist_off = off; off += cfg->n_hist * CDA_SNAPSHOT_DIM * 4; off = (off + 15) & ~15;
     P.lay.book_off = off; off += BOOK_BYTES;
     P.lay.stride = (off + 255) & ~255;
-    e->arena_bytes = (size_t)P.lay.stride * (size_t)n_markets;
+    const size_t records = (size_t)P.lay.stride * (size_t)n_markets;
+    e->arena_bytes = records + (((size_t)n_markets + 255) & ~(size_t)255);
     hipError_t he = hipMalloc((void**)&e->arena, e->arena_bytes);
     if (he != hipSuccess) { free(e); return he == hipErrorOutOfMemory ? CDA_ERR_NOMEM : hip_fail(he, "hipMalloc"); }
+    e->done_buf = e->arena + records;
     hipLaunchKernelGGL(k_init_arena, dim3((unsigned)((n_markets + 255) / 256)), dim3(256), 0, 0, e->arena, P);
     he = hipDeviceSynchronize();
     if (he != hipSuccess) { (void)hipFree(e->arena); free(e); return hip_fail(he, "k_init_arena"); }
@@ -574,8 +581,14 @@ int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const 
     S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
     if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
     S.phase_cycles = g_phase_cycles;
+    S.done_out = e->P.cfg.auto_reset ? e->done_buf : NULL;
     hipLaunchKernelGGL(k_step, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, S);
     HIPCHK(hipGetLastError());
+    if (e->P.cfg.auto_reset) {            // same stream: every market-wave of it exits at once unless its episode just ended
+        hipLaunchKernelGGL(k_reset, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P,
+                           (const uint64_t*)NULL, (const uint8_t*)e->done_buf, obs_out);
+        HIPCHK(hipGetLastError());
+    }
     return CDA_OK;
 }
 

@@ -106,6 +106,7 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
     model = ActorCritic(env.obs_dim).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     obs = env.reset(seed=seed).clone()
+    auto_reset = bool(getattr(env, "config", {}).get("auto_reset", False))
     history = []
     for it in range(iters):
         t0 = time.perf_counter()
@@ -118,7 +119,7 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
             done = (term | trunc)
             buf_obs.append(pobs); buf_act.append(actions); buf_logp.append(logp); buf_val.append(val)
             buf_rew.append((r.float() * reward_scale).reshape(-1)); buf_done.append(done.repeat_interleave(A).float())
-            if bool(done.any()):
+            if not auto_reset and bool(done.any()):                # (a host sync per step; auto_reset envs reset on the device)
                 env.reset(mask=done)                               # seed=None semantics: streams continue
             obs = env.obs.clone()
         with torch.no_grad():
@@ -148,7 +149,7 @@ def main(argv=None):
     p.add_argument("--max-step", type=int, default=4096)
     args = p.parse_args(argv)
     from .vec_env import CDAVecEnv
-    env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False},
+    env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False, "auto_reset": True},
                     n_markets=args.markets, device="cuda:0", with_info=False)
     train(env, iters=args.iters, horizon=args.horizon)
     env.close()

@@ -69,7 +69,11 @@ typedef struct cda_config {
     int32_t min_size;            /* min_size             (1)       */
     int32_t mkt_max_size;        /* mkt_max_size         (100)     */
     int32_t limit_size_multiple; /* limit_size_multiple  (10)      */
-    int32_t reserved0;
+    int32_t auto_reset;          /* extension, 0 = off (the reference has no such key; parity runs leave it 0). 1: a market whose
+                                    step ended its episode (terminated or truncated) is reset in place right after that step, with
+                                    reset(seed=None) semantics (the RNG stream continues, continuousDoubleAuction_env.py:186-188);
+                                    its obs row then holds the NEW episode's first observation, reward / flags / info are the
+                                    finished step's */
     double  order_penalty;       /* 0.1  */
     double  trade_penalty;       /* 0.05 */
     double  drawdown_penalty;    /* 0.2  */

@@ -123,3 +123,38 @@ def test_book_capacity_overflow_is_flagged_not_silent():
     assert bytes(env.get_state(0)) == bytes(ora.get_state(0))
     assert env.get_state(0).n_bids == K.BOOK_CAP
     env.close(); ora.close()
+
+
+def test_auto_reset_equals_step_then_masked_reset():
+    """cda_config.auto_reset: a market whose episode ended is reset on the device right after the step (seed=None
+    semantics).  Equivalent to the oracle's step followed by reset(mask=terminated|truncated): same rewards and
+    flags for the finished step, the new episode's first observation in the obs row, same states afterwards."""
+    from hip_env import HipEnv
+    import oracle_lib as O
+    n, a, steps = 96, 4, 70
+    cfg = {"num_of_agents": a, "init_cash": 1000000, "max_step": 16, "is_render": False}
+    hip = HipEnv(dict(cfg, auto_reset=True), n)
+    orc = O.OracleEnv(cfg, n_markets=n)
+    seeds = np.arange(900, 900 + n, dtype=np.uint64)
+    assert np.array_equal(hip.reset(seeds), orc.reset(seeds))
+    rng = np.random.default_rng(5)
+    n_resets = 0
+    for t in range(steps):
+        acts = _actions(rng, n, a)
+        if t == 20:                                       # desynchronise the episodes: reseed a third of the markets mid-run
+            m = (np.arange(n) % 3 == 0).astype(np.uint8)
+            assert np.array_equal(hip.reset(None, m)[m == 1], orc.reset(None, m)[m == 1])
+        ho, hr, ht, hu, _ = hip.step(*acts)
+        oo, orw, ot, ou, _ = orc.step(*acts)
+        oo, orw, ot, ou = oo.copy(), orw.copy(), ot.copy(), ou.copy()
+        done = ((ot != 0) | (ou != 0)).astype(np.uint8)
+        if done.any():
+            oo[done == 1] = orc.reset(None, done)[done == 1]
+            n_resets += int(done.sum())
+        assert np.array_equal(hr.view(np.uint64), orw.view(np.uint64)), t
+        assert np.array_equal(ht, ot) and np.array_equal(hu, ou), t
+        assert np.array_equal(ho.view(np.uint32), oo.view(np.uint32)), t
+    assert n_resets >= 3 * n
+    for i in range(0, n, 7):
+        assert bytes(hip.get_state(i)) == bytes(orc.get_state(i)), f"state of market {i}"
+    hip.close(); orc.close()
