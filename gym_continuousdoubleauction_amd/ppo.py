@@ -33,11 +33,13 @@ class ActorCritic(nn.Module):
 
     def dists(self, obs):
         o = self.pi(obs)
-        cat = torch.distributions.Categorical(logits=o[:, :CAT_N])
-        price = torch.distributions.Categorical(logits=o[:, CAT_N:CAT_N + PRICE_N])
-        off = torch.distributions.Categorical(logits=o[:, CAT_N + PRICE_N:CAT_N + PRICE_N + OFF_N])
+        # validate_args=False: the argument checks read a flag back to the host, which neither a captured HIP graph
+        # nor an asynchronous rollout can afford
+        cat = torch.distributions.Categorical(logits=o[:, :CAT_N], validate_args=False)
+        price = torch.distributions.Categorical(logits=o[:, CAT_N:CAT_N + PRICE_N], validate_args=False)
+        off = torch.distributions.Categorical(logits=o[:, CAT_N + PRICE_N:CAT_N + PRICE_N + OFF_N], validate_args=False)
         mu = o[:, -2:]
-        cont = torch.distributions.Normal(mu, self.log_std.exp().expand_as(mu))
+        cont = torch.distributions.Normal(mu, self.log_std.exp().expand_as(mu), validate_args=False)
         return cat, price, off, cont
 
     def act(self, obs):
@@ -77,7 +79,7 @@ def gae(rew, val, last_val, done, gamma=0.99, lam=0.95):
     return adv, adv + val
 
 
-def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch=16384, clip=0.2, vf_coef=0.5, ent_coef=0.01):
+def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch=65536, clip=0.2, vf_coef=0.5, ent_coef=0.01):
     B = obs.shape[0]
     adv = (adv - adv.mean()) / (adv.std() + 1e-8)
     stats = {}
@@ -94,34 +96,67 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
             loss.backward()
             nn.utils.clip_grad_norm_(model.parameters(), 0.5)
             opt.step()
-            stats = {"pg_loss": pg.item(), "v_loss": vl.item(), "entropy": ent.mean().item()}
-    return stats
+            stats = {"pg_loss": pg.detach(), "v_loss": vl.detach(), "entropy": ent.mean().detach()}
+    return {k: float(v) for k, v in stats.items()}          # one host sync per update, not one per minibatch
 
 
-def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print):
+def _capture_policy_step(model, env, N, A):
+    """HIP graph of: observation broadcast -> policy/value forward -> sampling -> env action tensors."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(3):                                           # warm-up outside capture (allocator, lazy init)
+            pobs = env.obs.repeat_interleave(A, dim=0)
+            actions, logp, val = model.act(pobs)
+            to_env_actions(actions, N, A)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        pobs = env.obs.repeat_interleave(A, dim=0)
+        actions, logp, val = model.act(pobs)
+        env_acts = tuple(x.contiguous() for x in to_env_actions(actions, N, A))
+    return g, (pobs, actions, logp, val, env_acts)
+
+
+def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True):
     """On-device PPO over a CDAVecEnv-shaped env. Returns per-iteration stats (incl. agent-steps/s)."""
     torch.manual_seed(seed)
     dev = env.obs.device
     N, A = env.n_markets, env.num_agents
     model = ActorCritic(env.obs_dim).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
-    obs = env.reset(seed=seed).clone()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, fused=dev.type == "cuda")     # one kernel per step instead of one per tensor
+    env.reset(seed=seed)
     auto_reset = bool(getattr(env, "config", {}).get("auto_reset", False))
     history = []
+    # The policy step of the rollout (MLP forward, five samplers, log-probabilities: ~60 small kernels) is launch bound
+    # next to a 55-us env step, so it is captured ONCE in a HIP graph that reads the env's own observation buffer and
+    # replayed every step; the env step itself is enqueued between replays on the same stream.
+    policy_step = None
+    if dev.type == "cuda" and use_graph:
+        try:
+            policy_step = _capture_policy_step(model, env, N, A)
+        except Exception as e:  # noqa: BLE001 - eager rollouts are always available
+            log(json.dumps({"hip_graph": f"capture failed, eager rollout: {e}"}))
     for it in range(iters):
         t0 = time.perf_counter()
         buf_obs, buf_act, buf_logp, buf_val, buf_rew, buf_done = [], [], [], [], [], []
         for _ in range(horizon):
-            pobs = obs.repeat_interleave(A, dim=0)               # every agent of a market sees the same vector
-            with torch.no_grad():
-                actions, logp, val = model.act(pobs)
-            o, r, term, trunc, _ = env.step(*to_env_actions(actions, N, A))
+            if policy_step is not None:
+                g, (pobs_s, actions_s, logp_s, val_s, env_acts_s) = policy_step
+                g.replay()                                           # reads env.obs (this step's observation)
+                pobs, actions, logp, val = pobs_s.clone(), tuple(x.clone() for x in actions_s), logp_s.clone(), val_s.clone()
+                o, r, term, trunc, _ = env.step(*env_acts_s)
+            else:
+                pobs = env.obs.repeat_interleave(A, dim=0)           # every agent of a market sees the same vector
+                with torch.no_grad():
+                    actions, logp, val = model.act(pobs)
+                o, r, term, trunc, _ = env.step(*to_env_actions(actions, N, A))
             done = (term | trunc)
             buf_obs.append(pobs); buf_act.append(actions); buf_logp.append(logp); buf_val.append(val)
             buf_rew.append((r.float() * reward_scale).reshape(-1)); buf_done.append(done.repeat_interleave(A).float())
             if not auto_reset and bool(done.any()):                # (a host sync per step; auto_reset envs reset on the device)
                 env.reset(mask=done)                               # seed=None semantics: streams continue
-            obs = env.obs.clone()
+        obs = env.obs
         with torch.no_grad():
             last_val = model.v(obs.repeat_interleave(A, dim=0)).squeeze(-1)
         rew, val, dn = torch.stack(buf_rew), torch.stack(buf_val), torch.stack(buf_done)
