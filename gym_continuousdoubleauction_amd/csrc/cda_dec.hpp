@@ -420,7 +420,7 @@ template <int NL> __device__ __forceinline__ D d_div_impl(D a, uint32_t n, int s
     while (exp < ideal) { WN<NL> t = x; if (w_divc<10u>(t) != 0) break; x = t; exp += 1; }
     return d_fix_impl<NL>(a.sign, x, exp);
 }
-__device__ __noinline__ D d_div_u32(D a, uint32_t n) {
+__device__ __noinline__ D d_div_general(D a, uint32_t n) {
     if (d_is_zero(a)) return d_make(0, 0, 0, a.exp, a.sign);
     {   // exact integer quotient (e.g. adding to a position at its own VWAP): the result is coefficient / n at the
         // ideal exponent a.exp - no scaling, no trailing-zero stripping, and it already has <= 28 digits
@@ -432,6 +432,55 @@ __device__ __noinline__ D d_div_u32(D a, uint32_t n) {
     int shift = ln - w_ndigits(xa) + 29;                    // >= 2; a * 10^shift has ln + 28 or ln + 29 digits
     if (ln <= 9) return d_div_impl<4>(a, n, shift);         // <= 38 digits < 2^127
     return d_div_impl<8>(a, n, shift);
+}
+__device__ __forceinline__ int ndigits_u32(uint32_t n) {     // len(str(n)), n >= 1
+    int d = 1;
+    d = n >= 10u ? 2 : d; d = n >= 100u ? 3 : d; d = n >= 1000u ? 4 : d; d = n >= 10000u ? 5 : d; d = n >= 100000u ? 6 : d;
+    d = n >= 1000000u ? 7 : d; d = n >= 10000000u ? 8 : d; d = n >= 100000000u ? 9 : d; d = n >= 1000000000u ? 10 : d;
+    return d;
+}
+// Inexact quotients (a VWAP after almost every fill) are rounded DIRECTLY to 28 digits: the coefficient is scaled so that
+// floor(c * 10^s / n) has 26..28 digits (s from the bit length of c and the digit count of n), the long division is
+// continued digit by digit from the 32-bit remainder until there are 28, and the final remainder against n/2 decides
+// half-even - the correctly rounded quotient, which is what Decimal.__truediv__ followed by _fix produces.  A zero
+// remainder anywhere means the quotient is exact at that scale; that case (ideal exponent, trailing zeros) is left to
+// d_div_general.
+__device__ __noinline__ D d_div_u32(D a, uint32_t n) {
+    const u128 c = d_c128(a);
+    const int ln = ndigits_u32(n);
+    if (c != 0 && ln <= 9) {
+        const int dn_hi = ((bits128(c) * 1233) >> 12) + 1;        // len(str(c)) or one more
+        int s = 27 + ln - dn_hi;
+        s = s < 0 ? 0 : s;                                        // c * 10^s < 10^(27 + ln) <= 10^36 < 2^120
+        W4 x = w4_from128(c);
+        w_mul_pow10(x, s);
+        uint32_t r = w_div_u32(x, n);
+        const double rn = 1.0 / (double)n;
+        #pragma unroll 1
+        while (r != 0 && !(x.w[2] > 0x033b2e3cu || (x.w[2] == 0x033b2e3cu && (x.w[1] > 0x9fd0803cu || (x.w[1] == 0x9fd0803cu && x.w[0] >= 0xe8000000u))))) {
+            const uint64_t r10 = (uint64_t)r * 10u;               // next quotient digit from the remainder (x < 10^27 so far)
+            uint32_t dg = (uint32_t)((double)r10 * rn);
+            int64_t rr = (int64_t)(r10 - (uint64_t)dg * n);
+            if (rr < 0) { dg -= 1; rr += n; }
+            if (rr >= (int64_t)n) { dg += 1; rr -= n; }
+            r = (uint32_t)rr;
+            uint64_t cy = dg;                                     // x = x * 10 + dg
+            #pragma unroll
+            for (int i = 0; i < 4; i++) { cy += (uint64_t)x.w[i] * 10u; x.w[i] = (uint32_t)cy; cy >>= 32; }
+            s += 1;
+        }
+        if (r != 0) {
+            const uint64_t twice = (uint64_t)r * 2u;
+            if (twice > n || (twice == n && (x.w[0] & 1u))) {
+                w_inc(x);
+                if (x.w[0] == 0x10000000u && x.w[1] == 0x3e250261u && x.w[2] == 0x204fce5eu) {    // reached 10^28
+                    x.w[0] = 0xe8000000u; x.w[1] = 0x9fd0803cu; x.w[2] = 0x033b2e3cu; s -= 1;     // 10^27
+                }
+            }
+            return d_make(x.w[0], x.w[1], x.w[2], a.exp - s, a.sign);
+        }
+    }
+    return d_div_general(a, n);
 }
 
 // ---- comparison: Decimal._cmp (_pydecimal.py:817): -1, 0, 1 ----
