@@ -43,15 +43,35 @@ __device__ __forceinline__ MarketPtrs market_ptrs(uint8_t* arena, const Params& 
     r.hist = (float*)(rec + P.lay.hist_off); r.book = (int32_t*)(rec + P.lay.book_off);
     return r;
 }
+// One 16-byte request per lane moves the accounts (36 lanes at 4 agents) and the history ring (42 lanes at n_hist 4):
+// both are issued before anything is waited for, next to the header word and the book prefetch, so the whole record
+// costs ONE HBM round trip.  (A word-by-word loop serialises a round trip per 64 words.)
+struct VecPrefetch { uint4 v; bool has; };
+__device__ __forceinline__ VecPrefetch vec_prefetch(const void* src, int nbytes, int lane) {
+    VecPrefetch p; p.has = lane < (nbytes >> 4);
+    p.v = make_uint4(0u, 0u, 0u, 0u);
+    if (p.has) p.v = reinterpret_cast<const uint4*>(src)[lane];
+    return p;
+}
+__device__ __forceinline__ void vec_finish(void* dst, const void* src, int nbytes, const VecPrefetch& p, int lane) {   // 16-byte aligned, nbytes % 4 == 0
+    const int n16 = nbytes >> 4;
+    if (p.has) reinterpret_cast<uint4*>(dst)[lane] = p.v;
+    for (int i = lane + WAVE; i < n16; i += WAVE) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (int w = (n16 << 2) + lane; w < (nbytes >> 2); w += WAVE) reinterpret_cast<uint32_t*>(dst)[w] = reinterpret_cast<const uint32_t*>(src)[w];
+}
 template <bool WITH_HIST = false>
 __device__ __forceinline__ void load_market(const MarketPtrs& mp, const Params& P, Lds& L, Mkt& m, int lane) {
     uint32_t hv = load_header_word(mp.hdr, lane);          // all the requests are in flight together
     BookPrefetch pre = prefetch_book(mp.book, lane);
-    copy_words((uint32_t*)&L.acc[0], mp.acc, P.cfg.num_agents * (int)(sizeof(Acc) / 4), lane);
+    const int acc_bytes = P.cfg.num_agents * (int)sizeof(Acc), hist_bytes = P.cfg.n_hist * CDA_SNAPSHOT_DIM * 4;
+    VecPrefetch pa = vec_prefetch(mp.acc, acc_bytes, lane);
+    VecPrefetch ph; ph.has = false;
     // k_step: the observation's history ring rides along, so that phase 6 does not pay an HBM round trip of its own
-    if (WITH_HIST) copy_words((uint32_t*)lds_hist(L, P.cfg.num_agents), (const uint32_t*)mp.hist, P.cfg.n_hist * CDA_SNAPSHOT_DIM, lane);
+    if (WITH_HIST) ph = vec_prefetch(mp.hist, hist_bytes, lane);
     decode_header(hv, m);
     finish_book_load(mp.book, pre, L.book, m, lane);
+    vec_finish(&L.acc[0], mp.acc, acc_bytes, pa, lane);
+    if (WITH_HIST) vec_finish(lds_hist(L, P.cfg.num_agents), mp.hist, hist_bytes, ph, lane);
     if (m.levels_valid && lane >= H_LEVELS && lane < H_LEVELS + 4 * CDA_K_ROWS) (&L.lvl_px[0][0])[lane - H_LEVELS] = (int32_t)hv;
     CDA_WSYNC();
 }
@@ -63,7 +83,10 @@ __device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params&
     CDA_WSYNC();
     store_header(mp.hdr, m, lane);
     store_book(mp.book, L.book, m, lane);
-    copy_words(mp.acc, (const uint32_t*)&L.acc[0], P.cfg.num_agents * (int)(sizeof(Acc) / 4), lane);
+    {
+        const int n16 = P.cfg.num_agents * (int)(sizeof(Acc) / 16);
+        for (int i = lane; i < n16; i += WAVE) reinterpret_cast<uint4*>(mp.acc)[i] = reinterpret_cast<const uint4*>(&L.acc[0])[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
