@@ -22,6 +22,14 @@ typedef unsigned __int128 u128;
 
 namespace cda {
 
+#ifdef CDA_PHASE_TIMING
+// debug builds: how often each out-of-line decimal routine runs (tools/phase_timing.py prints them per market-step)
+__device__ unsigned long long g_dec_calls[8];
+#define DEC_COUNT(i) atomicAdd(&g_dec_calls[i], 1ull)
+#else
+#define DEC_COUNT(i) do {} while (0)
+#endif
+
 template <int NL> struct WN { uint32_t w[NL]; };   // unsigned, NL x 32 bits, little endian
 typedef WN<8> W;
 typedef WN<4> W4;
@@ -56,13 +64,16 @@ __device__ const Pow5Tab POW5 = make_pow5();
 // LDS copy of 10^0 .. 10^38 as 4 limbs, at the start of the workgroup's dynamic LDS; filled by
 // dec_tables_init() at kernel entry.
 constexpr int DEC_LDS_POW = 39;
-constexpr int DEC_TABLE_BYTES = 640;                // 39 * 16 = 624, padded
+constexpr int DEC_RCP_OFF = 640;                    // 39 * 16 = 624, padded; then RN(1 / 10^k), k = 0..9, as doubles
+constexpr int DEC_TABLE_BYTES = 736;                // 640 + 10 * 8 = 720, padded
 extern __shared__ __attribute__((aligned(16))) unsigned char cda_smem[];
 __device__ __forceinline__ const uint32_t* lds_pow10(int k) { return reinterpret_cast<const uint32_t*>(cda_smem) + 4 * k; }
+__device__ __forceinline__ double lds_rcp10(int k) { return reinterpret_cast<const double*>(cda_smem + DEC_RCP_OFF)[k]; }   // k <= 9
 // every thread of the workgroup must call this once, before any decimal operation
 __device__ __forceinline__ void dec_tables_init() {
     uint32_t* t = reinterpret_cast<uint32_t*>(cda_smem);
     for (int i = (int)threadIdx.x; i < DEC_LDS_POW * 4; i += (int)blockDim.x) t[i] = POW10.v[i >> 2][i & 3];
+    if (threadIdx.x < 10) reinterpret_cast<double*>(cda_smem + DEC_RCP_OFF)[threadIdx.x] = 1.0 / (double)POW10.v[threadIdx.x][0];
     __syncthreads();
 }
 
@@ -157,6 +168,24 @@ template <int NL> __device__ __forceinline__ uint32_t w_div_u32(WN<NL>& x, uint3
     }
     return (uint32_t)rem;
 }
+// The same for a divisor below 2^30 with its reciprocal rd = RN(1/d) at hand: the quotient digit is one saturating
+// f64 -> u32 conversion and the remainder test fits signed 32-bit arithmetic (the true remainder of the estimate lies
+// in (-d, 2d)), so a limb costs about a dozen instructions.
+template <int NL> __device__ __forceinline__ uint32_t w_div_small(WN<NL>& x, uint32_t d, double rd) {
+    uint32_t rem = 0;
+    #pragma unroll
+    for (int i = NL - 1; i >= 0; i--) {
+        const double cur = __builtin_fma((double)rem, 4294967296.0, (double)x.w[i]);     // exact: < 2^62 with 30 + 32 bits... rounded to 53
+        uint32_t q = (uint32_t)(cur * rd);                      // v_cvt_u32_f64 saturates at 2^32 - 1; off by at most one
+        int32_t r = (int32_t)(x.w[i] - q * d);                  // (rem * 2^32 + limb - q * d) mod 2^32, as a signed value
+        const bool lo = r < 0;
+        q -= lo ? 1u : 0u; r += lo ? (int32_t)d : 0;
+        const bool hi = r >= (int32_t)d;
+        q += hi ? 1u : 0u; r -= hi ? (int32_t)d : 0;
+        x.w[i] = q; rem = (uint32_t)r;
+    }
+    return rem;
+}
 template <int NL> __device__ __forceinline__ int w_bits(const WN<NL>& a) {
     int b = 0;
     #pragma unroll
@@ -225,8 +254,8 @@ template <int NL> __device__ __forceinline__ D d_fix_impl(int sign, WN<NL> x, in
     }
     return d_make(x.w[0], x.w[1], x.w[2], exp, sign);
 }
-__device__ __noinline__ D d_fix_mid(int sign, W4 x, int exp) { return d_fix_impl<4>(sign, x, exp); }
-__device__ __noinline__ D d_fix_wide(int sign, W x, int exp) { return d_fix_impl<8>(sign, x, exp); }
+__device__ __noinline__ D d_fix_mid(int sign, W4 x, int exp) { DEC_COUNT(0); return d_fix_impl<4>(sign, x, exp); }
+__device__ __noinline__ D d_fix_wide(int sign, W x, int exp) { DEC_COUNT(1); return d_fix_impl<8>(sign, x, exp); }
 
 // ---- 128-bit helpers -----------------------------------------------------------------------
 __device__ __forceinline__ u128 d_c128(const D& a) { return ((u128)a.w2 << 64) | ((u128)a.w1 << 32) | (u128)a.w0; }
@@ -248,29 +277,35 @@ __device__ __forceinline__ bool scale_fits128(u128 c, int k) { return bits128(c)
 // D = (upper estimate of the digit count) - 28 comes from the bit length alone.  The quotient shows whether the
 // estimate was one too high (27 digits instead of 28); then the dropped digit is restored from the remainder with
 // 32-bit arithmetic.  No table, no digit count, no second long division; the remainder decides half-even exactly.
-__device__ __noinline__ D d_round_mid(int sign, u128 r, int exp) {
+__device__ __noinline__ D d_round_mid(int sign, u128 r, int exp) {      // a LEAF: no calls, so no return-address spill
+    DEC_COUNT(2);
     const int nd_hi = ((bits128(r) * 1233) >> 12) + 1;          // len(str(r)) is nd_hi or nd_hi - 1
-    int drop = nd_hi - 28;                                      // >= 1
-    if (drop > 9) return d_fix_mid(sign, w4_from128(r), exp);
-    uint32_t pw = pow10_sel(drop);
+    int drop = nd_hi - 28;                                      // 1 .. 11 (r < 2^127 < 10^39)
     W4 x = w4_from128(r);
-    uint32_t rem = w_div_u32(x, pw);
+    bool sticky = false;
+    if (drop > 9) {                                             // rare: peel the excess over nine digits first
+        const int pre = drop - 9;
+        sticky = w_div_small(x, lds_pow10(pre)[0], lds_rcp10(pre)) != 0;
+        drop = 9;
+    }
+    uint32_t pw = lds_pow10(drop)[0];
+    uint32_t rem = w_div_small(x, pw, lds_rcp10(drop));
     // 10^27 = 0x033b2e3c_9fd0803c_e8000000
     const bool full = x.w[2] > 0x033b2e3cu || (x.w[2] == 0x033b2e3cu && (x.w[1] > 0x9fd0803cu || (x.w[1] == 0x9fd0803cu && x.w[0] >= 0xe8000000u)));
     if (!full) {                                                // r has nd_hi - 1 digits: one digit fewer to drop
         drop -= 1;
-        pw = pow10_sel(drop);
-        uint32_t dg = (uint32_t)((double)rem * (1.0 / (double)pw));          // 0..9, off by at most one
-        int32_t rr = (int32_t)(rem - dg * pw);
-        if (rr < 0) { dg -= 1; rr += (int32_t)pw; }
-        if (rr >= (int32_t)pw) { dg += 1; rr -= (int32_t)pw; }
-        rem = (uint32_t)rr;
+        const uint32_t pw1 = lds_pow10(drop)[0];
+        uint32_t dg = (uint32_t)((double)rem * lds_rcp10(drop));            // 0..9, off by at most one
+        int32_t rr = (int32_t)(rem - dg * pw1);
+        if (rr < 0) { dg -= 1; rr += (int32_t)pw1; }
+        if (rr >= (int32_t)pw1) { dg += 1; rr -= (int32_t)pw1; }
+        rem = (uint32_t)rr; pw = pw1;
         w_mul_small(x, 10u);
         x.w[0] += dg;                                           // x * 10 ends in 0: no carry
     }
-    exp += drop;
+    exp += (nd_hi - 28) - (full ? 0 : 1);
     const uint32_t half = pw >> 1;                              // 5 * 10^(drop-1); drop == 0 cannot round (rem == 0, half == 0)
-    if (rem > half || (rem == half && drop > 0 && (x.w[0] & 1u))) {
+    if (rem > half || (rem == half && drop > 0 && (sticky || (x.w[0] & 1u)))) {
         w_inc(x);
         if (x.w[0] == 0x10000000u && x.w[1] == 0x3e250261u && x.w[2] == 0x204fce5eu) {    // reached 10^28
             x.w[0] = 0xe8000000u; x.w[1] = 0x9fd0803cu; x.w[2] = 0x033b2e3cu; exp += 1;   // 10^27
@@ -281,6 +316,7 @@ __device__ __noinline__ D d_round_mid(int sign, u128 r, int exp) {
 
 // ---- addition: Decimal.__add__ (_pydecimal.py:1157) with _normalize (:5640) and _rescale (:2612) ----
 __device__ __noinline__ D d_add_wide(D a, D b) {
+    DEC_COUNT(3);
     int exp = a.exp < b.exp ? a.exp : b.exp;
     bool az = d_is_zero(a), bz = d_is_zero(b);
     if (az && bz) return d_make(0, 0, 0, exp, a.sign < b.sign ? a.sign : b.sign);
@@ -312,6 +348,7 @@ __device__ __noinline__ D d_add_wide(D a, D b) {
 }
 // 128-bit tier, out of line: any exponent gap whose scaled operand still fits 128 bits, with rounding
 __device__ __noinline__ D d_add_mid(D a, D b) {
+    DEC_COUNT(4);
     bool swp = a.exp < b.exp;
     D t = swp ? b : a, o = swp ? a : b;                     // t: larger exponent (ties: a); both non-zero
     int diff = t.exp - o.exp;
@@ -355,7 +392,7 @@ __device__ __forceinline__ D d_add(D a, D b) {
         else {
             ok = (((bits128(co) - 1) * 1233) >> 12) >= diff - 1;   // no _normalize replacement (see d_add_mid)
             if ((t.w1 | t.w2) == 0 && diff <= 28) ct = mul_u32_pow10_lds(t.w0, diff);
-            else if (diff <= 9) ct = d_c128(t) * (u128)pow10_sel(diff);          // < 2^94 * 2^30
+            else if (diff <= 9) ct = d_c128(t) * (u128)lds_pow10(diff)[0];       // < 2^94 * 2^30
             else { ok = false; ct = 0; }
         }
         if (ok) {
@@ -421,6 +458,7 @@ template <int NL> __device__ __forceinline__ D d_div_impl(D a, uint32_t n, int s
     return d_fix_impl<NL>(a.sign, x, exp);
 }
 __device__ __noinline__ D d_div_general(D a, uint32_t n) {
+    DEC_COUNT(5);
     if (d_is_zero(a)) return d_make(0, 0, 0, a.exp, a.sign);
     {   // exact integer quotient (e.g. adding to a position at its own VWAP): the result is coefficient / n at the
         // ideal exponent a.exp - no scaling, no trailing-zero stripping, and it already has <= 28 digits
@@ -446,6 +484,7 @@ __device__ __forceinline__ int ndigits_u32(uint32_t n) {     // len(str(n)), n >
 // remainder anywhere means the quotient is exact at that scale; that case (ideal exponent, trailing zeros) is left to
 // d_div_general.
 __device__ __noinline__ D d_div_u32(D a, uint32_t n) {
+    DEC_COUNT(6);
     const u128 c = d_c128(a);
     const int ln = ndigits_u32(n);
     if (c != 0 && ln <= 9) {
@@ -454,8 +493,8 @@ __device__ __noinline__ D d_div_u32(D a, uint32_t n) {
         s = s < 0 ? 0 : s;                                        // c * 10^s < 10^(27 + ln) <= 10^36 < 2^120
         W4 x = w4_from128(c);
         w_mul_pow10(x, s);
-        uint32_t r = w_div_u32(x, n);
         const double rn = 1.0 / (double)n;
+        uint32_t r = n < (1u << 30) ? w_div_small(x, n, rn) : w_div_u32(x, n);
         #pragma unroll 1
         while (r != 0 && !(x.w[2] > 0x033b2e3cu || (x.w[2] == 0x033b2e3cu && (x.w[1] > 0x9fd0803cu || (x.w[1] == 0x9fd0803cu && x.w[0] >= 0xe8000000u))))) {
             const uint64_t r10 = (uint64_t)r * 10u;               // next quotient digit from the remainder (x < 10^27 so far)
@@ -514,8 +553,8 @@ __device__ __forceinline__ int d_cmp(D a, D b) {
     if (diff == 0) { ca = d_c128(a); cb = d_c128(b); }
     else if (diff > 0 && (a.w1 | a.w2) == 0 && diff <= 28) { ca = mul_u32_pow10_lds(a.w0, diff); cb = d_c128(b); }
     else if (diff < 0 && (b.w1 | b.w2) == 0 && diff >= -28) { ca = d_c128(a); cb = mul_u32_pow10_lds(b.w0, -diff); }
-    else if (diff > 0 && diff <= 9) { ca = d_c128(a) * (u128)pow10_sel(diff); cb = d_c128(b); }     // nav vs max_nav: two long
-    else if (diff < 0 && diff >= -9) { ca = d_c128(a); cb = d_c128(b) * (u128)pow10_sel(-diff); }    // coefficients, a few digits apart
+    else if (diff > 0 && diff <= 9) { ca = d_c128(a) * (u128)lds_pow10(diff)[0]; cb = d_c128(b); }  // nav vs max_nav: two long
+    else if (diff < 0 && diff >= -9) { ca = d_c128(a); cb = d_c128(b) * (u128)lds_pow10(-diff)[0]; } // coefficients, a few digits apart
     else return d_cmp_mid(a, b);
     return ca == cb ? 0 : (ca > cb ? s : -s);
 }
@@ -596,6 +635,7 @@ __device__ __forceinline__ bool d_to_double_dd(u128 c, int k, double* out) {
     return true;
 }
 __device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no caller state is forced to memory
+    DEC_COUNT(7);
     if (d_is_zero(a)) return a.sign ? -0.0 : 0.0;
     int k = -a.exp;
     double r;

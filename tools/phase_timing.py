@@ -31,7 +31,11 @@ names = ["load", "snapshot_pre", "decode+rng", "shuffle", "orders", "mtm", "snap
 acc = np.zeros(9); span = 0.0
 tot_all = []; worst = None; sub = np.zeros(14); sub_worst = None
 T, W = 300, 200
+L.cda_debug_dec_calls.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+calls = (C.c_ulonglong * 8)()
 for t in range(W + T):
+    if t == W:
+        torch.cuda.synchronize(); L.cda_debug_dec_calls(calls, 1)
     cat = torch.randint(0, 9, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
     price = torch.randint(0, 10, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
     off = torch.randint(0, 3, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
@@ -65,3 +69,7 @@ subn = ["approval", "find_own", "match+settle", "insert/remove(after match)", "c
         "mtm:add1", "mtm:mul", "mtm:shfl", "mtm:posval", "mtm:nav", "mtm:cmp+store", "x12", "x13"]
 print("orders phase breakdown, mean per wave per step:", {n: round(v / T, 1) for n, v in zip(subn, sub)})
 print("orders phase breakdown, slowest wave:", dict(zip(subn, sub_worst.astype(int).tolist())))
+
+torch.cuda.synchronize(); L.cda_debug_dec_calls(calls, 0)
+cn = ["d_fix_mid", "d_fix_wide", "d_round_mid", "d_add_wide", "d_add_mid", "d_div_general", "d_div_u32", "d_to_double_slow"]
+print("out-of-line decimal calls per market-step (lanes counted individually):", {n: round(calls[i] / (T * N), 2) for i, n in enumerate(cn)})
