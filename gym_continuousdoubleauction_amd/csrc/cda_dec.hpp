@@ -483,7 +483,8 @@ __device__ __forceinline__ int ndigits_u32(uint32_t n) {     // len(str(n)), n >
 // half-even - the correctly rounded quotient, which is what Decimal.__truediv__ followed by _fix produces.  A zero
 // remainder anywhere means the quotient is exact at that scale; that case (ideal exponent, trailing zeros) is left to
 // d_div_general.
-__device__ __noinline__ D d_div_u32(D a, uint32_t n) {
+constexpr int D_NOT_HANDLED = -0x40000000;                      // exponent sentinel of the leaf fast paths
+__device__ __noinline__ D d_div_inexact_leaf(D a, uint32_t n) { // a LEAF (no calls: no return-address spill to scratch)
     DEC_COUNT(6);
     const u128 c = d_c128(a);
     const int ln = ndigits_u32(n);
@@ -519,7 +520,12 @@ __device__ __noinline__ D d_div_u32(D a, uint32_t n) {
             return d_make(x.w[0], x.w[1], x.w[2], a.exp - s, a.sign);
         }
     }
-    return d_div_general(a, n);
+    return d_make(0, 0, 0, D_NOT_HANDLED, 0);
+}
+__device__ __forceinline__ D d_div_u32(D a, uint32_t n) {
+    D r = d_div_inexact_leaf(a, n);
+    if (r.exp == D_NOT_HANDLED) r = d_div_general(a, n);
+    return r;
 }
 
 // ---- comparison: Decimal._cmp (_pydecimal.py:817): -1, 0, 1 ----
@@ -608,7 +614,7 @@ __device__ __forceinline__ double pow10_exact(int k) {       // 10^k, 0 <= k <= 
 // unless the true value lies within that bound of a rounding boundary; the test below rejects everything within
 // 2^-30 of half an ulp (and exact powers of two, whose lower neighbour is half as far), and the caller then takes
 // the exact integer path.  Built with -ffp-contract=off; `/` on doubles is the correctly rounded IEEE division.
-__device__ __forceinline__ bool d_to_double_dd(u128 c, int k, double* out) {
+__device__ __noinline__ double d_to_double_dd(u128 c, int k) {     // a LEAF, by value; NaN = not certified
     const int sft = bits128(c) - 53;                          // 0 <= sft <= 41
     const uint64_t hi = (uint64_t)(c >> sft);
     const uint64_t lo = (uint64_t)(c & ((((u128)1) << sft) - 1));
@@ -628,20 +634,18 @@ __device__ __forceinline__ bool d_to_double_dd(u128 c, int k, double* out) {
     const double t = (q1 - s) + q2;                           // s + t == q1 + q2 exactly (|q1| >= |q2|)
     const uint64_t sb = (uint64_t)__double_as_longlong(s);
     const uint32_t e = (uint32_t)(sb >> 52) & 0x7ffu;
-    if ((sb & 0xfffffffffffffull) == 0 || e < 64u) return false;
+    const double not_certified = __longlong_as_double(0x7ff8000000000000LL);
+    if ((sb & 0xfffffffffffffull) == 0 || e < 64u) return not_certified;
     const double hu = __longlong_as_double((long long)((uint64_t)(e - 53u) << 52));   // half an ulp of s
-    if (!(__builtin_fabs(t) < hu * (1.0 - 9.313225746154785e-10))) return false;      // 2^-30 short of the boundary
-    *out = s;
-    return true;
+    if (!(__builtin_fabs(t) < hu * (1.0 - 9.313225746154785e-10))) return not_certified;   // 2^-30 short of the boundary
+    return s;
 }
 __device__ __noinline__ double d_to_double_slow(D a) {      // by value only: no caller state is forced to memory
     DEC_COUNT(7);
     if (d_is_zero(a)) return a.sign ? -0.0 : 0.0;
     int k = -a.exp;
     double r;
-    if (k >= 0 && k <= 44 && (a.w2 != 0 || a.w1 >= (1u << 21))) {
-        if (d_to_double_dd(d_c128(a), k, &r)) return a.sign ? -r : r;
-    }
+
     if (k > 54 && k <= 109) { r = d_to_double_deep(d_c128(a), k); return a.sign ? -r : r; }
     if (k < 0 || k > 109) {                                  // outside the exact domain (flagged by the inline wrapper)
         u128 c0 = d_c128(a);
@@ -726,6 +730,10 @@ __device__ __forceinline__ double d_to_double(D a, uint32_t* domain_err) {
         p *= (k & 4) ? 1.0e4 : 1.0; p *= (k & 8) ? 1.0e8 : 1.0; p *= (k & 16) ? 1.0e16 : 1.0;
         double r = (double)c / p;
         return a.sign ? -r : r;
+    }
+    if (k >= 0 && k <= 44 && (a.w2 != 0 || a.w1 >= (1u << 21))) {           // >= 2^53: certified double-double quotient
+        const double r = d_to_double_dd(d_c128(a), k);
+        if (r == r) return a.sign ? -r : r;
     }
     if ((k < 0 || k > 109) && !d_is_zero(a) && domain_err) *domain_err |= 0x4u;
     return d_to_double_slow(a);
