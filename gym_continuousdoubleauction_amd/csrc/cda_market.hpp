@@ -651,7 +651,7 @@ __device__ __forceinline__ bool order_approved(Lds& L, const Mkt& m, int tr, int
             }
         }
     }
-    return __shfl(ok, tr, WAVE) != 0;
+    return __ballot(ok != 0) != 0;                       // only lane `tr` can have set it
 }
 
 // Trader.place_order (agent/trader.py:49-106) with Trader._place_limit_order / _modify_limit_order /
