@@ -22,8 +22,8 @@ typedef unsigned __int128 u128;
 
 namespace cda {
 
-#ifdef CDA_PHASE_TIMING
-// debug builds: how often each out-of-line decimal routine runs (tools/phase_timing.py prints them per market-step)
+#ifdef CDA_DEC_COUNTERS
+// debug builds: how often each out-of-line decimal routine runs (tools/phase_timing.py --counters prints them per market-step)
 __device__ unsigned long long g_dec_calls[8];
 #define DEC_COUNT(i) atomicAdd(&g_dec_calls[i], 1ull)
 #else

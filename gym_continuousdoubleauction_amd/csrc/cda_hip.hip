@@ -805,7 +805,7 @@ int cda_debug_calib(void* dev_buf, size_t n_bytes, int mode, void* stream) {
 
 /* debug hook (not in include/cda.h): device buffer [N,24] of cycle stamps, used by tools/phase_timing.py */
 void cda_debug_set_phase_buffer(unsigned long long* dev_buf) { g_phase_cycles = dev_buf; }
-#ifdef CDA_PHASE_TIMING
+#ifdef CDA_DEC_COUNTERS
 int cda_debug_dec_calls(unsigned long long* host8, int reset) {
     if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(cda::g_dec_calls), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cda::g_dec_calls), z, sizeof z) != hipSuccess) return -1; }

@@ -13,8 +13,9 @@ import torch
 
 so = os.path.join(ROOT, "gpurun_out", "libcda_hip_timing.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
+COUNTERS = "--counters" in sys.argv      # atomics in every out-of-line decimal routine: call counts, but the cycle stamps are then meaningless
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                       "-DCDA_PHASE_TIMING", "-o", so, os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_hip.hip")])
+                       "-DCDA_PHASE_TIMING"] + (["-DCDA_DEC_COUNTERS"] if COUNTERS else []) + ["-o", so, os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_hip.hip")])
 from gym_continuousdoubleauction_amd import _lib
 _lib.LIB_PATH = so
 from gym_continuousdoubleauction_amd import CDAVecEnv
@@ -31,10 +32,11 @@ names = ["load", "snapshot_pre", "decode+rng", "shuffle", "orders", "mtm", "snap
 acc = np.zeros(9); span = 0.0
 tot_all = []; worst = None; sub = np.zeros(14); sub_worst = None
 T, W = 300, 200
-L.cda_debug_dec_calls.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 calls = (C.c_ulonglong * 8)()
+if COUNTERS:
+    L.cda_debug_dec_calls.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 for t in range(W + T):
-    if t == W:
+    if t == W and COUNTERS:
         torch.cuda.synchronize(); L.cda_debug_dec_calls(calls, 1)
     cat = torch.randint(0, 9, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
     price = torch.randint(0, 10, (N, A), generator=g, device="cuda:0", dtype=torch.int32)
@@ -70,6 +72,8 @@ subn = ["approval", "find_own", "match+settle", "insert/remove(after match)", "c
 print("orders phase breakdown, mean per wave per step:", {n: round(v / T, 1) for n, v in zip(subn, sub)})
 print("orders phase breakdown, slowest wave:", dict(zip(subn, sub_worst.astype(int).tolist())))
 
+if not COUNTERS:
+    sys.exit(0)
 torch.cuda.synchronize(); L.cda_debug_dec_calls(calls, 0)
 cn = ["d_fix_mid", "d_fix_wide", "d_round_mid", "d_add_wide", "d_add_mid", "d_div_general", "d_div_u32", "d_to_double_slow"]
 print("out-of-line decimal calls per market-step (lanes counted individually):", {n: round(calls[i] / (T * N), 2) for i, n in enumerate(cn)})
