@@ -68,7 +68,7 @@ print("max over the 4096 waves of one step: mean %.0f  (min %.0f, max %.0f)" % (
 print("slowest wave seen: %.0f cycles at step %d market %d; phases:" % (worst[0], worst[2], worst[3]), dict(zip(names, worst[1].astype(int).tolist())))
 
 subn = ["approval", "find_own", "match+settle", "insert/remove(after match)", "cancel/escrow/other", "fills",
-        "mtm:add1", "mtm:mul", "mtm:shfl", "mtm:posval", "mtm:nav", "mtm:cmp+store", "x12", "x13"]
+        "book_remove/in-place", "release transfer", "escrow transfer", "x9", "n_modify", "n_escrow", "x12", "x13"]
 print("orders phase breakdown, mean per wave per step:", {n: round(v / T, 1) for n, v in zip(subn, sub)})
 print("orders phase breakdown, slowest wave:", dict(zip(subn, sub_worst.astype(int).tolist())))
 
