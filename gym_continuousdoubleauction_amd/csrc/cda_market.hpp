@@ -688,11 +688,16 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
             int32_t op = bk.price[side][idx], oq = bk.qty[side][idx];
             int32_t ooid = (int32_t)((uint32_t)bk.oo[side][idx] >> 4);
             m.lob_time += 1;
+            TACC_END(m, 4);
             if (type == T_CANCEL) {                           // trader.py:237-252: cancel, then release the escrow
                 book_remove(bk, side, nside, idx, 1, lane); mkt_set_n(m, side, nside - 1);
+                TACC_END(m, 6);
                 cash_hold_transfer(L, tr, op, oq, +1, f, lane);
+                TACC_END(m, 7);
             } else {                                          // upsert / modify: release, then modify_order
                 cash_hold_transfer(L, tr, op, oq, +1, f, lane);
+                TACC_END(m, 7);
+                TACC_COUNT(m, 10, 1);
                 if (price == op && size <= oq) {              // in place: priority kept, timestamp := now
                     bk.qty[side][idx] = size; bk.ts[side][idx] = m.lob_time;
                     CDA_WSYNC();
@@ -701,6 +706,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
                     book_remove(bk, side, nside, idx, 1, lane); mkt_set_n(m, side, nside - 1);
                     do_match = true; can_rest = true; m_limit = price; rest_oid = ooid;
                 }
+                TACC_END(m, 6);
             }
         }
     }
@@ -716,8 +722,9 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
         }
         TACC_END(m, 3);
     }
-    if (rest_qty > 0) cash_hold_transfer(L, tr, rest_price, rest_qty, -1, f, lane);
     TACC_END(m, 4);
+    if (rest_qty > 0) { cash_hold_transfer(L, tr, rest_price, rest_qty, -1, f, lane); TACC_COUNT(m, 11, 1); }
+    TACC_END(m, 8);
     if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
 }
 
@@ -733,7 +740,6 @@ __device__ __forceinline__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
     const bool act = al < A && g < 3;
     D r1 = d_zero(), r2 = d_zero();
     uint32_t ap = 0;
-    TACC_BEGIN();
     if (act) {
         const Acc& a = L.acc[al];
         int32_t pos = a.net_position;
@@ -745,22 +751,16 @@ __device__ __forceinline__ void mark_to_mkt(Lds& L, Mkt& m, int A, int lane) {
             else { x = ld_dec(a.cash); y = ld_dec(a.hold); }
             r1 = d_add(x, y);
         }
-        TACC_END(m, 6);
         if (g != 2) r2 = d_mul_int(g == 0 ? r1 : vwap, ap);   // stage 2, one multiplication: g0 profit, g1 raw
-        TACC_END(m, 7);
     }
     D raw = d_shfl(r2, (lane + 16) & 63), ssum = d_shfl(r1, (lane + 32) & 63);
-    TACC_END(m, 8);
     if (act && g == 0) {
         Acc& a = L.acc[al];
         D posval = d_add(raw, r2);
-        TACC_END(m, 9);
         D nav = d_add(ssum, posval);
-        TACC_END(m, 10);
         a.prev_nav = a.nav;
         st_dec(a.posval, posval, f); st_dec(a.nav, nav, f);
         if (d_cmp(nav, ld_dec(a.max_nav)) > 0) st_dec(a.max_nav, nav, f);
-        TACC_END(m, 11);
     }
     CDA_WSYNC();
     if (__ballot(f != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
