@@ -151,61 +151,65 @@ def main():
     acts = gen_actions(torch, N, A, chunk, device, 2024 + rank)
     if gather:
         gathered = [torch.empty(world * env.slab_layout["bytes"], dtype=torch.uint8, device=device) for _ in range(2)]
-    in_flight = [None]
-
-    def do_gather(t):
-        if args.no_overlap:
-            dist.all_gather_into_tensor(gathered[t & 1], env.out_slab)
-            return
-        work = dist.all_gather_into_tensor(gathered[t & 1], env.out_slab, async_op=True)
-        if in_flight[0] is not None:
-            in_flight[0].wait()             # stream-level: step t+1 may overwrite the slab gather t-1 read
-        in_flight[0] = work
+    # N > 1, overlapped: two streams alternate.  Stream X runs step t and then its all-gather (a synchronous collective
+    # stays on the caller's stream); stream Y runs step t+1 as soon as ONE event says step t is done (the market state
+    # dependency), i.e. underneath gather t.  Step t+2 is back on X behind gather t, which is also what protects the
+    # slab gather t reads.  One cross-stream edge per step (~12 us on this platform, tools/host_overhead.py) instead of
+    # the two that an async_op collective on RCCL's own stream costs.
+    overlap = gather and not args.no_overlap
+    if overlap:
+        streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+        step_done = [torch.cuda.Event(), torch.cuda.Event()]
+    timed = {}                                                 # global step index -> (start, end) timing events
 
     def one_step(t):
         i = t % chunk
-        env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
-        if gather:
-            do_gather(t)
+        if not overlap:
+            ev = timed.get(t)
+            if ev:
+                ev[0].record()
+            env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+            if ev:
+                ev[1].record()
+            if gather:
+                dist.all_gather_into_tensor(gathered[t & 1], env.out_slab)
+            return
+        cur = streams[t & 1]
+        with torch.cuda.stream(cur):
+            if t > 0:
+                cur.wait_event(step_done[(t - 1) & 1])
+            ev = timed.get(t)
+            if ev:
+                ev[0].record(cur)
+            env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+            if ev:
+                ev[1].record(cur)
+            step_done[t & 1].record(cur)
+            dist.all_gather_into_tensor(gathered[t & 1], env.out_slab)
 
-    def drain():
-        if in_flight[0] is not None:
-            in_flight[0].wait()
-            in_flight[0] = None
-
+    torch.cuda.synchronize()                                   # reset and the action stream are complete before any side stream starts
     for t in range(W):
         one_step(t)
-    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     # HIP events on the stream the kernel is launched on (torch's current stream == the stream handed
     # to cda_step).  N == 1: one pair brackets the K back-to-back launches (nothing else is enqueued in
-    # between), so kernel_ms = span / K.  N > 1: the all-gather's stream dependencies sit between launches, so
-    # single launches get their own pair - every EV_STRIDE-th one only, a timing event pair costs ~8 us of
+    # between), so kernel_ms = span / K.  N > 1: the all-gather and the stream dependencies sit between launches, so
+    # single launches get their own pair - every EV_STRIDE-th one only, a timing event pair costs ~7 us of
     # stream time (tools/host_overhead.py).
     per_launch = gather
     EV_STRIDE = 16
     if per_launch:
-        timed_steps = list(range(0, K, EV_STRIDE))
-        ev0 = {t: torch.cuda.Event(enable_timing=True) for t in timed_steps}
-        ev1 = {t: torch.cuda.Event(enable_timing=True) for t in timed_steps}
+        timed.update({W + t: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for t in range(0, K, EV_STRIDE)})
     else:
         ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     if not per_launch:
         ev_a.record()
     for t in range(K):
-        i = (W + t) % chunk
-        if per_launch and t in ev0:
-            ev0[t].record()
-        env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
-        if per_launch and t in ev1:
-            ev1[t].record()
-        if gather:
-            do_gather(W + t)
-    drain()
+        one_step(W + t)
     if not per_launch:
         ev_b.record()
     torch.cuda.synchronize()
@@ -217,7 +221,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kernel_ms = (sum(ev0[t].elapsed_time(ev1[t]) for t in ev0) / len(ev0)) if per_launch else ev_a.elapsed_time(ev_b) / K
+    kernel_ms = (sum(a.elapsed_time(b) for a, b in timed.values()) / len(timed)) if per_launch else ev_a.elapsed_time(ev_b) / K
     flags = env.flags()
     n_flagged = int((flags != 0).sum().item())
 
@@ -244,7 +248,7 @@ def main():
             "config": {"workload": f"{N} markets x {A} random agents per GPU, book capacity {256} resting orders per market "
                                    f"(BASELINE configs[2]); global {world * N} markets",
                        "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info),
-                       "collective": ("all_gather(obs|reward|flags slab), " + ("serial" if args.no_overlap else "overlapped with the next step")) if gather else "none",
+                       "collective": ("all_gather(obs|reward|flags slab), " + ("serial" if args.no_overlap else "overlapped with the next step on alternating streams")) if gather else "none",
                        "flagged_markets": n_flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,

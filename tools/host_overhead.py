@@ -96,7 +96,33 @@ def main():
             evs[2 + (i & 1)].record()
         torch.cuda.current_stream().wait_event(evs[2 + ((i + 1) & 1)])
 
-    for name, fn in (("step only", st), ("step + 2 timing events", v_events), ("step + copy same stream", v_copy),
+    # alternating streams: stream X runs step(t) then its gather (a synchronous collective stays on the current stream),
+    # stream Y runs step(t+1) after ONE event edge on step(t); the gather of t overlaps step t+1 with one edge per step
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ev_step = [torch.cuda.Event() for _ in range(2)]
+    state = {"first": True}
+
+    def v_alt(i):
+        cur = sa if (i & 1) == 0 else sb
+        with torch.cuda.stream(cur):
+            if not state["first"]:
+                cur.wait_event(ev_step[(i + 1) & 1])          # market state: step i needs step i-1
+            state["first"] = False
+            st(i)
+            ev_step[i & 1].record(cur)
+            dist.all_gather_into_tensor(g[i & 1], env.out_slab)
+
+    def v_alt_copy(i):
+        cur = sa if (i & 1) == 0 else sb
+        with torch.cuda.stream(cur):
+            if not state["first"]:
+                cur.wait_event(ev_step[(i + 1) & 1])
+            state["first"] = False
+            st(i)
+            ev_step[i & 1].record(cur)
+            g[i & 1].copy_(env.out_slab)
+
+    for name, fn in (("step only", st), ("alternating streams + gather", v_alt), ("alternating streams + copy", v_alt_copy), ("step + 2 timing events", v_events), ("step + copy same stream", v_copy),
                      ("step + all_gather sync", v_ag_sync), ("step + all_gather async", v_ag_async),
                      ("step + copy side stream", v_side_copy)):
         print(f"loop: {name:28s} {loop(fn):8.1f} us/step")
