@@ -235,33 +235,44 @@ def main():
     base4 = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 256, "is_render": False}
     base8 = {"num_of_agents": 8, "init_cash": 1000000, "max_step": 256, "is_render": False}
     traces = {}
+    only = set(sys.argv[1:])              # optional: regenerate just the named traces
+
+    def add(name, *a, **k):
+        if not only or name in only:
+            traces[name] = run_trace(name, *a, **k)
+    base16 = {"num_of_agents": 16, "init_cash": 1000000, "max_step": 256, "is_render": False}
     for s in range(8):
-        traces[f"A4_s{s}"] = run_trace(f"A4_s{s}", base4, s, 256, 5000 + s)
+        add(f"A4_s{s}", base4, s, 256, 5000 + s)
     for s in range(8):
-        traces[f"A8_s{s}"] = run_trace(f"A8_s{s}", base8, s, 256, 6000 + s)
-    traces["default_s11"] = run_trace("default_s11", {"is_render": False}, 11, 80, 7011)
-    traces["lowcash_s21"] = run_trace("lowcash_s21", dict(base4, init_cash=3000), 21, 256, 7021)
-    traces["lowcash_s22"] = run_trace("lowcash_s22", dict(base4, init_cash=400), 22, 256, 7022, law="aggressive")
-    traces["aggr_s23"] = run_trace("aggr_s23", dict(base4), 23, 256, 7023, law="aggressive")
-    traces["aggr8_s24"] = run_trace("aggr8_s24", dict(base8), 24, 256, 7024, law="aggressive")
-    traces["edges_s25"] = run_trace("edges_s25", dict(base4), 25, 192, 7025, law="edges")
-    traces["subset_s31"] = run_trace("subset_s31", dict(base4), 31, 160, 7031, present_p=0.6)
-    traces["hist1_s41"] = run_trace("hist1_s41", dict(base4, n_hist=1), 41, 48, 7041)
-    traces["hist6_s42"] = run_trace("hist6_s42", dict(base4, n_hist=6), 42, 48, 7042)
-    traces["coef_s43"] = run_trace("coef_s43", dict(base4, order_penalty=0.3, trade_penalty=0.07, drawdown_penalty=0.11,
+        add(f"A8_s{s}", base8, s, 256, 6000 + s)
+    add("default_s11", {"is_render": False}, 11, 80, 7011)
+    add("lowcash_s21", dict(base4, init_cash=3000), 21, 256, 7021)
+    add("lowcash_s22", dict(base4, init_cash=400), 22, 256, 7022, law="aggressive")
+    add("aggr_s23", dict(base4), 23, 256, 7023, law="aggressive")
+    add("aggr8_s24", dict(base8), 24, 256, 7024, law="aggressive")
+    add("edges_s25", dict(base4), 25, 192, 7025, law="edges")
+    add("subset_s31", dict(base4), 31, 160, 7031, present_p=0.6)
+    add("hist1_s41", dict(base4, n_hist=1), 41, 48, 7041)
+    add("hist6_s42", dict(base4, n_hist=6), 42, 48, 7042)
+    add("coef_s43", dict(base4, order_penalty=0.3, trade_penalty=0.07, drawdown_penalty=0.11,
                                                     passive_bonus=0.9, loss_multiplier=2.25, initial_price_min=500,
                                                     initial_price_max=5000, min_size=2, mkt_max_size=40,
                                                     limit_size_multiple=3), 43, 128, 7043)
-    traces["reset_s51"] = run_trace("reset_s51", dict(base4, max_step=40), 51, 120, 7051, reseed_at={40: None, 80: 977})
-    traces["big_seed"] = run_trace("big_seed", dict(base4), 2 ** 63 + 12345, 64, 7061)
+    add("reset_s51", dict(base4, max_step=40), 51, 120, 7051, reseed_at={40: None, 80: 977})
+    add("big_seed", dict(base4), 2 ** 63 + 12345, 64, 7061)
     # bankruptcies: heavily short accounts are marked against a much higher price -> NAV <= 0 -> done_set, rejections,
     # and finally terminateds["__all__"]
     short = lambda v: {"cash": 100, "position_val": 10 * v, "VWAP": 10, "net_position": -v}   # noqa: E731
-    traces["bankrupt_s61"] = run_trace("bankrupt_s61", dict(base4, max_step=96), 61, 96, 7161,
+    add("bankrupt_s61", dict(base4, max_step=96), 61, 96, 7161,
                                        presets=[(3, 0, short(60000)), (20, 1, short(80000)), (40, 2, short(90000)), (60, 3, short(70000))])
-    traces["long_s100"] = run_trace("long_s100", dict(base4, max_step=2048), 100, 2048, 7100)
+    # the build's agent-count bound (CDA_MAX_AGENTS = 16): owner lanes 0-15, helper lanes 16-47 all busy
+    add("A16_s70", base16, 70, 160, 7070)
+    add("A16_aggr_s71", dict(base16, init_cash=200000), 71, 128, 7071, law="aggressive")
+    add("long_s100", dict(base4, max_step=2048), 100, 2048, 7100)
     for name, rec in traces.items():
         np.savez_compressed(os.path.join(out_dir, f"trace_{name}.npz"), **rec)
+    if only:
+        return 0
     tot = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir) if f.endswith(".npz"))
     print("total fixture bytes", tot)
 
