@@ -10,7 +10,7 @@
  * PINNING: this oracle is pinned against golden vectors cut from the reference itself, imported
  * in the build container (tests/golden/make_goldens.py -> tests/golden/ fixtures), by
  * tests/test_oracle_golden.py; its decimal arithmetic is pinned against CPython's `decimal`
- * (tests/golden/dec_kat.npz) and its RNG against numpy (live, in the tests).
+ * and its RNG against numpy, both live (tests/test_oracle_arith.py).
  *
  * Third-party arithmetic restated here (not under /root/reference):
  *   - numpy.random.Generator(PCG64(SeedSequence(seed))) - numpy==2.5.2 pinned by the reference
