@@ -227,3 +227,50 @@ def test_double_buffered_output_slabs_and_async_gather():
         prev, prev_ref = h, (ro.clone(), rr.clone(), rt.clone(), ru.clone())
     ref.close()
     sh.close()
+
+
+def test_ppo_loop_on_the_hip_env_with_graph_captured_policy_step():
+    """BASELINE config #5 in miniature: rollouts through a captured HIP graph of the policy step, device-side auto reset."""
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    from gym_continuousdoubleauction_amd import ppo
+    env = CDAVecEnv({"num_of_agents": 4, "init_cash": 1000000, "max_step": 12, "is_render": False, "auto_reset": True},
+                    n_markets=256, with_info=False)
+    logs = []
+    model, hist = ppo.train(env, iters=2, horizon=16, log=logs.append)
+    assert not any("capture failed" in x for x in logs), logs
+    assert len(hist) == 2 and all(math.isfinite(h["pg_loss"]) and math.isfinite(h["v_loss"]) and h["agent_steps"] == 256 * 4 * 16 for h in hist)
+    assert int(env.flags().abs().sum()) == 0
+    eager_model, eager_hist = ppo.train(env, iters=1, horizon=4, log=logs.append, use_graph=False)
+    assert math.isfinite(eager_hist[0]["v_loss"])
+    env.close()
+    del model, eager_model
+    torch.cuda.synchronize()
+
+
+def test_league_rollout_routes_modules_per_market():
+    """League slot mapping on the batched env: a trainable policy in slot 0, fixed random opponents and a champion elsewhere."""
+    import numpy as np
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    from gym_continuousdoubleauction_amd.league import LeagueSlotMapper, RandomModule, league_actions
+    n, a = 128, 4
+    env = CDAVecEnv({"num_of_agents": a, "init_cash": 1000000, "max_step": 64, "is_render": False}, n_markets=n, with_info=True)
+    mapper = LeagueSlotMapper(a, 1, 3, original_opponent_weight=1.0, champion_weight=3.0)
+    champ = mapper.add_champion()
+    assignment = mapper.assign([f"iter0-market{i}" for i in range(n)])
+    always_pass = lambda o: (torch.zeros(o.shape[0], dtype=torch.int32, device=o.device), torch.zeros(o.shape[0], device=o.device),   # noqa: E731
+                             torch.zeros(o.shape[0], device=o.device), torch.zeros(o.shape[0], dtype=torch.int32, device=o.device),
+                             torch.ones(o.shape[0], dtype=torch.int32, device=o.device))
+    modules = {name: RandomModule("cuda:0", seed=i) for i, name in enumerate(mapper.available_modules)}
+    modules[champ] = always_pass                               # the champion never trades: recognisable in the info tensors
+    obs = env.reset(seed=7)
+    for t in range(20):
+        obs, rew, term, trunc, info = env.step(*league_actions(mapper, assignment, modules, obs))
+    names = mapper.names(assignment)
+    is_champ = torch.as_tensor(names == champ, device="cuda:0")
+    assert bool(is_champ.any()) and bool((~is_champ).any())
+    assert bool(info["is_pass_action"].bool()[is_champ].all())              # last step: every champion slot passed
+    assert int(info["num_trades"][is_champ].sum()) == 0 and int(info["num_trades"][~is_champ].sum()) > 0
+    assert int(env.flags().abs().sum()) == 0
+    env.close()
