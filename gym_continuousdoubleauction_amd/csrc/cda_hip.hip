@@ -163,38 +163,30 @@ struct StepArgs {
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
-    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
-    int mi = (int)blockIdx.x * CDA_WPB + wave;
-    zig_tables_init();
-    dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit
-    if (mi >= P.n_markets) return;
-    Lds& L = wave_lds(P, wave, ZIG_LDS_BYTES);
-    const unsigned long long* zig_wi = reinterpret_cast<const unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
-    const unsigned long long* zig_ki = zig_wi + 256;
-    MarketPtrs mp = market_ptrs(arena, P, mi);
-    Mkt m;
-    const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
+// ---- the phases of one step, shared by k_step (one step per launch) and k_run_random (a whole episode per launch) ----
 #ifdef CDA_PHASE_TIMING
-    for (int i = 0; i < 14; i++) m.tacc[i] = 0;
+#define PH_MARK(ph, i) do { unsigned long long _t = __builtin_readcyclecounter(); if ((ph) && lane == 0) (ph)[i] = _t; } while (0)
+#else
+#define PH_MARK(ph, i) do {} while (0)
 #endif
-    PHASE_MARK(0);
-    load_market<true>(mp, P, L, m, lane);
-    PHASE_MARK(1);
+struct LaneAction { int cat, level, off; float mean, sigma; bool pres; };     // lane a: agent a's action words (unclamped)
 
+// phases 1-5: everything of a step that changes the market.  Returns the mask of agents that passed.
+__device__ __forceinline__ uint32_t step_market(Lds& L, Mkt& m, const Params& P, const unsigned long long* zig_wi, const unsigned long long* zig_ki,
+                                                const LaneAction& in, unsigned long long* ph, int lane) {
+    const int A = P.cfg.num_agents, tick = P.cfg.tick_size;
     // 1. pre-step snapshot (continuousDoubleAuction_env.py:274): prices of ALL orders resolve against it.  It equals the
     //    post-step aggregation of the previous step, which travels in the header; recomputed only when a test hook,
     //    set_state or reset touched the book in between.
     if (!m.levels_valid) aggregate_levels(L, m, lane);
-    PHASE_MARK(2);
+    PH_MARK(ph, 2);
     // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order; lane a
     //    decodes agent a.  Every agent's normal is first computed SPECULATIVELY in its own lane: the k-th present agent
     //    jumps the LCG ahead by k + 1 and takes the ziggurat's first candidate.  If every lane accepted (95 % of the steps at
     //    4 agents) those ARE the sequential draws; otherwise the draws are redone one after the other, wave-uniform.
     uint32_t act_mask = 0, pass_mask = 0;
     {
-        const size_t ab = (size_t)mi * (size_t)A;
-        const bool pres = lane < A && (!S.present || S.present[ab + lane]);
+        const bool pres = in.pres;
         const uint64_t pm = __ballot(pres);
         if (pm) {
             double z = 0.0;
@@ -219,9 +211,9 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
             bool ovf = false;
             int side = S_NONE;
             if (pres) {
-                int cat = clampi(S.category[ab + lane], 0, 8);
-                float mean = clampf(S.size_mean[ab + lane], -1.0f, 1.0f), sigma = clampf(S.size_sigma[ab + lane], 0.0f, 1.0f);
-                int level = clampi(S.price[ab + lane], 0, CDA_K_ROWS - 1), off = clampi(S.price_offset[ab + lane], 0, 2) - 1;
+                int cat = clampi(in.cat, 0, 8);
+                float mean = clampf(in.mean, -1.0f, 1.0f), sigma = clampf(in.sigma, 0.0f, 1.0f);
+                int level = clampi(in.level, 0, CDA_K_ROWS - 1), off = clampi(in.off, 0, 2) - 1;
                 side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
                 int type = cat == 0 ? T_MARKET : ((cat - 1) & 3);
                 float locf = (type == T_MARKET ? P.mkt_mul : P.lim_mul) * mean;      // float32 product (numpy NEP 50)
@@ -247,7 +239,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
         }
         CDA_WSYNC();
     }
-    PHASE_MARK(3);
+    PH_MARK(ph, 3);
     // 3. rand_exec_seq (action_helper.py:174-199): Fisher-Yates over the n non-pass orders, nibble-packed
     int n_acts = __popc(act_mask);
     uint64_t perm = 0xFEDCBA9876543210ull;
@@ -257,7 +249,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
         perm &= ~((0xFull << (4 * i)) | (0xFull << (4 * j)));
         perm |= (vj << (4 * i)) | (vi << (4 * j));
     }
-    PHASE_MARK(4);
+    PH_MARK(ph, 4);
     // 4. do_actions (action_helper.py:201-239): sequential, order dependent
     for (int i = 0; i < n_acts; i++) {
         int k = (int)((perm >> (4 * i)) & 0xFull);
@@ -267,10 +259,81 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
         int32_t tsp = L.act_tsp[tr], size = L.act_size[tr];
         place_order<true>(L, m, tr, tsp & 3, (tsp >> 2) & 3, size, (tsp >> 4) - 1, lane);     // mark_to_mkt below rewrites position_val
     }
-    PHASE_MARK(5);
+    PH_MARK(ph, 5);
     // 5. mark_to_mkt
     mark_to_mkt(L, m, A, lane);
-    PHASE_MARK(6);
+    PH_MARK(ph, 6);
+    return pass_mask;
+}
+
+// phase 7, Reward_Helper.set_reward (exchg/reward_helper.py:35-102) and Done_Helper.set_done (done_helper.py:3-18) for
+// lane a < A.  The two float(Decimal) conversions of the reward are independent: the owner lane converts nav - prev_nav
+// while its helper lane (a + 16) converts max_nav - nav, in the same instruction stream.
+struct StepReward { double r, t0, t1, t2, t3, t4, drawdown; bool bankrupt; };
+__device__ __forceinline__ StepReward step_reward(Lds& L, const Params& P, uint32_t& ferr, int lane) {
+    const int A = P.cfg.num_agents;
+    StepReward o; o.r = o.t0 = o.t1 = o.t2 = o.t3 = o.t4 = o.drawdown = 0.0; o.bankrupt = false;
+    double conv = 0.0;
+    if (lane_acc(lane) < A && lane_grp(lane) < 2) {
+        const Acc& a = L.acc[lane_acc(lane)];
+        const bool own = lane_grp(lane) == 0;
+        D nav = ld_dec(a.nav);
+        D x = own ? nav : ld_dec(a.max_nav), y = own ? ld_dec(a.prev_nav) : nav;
+        D df = d_sub(x, y);                                  // ONE call site each, so owner and helper stay converged
+        if (own || d_sgn(df) > 0) conv = d_to_double(df, &ferr);
+    }
+    const double conv_helper = __shfl(conv, (lane + 16) & 63, WAVE);
+    if (lane < A) {
+        const Acc& a = L.acc[lane];
+        double nav_change = conv;
+        double nav_term = nav_change * (nav_change < 0 ? P.cfg.loss_multiplier : 1.0);
+        o.drawdown = conv_helper;
+        o.t0 = nav_term;
+        o.t1 = -(P.cfg.order_penalty * (double)a.order_step_placed);
+        o.t2 = -(P.cfg.trade_penalty * (double)a.num_trades_step);
+        o.t3 = -(P.cfg.drawdown_penalty * o.drawdown);
+        o.t4 = P.cfg.passive_bonus * (double)a.num_passive_fills_step;
+        double r = 0.0; r += o.t0; r += o.t1; r += o.t2; r += o.t3; r += o.t4;   // left to right (reward_helper.py:92-94)
+        o.r = r;
+        o.bankrupt = d_sgn(ld_dec(a.nav)) <= 0;
+    }
+    return o;
+}
+__device__ __forceinline__ void clear_step_counters(Acc& a) {          // exchg_helper.py:116-120
+    a.num_trades_step = 0; a.num_passive_fills_step = 0; a.order_step_placed = 0; a.num_rejected_step = 0;
+}
+
+__global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
+    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
+    int mi = (int)blockIdx.x * CDA_WPB + wave;
+    zig_tables_init();
+    dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit
+    if (mi >= P.n_markets) return;
+    Lds& L = wave_lds(P, wave, ZIG_LDS_BYTES);
+    const unsigned long long* zig_wi = reinterpret_cast<const unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
+    const unsigned long long* zig_ki = zig_wi + 256;
+    MarketPtrs mp = market_ptrs(arena, P, mi);
+    Mkt m;
+    const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
+    unsigned long long* ph = nullptr;
+#ifdef CDA_PHASE_TIMING
+    for (int i = 0; i < 14; i++) m.tacc[i] = 0;
+    ph = S.phase_cycles ? S.phase_cycles + (size_t)mi * 24 : nullptr;
+#endif
+    PH_MARK(ph, 0);
+    load_market<true>(mp, P, L, m, lane);
+    PH_MARK(ph, 1);
+    LaneAction in;
+    {
+        const size_t ab = (size_t)mi * (size_t)A;
+        in.pres = lane < A && (!S.present || S.present[ab + lane]);
+        in.cat = 0; in.level = 0; in.off = 0; in.mean = 0.0f; in.sigma = 0.0f;
+        if (in.pres) {
+            in.cat = S.category[ab + lane]; in.mean = S.size_mean[ab + lane]; in.sigma = S.size_sigma[ab + lane];
+            in.level = S.price[ab + lane]; in.off = S.price_offset[ab + lane];
+        }
+    }
+    const uint32_t pass_mask = step_market(L, m, P, zig_wi, zig_ki, in, ph, lane);
     // 6. prep_next_state (state_helper.py:80-92): new frame, history ring, stacked observation
     aggregate_levels(L, m, lane);
     {
@@ -288,38 +351,14 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
         }
         m.hist_head = m.hist_head + 1 >= H ? 0 : m.hist_head + 1;
     }
-    PHASE_MARK(7);
+    PH_MARK(ph, 7);
     // 7. set_step_outputs (exchg_helper.py:93-124)
     uint32_t ferr = 0;
-    bool bankrupt = false;
-    // The two float(Decimal) conversions of the reward are independent: the owner lane converts nav - prev_nav while its
-    // helper lane (a + 16) converts max_nav - nav, in the same instruction stream.
-    double conv = 0.0;
-    if (lane_acc(lane) < A && lane_grp(lane) < 2) {
-        const Acc& a = L.acc[lane_acc(lane)];
-        const bool own = lane_grp(lane) == 0;
-        D nav = ld_dec(a.nav);
-        D x = own ? nav : ld_dec(a.max_nav), y = own ? ld_dec(a.prev_nav) : nav;
-        D df = d_sub(x, y);                                  // ONE call site each, so owner and helper stay converged
-        if (own || d_sgn(df) > 0) conv = d_to_double(df, &ferr);
-    }
-    const double conv_helper = __shfl(conv, (lane + 16) & 63, WAVE);
+    const StepReward rw = step_reward(L, P, ferr, lane);
     if (lane < A) {
         Acc& a = L.acc[lane];
         size_t ix = (size_t)mi * (size_t)A + (size_t)lane;
-        D nav = ld_dec(a.nav), mx = ld_dec(a.max_nav);
-        // Reward_Helper.set_reward (exchg/reward_helper.py:35-102)
-        double nav_change = conv;
-        double nav_term = nav_change * (nav_change < 0 ? P.cfg.loss_multiplier : 1.0);
-        double drawdown = conv_helper;
-        double t0 = nav_term;
-        double t1 = -(P.cfg.order_penalty * (double)a.order_step_placed);
-        double t2 = -(P.cfg.trade_penalty * (double)a.num_trades_step);
-        double t3 = -(P.cfg.drawdown_penalty * drawdown);
-        double t4 = P.cfg.passive_bonus * (double)a.num_passive_fills_step;
-        double r = 0.0; r += t0; r += t1; r += t2; r += t3; r += t4;          // left to right (reward_helper.py:92-94)
-        S.reward_out[ix] = r;
-        bankrupt = d_sgn(nav) <= 0;                                            // Done_Helper.set_done (done_helper.py:3-18)
+        S.reward_out[ix] = rw.r;
         if (S.has_info) {                                                      // Info_Helper.set_info (info_helper.py:30-116)
             const cda_info_ptrs& I = S.info;
             if (I.nav) I.nav[ix] = a.nav;
@@ -329,19 +368,19 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
             if (I.cash) I.cash[ix] = d_to_double(ld_dec(a.cash), &ferr);
             if (I.cash_on_hold) I.cash_on_hold[ix] = d_to_double(ld_dec(a.hold), &ferr);
             if (I.position_val) I.position_val[ix] = d_to_double(ld_dec(a.posval), &ferr);
-            if (I.drawdown) I.drawdown[ix] = drawdown;
-            if (I.max_nav) I.max_nav[ix] = d_to_double(mx, &ferr);
+            if (I.drawdown) I.drawdown[ix] = rw.drawdown;
+            if (I.max_nav) I.max_nav[ix] = d_to_double(ld_dec(a.max_nav), &ferr);
             if (I.num_trades_step) I.num_trades_step[ix] = a.num_trades_step;
             if (I.num_passive_fills_step) I.num_passive_fills_step[ix] = a.num_passive_fills_step;
             if (I.order_step_placed) I.order_step_placed[ix] = a.order_step_placed;
             if (I.num_rejected_step) I.num_rejected_step[ix] = a.num_rejected_step;
             if (I.is_pass_action) I.is_pass_action[ix] = (uint8_t)((pass_mask >> lane) & 1u);
-            if (I.reward_terms) { double* rt = I.reward_terms + ix * 5; rt[0] = t0; rt[1] = t1; rt[2] = t2; rt[3] = t3; rt[4] = t4; }
+            if (I.reward_terms) { double* rt = I.reward_terms + ix * 5; rt[0] = rw.t0; rt[1] = rw.t1; rt[2] = rw.t2; rt[3] = rw.t3; rt[4] = rw.t4; }
         }
-        a.num_trades_step = 0; a.num_passive_fills_step = 0; a.order_step_placed = 0; a.num_rejected_step = 0;
+        clear_step_counters(a);
     }
     if (__ballot(ferr != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
-    m.done_mask |= (uint32_t)__ballot(bankrupt);
+    m.done_mask |= (uint32_t)__ballot(rw.bankrupt);
     if (lane == 0) {
         if (S.has_info) {
             const cda_info_ptrs& I = S.info;
@@ -360,12 +399,12 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     }
     m.t_step += 1;
     m.levels_valid = 1;                                   // lvl_px/lvl_sz hold the post-step aggregation (phase 6)
-    PHASE_MARK(8);
+    PH_MARK(ph, 8);
     store_market(mp, P, L, m, lane);
     store_levels(mp, L, lane);
-    PHASE_MARK(9);
+    PH_MARK(ph, 9);
 #ifdef CDA_PHASE_TIMING
-    if (S.phase_cycles && lane == 0) for (int i = 0; i < 14; i++) S.phase_cycles[(size_t)mi * 24 + 10 + i] = m.tacc[i];
+    if (ph && lane == 0) for (int i = 0; i < 14; i++) ph[10 + i] = m.tacc[i];
 #endif
 }
 
