@@ -42,6 +42,9 @@ def parse():
     p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each step's all-gather before the next launch")
     p.add_argument("--force-gather", action="store_true",
                    help="run the N>1 code path (process group + all-gather) even with one rank; diagnostics")
+    p.add_argument("--fused", type=int, default=0, metavar="T",
+                   help="not the headline run: T steps per launch through cda_run_random (random agents sampled in the kernel, "
+                        "market state resident in LDS across steps, no per-step barrier between markets)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline sample")
     return p.parse_args()
@@ -138,7 +141,9 @@ def main():
     N, A, K, W = args.markets, args.agents, args.steps, args.warmup
     max_step = max(4096, K + W + 1)                   # no truncation inside the run
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
-    gather = use_dist and not args.no_gather
+    if args.fused and (args.steps % args.fused or args.warmup % args.fused):
+        raise SystemExit("--fused T needs --steps and --warmup to be multiples of T")
+    gather = use_dist and not args.no_gather and not args.fused
     # N > 1: the per-step outputs (obs | reward | flags: one contiguous slab written by k_step itself) are
     # all-gathered over xGMI with ONE collective per step and no packing pass.  The env rotates two slabs, so
     # the gather of step t runs on RCCL's stream underneath the kernel of step t+1.
@@ -164,6 +169,10 @@ def main():
 
     def one_step(t):
         i = t % chunk
+        if args.fused:
+            if t % args.fused == 0:
+                env.run_random(args.fused, action_seed=2024 + rank, market_index_base=first_market)
+            return
         if not overlap:
             ev = timed.get(t)
             if ev:
@@ -236,7 +245,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as fh:
                 pmc = json.load(fh)
-            if N == 4096 and A == 4 and not args.info:
+            if N == 4096 and A == 4 and not args.info and not args.fused:
                 traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc, calibrated)"
         except Exception:  # noqa: BLE001
             pass
@@ -246,13 +255,15 @@ def main():
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+dec28+f64", "data": "synthetic",
             "config": {"workload": f"{N} markets x {A} random agents per GPU, book capacity {256} resting orders per market "
-                                   f"(BASELINE configs[2]); global {world * N} markets",
+                                   f"(BASELINE configs[2]); global {world * N} markets"
+                                   + (f"; FUSED: {args.fused} steps per launch (cda_run_random)" if args.fused else ""),
                        "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info),
                        "collective": ("all_gather(obs|reward|flags slab), " + ("serial" if args.no_overlap else "overlapped with the next step on alternating streams")) if gather else "none",
                        "flagged_markets": n_flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_step", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": "k_run_random (per step)" if args.fused else "k_step", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

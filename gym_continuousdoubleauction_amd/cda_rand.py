@@ -43,14 +43,28 @@ def run_random(num_agents=None, max_step=None, init_cash=None, is_render=None, s
         env.close()
 
 
-def run_random_batched(n_markets, num_agents=None, max_step=None, init_cash=None, seed=0, device="cuda:0"):
-    """N markets in lockstep; actions ~ the RandomRLModule law (train/model/model_handler.py:38-53) drawn on the device.
+def run_random_batched(n_markets, num_agents=None, max_step=None, init_cash=None, seed=0, device="cuda:0", fused=True):
+    """N markets; actions ~ the RandomRLModule law (train/model/model_handler.py:38-53) drawn on the device.
+    fused=True: the whole episode of every market in ONE launch (`cda_run_random`: state stays in LDS, no market waits for
+    the slowest of the batch); fused=False: one launch per step with torch-generated actions.
     Returns (steps, agent_steps_per_second)."""
     import torch
     from .vec_env import CDAVecEnv
     cfg = _env_config(num_agents, max_step, init_cash)
     env = CDAVecEnv(cfg, n_markets=n_markets, device=device, with_info=False)
     n, a = env.n_markets, env.num_agents
+    if fused:
+        env.reset(seed=seed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, term, trunc, taken = env.run_random(cfg["max_step"], action_seed=seed)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if not bool((term | trunc).all()):
+            raise RuntimeError("every market must end its episode within max_step")
+        total = int(taken.sum().item())
+        env.close()
+        return int(taken.max().item()), total * a / dt
     gen = torch.Generator(device=device)
     gen.manual_seed(int(seed))
     env.reset(seed=seed)
@@ -79,9 +93,11 @@ def main(argv=None):
     ap.add_argument("--init-cash", type=int, default=DEFAULT_CASH)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--markets", type=int, default=1, help="> 1 runs the batched env")
+    ap.add_argument("--per-step-launch", action="store_true", help="batched env: one launch per step instead of one per episode")
     args = ap.parse_args(argv)
     if args.markets > 1:
-        steps, rate = run_random_batched(args.markets, args.agents, args.steps, args.init_cash, seed=args.seed or 0)
+        steps, rate = run_random_batched(args.markets, args.agents, args.steps, args.init_cash, seed=args.seed or 0,
+                                         fused=not args.per_step_launch)
         print(f"{args.markets} markets x {args.agents} random agents: {steps} steps, {rate / 1e6:.1f} M agent-steps/s")
     else:
         steps = run_random(args.agents, args.steps, args.init_cash, seed=args.seed)

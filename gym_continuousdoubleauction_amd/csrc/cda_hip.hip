@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include "../../include/cda.h"
+#include "../../include/cda_random_agents.h"
 #include "cda_dec.hpp"
 #include "cda_market.hpp"
 
@@ -409,6 +410,71 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
 }
 
 // ------------------------------------------------------------------------------------------
+// run_random - a whole random-agent episode per launch (CDA_rand.py:40-85)
+// ------------------------------------------------------------------------------------------
+struct RunArgs {
+    int32_t n_steps; uint64_t seed, market_base;
+    float* obs_out; double* return_out; uint8_t* terminated_out; uint8_t* truncated_out; int32_t* steps_out;
+};
+__global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_run_random(uint8_t* arena, Params P, RunArgs R) {
+    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    int mi = (int)blockIdx.x * CDA_WPB + wave;
+    zig_tables_init();
+    dec_tables_init();
+    if (mi >= P.n_markets) return;
+    Lds& L = wave_lds(P, wave, ZIG_LDS_BYTES);
+    const unsigned long long* zig_wi = reinterpret_cast<const unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
+    const unsigned long long* zig_ki = zig_wi + 256;
+    MarketPtrs mp = market_ptrs(arena, P, mi);
+    Mkt m;
+    const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
+#ifdef CDA_PHASE_TIMING
+    for (int i = 0; i < 14; i++) m.tacc[i] = 0;
+#endif
+    load_market<true>(mp, P, L, m, lane);
+    float* hist = lds_hist(L, A);                           // the history ring stays in LDS for the whole episode
+    double ret = 0.0;
+    int steps = 0;
+    bool term = false, trunc = false;
+    for (int it = 0; it < R.n_steps; it++) {
+        LaneAction in;
+        in.pres = lane < A; in.cat = 0; in.level = 0; in.off = 0; in.mean = 0.0f; in.sigma = 0.0f;
+        if (in.pres) cda_random_action(R.seed, R.market_base + (uint64_t)mi, (uint32_t)m.t_step, (uint32_t)lane, &in.cat, &in.mean, &in.sigma, &in.level, &in.off);
+        step_market(L, m, P, zig_wi, zig_ki, in, nullptr, lane);
+        aggregate_levels(L, m, lane);
+        if (lane < CDA_SNAPSHOT_DIM) hist[m.hist_head * CDA_SNAPSHOT_DIM + lane] = snapshot_value(L, m, tick, lane);
+        m.hist_head = m.hist_head + 1 >= H ? 0 : m.hist_head + 1;
+        uint32_t ferr = 0;
+        const StepReward rw = step_reward(L, P, ferr, lane);
+        if (lane < A) { ret += rw.r; clear_step_counters(L.acc[lane]); }
+        if (__ballot(ferr != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
+        m.done_mask |= (uint32_t)__ballot(rw.bankrupt);
+        term = __popc(m.done_mask) == A; trunc = m.t_step + 1 >= P.cfg.max_step;
+        m.t_step += 1;
+        m.levels_valid = 1;
+        steps += 1;
+        CDA_WSYNC();
+        if (term || trunc) break;
+    }
+    if (R.obs_out && lane < CDA_SNAPSHOT_DIM) {             // oldest frame first; hist_head is the oldest slot
+        const size_t ob = (size_t)mi * (size_t)(H * CDA_SNAPSHOT_DIM);
+        for (int j = 0; j < H; j++) {
+            int slot = m.hist_head + j; if (slot >= H) slot -= H;
+            R.obs_out[ob + (size_t)(j * CDA_SNAPSHOT_DIM + lane)] = hist[slot * CDA_SNAPSHOT_DIM + lane];
+        }
+    }
+    if (R.return_out && lane < A) R.return_out[(size_t)mi * (size_t)A + (size_t)lane] = ret;
+    if (lane == 0) {
+        if (R.terminated_out) R.terminated_out[mi] = (uint8_t)term;
+        if (R.truncated_out) R.truncated_out[mi] = (uint8_t)trunc;
+        if (R.steps_out) R.steps_out[mi] = steps;
+    }
+    store_market(mp, P, L, m, lane);
+    copy_words((uint32_t*)mp.hist, (const uint32_t*)hist, H * CDA_SNAPSHOT_DIM, lane);
+    store_levels(mp, L, lane);
+}
+
+// ------------------------------------------------------------------------------------------
 // test hooks and small kernels
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, int mi, int tr, int type, int side, int size, int price) {
@@ -651,6 +717,32 @@ int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const 
                            (const uint64_t*)NULL, (const uint8_t*)e->done_buf, obs_out);
         HIPCHK(hipGetLastError());
     }
+    return CDA_OK;
+}
+
+int cda_run_random(cda_env* e, int32_t n_steps, uint64_t action_seed, uint64_t market_index_base,
+                   float* obs_out, double* episode_return_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                   int32_t* steps_taken_out, void* stream) {
+    if (!e || n_steps < 0) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    RunArgs R;
+    R.n_steps = n_steps; R.seed = action_seed; R.market_base = market_index_base;
+    R.obs_out = obs_out; R.return_out = episode_return_out; R.terminated_out = terminated_out; R.truncated_out = truncated_out;
+    R.steps_out = steps_taken_out;
+    hipLaunchKernelGGL(k_run_random, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, R);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+
+int cda_random_actions_host(uint64_t action_seed, uint64_t market_index_base, int32_t step, int32_t n_markets, int32_t num_agents,
+                            int32_t* category, float* size_mean, float* size_sigma, int32_t* price, int32_t* price_offset) {
+    if (step < 0 || n_markets < 0 || num_agents < 1 || !category || !size_mean || !size_sigma || !price || !price_offset) return CDA_ERR_INVALID;
+    for (int32_t i = 0; i < n_markets; i++)
+        for (int32_t a = 0; a < num_agents; a++) {
+            const size_t ix = (size_t)i * (size_t)num_agents + (size_t)a;
+            cda_random_action(action_seed, market_index_base + (uint64_t)i, (uint32_t)step, (uint32_t)a, &category[ix], &size_mean[ix], &size_sigma[ix],
+                              &price[ix], &price_offset[ix]);
+        }
     return CDA_OK;
 }
 

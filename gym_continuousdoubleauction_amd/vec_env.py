@@ -152,6 +152,31 @@ class CDAVecEnv:
         self._keep = (cat, sm, ss, pr, po, ps)      # keep inputs alive until the async kernel has consumed them
         return self.obs, self.reward, self._term.view(torch.bool), self._trunc.view(torch.bool), self.info
 
+    def run_random(self, n_steps, action_seed=0, market_index_base=0):
+        """The reference's `CDA_rand.run_random` for every market, in ONE kernel launch: uniform random agents (the
+        counter-based sampler of include/cda_random_agents.h) play up to `n_steps` steps, each market stopping at its own
+        episode end.  Returns (obs f32[N,obs_dim], episode_return f64[N,A], terminated, truncated, steps_taken i32[N]);
+        bit-identical to `n_steps` calls of step() on `random_actions(t)`."""
+        N, A, dev = self.n_markets, self.num_agents, self.device
+        if not hasattr(self, "_rr_steps"):
+            self._rr_return = torch.zeros((N, A), dtype=torch.float64, device=dev)
+            self._rr_steps = torch.zeros(N, dtype=torch.int32, device=dev)
+        with torch.cuda.device(self.device):
+            check(lib().cda_run_random(self._h, int(n_steps), int(action_seed) & (2 ** 64 - 1), int(market_index_base) & (2 ** 64 - 1),
+                                       self.obs.data_ptr(), self._rr_return.data_ptr(), self._term.data_ptr(), self._trunc.data_ptr(),
+                                       self._rr_steps.data_ptr(), self._stream()), "cda_run_random")
+        return self.obs, self._rr_return, self._term.view(torch.bool), self._trunc.view(torch.bool), self._rr_steps
+
+    def random_actions(self, step, action_seed=0, market_index_base=0):
+        """The five [N,A] action arrays (numpy, host) the random agents of `run_random` play at step `step`."""
+        N, A = self.n_markets, self.num_agents
+        cat, price, off = (np.zeros((N, A), np.int32) for _ in range(3))
+        mean, sigma = (np.zeros((N, A), np.float32) for _ in range(2))
+        check(lib().cda_random_actions_host(int(action_seed) & (2 ** 64 - 1), int(market_index_base) & (2 ** 64 - 1), int(step), N, A,
+                                            cat.ctypes.data, mean.ctypes.data, sigma.ctypes.data, price.ctypes.data, off.ctypes.data),
+              "cda_random_actions_host")
+        return cat, mean, sigma, price, off
+
     # ------------------------------------------------------------------ diagnostics
     def place_order(self, market, trader, type_, side, size, price=1):
         check(lib().cda_place_order(self._h, market, trader, type_, side, size, price), "cda_place_order")

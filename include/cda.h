@@ -177,6 +177,23 @@ int cda_step(cda_env* env,
              float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
              const cda_info_ptrs* info_out, void* stream);
 
+/* Replaces CDA_rand.run_random (CDA_rand.py:40-85): every market plays uniform random agents (the law and the
+ * counter-based sampler of include/cda_random_agents.h, keyed by action_seed, market_index_base + market, the
+ * market's own step counter and the agent) for up to n_steps steps, stopping early at its episode's end
+ * (terminated or truncated), ALL INSIDE ONE LAUNCH: a market-wave keeps its state in LDS from step to step and
+ * never waits for the slower markets of the batch.  Bit-identical to n_steps calls of cda_step on the same actions.
+ *  Out (each nullable): obs f32[N,n_hist*42] after the last step taken, episode_return f64[N,A] = the sum, in step
+ *  order, of each agent's rewards over the steps taken, terminated / truncated u8[N] of the last step taken (0 if
+ *  none), steps_taken i32[N]. */
+int cda_run_random(cda_env* env, int32_t n_steps, uint64_t action_seed, uint64_t market_index_base,
+                   float* obs_out, double* episode_return_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                   int32_t* steps_taken_out, void* stream);
+/* The same sampler on the host (host pointers, [n_markets, num_agents] each): the actions cda_run_random plays at
+ * step `step`, for callers and tests that want to replay them through cda_step. */
+int cda_random_actions_host(uint64_t action_seed, uint64_t market_index_base, int32_t step, int32_t n_markets,
+                            int32_t num_agents, int32_t* category, float* size_mean, float* size_sigma,
+                            int32_t* price, int32_t* price_offset);
+
 /* Test/diagnostic hook: Trader.place_order (agent/trader.py:49-106) for ONE decoded order on one
  * market, bypassing decode and the RNG. type: 0 market, 1 limit, 2 modify, 3 cancel; side: 0 bid,
  * 1 ask; price in ticks (ignored for market). Synchronous. */

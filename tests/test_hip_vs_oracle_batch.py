@@ -158,3 +158,52 @@ def test_auto_reset_equals_step_then_masked_reset():
     for i in range(0, n, 7):
         assert bytes(hip.get_state(i)) == bytes(orc.get_state(i)), f"state of market {i}"
     hip.close(); orc.close()
+
+
+def test_fused_random_agent_episode_equals_stepwise_and_oracle():
+    """cda_run_random: a whole random-agent episode per launch (state in LDS from step to step, every market at its own
+    pace) must be bit-identical to stepping the same markets one launch per step on the same actions, and to the oracle."""
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    import oracle_lib as O
+    n, a, horizon, seed = 192, 4, 48, 20240927
+    cfg = {"num_of_agents": a, "init_cash": 1000000, "max_step": horizon, "is_render": False}
+    fused, stepw, chunk = (CDAVecEnv(cfg, n_markets=n, with_info=False) for _ in range(3))
+    orc = O.OracleEnv(cfg, n_markets=n)
+    seeds = np.arange(4000, 4000 + n, dtype=np.uint64)
+    for e in (fused, stepw, chunk):
+        e.reset(seed=seeds)
+    orc.reset(seeds)
+    # bankrupt a few accounts of market 5 so that at least one market ends early by termination, not truncation
+    obs, ret, term, trunc, steps = fused.run_random(64, action_seed=seed, market_index_base=7)
+    obs, ret, term, trunc, steps = obs.cpu().numpy(), ret.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy(), steps.cpu().numpy()
+    assert (steps == horizon).all() and trunc.all() and not term.any()
+    ret_ref = np.zeros((n, a), np.float64)
+    for t in range(horizon):
+        acts = stepw.random_actions(t, action_seed=seed, market_index_base=7)
+        so, sr, st, su, _ = stepw.step(*acts)
+        oo, orw, ot, ou, _ = orc.step(*acts)
+        assert np.array_equal(sr.cpu().numpy().view(np.uint64), orw.view(np.uint64)), t
+        ret_ref += orw                                          # the same left-to-right f64 sum the kernel forms
+    assert np.array_equal(obs.view(np.uint32), so.cpu().numpy().view(np.uint32))
+    assert np.array_equal(obs.view(np.uint32), oo.view(np.uint32))
+    assert np.array_equal(ret.view(np.uint64), ret_ref.view(np.uint64))
+    for i in list(range(0, n, 13)) + [n - 1]:
+        assert bytes(fused.get_state(i)) == bytes(stepw.get_state(i)) == bytes(orc.get_state(i)), f"state of market {i}"
+    # the sampler is keyed by the market's own step counter: 20 + 28 steps in two launches are the same episode
+    chunk.run_random(20, action_seed=seed, market_index_base=7)
+    o2, r2, t2, u2, s2 = chunk.run_random(64, action_seed=seed, market_index_base=7)
+    assert (s2.cpu().numpy() == horizon - 20).all() and u2.cpu().numpy().all()
+    assert np.array_equal(o2.cpu().numpy().view(np.uint32), obs.view(np.uint32))
+    for i in range(0, n, 29):
+        assert bytes(chunk.get_state(i)) == bytes(fused.get_state(i))
+    # the action law: ranges, and roughly uniform categories
+    cat, mean, sigma, price, off = fused.random_actions(3, action_seed=1)
+    assert cat.min() >= 0 and cat.max() <= 8 and price.min() >= 0 and price.max() <= 9 and off.min() >= 0 and off.max() <= 2
+    assert mean.min() >= -1 and mean.max() < 1 and sigma.min() >= 0 and sigma.max() < 1
+    big = np.concatenate([fused.random_actions(t, action_seed=9)[0].ravel() for t in range(40)])
+    assert np.abs(np.bincount(big, minlength=9) / big.size - 1 / 9).max() < 0.01
+    assert (fused.flags() == 0).all()
+    for e in (fused, stepw, chunk):
+        e.close()
+    orc.close()
