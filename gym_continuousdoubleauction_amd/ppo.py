@@ -46,7 +46,7 @@ class ActorCritic(nn.Module):
         cat, price, off, cont = self.dists(obs)
         # Normal.sample() checks std >= 0 on the host (a sync, illegal inside a captured graph): draw the noise directly
         a_cat, a_price, a_off = cat.sample(), price.sample(), off.sample()
-        a_cont = cont.loc + cont.scale * torch.randn_like(cont.loc)
+        a_cont = (cont.loc + cont.scale * torch.randn_like(cont.loc)).detach()
         logp = cat.log_prob(a_cat) + price.log_prob(a_price) + off.log_prob(a_off) + cont.log_prob(a_cont).sum(-1)
         return (a_cat, a_price, a_off, a_cont), logp, self.v(obs).squeeze(-1)
 
