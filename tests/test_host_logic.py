@@ -65,3 +65,30 @@ def test_pack_unpack_is_bit_preserving():
     assert torch.equal(o2.view(torch.int32), obs.view(torch.int32))
     assert torch.equal(r2.view(torch.int64), rew.view(torch.int64))
     assert torch.equal(t2, term) and torch.equal(u2, trunc)
+
+
+def test_random_agent_sampler_matches_its_specification():
+    """include/cda_random_agents.h through the library's host entry point vs an independent numpy statement of it."""
+    import ctypes as C
+    from gym_continuousdoubleauction_amd import _lib
+    L = _lib.lib()
+    n, a, step, seed, base = 37, 5, 11, 0xDEADBEEFCAFE, 1000
+    cat, price, off = (np.zeros((n, a), np.int32) for _ in range(3))
+    mean, sigma = (np.zeros((n, a), np.float32) for _ in range(2))
+    assert L.cda_random_actions_host(seed, base, step, n, a, cat.ctypes.data, mean.ctypes.data, sigma.ctypes.data, price.ctypes.data, off.ctypes.data) == 0
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9e3779b97f4a7c15) & M
+        z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & M
+        z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & M
+        return z ^ (z >> 31)
+    for i in range(n):
+        for k in range(a):
+            h0 = mix((seed + (base + i) * 0xd1342543de82ef95) & M)
+            w0 = mix((h0 + ((step << 32) | k)) & M)
+            w1 = mix(w0)
+            assert cat[i, k] == ((w0 & 0xffffffff) * 9) >> 32 and price[i, k] == ((w0 >> 32) * 10) >> 32
+            assert off[i, k] == ((w1 & 0xffffffff) * 3) >> 32
+            assert mean[i, k] == np.float32(((w1 >> 32) & 0xffffff) / 8388608.0 - 1.0) and sigma[i, k] == np.float32((w1 >> 40) / 16777216.0)
+    assert L.cda_random_actions_host(seed, base, -1, n, a, cat.ctypes.data, mean.ctypes.data, sigma.ctypes.data, price.ctypes.data, off.ctypes.data) != 0
