@@ -146,11 +146,6 @@ __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P
 // ------------------------------------------------------------------------------------------
 // step - the hot kernel
 // ------------------------------------------------------------------------------------------
-#ifdef CDA_PHASE_TIMING
-#define PHASE_MARK(i) do { unsigned long long _t = __builtin_readcyclecounter(); if (S.phase_cycles && lane == 0) S.phase_cycles[(size_t)mi * 24 + (i)] = _t; } while (0)
-#else
-#define PHASE_MARK(i) do {} while (0)
-#endif
 
 struct StepArgs {
     const int32_t* category; const float* size_mean; const float* size_sigma;
