@@ -237,6 +237,7 @@ __device__ __forceinline__ uint32_t step_market(Lds& L, Mkt& m, const Params& P,
     }
     PH_MARK(ph, 3);
     // 3. rand_exec_seq (action_helper.py:174-199): Fisher-Yates over the n non-pass orders, nibble-packed
+    m.fills = 0;
     int n_acts = __popc(act_mask);
     uint64_t perm = 0xFEDCBA9876543210ull;
     for (int i = n_acts - 1; i >= 1; i--) {

@@ -116,6 +116,7 @@ struct Mkt {
     uint32_t done_mask, flags;
     int32_t nb, na;              // resting orders per side (two scalars: a dynamically indexed array would force Mkt into scratch)
     int32_t seeded, hist_head, levels_valid;
+    int32_t fills;               // fills settled in the current step (issue priority of this wave grows with it)
 #ifdef CDA_PHASE_TIMING
     unsigned long long tacc[14];    // debug: cycles in approval / find / match+settle / insert+remove / escrow+cancel, fills, 8 free slots
 #endif
@@ -330,6 +331,7 @@ __device__ __forceinline__ void decode_header(uint32_t v, Mkt& m) {
     m.done_mask = RL(H_DONE_MASK); m.flags = RL(H_FLAGS);
     m.nb = (int32_t)RL(H_N_BIDS); m.na = (int32_t)RL(H_N_ASKS);
     m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD); m.levels_valid = (int32_t)RL(H_LEVELS_VALID);
+    m.fills = 0;
     #undef RL
 }
 __device__ __forceinline__ void store_header(uint32_t* hp, const Mkt& m, int lane) {
@@ -599,6 +601,12 @@ __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, i
         else { f = rq; qty -= rq; h++; }
         m.has_trade = 1; m.last_trade_price = p;
         TACC_COUNT(m, 5, 1);
+        // The launch ends with its slowest market-wave, and the slow ones are those that settle many fills: from the first
+        // fill on, this wave asks its SIMD for instruction-issue priority over the (lighter) waves it shares the SIMD with.
+        m.fills += 1;
+        if (m.fills == 1) __builtin_amdgcn_s_setprio(1);
+        else if (m.fills == 2) __builtin_amdgcn_s_setprio(2);
+        else if (m.fills == 3) __builtin_amdgcn_s_setprio(3);
         settle_fill<LAZY_POSVAL>(L, tr, c, f, p, own_side, m.flags, lane);
     }
     if (h) { book_remove(bk, opp, nopp, 0, h, lane); mkt_set_n(m, opp, nopp - h); }
