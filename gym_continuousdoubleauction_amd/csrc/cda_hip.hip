@@ -231,6 +231,8 @@ __device__ __forceinline__ uint32_t step_market(Lds& L, Mkt& m, const Params& P,
             }
             act_mask = (uint32_t)__ballot(pres && side != S_NONE);
             pass_mask = (uint32_t)__ballot(pres && side == S_NONE);
+            // two or more market orders: this step will most likely sweep - take the head start now (see match())
+            if (__popcll(__ballot(pres && side != S_NONE && (L.act_tsp[lane] & 3) == T_MARKET)) >= 2) __builtin_amdgcn_s_setprio(1);
             if (__ballot(ovf)) m.flags |= CDA_FLAG_INT_OVERFLOW;
         }
         CDA_WSYNC();
