@@ -63,6 +63,7 @@ INFO_FIELDS = [
     ("best_bid", C.c_double, False, ()),
     ("best_ask", C.c_double, False, ()),
     ("spread", C.c_double, False, ()),
+    ("lob_actions", C.c_int32, True, (4,)),
 ]
 
 

@@ -375,6 +375,12 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
             if (I.num_rejected_step) I.num_rejected_step[ix] = a.num_rejected_step;
             if (I.is_pass_action) I.is_pass_action[ix] = (uint8_t)((pass_mask >> lane) & 1u);
             if (I.reward_terms) { double* rt = I.reward_terms + ix * 5; rt[0] = rw.t0; rt[1] = rw.t1; rt[2] = rw.t2; rt[3] = rw.t3; rt[4] = rw.t4; }
+            if (I.lob_actions) {                                               // decoded orders as the env keeps them (agent order, passes left out)
+                int32_t* la = I.lob_actions + ix * 4;
+                const int32_t tsp = L.act_tsp[lane];
+                const bool has = in.pres && !((pass_mask >> lane) & 1u);
+                la[0] = has ? ((tsp >> 2) & 3) : -1; la[1] = has ? (tsp & 3) : -1; la[2] = has ? L.act_size[lane] : -1; la[3] = has ? (tsp >> 4) - 1 : -1;
+            }
         }
         clear_step_counters(a);
     }

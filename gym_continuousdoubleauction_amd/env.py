@@ -81,6 +81,7 @@ class CDAEnv(_Base):
         self.action_spaces = {a: act_space for a in agent_ids}
         self.traders = [_TraderView(self, i) for i in range(self.num_of_agents)]
         self.done_set = set()
+        self.LOB_actions = None
         self.pass_agents = set()
         self.t_step = 0
         self.model_actions = None
@@ -120,6 +121,7 @@ class CDAEnv(_Base):
     def reset(self, *, seed=None, options=None):
         obs = self._vec.reset(seed=None if seed is None else np.array([int(seed)], dtype=np.uint64))
         self.done_set = set()
+        self.LOB_actions = None
         self.pass_agents = set()
         self.t_step = 0
         ob = obs[0].cpu().numpy()
@@ -161,6 +163,11 @@ class CDAEnv(_Base):
         nn = lambda x: None if np.isnan(x) else float(x)       # noqa: E731
         infos = {}
         self.pass_agents = set()
+        # env.LOB_actions (continuousDoubleAuction_env.py:284-285): the decoded orders in agent order, passes left out
+        self.LOB_actions = [
+            {"ID": a, "side": ("bid", "ask")[int(row[0])], "type": ("market", "limit", "modify", "cancel")[int(row[1])],
+             "size": int(row[2]), "price": float(row[3])}
+            for a, row in zip(self.agents, info["lob_actions"]) if row[0] >= 0]
         for i, a in enumerate(self.agents):
             nav_dec = K.dec_to_decimal(nav[i])
             if nav_dec <= 0:

@@ -114,6 +114,9 @@ typedef struct cda_info_ptrs {
     double*  best_bid;               /* [N]  NaN encodes None                                */
     double*  best_ask;               /* [N]  NaN encodes None                                */
     double*  spread;                 /* [N]  NaN encodes None                                */
+    int32_t* lob_actions;            /* [N,A,4] env.LOB_actions (continuousDoubleAuction_env.py:284-285): agent a's decoded order
+                                        {side 0 bid / 1 ask, type 0 market / 1 limit / 2 modify / 3 cancel, size, price in ticks or
+                                        -1 for a market order}; side = -1 (row all -1) when the agent passed or was absent  */
 } cda_info_ptrs;
 
 /* ---- parity dump of one market (host struct) ------------------------------------------- */

@@ -696,6 +696,7 @@ static void market_step(const struct oracle_env* e, market_t* m, int mi,
     set_agg_lob(cfg, m, snap);
     /* 2. set_actions (action_helper.py:145-172, :241-283) */
     act_t acts[CDA_MAX_AGENTS]; int na = 0; uint32_t pass_mask = 0;
+    if (info && info->lob_actions) for (int k = 0; k < 4 * A; k++) info->lob_actions[(size_t)mi * (size_t)A * 4 + (size_t)k] = -1;
     for (int a = 0; a < A; a++) {
         if (present && !present[a]) continue;
         int cat = clampi(category[a], 0, 8);
@@ -723,6 +724,10 @@ static void market_step(const struct oracle_env* e, market_t* m, int mi,
             if (pr < cfg->tick_size) pr = cfg->tick_size;
         }
         if (trace) { trace->z[a] = z; trace->dec_type[a] = type; trace->dec_side[a] = side; trace->dec_size[a] = size; trace->dec_price[a] = pr; }
+        if (info && info->lob_actions && side != S_NONE) {                     /* env.LOB_actions (continuousDoubleAuction_env.py:284-285) */
+            int32_t* la = info->lob_actions + ((size_t)mi * (size_t)A + (size_t)a) * 4;
+            la[0] = side; la[1] = type; la[2] = size; la[3] = pr;
+        }
         if (side != S_NONE) { acts[na].tr = a; acts[na].type = type; acts[na].side = side; acts[na].size = size; acts[na].price = pr; na++; }
         else pass_mask |= 1u << a;
     }

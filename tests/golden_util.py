@@ -183,6 +183,11 @@ def run_group(env, recs, state_every=1, trace_getter=None, max_steps=None):
             for j, f in enumerate(COUNTERS):
                 _eq(f"info.{f}", info[f][i], r["counters"][t, :, j], ctx)
             _eq("info.is_pass_action", info["is_pass_action"][i], r["is_pass"][t], ctx)
+            if "lob_actions" in info:          # env.LOB_actions: the decoded orders the reference kept for this step
+                want = np.full((A, 4), -1, np.int64)
+                has = r["dec_type"][t] != -9
+                want[has] = np.stack([r["dec_side"][t], r["dec_type"][t], r["dec_size"][t], r["dec_price"][t]], axis=1)[has]
+                _eq("info.lob_actions", np.asarray(info["lob_actions"][i], np.int64), want, ctx)
             _eq("info.reward_terms", f64_bits(info["reward_terms"][i]), f64_bits(r["reward_terms"][t]), ctx)
             _eq("info.num_trades", info["num_trades"][i], r["num_trades"][t], ctx)
             _eq("info.net_position", info["net_position"][i], r["net_position"][t], ctx)

@@ -274,3 +274,25 @@ def test_league_rollout_routes_modules_per_market():
     assert int(info["num_trades"][is_champ].sum()) == 0 and int(info["num_trades"][~is_champ].sum()) > 0
     assert int(env.flags().abs().sum()) == 0
     env.close()
+
+
+def test_lob_actions_hold_the_decoded_orders():              # test_new_action_space.py:36-147, test_obs_normalization.py:314-338
+    from gym_continuousdoubleauction_amd import CDAEnv
+    env = CDAEnv({"num_of_agents": 3, "init_cash": 1000000, "max_step": 32, "is_render": False})
+    env.reset(seed=5)
+    assert env.LOB_actions is None
+    lp = env.last_price
+    one = lambda c, price=0, off=1: {"category": c, "size_mean": np.array([0.0], np.float32), "size_sigma": np.array([0.0], np.float32),   # noqa: E731
+                                     "price": price, "price_offset": off}
+    env.step({"agent_1": one(2, price=3, off=1)})           # bid limit on an empty book: last_price - (level + 1) ticks
+    assert len(env.LOB_actions) == 1
+    act = env.LOB_actions[0]
+    assert act == {"ID": "agent_1", "side": "bid", "type": "limit", "size": 1, "price": lp - 4.0}
+    env.step({"agent_0": one(5), "agent_1": one(0), "agent_2": one(8, price=0, off=0)})
+    got = {a["ID"]: a for a in env.LOB_actions}
+    assert set(got) == {"agent_0", "agent_2"}                # the passing agent is left out
+    assert got["agent_0"]["type"] == "market" and got["agent_0"]["side"] == "ask" and got["agent_0"]["price"] == -1.0
+    assert got["agent_2"]["type"] == "cancel" and got["agent_2"]["side"] == "ask" and got["agent_2"]["price"] > 0
+    env.reset(seed=5)
+    assert env.LOB_actions is None
+    env.close()
