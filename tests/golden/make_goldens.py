@@ -268,6 +268,11 @@ def main():
     # the build's agent-count bound (CDA_MAX_AGENTS = 16): owner lanes 0-15, helper lanes 16-47 all busy
     add("A16_s70", base16, 70, 160, 7070)
     add("A16_aggr_s71", dict(base16, init_cash=200000), 71, 128, 7071, law="aggressive")
+    # large sizes and balances (11-digit cash, positions in the 10^5 range: longer coefficients in every ledger product) and
+    # prices at the tick floor (the `price < tick -> tick` clamp, one-tick books)
+    add("bigsize_s81", dict(base4, init_cash=50000000000, mkt_max_size=5000, limit_size_multiple=20, min_size=3), 81, 192, 7081)
+    add("bigsize_aggr_s82", dict(base8, init_cash=50000000000, mkt_max_size=3000, limit_size_multiple=7), 82, 160, 7082, law="aggressive")
+    add("floor_s83", dict(base4, initial_price_min=1, initial_price_max=3), 83, 192, 7083)
     add("long_s100", dict(base4, max_step=2048), 100, 2048, 7100)
     for name, rec in traces.items():
         np.savez_compressed(os.path.join(out_dir, f"trace_{name}.npz"), **rec)
