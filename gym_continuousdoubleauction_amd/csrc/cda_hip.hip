@@ -437,6 +437,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_run_random(uint
 #endif
     load_market<true>(mp, P, L, m, lane);
     float* hist = lds_hist(L, A);                           // the history ring stays in LDS for the whole episode
+    int32_t* hist_raw = reinterpret_cast<int32_t*>(hist);
     double ret = 0.0;
     int steps = 0;
     bool term = false, trunc = false;
@@ -446,7 +447,11 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_run_random(uint
         if (in.pres) cda_random_action(R.seed, R.market_base + (uint64_t)mi, (uint32_t)m.t_step, (uint32_t)lane, &in.cat, &in.mean, &in.sigma, &in.level, &in.off);
         step_market(L, m, P, zig_wi, zig_ki, in, nullptr, lane);
         aggregate_levels(L, m, lane);
-        if (lane < CDA_SNAPSHOT_DIM) hist[m.hist_head * CDA_SNAPSHOT_DIM + lane] = snapshot_value(L, m, tick, lane);
+        // Nobody reads the observation while the episode runs: the ring keeps the RAW frame (the 2 x 2 x 10 level
+        // aggregation and last_price, 41 integers) and the normalisation (f64 divisions, square roots, log, log1p) is
+        // done after the loop, for the at most n_hist frames that are still in the window.
+        if (lane < 4 * CDA_K_ROWS) hist_raw[m.hist_head * CDA_SNAPSHOT_DIM + lane] = (&L.lvl_px[0][0])[lane];
+        else if (lane == 4 * CDA_K_ROWS) hist_raw[m.hist_head * CDA_SNAPSHOT_DIM + lane] = m.last_price;
         m.hist_head = m.hist_head + 1 >= H ? 0 : m.hist_head + 1;
         uint32_t ferr = 0;
         const StepReward rw = step_reward(L, P, ferr, lane);
@@ -459,6 +464,24 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_run_random(uint
         steps += 1;
         CDA_WSYNC();
         if (term || trunc) break;
+    }
+    {   // normalise the raw frames of this launch that are still in the window, oldest first: the newest one is converted
+        // last, which leaves L.lvl_* / m.last_price describing the current book again
+        const int n_raw = steps < H ? steps : H;
+        const int32_t last_price_now = m.last_price;
+        for (int k = 0; k < n_raw; k++) {
+            int slot = m.hist_head - n_raw + k; if (slot < 0) slot += H;
+            CDA_WSYNC();
+            if (lane < 4 * CDA_K_ROWS) (&L.lvl_px[0][0])[lane] = hist_raw[slot * CDA_SNAPSHOT_DIM + lane];
+            m.last_price = hist_raw[slot * CDA_SNAPSHOT_DIM + 4 * CDA_K_ROWS];
+            CDA_WSYNC();
+            float v = 0.0f;
+            if (lane < CDA_SNAPSHOT_DIM) v = snapshot_value(L, m, tick, lane);
+            CDA_WSYNC();
+            if (lane < CDA_SNAPSHOT_DIM) hist[slot * CDA_SNAPSHOT_DIM + lane] = v;
+        }
+        m.last_price = last_price_now;
+        CDA_WSYNC();
     }
     if (R.obs_out && lane < CDA_SNAPSHOT_DIM) {             // oldest frame first; hist_head is the oldest slot
         const size_t ob = (size_t)mi * (size_t)(H * CDA_SNAPSHOT_DIM);

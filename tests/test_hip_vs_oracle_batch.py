@@ -191,7 +191,10 @@ def test_fused_random_agent_episode_equals_stepwise_and_oracle():
     for i in list(range(0, n, 13)) + [n - 1]:
         assert bytes(fused.get_state(i)) == bytes(stepw.get_state(i)) == bytes(orc.get_state(i)), f"state of market {i}"
     # the sampler is keyed by the market's own step counter: 20 + 28 steps in two launches are the same episode
-    chunk.run_random(20, action_seed=seed, market_index_base=7)
+    # (2, 1, 0 and 17 steps first: fewer steps than history frames leaves older frames of the ring untouched)
+    for part in (2, 1, 0, 17):
+        chunk.run_random(part, action_seed=seed, market_index_base=7)
+        assert (chunk._rr_steps.cpu().numpy() == part).all()
     o2, r2, t2, u2, s2 = chunk.run_random(64, action_seed=seed, market_index_base=7)
     assert (s2.cpu().numpy() == horizon - 20).all() and u2.cpu().numpy().all()
     assert np.array_equal(o2.cpu().numpy().view(np.uint32), obs.view(np.uint32))
