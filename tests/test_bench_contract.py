@@ -44,3 +44,16 @@ def test_bench_multi_gpu_code_path_on_one_rank():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["value"] > 1e6 and "all_gather" in d["config"]["collective"]
         assert d["config"]["flagged_markets"] == 0 and d["roofline"]["kernel_ms"] > 0
+
+
+def test_bench_fused_mode_reports_the_same_contract():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "64", "--warmup", "32", "--markets", "512",
+                                   "--no-cpu-baseline", "--fused", "32"], cwd=ROOT, stderr=subprocess.DEVNULL, text=True, timeout=600)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["steps"] == 64 and "FUSED" in d["config"]["workload"] and d["roofline"]["traffic"] is None and d["value"] > 1e6
+    assert d["config"]["flagged_markets"] == 0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "32", "--markets", "64", "--no-cpu-baseline",
+                          "--fused", "32"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "multiples" in (bad.stderr + bad.stdout)
