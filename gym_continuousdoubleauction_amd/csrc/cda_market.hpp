@@ -433,22 +433,31 @@ __device__ __forceinline__ bool book_insert(Book& bk, int s, int n, int n_other,
     CDA_WSYNC();
     return true;
 }
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-    #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint64_t o = __shfl_xor(v, off, WAVE);
-        v = o < v ? o : v;
-    }
-    return v;
+// minimum of a 32-bit value over the wave with data-parallel-primitive moves (no LDS crossbar round trips): an inclusive
+// min-scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3
+// (row_bcast:31); lane 63 holds the result.  Lanes without a source keep the identity.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    const int ident = -1;                                   // 0xffffffff
+    #define CDA_DPP_MIN(ctrl, rmask) { uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, (ctrl), (rmask), 0xf, false); v = o < v ? o : v; }
+    CDA_DPP_MIN(0x111, 0xf) CDA_DPP_MIN(0x112, 0xf) CDA_DPP_MIN(0x114, 0xf) CDA_DPP_MIN(0x118, 0xf)
+    CDA_DPP_MIN(0x142, 0xa) CDA_DPP_MIN(0x143, 0xc)
+    #undef CDA_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // Trader._get_order_ID (agent/trader.py:254-287): index on the side or -1
 __device__ __forceinline__ int find_own_order(const Book& bk, int s, int n, int tr, int type, int price, int lane) {
-    if (type == T_MODIFY) {                 // oldest own order: minimum timestamp (unique)
-        uint64_t best = ~0ull;
+    if (type == T_MODIFY) {                 // oldest own order: minimum timestamp (LOB.time is unique per resting order)
+        uint32_t best = 0xffffffffu;
         for (int i = lane; i < n; i += WAVE)
-            if (oo_owner(bk.oo[s][i]) == tr) { uint64_t key = ((uint64_t)(uint32_t)bk.ts[s][i] << 32) | (uint32_t)i; best = key < best ? key : best; }
-        best = wave_min_u64(best);
-        return best == ~0ull ? -1 : (int)(uint32_t)best;
+            if (oo_owner(bk.oo[s][i]) == tr) { uint32_t ts = (uint32_t)bk.ts[s][i]; best = ts < best ? ts : best; }
+        const uint32_t mn = wave_min_u32(best);
+        if (mn == 0xffffffffu) return -1;
+        for (int base = 0; base < n; base += WAVE) {
+            int i = base + lane;
+            uint64_t mk = __ballot(i < n && oo_owner(bk.oo[s][i]) == tr && (uint32_t)bk.ts[s][i] == mn);
+            if (mk) return base + (__ffsll((long long)mk) - 1);
+        }
+        return -1;
     }
     // limit / cancel: first own order at that price in order_map insertion order == first in the
     // level's FIFO, i.e. first hit in queue order
