@@ -64,3 +64,19 @@ def test_oracle_normal_slow_paths_match_numpy():
     g.integers(0, 1)
     z = g.standard_normal(200000)
     assert np.array_equal(z.view(np.uint64), normals[0].view(np.uint64))
+
+
+def test_log_of_half_integer_mid_equals_log1p_form_at_float32():
+    """The device computes the observation's log(M) as log1p(M - 1) (one code path shared with the spread feature).
+    For the half-integer mids M = k/2 that is the same float32 as numpy.log(M) - checked here for k <= 2^18 against the
+    host libm (the device carries a restatement of glibc's log1p); the full device domain k <= 2^20 was checked once in the
+    build container."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.log1p.restype = ctypes.c_double
+    libm.log1p.argtypes = [ctypes.c_double]
+    k = np.arange(1, (1 << 18) + 1, dtype=np.float64)
+    M = k / 2
+    ref = np.log(M).astype(np.float32)
+    alt = np.array([libm.log1p(m - 1.0) for m in M], dtype=np.float64).astype(np.float32)
+    assert np.array_equal(ref.view(np.uint32), alt.view(np.uint32))
