@@ -828,11 +828,13 @@ __device__ __forceinline__ float snapshot_value(const Lds& L, const Mkt& m, int 
     else { M = (double)m.last_price; if (M <= 0) M = 100.0; }
     double out;
     if (j < 40) {
-        int row = j / CDA_K_ROWS, k = j % CDA_K_ROWS;
-        if (row == 0) { double bp = (double)L.lvl_px[0][k]; out = bp > 0 ? (M - bp) / M : 0.0; }
-        else if (row == 1) { double sz = (double)L.lvl_sz[0][k]; out = sz > 0 ? sqrt(sz) : 0.0; }
-        else if (row == 2) { double ap = (double)L.lvl_px[1][k]; out = ap != 0 ? -((ap - M) / M) : 0.0; }
-        else { double sz = (double)L.lvl_sz[1][k]; out = sz != 0 ? -sqrt(sz) : 0.0; }
+        // rows 0 / 2 (bid / ask price distance) share one division, rows 1 / 3 (sizes) one square root: the 20 + 20 lanes of
+        // a row pair run ONE instruction sequence instead of two
+        const int row = j / CDA_K_ROWS, k = j % CDA_K_ROWS, side = row >> 1;
+        const double raw = (double)((row & 1) ? L.lvl_sz[side][k] : L.lvl_px[side][k]);
+        if (raw == 0.0) out = 0.0;                                     // empty level (raw values are never negative)
+        else if (row & 1) { const double r = sqrt(raw); out = side ? -r : r; }
+        else { const double q = (side ? raw - M : M - raw) / M; out = side ? -q : q; }
     } else {
         // lanes 40 (log M) and 41 (log1p of the spread in ticks) share ONE evaluation: M is a half-integer, M - 1 is exact, and
         // float32(log1p(M - 1)) == float32(numpy.log(M)) for every M = k/2 up to 2^19 (checked exhaustively against numpy for
