@@ -413,6 +413,28 @@ __device__ __forceinline__ D d_add(D a, D b) {
     return d_add_wide(a, b);
 }
 __device__ __forceinline__ D d_sub(D a, D b) { return d_add(a, d_neg(b)); }
+constexpr int D_NOT_HANDLED = -0x40000000;                      // exponent sentinel of the leaf fast paths
+// field + v for a cash / cash_on_hold transfer, as a LEAF: `v` is an order value (coefficient below 2^32, exponent -1) and
+// does not lie below `field`; one table multiply scales it (10^0 when the exponents are equal), so the two lanes of a
+// transfer - a 28-digit cash, a short cash_on_hold - run the same instructions.  Anything that does not fit the shape, or
+// would need rounding, is handed back (exp == D_NOT_HANDLED) to the general addition.
+__device__ __noinline__ D d_add_order_value(D field, D v) {
+    const int diff = v.exp - field.exp;
+    const u128 co = d_c128(field);
+    const bool shape = (v.w1 | v.w2) == 0 && v.w0 != 0 && diff >= 0 && diff <= 28 &&
+                       (co == 0 || (((bits128(co) - 1) * 1233) >> 12) >= diff - 1);     // no _normalize replacement (see d_add_mid)
+    D bad = d_make(0, 0, 0, D_NOT_HANDLED, 0);
+    if (!shape) return bad;
+    const u128 ct = mul_u32_pow10_lds(v.w0, diff);
+    u128 r; int rs;
+    if (field.sign != v.sign && co != 0) {
+        if (ct == co) return d_make(0, 0, 0, field.exp, 0);
+        const bool vg = ct > co;
+        r = vg ? ct - co : co - ct; rs = vg ? v.sign : field.sign;
+    } else { r = ct + co; rs = co == 0 ? v.sign : field.sign; }        // a zero field only lends its exponent (Decimal.__add__, `if not self`)
+    if (!(r < p28_128())) return bad;
+    return d_from128(r, field.exp, rs);
+}
 
 // ---- multiplication: Decimal.__mul__ (_pydecimal.py:1267) for b = (+) m * 10^mexp with m < 2^32 ----
 __device__ __forceinline__ D d_mul_u32(D a, uint32_t m, int mexp) {
@@ -483,7 +505,6 @@ __device__ __forceinline__ int ndigits_u32(uint32_t n) {     // len(str(n)), n >
 // half-even - the correctly rounded quotient, which is what Decimal.__truediv__ followed by _fix produces.  A zero
 // remainder anywhere means the quotient is exact at that scale; that case (ideal exponent, trailing zeros) is left to
 // d_div_general.
-constexpr int D_NOT_HANDLED = -0x40000000;                      // exponent sentinel of the leaf fast paths
 __device__ __noinline__ D d_div_inexact_leaf(D a, uint32_t n) { // a LEAF (no calls: no return-address spill to scratch)
     DEC_COUNT(6);
     const u128 c = d_c128(a);

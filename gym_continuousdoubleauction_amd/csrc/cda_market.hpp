@@ -631,7 +631,9 @@ __device__ __forceinline__ void cash_hold_transfer(Lds& L, int tr, int32_t price
         D v = d_mul_u32(d_price(price), (uint32_t)qty, 0);
         cda_dec& fld = g == 0 ? a.cash : a.hold;
         v.sign = (g == 0) == (cash_dir > 0) ? 0 : 1;
-        D r = d_add(ld_dec(fld), v);
+        const D cur = ld_dec(fld);
+        D r = d_add_order_value(cur, v);
+        if (r.exp == D_NOT_HANDLED) r = d_add(cur, v);
         st_dec(fld, r, flags);
     }
     CDA_WSYNC();
