@@ -60,21 +60,34 @@ __device__ __forceinline__ void vec_finish(void* dst, const void* src, int nbyte
     for (int i = lane + WAVE; i < n16; i += WAVE) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
     for (int w = (n16 << 2) + lane; w < (nbytes >> 2); w += WAVE) reinterpret_cast<uint32_t*>(dst)[w] = reinterpret_cast<const uint32_t*>(src)[w];
 }
+// The market record is loaded in two halves so that a kernel can put its per-workgroup table setup (global loads, LDS
+// writes, one __syncthreads) BETWEEN them: every request of the record is in flight while the tables are being staged.
+struct MarketPrefetch { uint32_t hv; BookPrefetch book; VecPrefetch acc, hist; };
+template <bool WITH_HIST>
+__device__ __forceinline__ MarketPrefetch load_market_issue(const MarketPtrs& mp, const Params& P, int lane) {
+    MarketPrefetch q;
+    q.hv = load_header_word(mp.hdr, lane);                 // all the requests are in flight together
+    q.book = prefetch_book(mp.book, lane);
+    q.acc = vec_prefetch(mp.acc, P.cfg.num_agents * (int)sizeof(Acc), lane);
+    q.hist.has = false; q.hist.v = make_uint4(0u, 0u, 0u, 0u);
+    // k_step: the observation's history ring rides along, so that phase 6 does not pay an HBM round trip of its own
+    if (WITH_HIST) q.hist = vec_prefetch(mp.hist, P.cfg.n_hist * CDA_SNAPSHOT_DIM * 4, lane);
+    return q;
+}
+template <bool WITH_HIST>
+__device__ __forceinline__ void load_market_finish(const MarketPtrs& mp, const Params& P, Lds& L, Mkt& m, const MarketPrefetch& q, int lane) {
+    const int acc_bytes = P.cfg.num_agents * (int)sizeof(Acc), hist_bytes = P.cfg.n_hist * CDA_SNAPSHOT_DIM * 4;
+    decode_header(q.hv, m);
+    finish_book_load(mp.book, q.book, L.book, m, lane);
+    vec_finish(&L.acc[0], mp.acc, acc_bytes, q.acc, lane);
+    if (WITH_HIST) vec_finish(lds_hist(L, P.cfg.num_agents), mp.hist, hist_bytes, q.hist, lane);
+    if (m.levels_valid && lane >= H_LEVELS && lane < H_LEVELS + 4 * CDA_K_ROWS) (&L.lvl_px[0][0])[lane - H_LEVELS] = (int32_t)q.hv;
+    CDA_WSYNC();
+}
 template <bool WITH_HIST = false>
 __device__ __forceinline__ void load_market(const MarketPtrs& mp, const Params& P, Lds& L, Mkt& m, int lane) {
-    uint32_t hv = load_header_word(mp.hdr, lane);          // all the requests are in flight together
-    BookPrefetch pre = prefetch_book(mp.book, lane);
-    const int acc_bytes = P.cfg.num_agents * (int)sizeof(Acc), hist_bytes = P.cfg.n_hist * CDA_SNAPSHOT_DIM * 4;
-    VecPrefetch pa = vec_prefetch(mp.acc, acc_bytes, lane);
-    VecPrefetch ph; ph.has = false;
-    // k_step: the observation's history ring rides along, so that phase 6 does not pay an HBM round trip of its own
-    if (WITH_HIST) ph = vec_prefetch(mp.hist, hist_bytes, lane);
-    decode_header(hv, m);
-    finish_book_load(mp.book, pre, L.book, m, lane);
-    vec_finish(&L.acc[0], mp.acc, acc_bytes, pa, lane);
-    if (WITH_HIST) vec_finish(lds_hist(L, P.cfg.num_agents), mp.hist, hist_bytes, ph, lane);
-    if (m.levels_valid && lane >= H_LEVELS && lane < H_LEVELS + 4 * CDA_K_ROWS) (&L.lvl_px[0][0])[lane - H_LEVELS] = (int32_t)hv;
-    CDA_WSYNC();
+    const MarketPrefetch q = load_market_issue<WITH_HIST>(mp, P, lane);
+    load_market_finish<WITH_HIST>(mp, P, L, m, q, lane);
 }
 // the level aggregation currently in LDS describes the book as it is being stored: keep it for the next step
 __device__ __forceinline__ void store_levels(const MarketPtrs& mp, const Lds& L, int lane) {
@@ -305,13 +318,16 @@ __device__ __forceinline__ void clear_step_counters(Acc& a) {          // exchg_
 __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
     int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
     int mi = (int)blockIdx.x * CDA_WPB + wave;
+    const bool live = mi < P.n_markets;       // (a workgroup's surplus waves still take part in the table setup)
+    MarketPtrs mp = market_ptrs(arena, P, live ? mi : 0);
+    MarketPrefetch mq;
+    if (live) mq = load_market_issue<true>(mp, P, lane);    // the record's requests fly while the tables are staged
     zig_tables_init();
     dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit
-    if (mi >= P.n_markets) return;
+    if (!live) return;
     Lds& L = wave_lds(P, wave, ZIG_LDS_BYTES);
     const unsigned long long* zig_wi = reinterpret_cast<const unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
     const unsigned long long* zig_ki = zig_wi + 256;
-    MarketPtrs mp = market_ptrs(arena, P, mi);
     Mkt m;
     const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
     unsigned long long* ph = nullptr;
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     ph = S.phase_cycles ? S.phase_cycles + (size_t)mi * 24 : nullptr;
 #endif
     PH_MARK(ph, 0);
-    load_market<true>(mp, P, L, m, lane);
+    load_market_finish<true>(mp, P, L, m, mq, lane);
     PH_MARK(ph, 1);
     LaneAction in;
     {
