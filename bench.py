@@ -210,6 +210,30 @@ def main():
         for t in range(W):
             one_step(t)
         torch.cuda.synchronize()
+    # Which all-gather schedule is faster depends on what the transfer costs on THIS node's links against ~12 us of stream
+    # dependency per step; nothing could measure that before the driver's multi-GPU run, so both are timed for a few
+    # (untimed) steps and every rank adopts the one whose slowest rank is faster.
+    T0 = W                                                     # global index of the first timed step
+    schedule_note = None
+    if gather and overlap and not args.fused:
+        cal = 32
+        took = []
+        for mode in (False, True):
+            overlap = mode
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            for t in range(cal):
+                one_step(T0 + t)
+            torch.cuda.synchronize()
+            took.append(time.perf_counter() - c0)
+            T0 += cal
+        tk = torch.tensor(took, dtype=torch.float64, device=device)
+        dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        took = [float(x) for x in tk.tolist()]
+        overlap = took[1] <= took[0]
+        schedule_note = f"calibrated over {cal} steps each: serial {took[0] / cal * 1e6:.1f} us/step, overlapped {took[1] / cal * 1e6:.1f} us/step"
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -221,14 +245,14 @@ def main():
     per_launch = gather
     EV_STRIDE = 16
     if per_launch:
-        timed.update({W + t: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for t in range(0, K, EV_STRIDE)})
+        timed.update({T0 + t: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for t in range(0, K, EV_STRIDE)})
     else:
         ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     if not per_launch:
         ev_a.record()
     for t in range(K):
-        one_step(W + t)
+        one_step(T0 + t)
     if not per_launch:
         ev_b.record()
     torch.cuda.synchronize()
@@ -267,7 +291,7 @@ def main():
             "config": {"workload": f"{N} markets x {A} random agents per GPU, book capacity {256} resting orders per market "
                                    f"(BASELINE configs[2]); global {world * N} markets"
                                    + (f"; FUSED: {args.fused} steps per launch (cda_run_random)" if args.fused else ""),
-                       "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info),
+                       "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info), "gather_schedule": schedule_note,
                        "collective": ("all_gather(obs|reward|flags slab), " + ("overlapped with the next step on alternating streams" if overlap else "serial")) if gather else "none",
                        "flagged_markets": n_flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
