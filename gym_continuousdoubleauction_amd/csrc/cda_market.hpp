@@ -644,9 +644,12 @@ __device__ __forceinline__ bool order_approved(Lds& L, const Mkt& m, int tr, int
     int ok = 0;
     if (lane == tr) {
         const Acc& a = L.acc[lane];
-        D nav = ld_dec(a.nav);
+        // every LDS operand is requested up front (one round trip instead of four dependent ones)
+        const D nav = ld_dec(a.nav), cash = ld_dec(a.cash);
+        const int32_t pos32 = a.net_position;
+        const int32_t opp_best = L.book.price[side ^ 1][0];              // read even if that side is empty (slot 0 / CAP-1 exists)
         if (d_sgn(nav) > 0) {
-            int64_t pos = a.net_position, opening;
+            int64_t pos = pos32, opening;
             int64_t apos = pos < 0 ? -pos : pos;
             if ((side == S_BID && pos >= 0) || (side == S_ASK && pos <= 0)) opening = size;
             else { opening = (int64_t)size - apos; if (opening < 0) opening = 0; }
@@ -655,13 +658,12 @@ __device__ __forceinline__ bool order_approved(Lds& L, const Mkt& m, int tr, int
                 D est;
                 if (price < 0) {
                     int opp = side ^ 1;
-                    if (mkt_n(m, opp) > 0) est = d_price(L.book.price[opp][0]);
+                    if (mkt_n(m, opp) > 0) est = d_price(opp_best);
                     else if (m.has_trade) est = d_price(m.last_trade_price);
                     else est = d_from_u32(1);
                 } else est = d_price(price);
                 // order_val = opening * est = ov * 10^-1 with ov < 2^63 (est is a tick price or 1: coefficient < 2^28).  When the
                 // bit lengths alone prove cash > order_val the exact decimal compare is skipped (cash of 1e6 vs orders of 1e2..1e5).
-                D cash = ld_dec(a.cash);
                 uint64_t ov = (uint64_t)((uint32_t)est.w0) * (uint64_t)opening;          // exact: est.w1 == est.w2 == 0
                 int kdig = est.exp - cash.exp;                                            // cash coefficient is compared with ov * 10^kdig
                 int bc = bits128(d_c128(cash)), bo = 64 - __clzll(ov | 1ull);
