@@ -17,7 +17,7 @@ SYMBOLS = [
     "cda_default_config", "cda_create", "cda_destroy", "cda_reset", "cda_step", "cda_place_order",
     "cda_mark_to_mkt", "cda_get_state", "cda_set_state", "cda_get_raw_snapshot", "cda_last_flags",
     "cda_selftest_dec", "cda_selftest_rng", "cda_strerror", "cda_num_markets", "cda_obs_dim",
-    "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host",
+    "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host", "cda_nav_conservation",
 ]
 
 
@@ -42,6 +42,7 @@ def lib():
     L.cda_step.argtypes = [vp] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), vp]
     L.cda_run_random.argtypes = [vp, i32, u64, u64, vp, vp, vp, vp, vp, vp]
     L.cda_random_actions_host.argtypes = [u64, u64, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.cda_nav_conservation.argtypes = [vp, C.c_double, vp, vp, vp]
     L.cda_place_order.argtypes = [vp] + [i32] * 6
     L.cda_mark_to_mkt.argtypes = [vp, i32]
     L.cda_get_state.argtypes = [vp, i32, C.POINTER(K.MarketState)]

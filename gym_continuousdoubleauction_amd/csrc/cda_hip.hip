@@ -554,6 +554,21 @@ __global__ __launch_bounds__(64 * CDA_WPB) void k_raw_snapshot(uint8_t* arena, P
     aggregate_levels(L, m, lane);
     if (lane < CDA_RAW_DIM) raw_out[(size_t)mi * CDA_RAW_DIM + (size_t)lane] = raw_value(L, lane);
 }
+// Sum-of-NAV conservation check, one thread per market (callbk/league_based_self_play_callback.py:679-704)
+__global__ void k_nav_conservation(const uint8_t* arena, Params P, double tol, double* err_out, uint8_t* viol_out) {
+    dec_tables_init();
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= P.n_markets) return;
+    const Acc* acc = reinterpret_cast<const Acc*>(arena + (size_t)i * (size_t)P.lay.stride + (size_t)P.lay.acc_off);
+    D total = d_zero();
+    for (int a = 0; a < P.cfg.num_agents; a++) total = d_add(total, ld_dec(acc[a].nav));
+    D err = d_sub(total, d_mul_int(d_from_i64(P.cfg.init_cash), (uint32_t)P.cfg.num_agents));
+    err.sign = 0;
+    uint32_t ferr = 0;
+    const double e = d_to_double(err, &ferr);
+    err_out[i] = e;
+    if (viol_out) viol_out[i] = (uint8_t)(e > tol || ferr != 0);
+}
 __global__ void k_flags(uint8_t* arena, Params P, uint32_t* out) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i < P.n_markets) out[i] = ((const uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride))[H_FLAGS];
@@ -786,6 +801,15 @@ int cda_random_actions_host(uint64_t action_seed, uint64_t market_index_base, in
             cda_random_action(action_seed, market_index_base + (uint64_t)i, (uint32_t)step, (uint32_t)a, &category[ix], &size_mean[ix], &size_sigma[ix],
                               &price[ix], &price_offset[ix]);
         }
+    return CDA_OK;
+}
+
+int cda_nav_conservation(cda_env* e, double tolerance, double* abs_error_out, uint8_t* violated_out, void* stream) {
+    if (!e || !abs_error_out) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_nav_conservation, dim3((unsigned)((e->P.n_markets + 63) / 64)), dim3(64), DEC_TABLE_BYTES, (hipStream_t)stream,
+                       (const uint8_t*)e->arena, e->P, tolerance, abs_error_out, violated_out);
+    HIPCHK(hipGetLastError());
     return CDA_OK;
 }
 

@@ -206,6 +206,15 @@ class CDAVecEnv:
             check(lib().cda_last_flags(self._h, f.data_ptr(), self._stream()), "cda_last_flags")
         return f
 
+    def nav_conservation(self, tolerance=1e-6):
+        """The reference's end-of-episode invariant for every market, computed on the device in the ledger's own decimal
+        arithmetic: (float(|sum of NAV - A * init_cash|) f64[N], violated bool[N])."""
+        err = torch.zeros(self.n_markets, dtype=torch.float64, device=self.device)
+        bad = torch.zeros(self.n_markets, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().cda_nav_conservation(self._h, float(tolerance), err.data_ptr(), bad.data_ptr(), self._stream()), "cda_nav_conservation")
+        return err, bad.view(torch.bool)
+
     def state_bytes_per_market(self):
         return int(lib().cda_state_bytes_per_market(self._h))
 

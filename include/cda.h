@@ -197,6 +197,12 @@ int cda_random_actions_host(uint64_t action_seed, uint64_t market_index_base, in
                             int32_t num_agents, int32_t* category, float* size_mean, float* size_sigma,
                             int32_t* price, int32_t* price_offset);
 
+/* The reference's end-of-episode invariant (train/callbk/league_based_self_play_callback.py:679-704) for every market, on
+ * the device: total = Decimal(0); total += NAV_a for a = 0..A-1 (the accounts' current NAV, in that order, prec-28
+ * arithmetic); error = total - Decimal(init_cash) * A.  abs_error_out f64[N] (device) receives float(abs(error)),
+ * violated_out u8[N] (device, nullable) whether it exceeds `tolerance` (the reference's nav_tolerance, 1e-6). */
+int cda_nav_conservation(cda_env* env, double tolerance, double* abs_error_out, uint8_t* violated_out, void* stream);
+
 /* Test/diagnostic hook: Trader.place_order (agent/trader.py:49-106) for ONE decoded order on one
  * market, bypassing decode and the RNG. type: 0 market, 1 limit, 2 modify, 3 cancel; side: 0 bid,
  * 1 ask; price in ticks (ignored for market). Synchronous. */

@@ -210,3 +210,30 @@ def test_fused_random_agent_episode_equals_stepwise_and_oracle():
     for e in (fused, stepw, chunk):
         e.close()
     orc.close()
+
+
+def test_device_nav_conservation_check_equals_the_reference_rule():
+    """cda_nav_conservation vs the reference's own statement of the invariant (callbk:679-704) in CPython Decimal."""
+    from hip_env import HipEnv
+    n, a, cash = 256, 4, 1000000
+    env = HipEnv({"num_of_agents": a, "init_cash": cash, "max_step": 1000, "is_render": False}, n)
+    env.reset(np.arange(77, 77 + n, dtype=np.uint64))
+    rng = np.random.default_rng(11)
+    for t in range(120):
+        env.step(*_actions(rng, n, a))
+    err, bad = env.env.nav_conservation(1e-6)
+    err, bad = err.cpu().numpy(), bad.cpu().numpy()
+    for i in range(n):
+        st = env.get_state(i)
+        total = Decimal(0)
+        for k in range(a):
+            total += K.dec_to_decimal(st.acc[k].nav)
+        want = float(abs(total - Decimal(str(cash)) * a))
+        assert err[i] == want, (i, err[i], want)
+    assert not bad.any() and err.max() < 1e-15
+    s = env.get_state(5)                                       # break the invariant of one market
+    s.acc[2].nav.w[2] += 1                                    # + 2^64 units of the coefficient: ~0.02 at exponent -21
+    env.set_state(5, s)
+    err2, bad2 = env.env.nav_conservation(1e-6)
+    assert bool(bad2[5]) and int(bad2.sum()) == 1 and float(err2[5]) > 0
+    env.close()
