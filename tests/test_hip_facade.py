@@ -296,3 +296,34 @@ def test_lob_actions_hold_the_decoded_orders():              # test_new_action_s
     env.reset(seed=5)
     assert env.LOB_actions is None
     env.close()
+
+
+def test_reward_terms_follow_the_reference_formulas_exactly():      # test_reward_logic.py:15-110
+    """Every term recomputed from the exact NAV strings: nav_term = float(dNAV) * (1.5 if negative), the high-water mark
+    and drawdown, the three counter terms - bit for bit, over a random episode with trades, losses and passive fills."""
+    env = make()
+    env.reset(seed=12)
+    rng = np.random.default_rng(5)
+    prev = {a: Decimal(1000000) for a in env.agents}
+    high = dict(prev)
+    saw_loss = saw_gain = saw_passive = saw_drawdown = False
+    for _ in range(120):
+        _, rewards, _, _, infos = env.step(random_actions(env, rng))
+        for a in env.agents:
+            i, t = infos[a], infos[a]["reward_terms"]
+            nav = Decimal(i["NAV"])
+            change = float(nav - prev[a])
+            assert t["nav_term"] == change * (1.5 if change < 0 else 1.0)
+            high[a] = max(high[a], nav)                              # max_nav is a high-water mark of the exact NAV
+            assert i["max_nav"] == float(high[a])
+            dd = float(max(Decimal(0), high[a] - nav))
+            assert i["drawdown"] == dd and t["drawdown_penalty"] == -(0.2 * dd)
+            assert t["order_penalty"] == -(0.1 * i["order_step_placed"]) and t["trade_penalty"] == -(0.05 * i["num_trades_step"])
+            assert t["passive_bonus"] == 0.1 * i["num_passive_fills_step"] and i["num_passive_fills_step"] <= i["num_trades_step"]
+            saw_loss |= change < 0
+            saw_gain |= change > 0
+            saw_passive |= i["num_passive_fills_step"] > 0
+            saw_drawdown |= dd > 0
+            prev[a] = nav
+    assert saw_loss and saw_gain and saw_passive and saw_drawdown
+    env.close()
