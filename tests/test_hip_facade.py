@@ -327,3 +327,35 @@ def test_reward_terms_follow_the_reference_formulas_exactly():      # test_rewar
             prev[a] = nav
     assert saw_loss and saw_gain and saw_passive and saw_drawdown
     env.close()
+
+
+def test_observation_normalisation_rules():                          # test_obs_normalization.py:60-340
+    env = make()
+    obs, _ = env.reset(seed=9)
+    anchor = int(env.last_price)
+    f = obs["agent_0"][-42:]
+    assert env.agg_LOB_raw.shape == (40,) and not env.agg_LOB_raw.any()                    # empty book after reset
+    assert not f[:40].any() and f[40] == np.float32(math.log(anchor)) and f[41] == 0.0     # last_price is the anchor
+    sized = lambda c, mean, price, off=1: {"category": c, "size_mean": np.array([mean], np.float32), "size_sigma": np.array([0.0], np.float32),   # noqa: E731
+                                           "price": price, "price_offset": off}
+    # limit sizes: rint(|lim_mul * mean|) + min_size with lim_mul = (100 * 10 - 1) / 2 = 499.5
+    obs, *_ = env.step({"agent_0": sized(2, 0.1, 0), "agent_1": sized(2, 0.2, 2), "agent_2": sized(6, 0.05, 1)})
+    f = obs["agent_0"][-42:]
+    raw = env.agg_LOB_raw
+    bid0, bid1, ask0 = anchor - 1, anchor - 3, anchor + 2
+    size_of = lambda mean: int(np.rint(abs(np.float32(499.5) * np.float32(mean)))) + 1    # noqa: E731
+    s0, s1, sa = size_of(0.1), size_of(0.2), size_of(0.05)
+    assert list(raw[:2]) == [bid0, bid1] and list(raw[10:12]) == [s0, s1] and raw[20] == -ask0 and raw[30] == -sa
+    M = (bid0 + ask0) / 2.0
+    assert f[0] == np.float32((M - bid0) / M) and f[1] == np.float32((M - bid1) / M) and (f[:10] >= 0).all()      # bids >= 0
+    assert f[20] == np.float32(-((ask0 - M) / M)) and (f[20:30] <= 0).all()                                        # asks <= 0
+    assert f[10] == np.float32(math.sqrt(s0)) and f[11] == np.float32(math.sqrt(s1)) and f[30] == np.float32(-math.sqrt(sa))
+    assert f[0] == -f[20]                                                                  # level-1 distances are symmetric about the mid
+    assert all(a["price"] > 0 for a in env.LOB_actions)                                    # resolved action prices are raw and positive
+    # a zero last_price on an empty book falls back to M = 100
+    env2 = make()
+    env2.reset(seed=9)
+    env2.last_price = 0
+    obs2, *_ = env2.step({"agent_0": sized(0, 0.0, 0)})
+    assert obs2["agent_0"][-42:][40] == np.float32(math.log(100.0))
+    env.close(); env2.close()
