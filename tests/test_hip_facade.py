@@ -359,3 +359,14 @@ def test_observation_normalisation_rules():                          # test_obs_
     obs2, *_ = env2.step({"agent_0": sized(0, 0.0, 0)})
     assert obs2["agent_0"][-42:][40] == np.float32(math.log(100.0))
     env.close(); env2.close()
+
+
+def test_league_self_play_loop_on_the_hip_env():
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    from gym_continuousdoubleauction_amd.league_train import train_league
+    env = CDAVecEnv({"num_of_agents": 4, "init_cash": 1000000, "max_step": 16, "is_render": False}, n_markets=256, with_info=False)
+    model, mapper, hist = train_league(env, iters=3, promote_margin=-1e9, log=lambda s: None)
+    assert [h["promoted"] for h in hist] == ["champion_1", "champion_2", "champion_3"]
+    assert all(math.isfinite(h["v_loss"]) and math.isfinite(h["episode_return"]) for h in hist)
+    assert int(env.flags().abs().sum()) == 0
+    env.close()

@@ -52,3 +52,18 @@ def test_ppo_loop_runs_and_resets_truncated_markets():
     model, hist = ppo.train(env, iters=2, horizon=12, log=lambda s: None)
     assert len(hist) == 2 and all(np.isfinite(h["pg_loss"]) and np.isfinite(h["v_loss"]) for h in hist)
     assert hist[0]["agent_steps"] == 6 * 3 * 12
+
+
+def test_league_self_play_loop_grows_a_champion_pool():
+    from gym_continuousdoubleauction_amd.league_train import train_league
+
+    class _Env(_CpuEnv):
+        def __init__(self, n, a, max_step):
+            super().__init__(n, a, max_step)
+            self.max_step = max_step
+    env = _Env(8, 4, max_step=6)
+    model, mapper, hist = train_league(env, iters=3, num_trainable=1, promote_margin=-1e9, log=lambda s: None)
+    assert len(hist) == 3 and all(np.isfinite(h["pg_loss"]) and np.isfinite(h["episode_return"]) for h in hist)
+    assert hist[0]["promoted"] == "champion_1" and mapper.available_modules[:4] == ["policy_0", "policy_1", "policy_2", "policy_3"]
+    assert [n for n in mapper.available_modules if n.startswith("champion_")] == ["champion_1", "champion_2", "champion_3"]
+    assert hist[-1]["pool"][-1] == "champion_3"
