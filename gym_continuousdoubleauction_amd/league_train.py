@@ -40,8 +40,10 @@ class _FrozenPolicy:
 
 
 def train_league(env, iters=4, num_trainable=1, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, original_opponent_weight=1.0,
-                 champion_weight=3.0, promote_margin=0.0, max_champions=8, log=print):
-    """env: CDAVecEnv-shaped, its max_step is the episode length.  Returns (model, mapper, history)."""
+                 champion_weight=3.0, promote_margin=0.0, max_champions=8, recorder=None, log=print):
+    """env: CDAVecEnv-shaped, its max_step is the episode length.  Returns (model, mapper, history).
+    recorder: an `episode_record.BatchedEpisodeRecorder` (env built with_info=True): the episodes of its markets are written
+    in the reference's Parquet schema, `module_id` = the module that played each slot."""
     torch.manual_seed(seed)
     dev = env.obs.device
     N, A, T = env.n_markets, env.num_agents, int(env.max_step)
@@ -57,6 +59,10 @@ def train_league(env, iters=4, num_trainable=1, lr=5e-5, epochs=4, reward_scale=
         assignment = mapper.assign([f"iter{it}-market{i}" for i in range(N)])
         groups = {name: (torch.as_tensor(mk, device=dev), torch.as_tensor(sl, device=dev))
                   for name, (mk, sl) in mapper.group_by_module(assignment).items() if name in modules}
+        if recorder is not None:
+            recorder.iteration = it
+            names = mapper.names(assignment)
+            recorder.begin_episodes([f"iter{it}-market{int(i)}" for i in recorder.markets], module_ids=[list(names[int(i)]) for i in recorder.markets])
         buf_obs, buf_act, buf_logp, buf_val, buf_rew = [], [], [], [], []
         acts = [torch.zeros((N, A), dtype=dt, device=dev) for dt in (torch.int32, torch.float32, torch.float32, torch.int32, torch.int32)]
         for _ in range(T):
@@ -69,9 +75,13 @@ def train_league(env, iters=4, num_trainable=1, lr=5e-5, epochs=4, reward_scale=
             for name, (mk, sl) in groups.items():                        # one batched forward per opponent module
                 for dst, src in zip(acts, modules[name](obs.index_select(0, mk))):
                     dst[mk, sl] = src.to(dst.dtype)
-            _, r, _, _, _ = env.step(*acts)
+            o_next, r, _, _, info = env.step(*acts)
+            if recorder is not None:
+                recorder.record_step(o_next, r, info, acts)
             buf_obs.append(pobs); buf_act.append(a_tr); buf_logp.append(logp); buf_val.append(val)
             buf_rew.append((r[:, :k].float() * reward_scale).reshape(-1))
+        if recorder is not None:
+            recorder.finish(complete=True)
         rew, val = torch.stack(buf_rew), torch.stack(buf_val)
         done = torch.zeros_like(rew)
         done[-1] = 1.0                                                   # the episode ends with the rollout

@@ -364,8 +364,19 @@ def test_observation_normalisation_rules():                          # test_obs_
 def test_league_self_play_loop_on_the_hip_env():
     from gym_continuousdoubleauction_amd import CDAVecEnv
     from gym_continuousdoubleauction_amd.league_train import train_league
-    env = CDAVecEnv({"num_of_agents": 4, "init_cash": 1000000, "max_step": 16, "is_render": False}, n_markets=256, with_info=False)
-    model, mapper, hist = train_league(env, iters=3, promote_margin=-1e9, log=lambda s: None)
+    import tempfile
+    import pyarrow.parquet as pq
+    from gym_continuousdoubleauction_amd.episode_record import BatchedEpisodeRecorder
+    env = CDAVecEnv({"num_of_agents": 4, "init_cash": 1000000, "max_step": 16, "is_render": False}, n_markets=256, with_info=True)
+    out = tempfile.mkdtemp()
+    rec = BatchedEpisodeRecorder(out, num_agents=4, markets=[3, 200], run_id="league-test")
+    model, mapper, hist = train_league(env, iters=3, promote_margin=-1e9, recorder=rec, log=lambda s: None)
+    rec.close()
+    t = pq.read_table(rec.files).to_pandas()
+    assert len(t) == 3 * 2 * 16 * 4 and set(t["iteration"]) == {0, 1, 2} and t["episode_complete"].all()
+    assert (t[t.agent_id == "agent_0"]["module_id"] == "policy_0").all()                   # the trainable slot
+    late = t[(t.iteration == 2) & (t.agent_id != "agent_0")]["module_id"]
+    assert set(late) <= {"policy_1", "policy_2", "policy_3", "champion_1", "champion_2"}   # champion_3 joins after iteration 2
     assert [h["promoted"] for h in hist] == ["champion_1", "champion_2", "champion_3"]
     assert all(math.isfinite(h["v_loss"]) and math.isfinite(h["episode_return"]) for h in hist)
     assert int(env.flags().abs().sum()) == 0
