@@ -237,3 +237,33 @@ def test_device_nav_conservation_check_equals_the_reference_rule():
     err2, bad2 = env.env.nav_conservation(1e-6)
     assert bool(bad2[5]) and int(bad2.sum()) == 1 and float(err2[5]) > 0
     env.close()
+
+
+def test_hip_equals_oracle_on_random_configurations():
+    """Fuzz over the config space (agent counts up to the bound, balances from 400 to 5e10, size and price ranges, history
+    depths, reward coefficients, action laws, agent subsets): every output and the final states, HIP vs oracle.  The same
+    generator drives tests/golden/crosscheck_oracle.py, which pins the oracle to the reference on such episodes."""
+    from hip_env import HipEnv
+    import oracle_lib as O
+    from fuzz_cases import batch_actions, random_config
+    rng = np.random.default_rng(31337)
+    for case in range(14):
+        cfg, law, present_p = random_config(rng)
+        n, a, steps = 40, cfg["num_of_agents"], 56
+        env, ora = HipEnv(cfg, n), O.OracleEnv(cfg, n)
+        seeds = rng.integers(0, 2 ** 63, n).astype(np.uint64)
+        assert np.array_equal(env.reset(seeds).view(np.uint32), ora.reset(seeds).view(np.uint32)), (case, cfg)
+        for t in range(steps):
+            acts, present = batch_actions(rng, n, a, law, present_p)
+            obs, rew, term, trunc, info = env.step(*acts, present)
+            oo, orw, ot, otr, oi = ora.step(*acts, present)
+            ctx = f"case {case} {cfg} law={law} step {t}"
+            assert np.array_equal(obs.view(np.uint32), oo.view(np.uint32)), ctx
+            assert np.array_equal(rew.view(np.uint64), orw.view(np.uint64)), ctx
+            assert np.array_equal(term, ot) and np.array_equal(trunc, otr), ctx
+            for k in oi:
+                assert np.array_equal(np.ascontiguousarray(info[k]).view(np.uint8), np.ascontiguousarray(oi[k]).view(np.uint8)), f"{ctx} info.{k}"
+        for i in range(0, n, 9):
+            assert bytes(env.get_state(i)) == bytes(ora.get_state(i)), f"case {case} market {i}"
+        assert np.array_equal(env.flags(), ora.flags()), case
+        env.close(); ora.close()
