@@ -9,7 +9,8 @@
  *
  * PINNING: this oracle is pinned against golden vectors cut from the reference itself, imported
  * in the build container (tests/golden/make_goldens.py -> tests/golden/ fixtures), by
- * tests/test_oracle_golden.py; its decimal arithmetic is pinned against CPython's `decimal`
+ * tests/test_oracle_golden.py (35 traces), and was cross-checked against the reference on 2300 fresh random episodes
+ * over the whole config space (tests/golden/crosscheck_oracle.py); its decimal arithmetic is pinned against CPython's `decimal`
  * and its RNG against numpy, both live (tests/test_oracle_arith.py).
  *
  * Third-party arithmetic restated here (not under /root/reference):
