@@ -246,8 +246,9 @@ def test_hip_equals_oracle_on_random_configurations():
     from hip_env import HipEnv
     import oracle_lib as O
     from fuzz_cases import batch_actions, random_config
-    rng = np.random.default_rng(31337)
-    for case in range(14):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("CDA_FUZZ_SEED", "31337")))
+    for case in range(int(os.environ.get("CDA_FUZZ_CASES", "14"))):       # a longer soak: CDA_FUZZ_CASES=150 CDA_FUZZ_SEED=...
         cfg, law, present_p = random_config(rng)
         n, a, steps = 40, cfg["num_of_agents"], 56
         env, ora = HipEnv(cfg, n), O.OracleEnv(cfg, n)
