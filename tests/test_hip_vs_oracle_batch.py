@@ -268,3 +268,39 @@ def test_hip_equals_oracle_on_random_configurations():
             assert bytes(env.get_state(i)) == bytes(ora.get_state(i)), f"case {case} market {i}"
         assert np.array_equal(env.flags(), ora.flags()), case
         env.close(); ora.close()
+
+
+def test_fused_episodes_equal_stepwise_on_random_configurations():
+    """cda_run_random vs one launch per step over random configurations (agent counts, balances, sizes, history depths)."""
+    import os
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    from fuzz_cases import random_config
+    rng = np.random.default_rng(int(os.environ.get("CDA_FUZZ_SEED", "777")))
+    for case in range(int(os.environ.get("CDA_FUZZ_CASES", "10"))):
+        cfg, _, _ = random_config(rng)
+        cfg["max_step"] = int(rng.integers(5, 40))
+        n, T = 48, cfg["max_step"] + 3
+        fused, stepw = CDAVecEnv(cfg, n_markets=n, with_info=False), CDAVecEnv(cfg, n_markets=n, with_info=False)
+        seeds = rng.integers(0, 2 ** 63, n).astype(np.uint64)
+        fused.reset(seed=seeds); stepw.reset(seed=seeds)
+        aseed, base = int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 10 ** 6))
+        obs, ret, term, trunc, steps = fused.run_random(T, action_seed=aseed, market_index_base=base)
+        ret_ref = np.zeros((n, cfg["num_of_agents"]))
+        alive = np.ones(n, bool)
+        taken = np.zeros(n, np.int32)
+        for t in range(cfg["max_step"]):                       # every market runs to truncation unless it terminates first
+            so, sr, st, su, _ = stepw.step(*stepw.random_actions(t, action_seed=aseed, market_index_base=base))
+            sr, st, su = sr.cpu().numpy(), st.cpu().numpy(), su.cpu().numpy()
+            ret_ref[alive] += sr[alive]
+            taken[alive] += 1
+            alive &= ~(st | su)
+            if not alive.any():
+                break
+        assert np.array_equal(steps.cpu().numpy(), taken), (case, cfg)
+        assert np.array_equal(ret.cpu().numpy().view(np.uint64), ret_ref.view(np.uint64)), (case, cfg)
+        full = taken == cfg["max_step"]                        # markets that ended together with the stepwise run: same final state
+        assert full.any()
+        for i in np.flatnonzero(full)[::7]:
+            assert bytes(fused.get_state(int(i))) == bytes(stepw.get_state(int(i))), (case, int(i))
+        assert np.array_equal(obs.cpu().numpy()[full].view(np.uint32), so.cpu().numpy()[full].view(np.uint32)), case
+        fused.close(); stepw.close()
