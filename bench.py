@@ -125,13 +125,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # diagnostics only: CDA_BENCH_DEVICE pins every rank to one GPU and CDA_BENCH_BACKEND=gloo replaces RCCL, so that the
+    # multi-rank code path can be exercised on a single-GPU box (tests/test_bench_contract.py)
+    if os.environ.get("CDA_BENCH_DEVICE"):
+        local_rank = int(os.environ["CDA_BENCH_DEVICE"])
+    backend = os.environ.get("CDA_BENCH_BACKEND", "nccl")
     use_dist = world > 1 or args.force_gather
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)

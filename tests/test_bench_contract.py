@@ -57,3 +57,21 @@ def test_bench_fused_mode_reports_the_same_contract():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "32", "--markets", "64", "--no-cpu-baseline",
                           "--fused", "32"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "multiples" in (bad.stderr + bad.stdout)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """Two processes under torch.distributed.run, both pinned to GPU 0, gloo instead of RCCL: the multi-rank logic of bench.py
+    (global-index seeds per rank, slab all-gather sized by the world, schedule calibration with its all-reduce, max-over-ranks
+    timing) runs for real; only the transport differs from the driver's 2-GPU launch."""
+    env = dict(os.environ, CDA_BENCH_DEVICE="0", CDA_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "48",
+                          "--warmup", "16", "--markets", "256", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 48 and "all_gather" in d["config"]["collective"] and d["config"]["flagged_markets"] == 0
+    assert "calibrated" in (d["config"]["gather_schedule"] or "") and "global 512 markets" in d["config"]["workload"]
+    assert abs(d["value"] - 2 * 256 * 4 * 48 / (d["ms_per_step"] * 1e-3 * 48)) / d["value"] < 1e-6
