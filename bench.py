@@ -5,13 +5,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one env step() of every market of the batch (one launch of the k_step kernel per rank).
-Workload (BASELINE.json configs[2], the configuration the >=1M agent-steps/s target is quoted on):
-4096 independent markets x 4 synthetic random agents PER GPU (weak scaling: markets are sharded,
-there is no collective on the simulation path); for N > 1 the per-rank obs/reward shards are
-all-gathered over RCCL each step - the hand-back to a central learner that north_star names.
-Actions are pre-generated on the device (uniform random-agent law, train/model/model_handler.py:38-53
-of the reference) so that the timed region starts with every input resident in HBM.
+A "step" is one env step() of every market of the batch.  Workload (BASELINE.json configs[2], the configuration the
+>=1M agent-steps/s target is quoted on; `--config c3`): 4096 independent markets x 4 synthetic random agents PER GPU
+(weak scaling: markets are sharded, there is no collective on the simulation path); `--config c4` is the per-GPU share of
+BASELINE configs[3] (2048 markets x 8 agents).  For N > 1 the per-rank obs/reward shards are all-gathered over RCCL each
+step - the hand-back to a central learner that north_star names.
+
+Inputs: the action of (step, market, agent) comes from the counter-based generator of
+include/cda_random_agents.h keyed (2024, step, GLOBAL market index, agent) - the uniform random-agent law of the
+reference (train/model/model_handler.py:38-53).  The whole stream is generated on the device before the timed region
+(cda_random_actions), so every input is resident in HBM; the cpu_baseline leg replays the SAME stream.
+
+On one GPU the batch is stepped as `--groups` (default 2) contiguous market groups, each a chain of k_step launches on
+its own stream (cda_step_groups): markets never interact, so the batch-wide barrier of a single launch is not part of
+the reference's semantics, and a group's slowest market then overlaps the other group's work.
 
 Prints ONE JSON line on rank 0; see the fields `roofline` and `cpu_baseline` in DESIGN.md.
 """
@@ -28,6 +35,11 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_CONST = 1444      # B(A) = 1444 + 324*A bytes per market-step
 ALG_BYTES_PER_AGENT = 324
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+GPU_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: peak engine clock
+N_SIMD = 1024               # 256 CUs x 4 SIMDs
+ACTION_SEED = 2024          # bench_seed
+SEED_BASE = 1000            # market i is seeded SeedSequence(1000 + i)
+CONFIGS = {"c3": (4096, 4), "c4": (2048, 8)}
 
 
 def parse():
@@ -35,9 +47,13 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=1000)
     p.add_argument("--warmup", type=int, default=64)
-    p.add_argument("--markets", type=int, default=4096, help="markets per GPU")
-    p.add_argument("--agents", type=int, default=4)
-    p.add_argument("--info", action="store_true", help="also emit the info tensors every step")
+    p.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="c3: 4096 markets x 4 agents per GPU (BASELINE configs[2]); "
+                   "c4: 2048 x 8 per GPU (the per-GPU share of BASELINE configs[3], 16384 x 8 over 8 GPUs)")
+    p.add_argument("--markets", type=int, default=None, help="markets per GPU (overrides --config)")
+    p.add_argument("--agents", type=int, default=None)
+    p.add_argument("--groups", type=int, default=None, help="concurrent market groups per GPU (default 2; 1 with the all-gather)")
+    p.add_argument("--info", action="store_true", help="headline run WITH the info tensors (a14); otherwise info-on is timed as a second leg")
+    p.add_argument("--no-info-leg", action="store_true", help="skip the second (info tensors on) timed leg")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the obs/reward all-gather")
     p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each step's all-gather before the next launch")
     p.add_argument("--force-gather", action="store_true",
@@ -50,63 +66,62 @@ def parse():
     return p.parse_args()
 
 
-def gen_actions(torch, n, a, steps, device, seed):
-    """Uniform random-agent law, generated on the device, [steps, n, a] per field."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    cat = torch.randint(0, 9, (steps, n, a), generator=g, device=device, dtype=torch.int32)
-    price = torch.randint(0, 10, (steps, n, a), generator=g, device=device, dtype=torch.int32)
-    off = torch.randint(0, 3, (steps, n, a), generator=g, device=device, dtype=torch.int32)
-    mean = torch.rand((steps, n, a), generator=g, device=device, dtype=torch.float32) * 2.0 - 1.0
-    sigma = torch.rand((steps, n, a), generator=g, device=device, dtype=torch.float32)
-    return cat, mean, sigma, price, off
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(markets, agents, budget_s, max_step):
-    """The CPU oracle (a plain-C port of the reference path, bit-identical to it on the golden
-    vectors) timed on the host cores: markets partitioned over one thread per core."""
+def cpu_baseline(markets, agents, budget_s, max_step, first_market):
+    """The CPU oracle (a plain-C port of the reference path, bit-identical to it on the golden vectors) timed on the
+    host cores on the SAME action stream the GPU leg consumes (random agents keyed (2024, step, global market, agent),
+    same market seeds): all cores (markets partitioned, one foreign call per thread) and one thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n = markets
     cfg = {"num_of_agents": agents, "init_cash": 1000000, "max_step": max_step, "is_render": False}
-    env = O.OracleEnv(cfg, n_markets=n)
-    env.reset(seeds=np.arange(1000, 1000 + n, dtype=np.uint64))
-    rng = np.random.default_rng(2024)
-    T = 32
-    cat = rng.integers(0, 9, (T, n, agents)).astype(np.int32)
-    mean = rng.uniform(-1, 1, (T, n, agents)).astype(np.float32)
-    sigma = rng.uniform(0, 1, (T, n, agents)).astype(np.float32)
-    price = rng.integers(0, 10, (T, n, agents)).astype(np.int32)
-    off = rng.integers(0, 3, (T, n, agents)).astype(np.int32)
     lib = O.lib()
-    cores = min(cores, n)
-    bounds = [(i * n // cores, (i + 1) * n // cores) for i in range(cores)]
-    bounds = [(lo, hi) for lo, hi in bounds if hi > lo]
+    seeds = np.arange(SEED_BASE + first_market, SEED_BASE + first_market + n, dtype=np.uint64)
 
-    def run_steps(count):
+    def timed(n_markets, n_threads, steps):
+        env = O.OracleEnv(cfg, n_markets=n_markets)
+        env.reset(seeds=seeds[:n_markets])
+        bounds = [(i * n_markets // n_threads, (i + 1) * n_markets // n_threads) for i in range(n_threads)]
+        bounds = [(lo, hi) for lo, hi in bounds if hi > lo]
+
         def work(lo, hi):      # ONE foreign call per thread; ctypes releases the GIL for its duration
-            lib.oracle_run_range(env.h, lo, hi - lo, count, T, cat.ctypes.data, mean.ctypes.data, sigma.ctypes.data,
-                                 price.ctypes.data, off.ctypes.data, env.obs.ctypes.data, env.reward.ctypes.data,
-                                 env.term.ctypes.data, env.trunc.ctypes.data)
+            lib.oracle_run_random_range(env.h, lo, hi - lo, 0, steps, ACTION_SEED, first_market, env.obs.ctypes.data, env.reward.ctypes.data,
+                                        env.term.ctypes.data, env.trunc.ctypes.data)
         th = [threading.Thread(target=work, args=b) for b in bounds]
         t0 = time.perf_counter()
         for x in th:
             x.start()
         for x in th:
             x.join()
-        return time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        env.close()
+        return dt, len(bounds)
 
-    dt = run_steps(8)                      # calibration
-    per_step = dt / 8
-    steps = int(max(16, min(4000, budget_s / max(per_step, 1e-6))))
-    dt = run_steps(steps)
+    threads = min(cores, n)
+    dt, _ = timed(n, threads, 8)                                   # calibration on a throw-away env
+    steps = int(max(16, min(max_step - 1, 0.8 * budget_s / max(dt / 8, 1e-6))))
+    dt, used = timed(n, threads, steps)                            # steps 0 .. steps-1 of the GPU leg's stream
     value = n * agents * steps / dt
-    env.close()
-    return {"value": value, "unit": "agent-steps/s", "cores": len(bounds), "kind": "port",
-            "sample": f"{n} markets x {agents} agents x {steps} steps ({dt:.1f} s wall), C oracle, "
-                      f"{len(bounds)} threads, obs+reward outputs only"}
+    n1 = min(n, 64)
+    dt1, _ = timed(n1, 1, 4)
+    steps1 = int(max(8, min(max_step - 1, 0.2 * budget_s / max(dt1 / 4, 1e-6))))
+    dt1, _ = timed(n1, 1, steps1)
+    value1 = n1 * agents * steps1 / dt1
+    return {"value": value, "unit": "agent-steps/s", "cores": used, "kind": "port", "value_1thread": value1, "cpu_model": cpu_model(),
+            "sample": f"{n} markets x {agents} agents x steps 0..{steps - 1} of the GPU leg's action stream ({dt:.1f} s wall), C oracle, "
+                      f"{used} threads, obs+reward outputs only; 1 thread: {n1} markets x {steps1} steps ({dt1:.1f} s)"}
 
 
 def main():
@@ -146,22 +161,38 @@ def main():
 
     from gym_continuousdoubleauction_amd import CDAVecEnv
 
-    N, A, K, W = args.markets, args.agents, args.steps, args.warmup
-    max_step = max(4096, K + W + 1)                   # no truncation inside the run
-    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
+    N, A = CONFIGS[args.config]
+    N = args.markets if args.markets is not None else N
+    A = args.agents if args.agents is not None else A
+    K, W = args.steps, args.warmup
     if args.fused and (args.steps % args.fused or args.warmup % args.fused):
         raise SystemExit("--fused T needs --steps and --warmup to be multiples of T")
     gather = use_dist and not args.no_gather and not args.fused
-    # N > 1: the per-step outputs (obs | reward | flags: one contiguous slab written by k_step itself) are
-    # all-gathered over xGMI with ONE collective per step and no packing pass.  The env rotates two slabs, so
-    # the gather of step t runs on RCCL's stream underneath the kernel of step t+1.
-    env = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=args.info, out_buffers=2 if gather else 1)
-    first_market = rank * N                           # global market index -> seed, independent of the GPU count
-    seeds = (1000 + first_market + torch.arange(N, dtype=torch.int64)).numpy().astype("uint64")
-    env.reset(seed=seeds)
-    # action stream: chunks of <= 256 steps keep the resident set small (20 B per agent-step)
-    chunk = min(256, K + W)
-    acts = gen_actions(torch, N, A, chunk, device, 2024 + rank)
+    CAL = 32 if gather and not args.no_overlap else 0             # untimed steps of each all-gather schedule (calibration)
+    total_steps = W + 2 * CAL + K
+    max_step = max(4096, total_steps + 1)                          # no truncation inside the run
+    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
+    groups = args.groups if args.groups is not None else (1 if (gather or args.fused) else 2)
+    groups = max(1, min(groups, N))
+    if gather and groups != 1:
+        raise SystemExit("the all-gather schedule steps the shard as one launch: use --groups 1")
+    first_market = rank * N                           # global market index -> seed and action key, independent of the GPU count
+    seeds = (SEED_BASE + first_market + torch.arange(N, dtype=torch.int64)).numpy().astype("uint64")
+
+    def make_env(with_info):
+        # N > 1: the per-step outputs (obs | reward | flags: one contiguous slab written by k_step itself) are all-gathered
+        # over xGMI with ONE collective per step and no packing pass; the env rotates two slabs, so the gather of step t
+        # runs underneath the kernel of step t+1.
+        e = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=with_info, out_buffers=2 if gather else 1, groups=groups)
+        e.reset(seed=seeds)
+        return e
+
+    env = make_env(args.info)
+    # The action stream of the whole run, resident in HBM (20 B per agent-step: 350 MB for the default 1064 steps of
+    # 4096 x 4); beyond MAX_RESIDENT steps the run cycles through the first MAX_RESIDENT (reported in `data`).
+    MAX_RESIDENT = 4096
+    period = min(total_steps, MAX_RESIDENT)
+    acts = None if args.fused else env.random_actions_device(0, period, action_seed=ACTION_SEED, market_index_base=first_market)
     if gather:
         gathered = [torch.empty(world * env.slab_layout["bytes"], dtype=torch.uint8, device=device) for _ in range(2)]
     # N > 1, overlapped: two streams alternate.  Stream X runs step t and then its all-gather (a synchronous collective
@@ -175,21 +206,21 @@ def main():
         step_done = [torch.cuda.Event(), torch.cuda.Event()]
     timed = {}                                                 # global step index -> (start, end) timing events
 
-    def one_step(t):
-        i = t % chunk
+    def one_step(e, t):
+        i = t % period
         if args.fused:
             if t % args.fused == 0:
-                env.run_random(args.fused, action_seed=2024 + rank, market_index_base=first_market)
+                e.run_random(args.fused, action_seed=ACTION_SEED, market_index_base=first_market)
             return
         if not overlap:
             ev = timed.get(t)
             if ev:
                 ev[0].record()
-            env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+            e.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
             if ev:
                 ev[1].record()
             if gather:
-                dist.all_gather_into_tensor(gathered[t & 1], env.out_slab)
+                dist.all_gather_into_tensor(gathered[t & 1], e.out_slab)
             return
         cur = streams[t & 1]
         with torch.cuda.stream(cur):
@@ -198,33 +229,53 @@ def main():
             ev = timed.get(t)
             if ev:
                 ev[0].record(cur)
-            env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+            e.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
             if ev:
                 ev[1].record(cur)
             step_done[t & 1].record(cur)
-            dist.all_gather_into_tensor(gathered[t & 1], env.out_slab)
+            dist.all_gather_into_tensor(gathered[t & 1], e.out_slab)
+
+    def agree(flag):
+        """N > 1: every rank must take the same branch (a rank-local decision would deadlock the next collective)."""
+        if not use_dist:
+            return flag
+        v = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return bool(v.item() > 0)
 
     torch.cuda.synchronize()                                   # reset and the action stream are complete before any side stream starts
+    failed = False
     try:
         for t in range(W):
-            one_step(t)
+            one_step(env, t)
         torch.cuda.synchronize()
-    except Exception as e:  # noqa: BLE001 - the overlapped schedule could not be exercised on a multi-GPU node before the driver's run
+    except Exception as ex:  # noqa: BLE001 - the overlapped schedule could not be exercised on a multi-GPU node before the driver's run
         if not overlap:
             raise
-        print(f"[bench] overlapped all-gather failed in warm-up ({e}); falling back to the serial schedule", file=sys.stderr)
-        overlap = False
+        print(f"[bench] rank {rank}: overlapped all-gather failed in warm-up ({ex})", file=sys.stderr)
+        failed = True
+    if overlap and agree(failed):
+        # a collective that raised leaves the process group unusable: rebuild it, then every rank takes the serial schedule
+        print("[bench] falling back to the serial all-gather schedule on a fresh process group", file=sys.stderr)
+        overlap, CAL = False, 0
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        env.close()
+        env = make_env(args.info)
         torch.cuda.synchronize()
         for t in range(W):
-            one_step(t)
+            one_step(env, t)
         torch.cuda.synchronize()
     # Which all-gather schedule is faster depends on what the transfer costs on THIS node's links against ~12 us of stream
     # dependency per step; nothing could measure that before the driver's multi-GPU run, so both are timed for a few
     # (untimed) steps and every rank adopts the one whose slowest rank is faster.
     T0 = W                                                     # global index of the first timed step
-    schedule_note = None
-    if gather and overlap and not args.fused:
-        cal = 32
+    schedule_note, schedule_us = None, None
+    if gather and overlap:
         took = []
         for mode in (False, True):
             overlap = mode
@@ -232,86 +283,137 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
             c0 = time.perf_counter()
-            for t in range(cal):
-                one_step(T0 + t)
+            for t in range(CAL):
+                one_step(env, T0 + t)
             torch.cuda.synchronize()
             took.append(time.perf_counter() - c0)
-            T0 += cal
+            T0 += CAL
         tk = torch.tensor(took, dtype=torch.float64, device=device)
         dist.all_reduce(tk, op=dist.ReduceOp.MAX)
         took = [float(x) for x in tk.tolist()]
         overlap = took[1] <= took[0]
-        schedule_note = f"calibrated over {cal} steps each: serial {took[0] / cal * 1e6:.1f} us/step, overlapped {took[1] / cal * 1e6:.1f} us/step"
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events on the stream the kernel is launched on (torch's current stream == the stream handed
-    # to cda_step).  N == 1: one pair brackets the K back-to-back launches (nothing else is enqueued in
-    # between), so kernel_ms = span / K.  N > 1: the all-gather and the stream dependencies sit between launches, so
-    # single launches get their own pair - every EV_STRIDE-th one only, a timing event pair costs ~7 us of
-    # stream time (tools/host_overhead.py).
-    per_launch = gather
-    EV_STRIDE = 16
-    if per_launch:
-        timed.update({T0 + t: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for t in range(0, K, EV_STRIDE)})
-    else:
-        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    if not per_launch:
-        ev_a.record()
-    for t in range(K):
-        one_step(T0 + t)
-    if not per_launch:
-        ev_b.record()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kernel_ms = (sum(a.elapsed_time(b) for a, b in timed.values()) / len(timed)) if per_launch else ev_a.elapsed_time(ev_b) / K
+        schedule_us = {"serial_us_per_step": took[0] / CAL * 1e6, "overlapped_us_per_step": took[1] / CAL * 1e6}
+        schedule_note = f"calibrated over {CAL} steps each: serial {took[0] / CAL * 1e6:.1f} us/step, overlapped {took[1] / CAL * 1e6:.1f} us/step"
+
+    def timed_leg(e, first_t, with_events):
+        """K steps of env `e` bracketed by barrier + synchronize; returns (elapsed s, [per-launch kernel ms per stream])."""
+        if use_dist:
+            dist.barrier()
+        e.join()
+        torch.cuda.synchronize()
+        # HIP events on the stream(s) the kernel is launched on.  groups == 1, N == 1: one pair on torch's current stream
+        # (== the stream handed to cda_step) brackets the K back-to-back launches, kernel_ms = span / K.  groups > 1: one
+        # pair per group stream, each bracketing that group's K launches.  N > 1 with the all-gather: collectives and
+        # stream dependencies sit between launches, so single launches get their own pair - every EV_STRIDE-th one only,
+        # a timing event pair costs ~7 us of stream time (tools/host_overhead.py).
+        per_launch = gather
+        EV_STRIDE = 16
+        evs = []
+        if with_events and per_launch:
+            timed.update({first_t + t: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for t in range(0, K, EV_STRIDE)})
+        elif with_events:
+            lanes = e.group_streams if e.groups > 1 else [torch.cuda.current_stream(device)]
+            if e.groups > 1:
+                e.fork()
+            evs = [(s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in lanes]
+        t0 = time.perf_counter()
+        for s, a, _ in evs:
+            a.record(s)
+        for t in range(K):
+            one_step(e, first_t + t)
+        for s, _, b in evs:
+            b.record(s)
+        e.join()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        if not with_events:
+            return elapsed, []
+        if per_launch:
+            return elapsed, [sum(a.elapsed_time(b) for a, b in timed.values()) / len(timed)]
+        return elapsed, [a.elapsed_time(b) / K for _, a, b in evs]
+
+    elapsed, kernel_ms_lanes = timed_leg(env, T0, True)
     flags = env.flags()
     n_flagged = int((flags != 0).sum().item())
+    peak_orders = int(env.book_peak().max().item())
+
+    # second leg, one rank only: the same K steps with every info tensor of Info_Helper.set_info (row a14) emitted inside the
+    # timed region - the reference's step() always builds info - or, with --info, the info-less leg.
+    other = None
+    if world == 1 and not args.no_info_leg and not args.fused and not gather:
+        env2 = make_env(not args.info)
+        for t in range(W):
+            one_step(env2, t)
+        e2, _ = timed_leg(env2, W, False)
+        other = {"elapsed": e2, "flagged": int((env2.flags() != 0).sum().item())}
+        env2.close()
 
     if rank == 0:
         total_agent_steps = float(world) * N * A * K
         value = total_agent_steps / elapsed
-        alg_bytes = (ALG_BYTES_CONST + ALG_BYTES_PER_AGENT * A) * N            # per launch (one rank)
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, calibrated on a known byte count in
-        # this library's access pattern by tools/profile_gpu.sh); a committed measurement of THIS workload, not live
-        traffic, traffic_src = None, None
+        B = ALG_BYTES_CONST + ALG_BYTES_PER_AGENT * A                         # algorithmic bytes per market-step
+        n_lanes = max(1, len(kernel_ms_lanes))
+        markets_per_launch = [c for _, c in env.group_ranges] if env.groups > 1 else [N]
+        # `achieved`: algorithmic bytes of one launch / that launch's duration.  With G concurrent group chains G launches are
+        # in flight at any time; the aggregate rate of the device is the sum over the concurrent launches.
+        per_launch_gbps = [B * m / (ms * 1e-3) / 1e9 for m, ms in zip(markets_per_launch, kernel_ms_lanes)]
+        achieved = sum(per_launch_gbps)
+        kernel_ms = sum(kernel_ms_lanes) / n_lanes
+        # HBM bytes and issued wave-instructions per market-step from the PMC passes (rocprofv3 --pmc, each counter group in
+        # its own run; FETCH_SIZE / WRITE_SIZE calibrated on known byte counts by tools/profile_gpu.sh): committed
+        # measurements of THIS workload and build, not live - reported only for the shape they were taken on.
+        traffic = traffic_src = issue_frac = valu_busy = None
         try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)
-            if N == 4096 and A == 4 and not args.info and not args.fused:
-                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc, calibrated)"
+            if (pmc.get("markets"), pmc.get("agents"), bool(pmc.get("info")), pmc.get("groups")) == (N, A, bool(args.info), env.groups) and not args.fused and not gather:
+                traffic = pmc["hbm_bytes_per_market_step"] * markets_per_launch[0]
+                traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, calibrated; per market-step x markets of one launch)"
+                cycles = elapsed / K * GPU_CLOCK_GHZ * 1e9                     # device cycles per step of the whole batch
+                issue_frac = pmc["wave_insts_per_market_step"] * N / (N_SIMD * cycles)
+                valu_busy = 4.0 * pmc["valu_insts_per_market_step"] * N / (N_SIMD * cycles)
         except Exception:  # noqa: BLE001
             pass
         out = {
             "metric": "agent-steps/sec (whole node), 4 agents x N parallel markets",
             "value": value, "unit": "agent-steps/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32+dec28+f64", "data": "synthetic",
-            "config": {"workload": f"{N} markets x {A} random agents per GPU, book capacity {256} resting orders per market "
-                                   f"(BASELINE configs[2]); global {world * N} markets"
+            "dtype": "int32+dec28+f64",
+            "data": "synthetic" + ("" if total_steps <= MAX_RESIDENT or args.fused else f" (action stream cycles with period {MAX_RESIDENT} steps)"),
+            "config": {"workload": f"{N} markets x {A} random agents per GPU ({'BASELINE configs[2]' if (N, A) == CONFIGS['c3'] else 'per-GPU share of BASELINE configs[3]' if (N, A) == CONFIGS['c4'] else 'custom shape'}); "
+                                   f"book pool of 256 resting orders per market shared by both sides (= 128 per side on average; "
+                                   f"the reference is unbounded; most held by any market in this run: {peak_orders}); global {world * N} markets"
                                    + (f"; FUSED: {args.fused} steps per launch (cda_run_random)" if args.fused else ""),
-                       "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info), "gather_schedule": schedule_note,
+                       "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info), "groups": env.groups,
+                       "actions": f"cda_random_actions(seed {ACTION_SEED}, step, global market, agent), resident in HBM",
+                       "gather_schedule": schedule_note, "gather_calibration": schedule_us,
                        "collective": ("all_gather(obs|reward|flags slab), " + ("overlapped with the next step on alternating streams" if overlap else "serial")) if gather else "none",
-                       "flagged_markets": n_flagged},
+                       "flagged_markets": n_flagged, "peak_resting_orders": peak_orders},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_run_random (per step)" if args.fused else "k_step", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "concurrent_launches": n_lanes, "markets_per_launch": markets_per_launch[0],
+                         "algorithmic_bytes_per_launch": B * markets_per_launch[0], "achieved_per_launch": per_launch_gbps[0] if per_launch_gbps else None,
+                         "issue_frac": issue_frac, "valu_busy_frac": valu_busy},
         }
+        if other is not None:
+            v2 = total_agent_steps / other["elapsed"]
+            key = "without_info" if args.info else "with_info"
+            out[f"value_{key}"] = v2
+            out[f"ms_per_step_{key}"] = other["elapsed"] / K * 1e3
+            out["config"][f"flagged_markets_{key}"] = other["flagged"]
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(N, A, args.cpu_seconds, max_step)
-            except Exception as e:  # noqa: BLE001 - the baseline is a reported extra, never the measured path
-                out["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+                out["cpu_baseline"] = cpu_baseline(N, A, args.cpu_seconds, max_step, first_market)
+            except Exception as ex:  # noqa: BLE001 - the baseline is a reported extra, never the measured path
+                out["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(out))
     env.close()
     if use_dist:

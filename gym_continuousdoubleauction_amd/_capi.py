@@ -12,6 +12,7 @@ RAW_DIM = 40
 MAX_HIST = 16
 MAX_AGENTS = 16
 BOOK_CAP = 256
+MAX_GROUPS = 16
 NUM_REWARD_TERMS = 5
 
 OK = 0

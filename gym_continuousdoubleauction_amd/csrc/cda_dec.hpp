@@ -67,10 +67,17 @@ constexpr int DEC_LDS_POW = 39;
 constexpr int DEC_RCP_OFF = 640;                    // 39 * 16 = 624, padded; then RN(1 / 10^k), k = 0..9, as doubles
 constexpr int DEC_TABLE_BYTES = 736;                // 640 + 10 * 8 = 720, padded
 extern __shared__ __attribute__((aligned(16))) unsigned char cda_smem[];
-__device__ __forceinline__ const uint32_t* lds_pow10(int k) { return reinterpret_cast<const uint32_t*>(cda_smem) + 4 * k; }
-__device__ __forceinline__ double lds_rcp10(int k) { return reinterpret_cast<const double*>(cda_smem + DEC_RCP_OFF)[k]; }   // k <= 9
+// The tables are read through ABSOLUTE LDS addresses.  None of these kernels has static __shared__ data, so the dynamic
+// segment - and with it the table - starts at LDS address 0 (dec_tables_init() traps if that ever stops being true).
+// Going through the `cda_smem` symbol instead costs every out-of-line routine a lookup of the kernel's dynamic-LDS
+// offset in a table in memory (s_getpc + s_load_dword + s_waitcnt lgkmcnt(0)) on each call: two per d_round_mid.
+typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;
+typedef const __attribute__((address_space(3))) double* lds_f64p;
+__device__ __forceinline__ lds_u32p lds_pow10(int k) { return reinterpret_cast<lds_u32p>((uintptr_t)(16u * (uint32_t)k)); }
+__device__ __forceinline__ double lds_rcp10(int k) { return *reinterpret_cast<lds_f64p>((uintptr_t)((uint32_t)DEC_RCP_OFF + 8u * (uint32_t)k)); }   // k <= 9
 // every thread of the workgroup must call this once, before any decimal operation
 __device__ __forceinline__ void dec_tables_init() {
+    if ((uint32_t)(uintptr_t)cda_smem != 0u) __builtin_trap();          // see lds_pow10()
     uint32_t* t = reinterpret_cast<uint32_t*>(cda_smem);
     for (int i = (int)threadIdx.x; i < DEC_LDS_POW * 4; i += (int)blockDim.x) t[i] = POW10.v[i >> 2][i & 3];
     if (threadIdx.x < 10) reinterpret_cast<double*>(cda_smem + DEC_RCP_OFF)[threadIdx.x] = 1.0 / (double)POW10.v[threadIdx.x][0];
@@ -200,7 +207,7 @@ template <> __device__ __forceinline__ W w_pow10<8>(int k) {        // global ta
     return r;
 }
 template <> __device__ __forceinline__ W4 w_pow10<4>(int k) {       // LDS table, k <= 38
-    const uint32_t* p = lds_pow10(k);
+    const lds_u32p p = lds_pow10(k);
     W4 r; r.w[0] = p[0]; r.w[1] = p[1]; r.w[2] = p[2]; r.w[3] = p[3];
     return r;
 }
@@ -372,7 +379,7 @@ __device__ __noinline__ D d_add_mid(D a, D b) {
 }
 // u32 * 10^k (k <= 28) from the LDS table: < 2^32 * 10^28 < 2^126
 __device__ __forceinline__ u128 mul_u32_pow10_lds(uint32_t c, int k) {
-    const uint32_t* p = lds_pow10(k);
+    const lds_u32p p = lds_pow10(k);
     u128 pw = ((u128)p[2] << 64) | ((u128)p[1] << 32) | (u128)p[0];      // 10^28 < 2^94: three limbs
     return pw * (u128)c;
 }

@@ -117,10 +117,10 @@ __device__ __forceinline__ void zig_tables_init() {       // every thread of the
     for (int i = (int)threadIdx.x; i < PCG_JUMP_WORDS64; i += (int)blockDim.x) t[512 + i] = reinterpret_cast<const unsigned long long*>(&PCG_JUMP)[i];
 }
 
-__global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out) {
+__global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out, int first_market, int end_market) {
     int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
-    int mi = (int)blockIdx.x * CDA_WPB + wave;
-    if (mi >= P.n_markets) return;
+    int mi = first_market + (int)blockIdx.x * CDA_WPB + wave;
+    if (mi >= end_market) return;
     if (mask && !mask[mi]) return;
     Lds& L = wave_lds(P, wave);
     MarketPtrs mp = market_ptrs(arena, P, mi);
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P
     else if (!m.seeded) { rng_seed(m, (uint64_t)mi); m.seeded = 1; }
     m.nb = 0; m.na = 0;
     m.t_step = 0; m.lob_time = 0; m.next_oid = 0; m.has_trade = 0; m.last_trade_price = 0; m.done_mask = 0; m.flags = 0;
+    m.peak_orders = 0;
     m.last_price = rng_integers(m, P.cfg.initial_price_min, P.cfg.initial_price_max);
     int A = P.cfg.num_agents;
     if (lane < A) {                                     // Account.reset_acc (account/account.py:55-82)
@@ -166,7 +167,8 @@ struct StepArgs {
     float* obs_out; double* reward_out; uint8_t* terminated_out; uint8_t* truncated_out;
     uint8_t* done_out;                  // auto_reset only: terminated | truncated, the mask of the k_reset launch that follows
     cda_info_ptrs info; int has_info;
-    unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,24] cycle stamps
+    int first_market, end_market;       // this launch steps the markets [first_market, end_market); every array argument is the full [N, ...] one
+    unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,40] cycle stamps
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
@@ -281,20 +283,25 @@ __device__ __forceinline__ uint32_t step_market(Lds& L, Mkt& m, const Params& P,
 // phase 7, Reward_Helper.set_reward (exchg/reward_helper.py:35-102) and Done_Helper.set_done (done_helper.py:3-18) for
 // lane a < A.  The two float(Decimal) conversions of the reward are independent: the owner lane converts nav - prev_nav
 // while its helper lane (a + 16) converts max_nav - nav, in the same instruction stream.
-struct StepReward { double r, t0, t1, t2, t3, t4, drawdown; bool bankrupt; };
-__device__ __forceinline__ StepReward step_reward(Lds& L, const Params& P, uint32_t& ferr, int lane) {
+struct StepReward { double r, t0, t1, t2, t3, t4, drawdown, max_nav; bool bankrupt; };
+// WITH_MAX_NAV (info outputs): a third lane (a + 32) converts max_nav itself through the same call site, so the info
+// tensor float(max_nav) costs no conversion of its own.
+__device__ __forceinline__ StepReward step_reward(Lds& L, const Params& P, uint32_t& ferr, int lane, bool with_max_nav = false) {
     const int A = P.cfg.num_agents;
-    StepReward o; o.r = o.t0 = o.t1 = o.t2 = o.t3 = o.t4 = o.drawdown = 0.0; o.bankrupt = false;
+    StepReward o; o.r = o.t0 = o.t1 = o.t2 = o.t3 = o.t4 = o.drawdown = o.max_nav = 0.0; o.bankrupt = false;
     double conv = 0.0;
-    if (lane_acc(lane) < A && lane_grp(lane) < 2) {
+    if (lane_acc(lane) < A && lane_grp(lane) < (with_max_nav ? 3 : 2)) {
         const Acc& a = L.acc[lane_acc(lane)];
-        const bool own = lane_grp(lane) == 0;
-        D nav = ld_dec(a.nav);
-        D x = own ? nav : ld_dec(a.max_nav), y = own ? ld_dec(a.prev_nav) : nav;
-        D df = d_sub(x, y);                                  // ONE call site each, so owner and helper stay converged
-        if (own || d_sgn(df) > 0) conv = d_to_double(df, &ferr);
+        const int g = lane_grp(lane);
+        const bool own = g == 0;
+        D nav = ld_dec(a.nav), mx = ld_dec(a.max_nav);
+        D x = own ? nav : mx, y = own ? ld_dec(a.prev_nav) : nav;
+        D df = d_sub(x, y);                                  // ONE call site each, so owner and helpers stay converged
+        if (g == 2) df = mx;
+        if (g != 1 || d_sgn(df) > 0) conv = d_to_double(df, &ferr);
     }
     const double conv_helper = __shfl(conv, (lane + 16) & 63, WAVE);
+    o.max_nav = __shfl(conv, (lane + 32) & 63, WAVE);
     if (lane < A) {
         const Acc& a = L.acc[lane];
         double nav_change = conv;
@@ -317,8 +324,8 @@ __device__ __forceinline__ void clear_step_counters(Acc& a) {          // exchg_
 
 __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
     int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
-    int mi = (int)blockIdx.x * CDA_WPB + wave;
-    const bool live = mi < P.n_markets;       // (a workgroup's surplus waves still take part in the table setup)
+    int mi = S.first_market + (int)blockIdx.x * CDA_WPB + wave;
+    const bool live = mi < S.end_market;      // (a workgroup's surplus waves still take part in the table setup)
     MarketPtrs mp = market_ptrs(arena, P, live ? mi : 0);
     MarketPrefetch mq;
     if (live) mq = load_market_issue<true>(mp, P, lane);    // the record's requests fly while the tables are staged
@@ -332,8 +339,8 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
     unsigned long long* ph = nullptr;
 #ifdef CDA_PHASE_TIMING
-    for (int i = 0; i < 14; i++) m.tacc[i] = 0;
-    ph = S.phase_cycles ? S.phase_cycles + (size_t)mi * 24 : nullptr;
+    for (int i = 0; i < 24; i++) m.tacc[i] = 0;
+    ph = S.phase_cycles ? S.phase_cycles + (size_t)mi * 40 : nullptr;
 #endif
     PH_MARK(ph, 0);
     load_market_finish<true>(mp, P, L, m, mq, lane);
@@ -369,22 +376,30 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     PH_MARK(ph, 7);
     // 7. set_step_outputs (exchg_helper.py:93-124)
     uint32_t ferr = 0;
-    const StepReward rw = step_reward(L, P, ferr, lane);
+    const StepReward rw = step_reward(L, P, ferr, lane, S.has_info != 0);
+    if (S.has_info) {                                                          // Info_Helper.set_info (info_helper.py:30-116)
+        // the four float(Decimal) fields of an account are converted by four lanes (a, a+16, a+32, a+48) through ONE call site
+        const cda_info_ptrs& I = S.info;
+        const int al = lane_acc(lane), g = lane_grp(lane);
+        if (al < A) {
+            const Acc& a = L.acc[al];
+            const cda_dec& src = g == 0 ? a.vwap : (g == 1 ? a.cash : (g == 2 ? a.hold : a.posval));
+            double* dst = g == 0 ? I.vwap : (g == 1 ? I.cash : (g == 2 ? I.cash_on_hold : I.position_val));
+            const double v = d_to_double(ld_dec(src), &ferr);
+            if (dst) dst[(size_t)mi * (size_t)A + (size_t)al] = v;
+        }
+    }
     if (lane < A) {
         Acc& a = L.acc[lane];
         size_t ix = (size_t)mi * (size_t)A + (size_t)lane;
         S.reward_out[ix] = rw.r;
-        if (S.has_info) {                                                      // Info_Helper.set_info (info_helper.py:30-116)
+        if (S.has_info) {
             const cda_info_ptrs& I = S.info;
             if (I.nav) I.nav[ix] = a.nav;
             if (I.num_trades) I.num_trades[ix] = a.num_trades;
             if (I.net_position) I.net_position[ix] = a.net_position;
-            if (I.vwap) I.vwap[ix] = d_to_double(ld_dec(a.vwap), &ferr);
-            if (I.cash) I.cash[ix] = d_to_double(ld_dec(a.cash), &ferr);
-            if (I.cash_on_hold) I.cash_on_hold[ix] = d_to_double(ld_dec(a.hold), &ferr);
-            if (I.position_val) I.position_val[ix] = d_to_double(ld_dec(a.posval), &ferr);
             if (I.drawdown) I.drawdown[ix] = rw.drawdown;
-            if (I.max_nav) I.max_nav[ix] = d_to_double(ld_dec(a.max_nav), &ferr);
+            if (I.max_nav) I.max_nav[ix] = rw.max_nav;
             if (I.num_trades_step) I.num_trades_step[ix] = a.num_trades_step;
             if (I.num_passive_fills_step) I.num_passive_fills_step[ix] = a.num_passive_fills_step;
             if (I.order_step_placed) I.order_step_placed[ix] = a.order_step_placed;
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* a
     store_levels(mp, L, lane);
     PH_MARK(ph, 9);
 #ifdef CDA_PHASE_TIMING
-    if (ph && lane == 0) for (int i = 0; i < 14; i++) ph[10 + i] = m.tacc[i];
+    if (ph && lane == 0) for (int i = 0; i < 24; i++) ph[10 + i] = m.tacc[i];
 #endif
 }
 
@@ -449,7 +464,7 @@ __global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_run_random(uint
     Mkt m;
     const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
 #ifdef CDA_PHASE_TIMING
-    for (int i = 0; i < 14; i++) m.tacc[i] = 0;
+    for (int i = 0; i < 24; i++) m.tacc[i] = 0;
 #endif
     load_market<true>(mp, P, L, m, lane);
     float* hist = lds_hist(L, A);                           // the history ring stays in LDS for the whole episode
@@ -573,12 +588,33 @@ __global__ void k_flags(uint8_t* arena, Params P, uint32_t* out) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i < P.n_markets) out[i] = ((const uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride))[H_FLAGS];
 }
+// cda_create: every market record is built the way the reference's __init__ leaves a fresh env (accounts at init_cash:
+// agent/trader.py:21-23 -> account/account.py:13-53; empty book; zero history), so that a step / run_random / place_order
+// on a never-reset env works on defined state.  One thread per market; word loops (runs once per env).
 __global__ void k_init_arena(uint8_t* arena, Params P) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i < P.n_markets) {
-        uint32_t* h = (uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride);
-        for (int k = 0; k < H_WORDS; k++) h[k] = 0;
+    if (i >= P.n_markets) return;
+    uint8_t* rec = arena + (size_t)i * (size_t)P.lay.stride;
+    uint32_t* w = (uint32_t*)rec;
+    for (int k = 0; k < P.lay.stride / 4; k++) w[k] = 0;
+    Acc* acc = (Acc*)(rec + P.lay.acc_off);
+    uint32_t f = 0;
+    const D cash = d_from_i64(P.cfg.init_cash);
+    for (int a = 0; a < P.cfg.num_agents; a++) { st_dec(acc[a].cash, cash, f); st_dec(acc[a].nav, cash, f); st_dec(acc[a].prev_nav, cash, f); st_dec(acc[a].max_nav, cash, f); }
+}
+// the random agents' actions of steps [step0, step0 + n_steps) for n_markets markets: one thread per (step, market, agent)
+__global__ void k_random_actions(uint64_t seed, uint64_t market_base, int step0, int n_steps, int n_markets, int num_agents,
+                                 int32_t* category, float* size_mean, float* size_sigma, int32_t* price, int32_t* price_offset) {
+    const size_t per_step = (size_t)n_markets * (size_t)num_agents, total = per_step * (size_t)n_steps;
+    for (size_t ix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ix < total; ix += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = ix / per_step, r = ix - t * per_step;
+        const size_t mk = r / (size_t)num_agents, a = r - mk * (size_t)num_agents;
+        cda_random_action(seed, market_base + (uint64_t)mk, (uint32_t)(step0 + (int)t), (uint32_t)a, &category[ix], &size_mean[ix], &size_sigma[ix], &price[ix], &price_offset[ix]);
     }
+}
+__global__ void k_book_peak(const uint8_t* arena, Params P, int32_t* out) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < P.n_markets) out[i] = (int32_t)((const uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride))[H_PEAK_ORDERS];
 }
 
 // debug micro-benchmark (tools/opbench.py): cycles of one decimal operation on representative ledger operands,
@@ -664,7 +700,7 @@ struct cda_env {
 };
 
 static thread_local char g_err[256] = "";
-static unsigned long long* g_phase_cycles = NULL;   // debug (CDA_PHASE_TIMING builds): device buffer [N,24]
+static unsigned long long* g_phase_cycles = NULL;   // debug (CDA_PHASE_TIMING builds): device buffer [N,40]
 static int hip_fail(hipError_t e, const char* what) {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
     return CDA_ERR_HIP;
@@ -700,6 +736,11 @@ static int cfg_ok(const cda_config* c) {
     if (c->tick_size != 1) return CDA_ERR_UNSUPPORTED;
     if (c->initial_price_max < c->initial_price_min || c->initial_price_min < 0) return CDA_ERR_INVALID;
     if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;
+    // Sizes are int32 on the device and a price level sums up to CDA_BOOK_CAP of them: the largest decodable size is
+    // (mkt_max_size * limit_size_multiple - min_size) / 2 * |mean| + sigma * z + min_size, clamped at 1e9 (flagged).  Keep
+    // the configured scale itself well inside int32 so that neither the product nor a level sum can wrap silently.
+    if ((int64_t)c->mkt_max_size * (int64_t)c->limit_size_multiple + (int64_t)c->min_size > (int64_t)(1 << 30) / CDA_BOOK_CAP) return CDA_ERR_INVALID;
+    if (c->max_step < 1) return CDA_ERR_INVALID;
     if (c->init_cash > (1LL << 62) || c->init_cash < -(1LL << 62)) return CDA_ERR_INVALID;
     if (c->auto_reset != 0 && c->auto_reset != 1) return CDA_ERR_INVALID;
     return CDA_OK;
@@ -721,7 +762,7 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     Params& P = e->P;
     P.cfg = *cfg; P.n_markets = n_markets;
     P.mkt_mul = (float)((double)(cfg->mkt_max_size - cfg->min_size) / 2.0);
-    P.lim_mul = (float)((double)(cfg->mkt_max_size * cfg->limit_size_multiple - cfg->min_size) / 2.0);
+    P.lim_mul = (float)((double)((int64_t)cfg->mkt_max_size * (int64_t)cfg->limit_size_multiple - (int64_t)cfg->min_size) / 2.0);
     int off = HEADER_BYTES;
     P.lay.acc_off = off; off += cfg->num_agents * (int)sizeof(Acc);
     P.lay.hist_off = off; off += cfg->n_hist * CDA_SNAPSHOT_DIM * 4; off = (off + 15) & ~15;
@@ -747,33 +788,91 @@ int cda_destroy(cda_env* e) {
     return CDA_OK;
 }
 
-int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs_out, void* stream) {
-    if (!e) return CDA_ERR_INVALID;
+static int range_ok(const cda_env* e, int32_t first, int32_t n) { return first >= 0 && n >= 1 && (int64_t)first + (int64_t)n <= (int64_t)e->P.n_markets; }
+
+int cda_reset_range(cda_env* e, int32_t first_market, int32_t n_markets, const uint64_t* seeds, const uint8_t* mask, float* obs_out, void* stream) {
+    if (!e || !range_ok(e, first_market, n_markets)) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_reset, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out);
+    hipLaunchKernelGGL(k_reset, grid_for(n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out,
+                       (int)first_market, (int)(first_market + n_markets));
     HIPCHK(hipGetLastError());
     return CDA_OK;
+}
+int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs_out, void* stream) {
+    if (!e) return CDA_ERR_INVALID;
+    return cda_reset_range(e, 0, e->P.n_markets, seeds, mask, obs_out, stream);
+}
+
+// one launch of k_step (+ the auto-reset pass) over [first, first + n) on `stream`; arguments validated by the callers
+static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0, hipStream_t stream) {
+    StepArgs S = S0;
+    S.first_market = first; S.end_market = first + n;
+    hipLaunchKernelGGL(k_step, grid_for(n), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, stream, e->arena, e->P, S);
+    HIPCHK(hipGetLastError());
+    if (e->P.cfg.auto_reset) {            // same stream: every market-wave of it exits at once unless its episode just ended
+        hipLaunchKernelGGL(k_reset, grid_for(n), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), stream, e->arena, e->P,
+                           (const uint64_t*)NULL, (const uint8_t*)e->done_buf, S.obs_out, (int)first, (int)(first + n));
+        HIPCHK(hipGetLastError());
+    }
+    return CDA_OK;
+}
+static int fill_step_args(cda_env* e, StepArgs& S, const int32_t* category, const float* size_mean, const float* size_sigma,
+                          const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                          float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out, const cda_info_ptrs* info_out) {
+    if (!e || !category || !size_mean || !size_sigma || !price || !price_offset) return CDA_ERR_INVALID;
+    if (!obs_out || !reward_out || !terminated_out || !truncated_out) return CDA_ERR_INVALID;
+    S.category = category; S.size_mean = size_mean; S.size_sigma = size_sigma; S.price = price; S.price_offset = price_offset;
+    S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
+    if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
+    S.phase_cycles = g_phase_cycles;
+    S.done_out = e->P.cfg.auto_reset ? e->done_buf : NULL;
+    S.first_market = 0; S.end_market = e->P.n_markets;
+    return CDA_OK;
+}
+
+int cda_step_range(cda_env* e, int32_t first_market, int32_t n_markets,
+                   const int32_t* category, const float* size_mean, const float* size_sigma,
+                   const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                   float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                   const cda_info_ptrs* info_out, void* stream) {
+    StepArgs S;
+    int rc = fill_step_args(e, S, category, size_mean, size_sigma, price, price_offset, present, obs_out, reward_out, terminated_out, truncated_out, info_out);
+    if (rc) return rc;
+    if (!range_ok(e, first_market, n_markets)) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    return launch_step(e, first_market, n_markets, S, (hipStream_t)stream);
 }
 
 int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const float* size_sigma,
              const int32_t* price, const int32_t* price_offset, const uint8_t* present,
              float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
              const cda_info_ptrs* info_out, void* stream) {
-    if (!e || !category || !size_mean || !size_sigma || !price || !price_offset) return CDA_ERR_INVALID;
-    if (!obs_out || !reward_out || !terminated_out || !truncated_out) return CDA_ERR_INVALID;
-    HIPCHK(hipSetDevice(e->device));
+    if (!e) return CDA_ERR_INVALID;
+    return cda_step_range(e, 0, e->P.n_markets, category, size_mean, size_sigma, price, price_offset, present,
+                          obs_out, reward_out, terminated_out, truncated_out, info_out, stream);
+}
+
+void cda_group_range(int32_t n_markets, int32_t n_groups, int32_t group, int32_t* first_out, int32_t* count_out) {
+    const int64_t lo = (int64_t)n_markets * group / n_groups, hi = (int64_t)n_markets * (group + 1) / n_groups;
+    if (first_out) *first_out = (int32_t)lo;
+    if (count_out) *count_out = (int32_t)(hi - lo);
+}
+
+int cda_step_groups(cda_env* e, int32_t n_groups,
+                    const int32_t* category, const float* size_mean, const float* size_sigma,
+                    const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                    float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                    const cda_info_ptrs* info_out, void* const* streams) {
     StepArgs S;
-    S.category = category; S.size_mean = size_mean; S.size_sigma = size_sigma; S.price = price; S.price_offset = price_offset;
-    S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
-    if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
-    S.phase_cycles = g_phase_cycles;
-    S.done_out = e->P.cfg.auto_reset ? e->done_buf : NULL;
-    hipLaunchKernelGGL(k_step, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, S);
-    HIPCHK(hipGetLastError());
-    if (e->P.cfg.auto_reset) {            // same stream: every market-wave of it exits at once unless its episode just ended
-        hipLaunchKernelGGL(k_reset, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P,
-                           (const uint64_t*)NULL, (const uint8_t*)e->done_buf, obs_out);
-        HIPCHK(hipGetLastError());
+    int rc = fill_step_args(e, S, category, size_mean, size_sigma, price, price_offset, present, obs_out, reward_out, terminated_out, truncated_out, info_out);
+    if (rc) return rc;
+    if (!streams || n_groups < 1 || n_groups > e->P.n_markets || n_groups > CDA_MAX_GROUPS) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    for (int32_t g = 0; g < n_groups; g++) {
+        int32_t first, n;
+        cda_group_range(e->P.n_markets, n_groups, g, &first, &n);
+        rc = launch_step(e, first, n, S, (hipStream_t)streams[g]);
+        if (rc) return rc;
     }
     return CDA_OK;
 }
@@ -801,6 +900,26 @@ int cda_random_actions_host(uint64_t action_seed, uint64_t market_index_base, in
             cda_random_action(action_seed, market_index_base + (uint64_t)i, (uint32_t)step, (uint32_t)a, &category[ix], &size_mean[ix], &size_sigma[ix],
                               &price[ix], &price_offset[ix]);
         }
+    return CDA_OK;
+}
+
+int cda_random_actions(uint64_t action_seed, uint64_t market_index_base, int32_t step0, int32_t n_steps, int32_t n_markets, int32_t num_agents,
+                       int32_t* category, float* size_mean, float* size_sigma, int32_t* price, int32_t* price_offset, void* stream) {
+    if (step0 < 0 || n_steps < 0 || n_markets < 0 || num_agents < 1 || !category || !size_mean || !size_sigma || !price || !price_offset) return CDA_ERR_INVALID;
+    const size_t total = (size_t)n_steps * (size_t)n_markets * (size_t)num_agents;
+    if (total == 0) return CDA_OK;
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_random_actions, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream, action_seed, market_index_base,
+                       (int)step0, (int)n_steps, (int)n_markets, (int)num_agents, category, size_mean, size_sigma, price, price_offset);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+
+int cda_book_peak(cda_env* e, int32_t* peak_out, void* stream) {
+    if (!e || !peak_out) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_book_peak, dim3((unsigned)((e->P.n_markets + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)e->arena, e->P, peak_out);
+    HIPCHK(hipGetLastError());
     return CDA_OK;
 }
 
@@ -1001,7 +1120,7 @@ int cda_debug_calib(void* dev_buf, size_t n_bytes, int mode, void* stream) {
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
-/* debug hook (not in include/cda.h): device buffer [N,24] of cycle stamps, used by tools/phase_timing.py */
+/* debug hook (not in include/cda.h): device buffer [N,40] of cycle stamps, used by tools/phase_timing.py */
 void cda_debug_set_phase_buffer(unsigned long long* dev_buf) { g_phase_cycles = dev_buf; }
 #ifdef CDA_DEC_COUNTERS
 int cda_debug_dec_calls(unsigned long long* host8, int reset) {

@@ -46,6 +46,7 @@ enum {
     H_RNG_STATE_LO = 0, H_RNG_STATE_HI = 2, H_RNG_INC_LO = 4, H_RNG_INC_HI = 6, H_HAS_U32 = 8, H_UINTEGER = 9,
     H_T_STEP = 10, H_LOB_TIME = 11, H_NEXT_OID = 12, H_LAST_PRICE = 13, H_HAS_TRADE = 14, H_LAST_TRADE_PRICE = 15,
     H_DONE_MASK = 16, H_FLAGS = 17, H_N_BIDS = 18, H_N_ASKS = 19, H_SEEDED = 20, H_HIST_HEAD = 21, H_LEVELS_VALID = 22,
+    H_PEAK_ORDERS = 23,       // most resting orders (both sides together) the market has held since its last reset (cda_book_peak)
     H_LEVELS = 24,            // 40 words: the top-10 aggregation (lvl_px[2][10], lvl_sz[2][10]) of the book as stored,
                               // so that the next step's pre-step snapshot is a copy instead of a scan (valid flag above)
     H_WORDS = 64
@@ -116,16 +117,29 @@ struct Mkt {
     uint32_t done_mask, flags;
     int32_t nb, na;              // resting orders per side (two scalars: a dynamically indexed array would force Mkt into scratch)
     int32_t seeded, hist_head, levels_valid;
+    int32_t peak_orders;         // census: see H_PEAK_ORDERS
     int32_t fills;               // fills settled in the current step (issue priority of this wave grows with it)
 #ifdef CDA_PHASE_TIMING
-    unsigned long long tacc[14];    // debug: cycles in approval / find / match+settle / insert+remove / escrow+cancel, fills, 8 free slots
+    unsigned long long tacc[24];    // debug: cycles in approval / find / match+settle / insert+remove / escrow+cancel, fills, ...; 14..20: inside a fill
 #endif
 };
 #ifdef CDA_PHASE_TIMING
 #define TACC_BEGIN() unsigned long long _tb = __builtin_readcyclecounter()
 #define TACC_END(m, i) do { unsigned long long _te = __builtin_readcyclecounter(); (m).tacc[i] += _te - _tb; _tb = _te; } while (0)
 #define TACC_COUNT(m, i, n) do { (m).tacc[i] += (n); } while (0)
+#define CDA_TF_PARAM , unsigned long long* tf
+#define CDA_TF_ARG(m) , (m).tacc
+#define TF_BEGIN() unsigned long long _fb = __builtin_readcyclecounter()
+#define TF_END(i) do { unsigned long long _fe = __builtin_readcyclecounter(); tf[i] += _fe - _fb; _fb = _fe; } while (0)
+#define TF_COUNT(i) do { tf[i] += 1; } while (0)
+#define TF_RESYNC() do { _fb = __builtin_readcyclecounter(); } while (0)
 #else
+#define CDA_TF_PARAM
+#define CDA_TF_ARG(m)
+#define TF_BEGIN() do {} while (0)
+#define TF_END(i) do {} while (0)
+#define TF_COUNT(i) do {} while (0)
+#define TF_RESYNC() do {} while (0)
 #define TACC_BEGIN() do {} while (0)
 #define TACC_END(m, i) do {} while (0)
 #define TACC_COUNT(m, i, n) do {} while (0)
@@ -331,6 +345,7 @@ __device__ __forceinline__ void decode_header(uint32_t v, Mkt& m) {
     m.done_mask = RL(H_DONE_MASK); m.flags = RL(H_FLAGS);
     m.nb = (int32_t)RL(H_N_BIDS); m.na = (int32_t)RL(H_N_ASKS);
     m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD); m.levels_valid = (int32_t)RL(H_LEVELS_VALID);
+    m.peak_orders = (int32_t)RL(H_PEAK_ORDERS);
     m.fills = 0;
     #undef RL
 }
@@ -346,6 +361,7 @@ __device__ __forceinline__ void store_header(uint32_t* hp, const Mkt& m, int lan
         hp[H_DONE_MASK] = m.done_mask; hp[H_FLAGS] = m.flags;
         hp[H_N_BIDS] = (uint32_t)m.nb; hp[H_N_ASKS] = (uint32_t)m.na;
         hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head; hp[H_LEVELS_VALID] = (uint32_t)m.levels_valid;
+        hp[H_PEAK_ORDERS] = (uint32_t)m.peak_orders;
     }
 }
 // book record in HBM: [field][CAP] int32, pooled like the LDS image; only the live prefix of each side moves.
@@ -521,8 +537,9 @@ __device__ __forceinline__ D posval_from(Acc& a, uint32_t n, int32_t price, bool
 // _size_increase/_size_decrease store is therefore dead there and its four decimal operations are skipped; the paths
 // that READ position_val (_neutral, _covered) are untouched.  The one-order test hook keeps the full semantics.
 template <bool LAZY_POSVAL>
-__device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t price, int init_side, uint32_t& flags, int lane) {
+__device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t q, int32_t price, int init_side, uint32_t& flags, int lane CDA_TF_PARAM) {
     uint32_t f = 0;
+    TF_BEGIN();
     const int al = lane_acc(lane), g = lane_grp(lane);
     if (counter != tr) {
         if ((al == tr || al == counter) && g < 3) {
@@ -538,7 +555,9 @@ __device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t
             else mode = ap > (uint32_t)q ? 2 : (ap == (uint32_t)q ? 3 : 4);
             const D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);             // trade value
             D X = d_zero(), mkt = d_zero();
+            TF_END(14);
             if (g == 0 && mode != 0) X = d_mul_int(ld_dec(a.vwap), ap);         // stage 1
+            TF_END(15);
             D x2 = d_zero(), y2 = d_zero();
             cda_dec* dst = nullptr;
             bool s2 = false;
@@ -558,7 +577,9 @@ __device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t
                 }
             }
             D Y = d_zero();
+            TF_END(16);
             if (s2) { Y = d_add(x2, y2); if (dst) st_dec(*dst, Y, f); }        // stage 2
+            TF_END(17);
             if (g == 0) {                                    // stage 3
                 a.num_trades += 1; a.num_trades_step += 1; if (is_counter) a.num_passive_fills_step += 1;
                 if (mode == 0) st_dec(a.vwap, d_price(price), f);
@@ -583,8 +604,10 @@ __device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t
                 if (np > 2147483647LL || np < -2147483647LL) f |= CDA_FLAG_INT_OVERFLOW << 8;
                 a.net_position = (int32_t)np;
             }
+            TF_END(18); TF_COUNT(20);
         }
         CDA_WSYNC();
+        TF_RESYNC();
     } else if (lane == tr) {                             // init_is_counter_cash_transfer (cash_processor.py:55-62)
         Acc& a = L.acc[lane];
         D tv = d_mul_u32(d_price(price), (uint32_t)q, 0);
@@ -593,6 +616,7 @@ __device__ __forceinline__ void settle_fill(Lds& L, int tr, int counter, int32_t
     }
     if (__ballot((f & 0xffu) != 0)) flags |= CDA_FLAG_DEC_DOMAIN;
     if (__ballot((f >> 8) != 0)) flags |= CDA_FLAG_INT_OVERFLOW;
+    TF_END(19);
 }
 
 // matching loops of OrderBook.process_order_list / process_market_order / process_limit_order
@@ -616,7 +640,7 @@ __device__ __forceinline__ int32_t match(Lds& L, Mkt& m, int tr, int own_side, i
         if (m.fills == 1) __builtin_amdgcn_s_setprio(1);
         else if (m.fills == 2) __builtin_amdgcn_s_setprio(2);
         else if (m.fills == 3) __builtin_amdgcn_s_setprio(3);
-        settle_fill<LAZY_POSVAL>(L, tr, c, f, p, own_side, m.flags, lane);
+        settle_fill<LAZY_POSVAL>(L, tr, c, f, p, own_side, m.flags, lane CDA_TF_ARG(m));
     }
     if (h) { book_remove(bk, opp, nopp, 0, h, lane); mkt_set_n(m, opp, nopp - h); }
     return qty;
@@ -738,7 +762,7 @@ __device__ __forceinline__ void place_order(Lds& L, Mkt& m, int tr, int type, in
         TACC_END(m, 2);
         if (left > 0 && can_rest) {
             const int nown = mkt_n(m, side);
-            if (book_insert(bk, side, nown, mkt_n(m, side ^ 1), price, left, tr, rest_oid, m.lob_time, lane)) { mkt_set_n(m, side, nown + 1); rest_price = price; rest_qty = left; }
+            if (book_insert(bk, side, nown, mkt_n(m, side ^ 1), price, left, tr, rest_oid, m.lob_time, lane)) { mkt_set_n(m, side, nown + 1); rest_price = price; rest_qty = left; m.peak_orders = max(m.peak_orders, m.nb + m.na); }
             else m.flags |= CDA_FLAG_BOOK_OVERFLOW;
         }
         TACC_END(m, 3);

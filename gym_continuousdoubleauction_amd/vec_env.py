@@ -23,7 +23,7 @@ class CDAVecEnv:
     """Batched env.  Tensors: actions [N,A]; obs f32[N, n_hist*42]; reward f64[N,A];
     terminated/truncated bool[N] (the reference's "__all__" flags); info = dict of SoA tensors."""
 
-    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True, out_buffers=1):
+    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True, out_buffers=1, groups=1):
         self.cfg_struct, self.config = K.make_config(config)
         self.n_markets = int(n_markets)
         self.num_agents = self.cfg_struct.num_agents
@@ -66,6 +66,26 @@ class CDAVecEnv:
                 self.info[name] = t
                 setattr(self._info_ptrs, name, t.data_ptr())
         self._info_ref = C.byref(self._info_ptrs) if self.with_info else None
+        # groups > 1: step() launches the batch as `groups` contiguous market groups, each an independent chain of
+        # launches on its own stream (cda_step_groups).  Markets never interact, so nothing is lost - and a group's
+        # slowest market no longer stalls the markets of the other groups.  See group_streams / join().
+        self.groups = int(groups)
+        if not 1 <= self.groups <= min(K.MAX_GROUPS, self.n_markets):
+            raise ValueError(f"groups must be in 1..{min(K.MAX_GROUPS, self.n_markets)}")
+        self.group_ranges = []
+        for g in range(self.groups):
+            first, cnt = C.c_int32(), C.c_int32()
+            lib().cda_group_range(self.n_markets, self.groups, g, C.byref(first), C.byref(cnt))
+            self.group_ranges.append((first.value, cnt.value))
+        self.group_streams = []
+        if self.groups > 1:
+            from .streams import concurrent_streams
+            self.group_streams = list(concurrent_streams(dev, self.groups))     # streams on DISTINCT hardware queues (measured once per process)
+            self._stream_arr = (C.c_void_p * self.groups)(*[s.cuda_stream for s in self.group_streams])
+            self._groups_call = lib().cda_step_groups
+            self._fork_ev = torch.cuda.Event()
+            self._join_ev = [torch.cuda.Event() for _ in range(self.groups)]
+            self._need_fork = True
 
     def _bind_outputs(self):
         self.out_slab = self._slabs[self._cur]
@@ -107,12 +127,35 @@ class CDAVecEnv:
             mask_t = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
             if mask_t.shape != (self.n_markets,):
                 raise ValueError("mask must have shape [n_markets]")
+        self.join()                         # (groups > 1: the reset is issued on the caller's stream, after every group's last step)
         with torch.cuda.device(self.device):
             check(lib().cda_reset(self._h, seeds_t.data_ptr() if seeds_t is not None else None,
                                   mask_t.data_ptr() if mask_t is not None else None,
                                   self.obs.data_ptr(), self._stream()), "cda_reset")
         self._keep = (seeds_t, mask_t)
+        if self.groups > 1:
+            self._need_fork = True          # the group streams must see this reset (issued on the caller's stream)
         return self.obs
+
+    # ------------------------------------------------------------------ market groups (groups > 1)
+    def fork(self):
+        """Order every group stream after the work enqueued so far on the caller's current stream (the reset, the
+        actions a policy just produced).  step() does it by itself after reset() and join()."""
+        self._fork_ev.record(torch.cuda.current_stream(self.device))
+        for s in self.group_streams:
+            s.wait_event(self._fork_ev)
+        self._need_fork = False
+
+    def join(self):
+        """Order the caller's current stream after every group's last step, so that the outputs can be consumed there;
+        the next step() forks again.  A caller that pipelines per group works inside `torch.cuda.stream(group_streams[g])`
+        on the rows `group_ranges[g]` instead and never joins."""
+        if self.groups > 1:
+            cur = torch.cuda.current_stream(self.device)
+            for ev, s in zip(self._join_ev, self.group_streams):
+                ev.record(s)
+                cur.wait_event(ev)
+            self._need_fork = True
 
     def _prep(self, x, dtype):
         if (isinstance(x, torch.Tensor) and x.dtype == dtype and x.device == self.device and x.is_contiguous()
@@ -139,14 +182,22 @@ class CDAVecEnv:
         if len(self._views) > 1:
             self._cur = (self._cur + 1) % len(self._views)
             self._bind_outputs()
-        call = (self._h, cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
-                ps.data_ptr() if ps is not None else None, *self._out_ptrs[self._cur],
-                self._info_ref, torch.cuda.current_stream(self.device).cuda_stream)
+        if self.groups > 1:
+            if self._need_fork:
+                self.fork()
+            fn = self._groups_call
+            call = (self._h, self.groups, cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
+                    ps.data_ptr() if ps is not None else None, *self._out_ptrs[self._cur], self._info_ref, self._stream_arr)
+        else:
+            fn = self._step_call
+            call = (self._h, cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
+                    ps.data_ptr() if ps is not None else None, *self._out_ptrs[self._cur],
+                    self._info_ref, torch.cuda.current_stream(self.device).cuda_stream)
         if torch.cuda.current_device() == self.device_index:
-            rc = self._step_call(*call)
+            rc = fn(*call)
         else:                               # the library selects its own device; keep the caller's current one intact
             with torch.cuda.device(self.device):
-                rc = self._step_call(*call)
+                rc = fn(*call)
         if rc != 0:
             check(rc, "cda_step")
         self._keep = (cat, sm, ss, pr, po, ps)      # keep inputs alive until the async kernel has consumed them
@@ -158,6 +209,7 @@ class CDAVecEnv:
         episode end.  Returns (obs f32[N,obs_dim], episode_return f64[N,A], terminated, truncated, steps_taken i32[N]);
         bit-identical to `n_steps` calls of step() on `random_actions(t)`."""
         N, A, dev = self.n_markets, self.num_agents, self.device
+        self.join()
         if not hasattr(self, "_rr_steps"):
             self._rr_return = torch.zeros((N, A), dtype=torch.float64, device=dev)
             self._rr_steps = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -166,6 +218,17 @@ class CDAVecEnv:
                                        self.obs.data_ptr(), self._rr_return.data_ptr(), self._term.data_ptr(), self._trunc.data_ptr(),
                                        self._rr_steps.data_ptr(), self._stream()), "cda_run_random")
         return self.obs, self._rr_return, self._term.view(torch.bool), self._trunc.view(torch.bool), self._rr_steps
+
+    def random_actions_device(self, step0, n_steps, action_seed=0, market_index_base=0):
+        """The same stream generated on the device: five [n_steps, N, A] tensors for steps step0 .. step0 + n_steps - 1."""
+        N, A, dev = self.n_markets, self.num_agents, self.device
+        cat, price, off = (torch.empty((n_steps, N, A), dtype=torch.int32, device=dev) for _ in range(3))
+        mean, sigma = (torch.empty((n_steps, N, A), dtype=torch.float32, device=dev) for _ in range(2))
+        with torch.cuda.device(self.device):
+            check(lib().cda_random_actions(int(action_seed) & (2 ** 64 - 1), int(market_index_base) & (2 ** 64 - 1), int(step0), int(n_steps), N, A,
+                                           cat.data_ptr(), mean.data_ptr(), sigma.data_ptr(), price.data_ptr(), off.data_ptr(), self._stream()),
+                  "cda_random_actions")
+        return cat, mean, sigma, price, off
 
     def random_actions(self, step, action_seed=0, market_index_base=0):
         """The five [N,A] action arrays (numpy, host) the random agents of `run_random` play at step `step`."""
@@ -195,20 +258,31 @@ class CDAVecEnv:
         check(lib().cda_set_state(self._h, market, C.byref(state)), "cda_set_state")
 
     def raw_snapshot(self):
+        self.join()
         raw = torch.zeros((self.n_markets, K.RAW_DIM), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             check(lib().cda_get_raw_snapshot(self._h, raw.data_ptr(), self._stream()), "cda_get_raw_snapshot")
         return raw
 
     def flags(self):
+        self.join()
         f = torch.zeros(self.n_markets, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             check(lib().cda_last_flags(self._h, f.data_ptr(), self._stream()), "cda_last_flags")
         return f
 
+    def book_peak(self):
+        """Census: the most resting orders (both sides together) each market has held since its last reset, int32[N]."""
+        self.join()
+        p = torch.zeros(self.n_markets, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().cda_book_peak(self._h, p.data_ptr(), self._stream()), "cda_book_peak")
+        return p
+
     def nav_conservation(self, tolerance=1e-6):
         """The reference's end-of-episode invariant for every market, computed on the device in the ledger's own decimal
         arithmetic: (float(|sum of NAV - A * init_cash|) f64[N], violated bool[N])."""
+        self.join()
         err = torch.zeros(self.n_markets, dtype=torch.float64, device=self.device)
         bad = torch.zeros(self.n_markets, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):

@@ -39,6 +39,7 @@ extern "C" {
 #define CDA_BOOK_CAP      256           /* resting orders per market, both sides together (reference: unbounded) */
 #endif
 #define CDA_NUM_REWARD_TERMS 5          /* reward_helper.py:75-81 */
+#define CDA_MAX_GROUPS    16            /* cda_step_groups: concurrent market groups per env */
 
 typedef enum cda_status {
     CDA_OK = 0,
@@ -180,6 +181,30 @@ int cda_step(cda_env* env,
              float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
              const cda_info_ptrs* info_out, void* stream);
 
+/* The same step for the markets [first_market, first_market + n_markets) only.  Every array argument is still the
+ * FULL [N, ...] array (the kernel indexes it by global market); only the launch covers fewer markets.  Markets never
+ * interact, so disjoint sub-ranges of one env may be stepped CONCURRENTLY on different streams: the reference's step()
+ * has no cross-env barrier either (one env object per market, continuousDoubleAuction_env.py:86,197), the batch-wide
+ * barrier of cda_step is an artefact of launching all markets as one grid. */
+int cda_step_range(cda_env* env, int32_t first_market, int32_t n_markets,
+                   const int32_t* category, const float* size_mean, const float* size_sigma,
+                   const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                   float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                   const cda_info_ptrs* info_out, void* stream);
+int cda_reset_range(cda_env* env, int32_t first_market, int32_t n_markets, const uint64_t* seeds, const uint8_t* mask,
+                    float* obs_out, void* stream);
+/* cda_step as n_groups (<= CDA_MAX_GROUPS) launches, group g = the markets cda_group_range() names, on streams[g].
+ * One host call; each group is an independent chain of launches on its own stream, so one group's slowest market
+ * overlaps the other groups' work instead of stalling the whole batch.  The outputs of group g are complete when
+ * streams[g] reaches this point; ordering against other streams is the caller's business (events). */
+int cda_step_groups(cda_env* env, int32_t n_groups,
+                    const int32_t* category, const float* size_mean, const float* size_sigma,
+                    const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                    float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                    const cda_info_ptrs* info_out, void* const* streams);
+/* markets of group `group` of `n_groups`: [first, first + count) with first = N*group/n_groups (integer division) */
+void cda_group_range(int32_t n_markets, int32_t n_groups, int32_t group, int32_t* first_out, int32_t* count_out);
+
 /* Replaces CDA_rand.run_random (CDA_rand.py:40-85): every market plays uniform random agents (the law and the
  * counter-based sampler of include/cda_random_agents.h, keyed by action_seed, market_index_base + market, the
  * market's own step counter and the agent) for up to n_steps steps, stopping early at its episode's end
@@ -196,6 +221,12 @@ int cda_run_random(cda_env* env, int32_t n_steps, uint64_t action_seed, uint64_t
 int cda_random_actions_host(uint64_t action_seed, uint64_t market_index_base, int32_t step, int32_t n_markets,
                             int32_t num_agents, int32_t* category, float* size_mean, float* size_sigma,
                             int32_t* price, int32_t* price_offset);
+
+/* The same sampler on the device: the actions of steps [step0, step0 + n_steps), five [n_steps, n_markets, num_agents]
+ * device arrays - the resident synthetic input of bench.py (generator keyed (seed, step, market, agent)). */
+int cda_random_actions(uint64_t action_seed, uint64_t market_index_base, int32_t step0, int32_t n_steps, int32_t n_markets,
+                       int32_t num_agents, int32_t* category, float* size_mean, float* size_sigma, int32_t* price,
+                       int32_t* price_offset, void* stream);
 
 /* The reference's end-of-episode invariant (train/callbk/league_based_self_play_callback.py:679-704) for every market, on
  * the device: total = Decimal(0); total += NAV_a for a = 0..A-1 (the accounts' current NAV, in that order, prec-28
@@ -220,6 +251,9 @@ int cda_get_raw_snapshot(cda_env* env, float* raw_out, void* stream);
 
 /* Per-market sticky flags u32[N] -> device buffer. */
 int cda_last_flags(cda_env* env, uint32_t* flags_out, void* stream);
+/* Book census i32[N] -> device buffer: the most resting orders (both sides together) each market has held since its
+ * last reset.  The reference's OrderTree is unbounded (ordertree.py:5-58); this build holds CDA_BOOK_CAP. */
+int cda_book_peak(cda_env* env, int32_t* peak_out, void* stream);
 
 /* Device self-tests of the ledger arithmetic and the RNG (host pointers; synchronous).
  * op: 0 add, 1 sub, 2 mul, 3 div, 4 cmp (result in out[i].w[0]: 0 lt, 1 eq, 2 gt), 5 to-double

@@ -24,6 +24,7 @@
  * Reference citations are relative to /root/reference/gym_continuousDoubleAuction/envs/.
  */
 #include "cda_oracle.h"
+#include "../include/cda_random_agents.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -372,8 +373,9 @@ static double rng_std_normal(rng_t* r) {
  * ==================================================================================== */
 typedef struct { int32_t price, qty, owner, order_id, timestamp; } order_t;
 typedef struct {
-    int n;
-    order_t o[CDA_BOOK_CAP];   /* queue order: best price first, FIFO inside a level */
+    int n, alloc;
+    order_t* o;                /* queue order: best price first, FIFO inside a level; grown on demand (the reference's
+                                  OrderTree is unbounded, orderbook/ordertree.py:5-58) */
 } side_t;
 
 typedef struct {
@@ -387,6 +389,8 @@ typedef struct {
     int32_t t_step, lob_time, next_order_id, last_price, has_trade, last_trade_price;
     uint32_t done_mask, flags;
     side_t side[2];            /* 0 bids, 1 asks */
+    int32_t book_cap;          /* resting orders the market may hold, both sides together; 0 = unbounded like the reference */
+    int32_t peak_orders;       /* census: most resting orders held since the last reset */
     acc_t acc[CDA_MAX_AGENTS];
     float hist[CDA_MAX_HIST * CDA_SNAPSHOT_DIM];
     float raw[CDA_RAW_DIM];    /* agg_LOB_raw of the last set_agg_LOB */
@@ -395,6 +399,7 @@ typedef struct {
 struct oracle_env {
     cda_config cfg;
     int32_t n;
+    int32_t book_cap;          /* CDA_BOOK_CAP (the product's capacity) unless oracle_set_book_cap changed it; 0 = unbounded */
     float mkt_mul, lim_mul;
     market_t* m;
 };
@@ -403,7 +408,11 @@ enum { T_MARKET = 0, T_LIMIT = 1, T_MODIFY = 2, T_CANCEL = 3 };
 enum { S_BID = 0, S_ASK = 1, S_NONE = 2 };
 
 typedef struct { int32_t price, qty, counter, counter_oid, init_side; } fill_t;
-#define MAX_FILLS (CDA_BOOK_CAP + 1)
+typedef struct { fill_t* f; int n, alloc; } fills_t;       /* the trades of one order, grown on demand */
+static void fills_push(fills_t* fl, fill_t f) {
+    if (fl->n == fl->alloc) { fl->alloc = fl->alloc ? 2 * fl->alloc : 16; fl->f = (fill_t*)realloc(fl->f, (size_t)fl->alloc * sizeof(fill_t)); if (!fl->f) abort(); }
+    fl->f[fl->n++] = f;
+}
 
 static int better_or_equal(int s, int32_t resting, int32_t p) { return s == S_BID ? resting >= p : resting <= p; }
 
@@ -412,19 +421,22 @@ static void side_remove(side_t* sd, int idx) {
     sd->n--;
 }
 /* OrderTree.insert_order (orderbook/ordertree.py:44-58): tail of its price level */
-static int side_insert(side_t* sd, const side_t* other, int s, order_t o) {
-    if (sd->n + other->n >= CDA_BOOK_CAP) return 0;       /* the build's capacity: CDA_BOOK_CAP resting orders per market */
+static int side_insert(market_t* m, int s, order_t o) {
+    side_t* sd = &m->side[s]; const side_t* other = &m->side[s ^ 1];
+    if (m->book_cap > 0 && sd->n + other->n >= m->book_cap) return 0;       /* the product's capacity (CDA_BOOK_CAP resting orders per market) when mirrored */
+    if (sd->n == sd->alloc) { sd->alloc = sd->alloc ? 2 * sd->alloc : 64; sd->o = (order_t*)realloc(sd->o, (size_t)sd->alloc * sizeof(order_t)); if (!sd->o) abort(); }
     int pos = 0;
     while (pos < sd->n && better_or_equal(s, sd->o[pos].price, o.price)) pos++;
     for (int i = sd->n; i > pos; i--) sd->o[i] = sd->o[i - 1];
     sd->o[pos] = o; sd->n++;
+    if (sd->n + other->n > m->peak_orders) m->peak_orders = sd->n + other->n;
     return 1;
 }
 
 /* OrderBook.process_order_list / process_market_order / process_limit_order matching loops
  * (orderbook/orderbook.py:61-194): fills at the resting order's price, head first. `limit` < 0
  * means a market order.  Returns the unfilled quantity. */
-static int32_t match(market_t* m, int own_side, int32_t qty, int32_t limit, fill_t* fills, int* nf) {
+static int32_t match(market_t* m, int own_side, int32_t qty, int32_t limit, fills_t* fills) {
     side_t* opp = &m->side[own_side ^ 1];
     while (qty > 0 && opp->n > 0) {
         order_t* h = &opp->o[0];
@@ -432,7 +444,7 @@ static int32_t match(market_t* m, int own_side, int32_t qty, int32_t limit, fill
         fill_t f; f.price = h->price; f.counter = h->owner; f.counter_oid = h->order_id; f.init_side = own_side;
         if (qty < h->qty) { f.qty = qty; h->qty -= qty; qty = 0; }
         else { f.qty = h->qty; qty -= h->qty; side_remove(opp, 0); }
-        fills[(*nf)++] = f;
+        fills_push(fills, f);
         m->has_trade = 1; m->last_trade_price = f.price;
     }
     return qty;
@@ -547,7 +559,7 @@ static int find_own_order(market_t* m, int tr, int side, int type, int32_t price
 
 /* Trader.__modify_limit_order + OrderBook.modify_order (trader.py:219-235, orderbook.py:210-266) */
 static void modify_order(market_t* m, int tr, int side, int idx, int32_t new_price, int32_t new_qty,
-                         fill_t* fills, int* nf, int32_t* rest_price, int32_t* rest_qty) {
+                         fills_t* fills, int32_t* rest_price, int32_t* rest_qty) {
     side_t* sd = &m->side[side];
     order_t old = sd->o[idx];
     cancel_cash_transfer(&m->acc[tr], old.price, old.qty);
@@ -558,10 +570,10 @@ static void modify_order(market_t* m, int tr, int side, int idx, int32_t new_pri
         return;
     }
     side_remove(sd, idx);
-    int32_t left = match(m, side, new_qty, new_price, fills, nf);
+    int32_t left = match(m, side, new_qty, new_price, fills);
     if (left > 0) {
         order_t o; o.price = new_price; o.qty = left; o.owner = old.owner; o.order_id = old.order_id; o.timestamp = m->lob_time;
-        if (side_insert(sd, &m->side[side ^ 1], side, o)) { *rest_price = new_price; *rest_qty = left; }
+        if (side_insert(m, side, o)) { *rest_price = new_price; *rest_qty = left; }
         else m->flags |= CDA_FLAG_BOOK_OVERFLOW;
     }
 }
@@ -572,25 +584,25 @@ static void place_order(market_t* m, int tr, int type, int side, int32_t size, i
     if (side == S_NONE) return;
     if (!order_approved(m, tr, side, size, type == T_MARKET ? -1 : price)) { a->num_rejected_step += 1; return; }
     if (type == T_MARKET || type == T_LIMIT) a->order_step_placed = 1;
-    fill_t fills[MAX_FILLS]; int nf = 0;
+    fills_t fills = {NULL, 0, 0};
     int32_t rest_price = 0, rest_qty = 0;
     if (type == T_MARKET) {
         m->lob_time += 1; m->next_order_id += 1;            /* orderbook.py:39-44 */
-        match(m, side, size, -1, fills, &nf);
+        match(m, side, size, -1, &fills);
     } else if (type == T_LIMIT) {
         int idx = find_own_order(m, tr, side, T_LIMIT, price);
         if (idx < 0) {
             m->lob_time += 1; m->next_order_id += 1;
-            int32_t left = match(m, side, size, price, fills, &nf);
+            int32_t left = match(m, side, size, price, &fills);
             if (left > 0) {
                 order_t o; o.price = price; o.qty = left; o.owner = tr; o.order_id = m->next_order_id; o.timestamp = m->lob_time;
-                if (side_insert(&m->side[side], &m->side[side ^ 1], side, o)) { rest_price = price; rest_qty = left; }
+                if (side_insert(m, side, o)) { rest_price = price; rest_qty = left; }
                 else m->flags |= CDA_FLAG_BOOK_OVERFLOW;
             }
-        } else modify_order(m, tr, side, idx, price, size, fills, &nf, &rest_price, &rest_qty);
+        } else modify_order(m, tr, side, idx, price, size, &fills, &rest_price, &rest_qty);
     } else if (type == T_MODIFY) {
         int idx = find_own_order(m, tr, side, T_MODIFY, price);
-        if (idx >= 0) modify_order(m, tr, side, idx, price, size, fills, &nf, &rest_price, &rest_qty);
+        if (idx >= 0) modify_order(m, tr, side, idx, price, size, &fills, &rest_price, &rest_qty);
     } else { /* cancel: trader.py:237-252, orderbook.py:196-208 */
         int idx = find_own_order(m, tr, side, T_CANCEL, price);
         if (idx >= 0) {
@@ -600,7 +612,8 @@ static void place_order(market_t* m, int tr, int type, int side, int32_t size, i
             cancel_cash_transfer(a, old.price, old.qty);
         }
     }
-    if (nf) settle(m, tr, fills, nf);
+    if (fills.n) settle(m, tr, fills.f, fills.n);
+    free(fills.f);
     if (rest_qty > 0) escrow_rest(a, rest_price, rest_qty);
 }
 
@@ -665,7 +678,7 @@ static void emit_obs(const cda_config* cfg, const market_t* m, float* obs) {
 static void market_reset(const cda_config* cfg, market_t* m, int have_seed, uint64_t seed, int index, float* obs) {
     if (have_seed) { rng_seed(&m->rng, seed); m->seeded = 1; }
     else if (!m->seeded) { rng_seed(&m->rng, (uint64_t)index); m->seeded = 1; }
-    m->side[0].n = m->side[1].n = 0;
+    m->side[0].n = m->side[1].n = 0; m->peak_orders = 0;
     m->t_step = 0; m->lob_time = 0; m->next_order_id = 0; m->has_trade = 0; m->last_trade_price = 0;
     m->done_mask = 0; m->flags = 0;
     m->last_price = (int32_t)rng_integers(&m->rng, cfg->initial_price_min, cfg->initial_price_max);
@@ -815,16 +828,37 @@ int oracle_create(const cda_config* cfg, int32_t n_markets, oracle_env** out) {
     int rc = cfg_ok(cfg); if (rc) return rc;
     oracle_env* e = (oracle_env*)calloc(1, sizeof *e);
     if (!e) return CDA_ERR_NOMEM;
-    e->cfg = *cfg; e->n = n_markets;
+    e->cfg = *cfg; e->n = n_markets; e->book_cap = CDA_BOOK_CAP;
     e->mkt_mul = (float)((double)(cfg->mkt_max_size - cfg->min_size) / 2.0);
-    e->lim_mul = (float)((double)(cfg->mkt_max_size * cfg->limit_size_multiple - cfg->min_size) / 2.0);
+    e->lim_mul = (float)((double)((int64_t)cfg->mkt_max_size * (int64_t)cfg->limit_size_multiple - (int64_t)cfg->min_size) / 2.0);
     e->m = (market_t*)calloc((size_t)n_markets, sizeof(market_t));
     if (!e->m) { free(e); return CDA_ERR_NOMEM; }
-    for (int i = 0; i < n_markets; i++) market_reset(cfg, &e->m[i], 0, 0, i, NULL);
+    for (int i = 0; i < n_markets; i++) { e->m[i].book_cap = e->book_cap; market_reset(cfg, &e->m[i], 0, 0, i, NULL); }
     for (int i = 0; i < n_markets; i++) e->m[i].seeded = 0;   /* construction does not count as seeding */
     *out = e; return CDA_OK;
 }
-int oracle_destroy(oracle_env* e) { if (e) { free(e->m); free(e); } return CDA_OK; }
+int oracle_destroy(oracle_env* e) {
+    if (e) { for (int i = 0; i < e->n; i++) { free(e->m[i].side[0].o); free(e->m[i].side[1].o); } free(e->m); free(e); }
+    return CDA_OK;
+}
+/* 0 = unbounded book (the reference); CDA_BOOK_CAP (default) mirrors the product's capacity and its overflow flag */
+int oracle_set_book_cap(oracle_env* e, int32_t cap) {
+    if (!e || cap < 0) return CDA_ERR_INVALID;
+    e->book_cap = cap;
+    for (int i = 0; i < e->n; i++) e->m[i].book_cap = cap;
+    return CDA_OK;
+}
+int oracle_book_peak(oracle_env* e, int32_t* peak_out) {
+    if (!e || !peak_out) return CDA_ERR_INVALID;
+    for (int i = 0; i < e->n; i++) peak_out[i] = e->m[i].peak_orders;
+    return CDA_OK;
+}
+int oracle_book_size(oracle_env* e, int32_t market, int32_t* n_bids, int32_t* n_asks) {
+    if (!e || market < 0 || market >= e->n) return CDA_ERR_INVALID;
+    if (n_bids) *n_bids = e->m[market].side[0].n;
+    if (n_asks) *n_asks = e->m[market].side[1].n;
+    return CDA_OK;
+}
 
 int oracle_reset(oracle_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs_out) {
     if (!e) return CDA_ERR_INVALID;
@@ -880,6 +914,27 @@ int oracle_run_range(oracle_env* e, int32_t first, int32_t count, int32_t n_step
     return CDA_OK;
 }
 
+/* The random-agent driver on the CPU (CDA_rand.py:40-85 with the counter-based sampler of include/cda_random_agents.h):
+ * markets [first, first+count) play n_steps steps each; the action of (market i, step step0 + s, agent a) is
+ * cda_random_action(action_seed, market_index_base + i, step0 + s, a) - the stream cda_random_actions() puts in HBM for
+ * the GPU leg of bench.py, so both legs consume identical inputs.  Outputs are the last step's (global indexing). */
+int oracle_run_random_range(oracle_env* e, int32_t first, int32_t count, int32_t step0, int32_t n_steps,
+                            uint64_t action_seed, uint64_t market_index_base,
+                            float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out) {
+    if (!e || first < 0 || count < 0 || first + count > e->n || step0 < 0 || n_steps < 0) return CDA_ERR_INVALID;
+    const int A = e->cfg.num_agents; const size_t od = (size_t)e->cfg.n_hist * CDA_SNAPSHOT_DIM;
+    for (int i = first; i < first + count; i++) {
+        int32_t cat[CDA_MAX_AGENTS], pr[CDA_MAX_AGENTS], po[CDA_MAX_AGENTS]; float sm[CDA_MAX_AGENTS], ss[CDA_MAX_AGENTS];
+        const size_t o = (size_t)i * (size_t)A;
+        for (int s = 0; s < n_steps; s++) {
+            for (int a = 0; a < A; a++) cda_random_action(action_seed, market_index_base + (uint64_t)i, (uint32_t)(step0 + s), (uint32_t)a, &cat[a], &sm[a], &ss[a], &pr[a], &po[a]);
+            market_step(e, &e->m[i], i, cat, sm, ss, pr, po, NULL, obs_out ? obs_out + od * (size_t)i : NULL, reward_out ? reward_out + o : NULL,
+                        terminated_out ? terminated_out + i : NULL, truncated_out ? truncated_out + i : NULL, NULL, NULL);
+        }
+    }
+    return CDA_OK;
+}
+
 int oracle_place_order(oracle_env* e, int32_t market, int32_t trader, int32_t type, int32_t side, int32_t size, int32_t price) {
     if (!e || market < 0 || market >= e->n || trader < 0 || trader >= e->cfg.num_agents) return CDA_ERR_INVALID;
     if (type < 0 || type > 3 || side < 0 || side > 1 || size < 1) return CDA_ERR_INVALID;
@@ -902,7 +957,7 @@ int oracle_get_state(oracle_env* e, int32_t market, cda_market_state* s) {
     s->last_price = m->last_price; s->has_trade = m->has_trade; s->last_trade_price = m->last_trade_price;
     s->done_mask = m->done_mask; s->flags = m->flags;
     s->n_bids = m->side[0].n; s->n_asks = m->side[1].n;
-    for (int sd = 0; sd < 2; sd++) for (int i = 0; i < m->side[sd].n; i++) {
+    for (int sd = 0; sd < 2; sd++) for (int i = 0; i < m->side[sd].n && i < CDA_BOOK_CAP; i++) {   /* (an unbounded book's tail beyond the struct's capacity is not dumped) */
         cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i]; const order_t* q = &m->side[sd].o[i];
         o->price = q->price; o->qty = q->qty; o->owner = q->owner; o->order_id = q->order_id; o->timestamp = q->timestamp;
     }
@@ -927,7 +982,11 @@ int oracle_set_state(oracle_env* e, int32_t market, const cda_market_state* s) {
     m->t_step = s->t_step; m->lob_time = s->lob_time; m->next_order_id = s->next_order_id;
     m->last_price = s->last_price; m->has_trade = s->has_trade; m->last_trade_price = s->last_trade_price;
     m->done_mask = s->done_mask; m->flags = s->flags;
-    m->side[0].n = s->n_bids; m->side[1].n = s->n_asks;
+    for (int sd = 0; sd < 2; sd++) {
+        const int need = sd == 0 ? s->n_bids : s->n_asks; side_t* q = &m->side[sd];
+        if (q->alloc < need) { q->alloc = need; q->o = (order_t*)realloc(q->o, (size_t)need * sizeof(order_t)); if (!q->o) abort(); }
+        q->n = need;
+    }
     for (int sd = 0; sd < 2; sd++) for (int i = 0; i < m->side[sd].n; i++) {
         const cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i]; order_t* q = &m->side[sd].o[i];
         q->price = o->price; q->qty = o->qty; q->owner = o->owner; q->order_id = o->order_id; q->timestamp = o->timestamp;

@@ -42,6 +42,17 @@ int oracle_run_range(oracle_env* env, int32_t first, int32_t count, int32_t n_st
                      const int32_t* category, const float* size_mean, const float* size_sigma,
                      const int32_t* price, const int32_t* price_offset,
                      float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out);
+/* Random agents of include/cda_random_agents.h for markets [first, first+count), steps step0 .. step0+n_steps-1: the
+ * CPU leg of bench.py (the same action stream the GPU leg reads from HBM) and the replay side of the parity tests. */
+int oracle_run_random_range(oracle_env* env, int32_t first, int32_t count, int32_t step0, int32_t n_steps,
+                            uint64_t action_seed, uint64_t market_index_base,
+                            float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out);
+/* Book capacity mirrored by the oracle: CDA_BOOK_CAP by default (the product's pool, with its overflow flag);
+ * 0 = unbounded, as the reference's OrderTree (ordertree.py:5-58).  oracle_book_peak: most resting orders each market
+ * has held since its last reset; oracle_book_size: current orders per side (get_state dumps at most CDA_BOOK_CAP per side). */
+int oracle_set_book_cap(oracle_env* env, int32_t cap);
+int oracle_book_peak(oracle_env* env, int32_t* peak_out /* [N] */);
+int oracle_book_size(oracle_env* env, int32_t market, int32_t* n_bids, int32_t* n_asks);
 int oracle_place_order(oracle_env* env, int32_t market, int32_t trader, int32_t type, int32_t side,
                        int32_t size, int32_t price);
 int oracle_mark_to_mkt(oracle_env* env, int32_t market);

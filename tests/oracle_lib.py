@@ -40,6 +40,10 @@ def lib():
         _lib.oracle_step.argtypes = [vp] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), vp]
         _lib.oracle_step_range.argtypes = [vp, C.c_int32, C.c_int32] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), vp]
         _lib.oracle_run_range.argtypes = [vp] + [C.c_int32] * 4 + [vp] * 9
+        _lib.oracle_run_random_range.argtypes = [vp] + [C.c_int32] * 4 + [C.c_uint64] * 2 + [vp] * 4
+        _lib.oracle_set_book_cap.argtypes = [vp, C.c_int32]
+        _lib.oracle_book_peak.argtypes = [vp, vp]
+        _lib.oracle_book_size.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         _lib.oracle_place_order.argtypes = [vp] + [C.c_int32] * 6
         _lib.oracle_mark_to_mkt.argtypes = [vp, C.c_int32]
         _lib.oracle_get_state.argtypes = [vp, C.c_int32, C.POINTER(K.MarketState)]
@@ -123,6 +127,28 @@ class OracleEnv:
             rc = lib().oracle_step_range(self.h, first, count, *args)
         assert rc == 0, rc
         return self.obs, self.reward, self.term, self.trunc, self.info
+
+    def run_random(self, step0, n_steps, action_seed=0, market_index_base=0, first=0, count=None):
+        """Random agents of include/cda_random_agents.h: steps step0 .. step0+n_steps-1 of markets [first, first+count)."""
+        count = self.n - first if count is None else count
+        rc = lib().oracle_run_random_range(self.h, first, count, step0, n_steps, action_seed, market_index_base,
+                                           _ptr(self.obs), _ptr(self.reward), _ptr(self.term), _ptr(self.trunc))
+        assert rc == 0, rc
+        return self.obs, self.reward, self.term, self.trunc
+
+    def set_book_cap(self, cap):
+        """0 = unbounded book (the reference); default CDA_BOOK_CAP mirrors the product's pool."""
+        assert lib().oracle_set_book_cap(self.h, int(cap)) == 0
+
+    def book_peak(self):
+        p = np.zeros(self.n, np.int32)
+        assert lib().oracle_book_peak(self.h, _ptr(p)) == 0
+        return p
+
+    def book_size(self, market=0):
+        nb, na = C.c_int32(), C.c_int32()
+        assert lib().oracle_book_size(self.h, market, C.byref(nb), C.byref(na)) == 0
+        return nb.value, na.value
 
     def place_order(self, market, trader, type_, side, size, price):
         rc = lib().oracle_place_order(self.h, market, trader, type_, side, size, price)

@@ -26,8 +26,29 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert "traffic" in r and r["kernel"] == "k_step" and r["kernel_ms"] > 0
+    # two concurrent group chains by default: `achieved` is the sum over the launches in flight
+    assert d["config"]["groups"] == 2 and r["concurrent_launches"] == 2 and r["markets_per_launch"] == 256
+    assert abs(r["achieved"] - 2 * r["achieved_per_launch"]) / r["achieved"] < 0.2
+    assert abs(r["achieved_per_launch"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved_per_launch"] < 0.2
+    assert "issue_frac" in r and "valu_busy_frac" in r
+    # row a14 inside the timed region: the info-on figure sits next to the headline
+    assert d["config"]["info_outputs"] is False and 0 < d["value_with_info"] <= d["value"] * 1.05 and d["ms_per_step_with_info"] > 0
+    assert d["config"]["flagged_markets"] == 0 and d["config"]["flagged_markets_with_info"] == 0
+    assert "cda_random_actions" in d["config"]["actions"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "agent-steps/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert c["value_1thread"] > 0 and isinstance(c["cpu_model"], str) and c["cpu_model"]
+    assert "GPU leg's action stream" in c["sample"]
+
+
+def test_bench_named_config_c4_and_single_group():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup", "8", "--config", "c4", "--groups", "1",
+                                   "--no-cpu-baseline", "--no-info-leg"], cwd=ROOT, stderr=subprocess.DEVNULL, text=True, timeout=600)
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["markets_per_gpu"] == 2048 and d["config"]["agents"] == 8 and "configs[3]" in d["config"]["workload"]
+    assert d["config"]["groups"] == 1 and d["roofline"]["concurrent_launches"] == 1 and d["config"]["flagged_markets"] == 0
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == (1444 + 324 * 8) * 2048
+    assert abs(d["value"] - 2048 * 8 * 24 / (d["ms_per_step"] * 1e-3 * 24)) / d["value"] < 1e-6
 
 
 def test_bench_multi_gpu_code_path_on_one_rank():
@@ -43,6 +64,8 @@ def test_bench_multi_gpu_code_path_on_one_rank():
         assert len(lines) == 1, out[-2000:]
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["value"] > 1e6 and "all_gather" in d["config"]["collective"]
+        if not extra:                                    # the calibrated schedule figures are reported even with one rank
+            assert d["config"]["gather_calibration"]["serial_us_per_step"] > 0 and d["config"]["gather_calibration"]["overlapped_us_per_step"] > 0
         assert d["config"]["flagged_markets"] == 0 and d["roofline"]["kernel_ms"] > 0
 
 

@@ -1,0 +1,78 @@
+"""CPU: the oracle's book is unbounded like the reference's OrderTree (ordertree.py:5-58) unless told to mirror the
+product's pool of CDA_BOOK_CAP orders; its random-agent runner replays include/cda_random_agents.h."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as O
+from gym_continuousdoubleauction_amd import _capi as K
+
+
+
+def _host_actions(step, n, a, seed, base):
+    """cda_random_action restated in numpy (splitmix64 finaliser), independent of both libraries."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(z):
+        z = (z + np.uint64(0x9e3779b97f4a7c15)) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        mk = np.arange(n, dtype=np.uint64)[:, None] + np.uint64(base)
+        ag = np.arange(a, dtype=np.uint64)[None, :]
+        h0 = mix(np.uint64(seed) + mk * np.uint64(0xd1342543de82ef95))
+        w0 = mix(h0 + ((np.uint64(step) << np.uint64(32)) | ag))
+        w1 = mix(w0)
+        cat = (((w0 & np.uint64(0xffffffff)) * np.uint64(9)) >> np.uint64(32)).astype(np.int32)
+        price = (((w0 >> np.uint64(32)) * np.uint64(10)) >> np.uint64(32)).astype(np.int32)
+        off = (((w1 & np.uint64(0xffffffff)) * np.uint64(3)) >> np.uint64(32)).astype(np.int32)
+        mean = ((w1 >> np.uint64(32)) & np.uint64(0xffffff)).astype(np.float32) * np.float32(1.0 / 8388608.0) - np.float32(1.0)
+        sigma = (w1 >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return cat, mean, sigma, price, off
+
+
+def test_run_random_equals_stepping_the_same_stream():
+    n, a, steps = 24, 4, 40
+    cfg = {"num_of_agents": a, "init_cash": 1000000, "max_step": 1000, "is_render": False}
+    x, y = O.OracleEnv(cfg, n), O.OracleEnv(cfg, n)
+    seeds = np.arange(50, 50 + n, dtype=np.uint64)
+    x.reset(seeds); y.reset(seeds)
+    x.run_random(0, steps, action_seed=2024, market_index_base=7)
+    for t in range(steps):
+        y.step(*_host_actions(t, n, a, 2024, 7))
+    assert np.array_equal(x.obs.view(np.uint32), y.obs.view(np.uint32)) and np.array_equal(x.reward.view(np.uint64), y.reward.view(np.uint64))
+    for i in range(n):
+        assert bytes(x.get_state(i)) == bytes(y.get_state(i))
+    x.close(); y.close()
+
+
+def test_unbounded_book_equals_the_capped_one_while_no_overflow_is_flagged():
+    n, a, steps = 16, 16, 300
+    cfg = {"num_of_agents": a, "init_cash": 10 ** 8, "max_step": 10000, "is_render": False}
+    cap, unb = O.OracleEnv(cfg, n), O.OracleEnv(cfg, n)
+    unb.set_book_cap(0)
+    seeds = np.arange(900, 900 + n, dtype=np.uint64)
+    cap.reset(seeds); unb.reset(seeds)
+    cap.run_random(0, steps, action_seed=5)
+    unb.run_random(0, steps, action_seed=5)
+    clear = cap.flags() == 0
+    assert clear.any()
+    for i in np.nonzero(clear)[0]:
+        assert bytes(cap.get_state(int(i))) == bytes(unb.get_state(int(i)))
+    assert (unb.flags() & K.FLAG_BOOK_OVERFLOW == 0).all()
+    assert (unb.book_peak() >= cap.book_peak()).all() and cap.book_peak().max() <= K.BOOK_CAP
+    cap.close(); unb.close()
+
+
+def test_unbounded_book_holds_more_than_the_product_pool():
+    cfg = {"num_of_agents": 2, "init_cash": 10 ** 12, "max_step": 10000, "is_render": False}
+    cap, unb = O.OracleEnv(cfg, 1), O.OracleEnv(cfg, 1)
+    unb.set_book_cap(0)
+    for e in (cap, unb):
+        e.reset(np.array([1], np.uint64))
+        for i in range(K.BOOK_CAP + 40):                       # distinct prices: every limit order rests as a new order
+            e.place_order(0, 0, K.T_LIMIT, K.S_BID, 1, 5 + i)
+    assert sum(cap.book_size(0)) == K.BOOK_CAP and cap.flags()[0] & K.FLAG_BOOK_OVERFLOW
+    assert sum(unb.book_size(0)) == K.BOOK_CAP + 40 and unb.flags()[0] == 0 and unb.book_peak()[0] == K.BOOK_CAP + 40
+    cap.close(); unb.close()

@@ -10,7 +10,6 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT))
-from bench import gen_actions  # noqa: E402
 from gym_continuousdoubleauction_amd import CDAVecEnv  # noqa: E402
 
 
@@ -35,7 +34,7 @@ def main():
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 100000, "is_render": False}
     env = CDAVecEnv(cfg, n_markets=N, with_info=False, out_buffers=2)
     env.reset(seed=1000)
-    acts = gen_actions(torch, N, A, 64, torch.device("cuda:0"), 1)
+    acts = env.random_actions_device(0, 64, action_seed=1)
     g = [torch.empty(env.slab_layout["bytes"], dtype=torch.uint8, device="cuda:0") for _ in range(2)]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(400)]
     res = {}

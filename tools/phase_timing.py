@@ -23,14 +23,14 @@ from gym_continuousdoubleauction_amd import CDAVecEnv
 N, A = 4096, 4
 env = CDAVecEnv({"num_of_agents": A, "init_cash": 1000000, "max_step": 100000, "is_render": False}, n_markets=N, with_info=False)
 env.reset(seed=np.arange(1000, 1000 + N, dtype=np.uint64))
-buf = torch.zeros((N, 24), dtype=torch.int64, device="cuda:0")
+buf = torch.zeros((N, 40), dtype=torch.int64, device="cuda:0")
 L = _lib.lib()
 L.cda_debug_set_phase_buffer.argtypes = [C.c_void_p]
 L.cda_debug_set_phase_buffer(C.c_void_p(buf.data_ptr()))
 g = torch.Generator(device="cuda:0"); g.manual_seed(1)
 names = ["load", "snapshot_pre", "decode+rng", "shuffle", "orders", "mtm", "snapshot_post+obs", "reward/info", "store"]
 acc = np.zeros(9); span = 0.0
-tot_all = []; worst = None; sub = np.zeros(14); sub_worst = None
+tot_all = []; worst = None; sub = np.zeros(24); sub_worst = None
 T, W = 300, 200
 calls = (C.c_ulonglong * 8)()
 if COUNTERS:
@@ -49,12 +49,12 @@ for t in range(W + T):
         d = b[:, 1:10] - b[:, 0:9]
         acc += d.mean(axis=0)
         span += (b[:, 9].max() - b[:, 0].min())
-        sub += b[:, 10:24].mean(axis=0)
+        sub += b[:, 10:34].mean(axis=0)
         tw = d.sum(axis=1)
         tot_all.append(tw)
         i = int(tw.argmax())
         if worst is None or tw[i] > worst[0]:
-            worst = (tw[i], d[i].copy(), t, i); sub_worst = b[i, 10:24].copy()
+            worst = (tw[i], d[i].copy(), t, i); sub_worst = b[i, 10:34].copy()
 acc /= T
 tot = acc.sum()
 print(f"mean cycles per wave per step: {tot:.0f}; kernel span (first start -> last end) {span / T:.0f} cycles")
@@ -68,7 +68,8 @@ print("max over the 4096 waves of one step: mean %.0f  (min %.0f, max %.0f)" % (
 print("slowest wave seen: %.0f cycles at step %d market %d; phases:" % (worst[0], worst[2], worst[3]), dict(zip(names, worst[1].astype(int).tolist())))
 
 subn = ["approval", "find_own", "match+settle", "insert/remove(after match)", "cancel/escrow/other", "fills",
-        "book_remove/in-place", "release transfer", "escrow transfer", "x9", "n_modify", "n_escrow", "x12", "x13"]
+        "book_remove/in-place", "release transfer", "escrow transfer", "x9", "n_modify", "n_escrow", "x12", "x13",
+        "fill:prep(mode,tv)", "fill:stage1 mul", "fill:stage2 select", "fill:stage2 add", "fill:stage3", "fill:tail(sync,ballots)", "fills with lane 0 involved", "x21", "x22", "x23"]
 print("orders phase breakdown, mean per wave per step:", {n: round(v / T, 1) for n, v in zip(subn, sub)})
 print("orders phase breakdown, slowest wave:", dict(zip(subn, sub_worst.astype(int).tolist())))
 
