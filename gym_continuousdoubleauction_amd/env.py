@@ -1,20 +1,29 @@
-"""CDAEnv - the single-market facade with the reference's exact dict-shaped surface.
+"""Dict-shaped facades over the batched HIP env.
 
-Drop-in for `continuousDoubleAuctionEnv` (continuousDoubleAuction_env.py:21) where RLlib attaches:
-    tune.register_env(name, lambda cfg: CDAEnv(cfg))          # train/train.py:441-443
-Same constructor config keys and defaults (config/env_defaults.json:8-27), `agents`,
-`possible_agents`, `observation_spaces`, `action_spaces`, `reset(*, seed=None, options=None)` and
-`step(action_dict)` returning (obs, rewards, terminateds, truncateds, infos) dicts keyed "agent_i"
-(+ "__all__").  The env state lives on the GPU; this class only marshals dicts <-> tensors.
+CDAEnv              - ONE market with the reference's exact MultiAgentEnv surface.  Drop-in for
+                      `continuousDoubleAuctionEnv` (continuousDoubleAuction_env.py:21) where RLlib attaches:
+                          tune.register_env(name, lambda cfg: CDAEnv(cfg))          # train/train.py:441-443
+CDAVecMultiAgentEnv - N markets behind ONE object: the batched attach point (RLlib's `num_envs_per_env_runner`,
+                      train/train.py:509-518).  `step_batch` takes / returns device tensors keyed by agent id - views,
+                      nothing is copied; `step` / `reset` speak the list-of-dicts vector protocol (one sub-env per
+                      market) and cost ONE device-to-host copy per step for the whole batch.
 
-One deliberate canonicalisation: the reference assigns its per-agent RNG draws in the
-caller's dict iteration order; here agents are always processed in ascending index order.
+Same constructor config keys and defaults (config/env_defaults.json:8-27), `agents`, `possible_agents`,
+`observation_spaces`, `action_spaces`, `reset(*, seed=None, options=None)` and `step(action_dict)` returning
+(obs, rewards, terminateds, truncateds, infos) dicts keyed "agent_i" (+ "__all__").  The env state lives on the GPU;
+these classes only marshal dicts <-> tensors.
+
+One deliberate canonicalisation: the reference assigns its per-agent RNG draws in the caller's dict
+iteration order; here agents are always processed in ascending index order.
 """
+import numbers
+
 import numpy as np
+import torch
 
 from . import _capi as K
 from . import spaces as _spaces
-from .vec_env import CDAVecEnv, DEC_DTYPE
+from .vec_env import CDAVecEnv, DEC_DTYPE, ACTION_KEYS
 
 try:  # pragma: no cover - ray is absent from the build image
     from ray.rllib.env.multi_agent_env import MultiAgentEnv as _Base
@@ -24,27 +33,48 @@ except Exception:  # noqa: BLE001
             pass
 
 _TERM_NAMES = ("nav_term", "order_penalty", "trade_penalty", "drawdown_penalty", "passive_bonus")
+_DEC_FIELDS = ("cash", "cash_on_hold", "position_val", "vwap", "nav", "prev_nav", "max_nav")
+_INT_FIELDS = ("net_position", "num_trades", "num_trades_step", "num_passive_fills_step", "order_step_placed", "num_rejected_step")
+_ALIAS = {"VWAP": "vwap"}
+
+
+def _entropy_seed():
+    """What gymnasium's `np_random` does on an unseeded first reset: fresh OS entropy (64 bits of it here)."""
+    return int(np.random.SeedSequence().entropy) & (2 ** 64 - 1)
 
 
 class _AccountView:
-    """Read-only view of one trader's account (envs/account/account.py:12-53) as exact Decimals."""
+    """One trader's account (envs/account/account.py:12-53) as exact Decimals, read from and written to the device
+    record (`traders[i].acc.cash = Decimal(900)`, as the reference's own tests do, test/test_accounting.py:143-150)."""
 
     def __init__(self, env, idx):
-        self._env, self._idx = env, idx
-
-    def _acc(self):
-        return self._env._vec.get_state(0).acc[self._idx]
+        object.__setattr__(self, "_env", env)
+        object.__setattr__(self, "_idx", idx)
 
     def __getattr__(self, name):
-        alias = {"VWAP": "vwap"}
-        f = alias.get(name, name)
-        acc = self._acc()
-        if f in ("cash", "cash_on_hold", "position_val", "vwap", "nav", "prev_nav", "max_nav"):
+        f = _ALIAS.get(name, name)
+        acc = self._env._vec.get_state(self._env._market).acc[self._idx]
+        if f in _DEC_FIELDS:
             return K.dec_to_decimal(getattr(acc, f))
-        if f in ("net_position", "num_trades", "num_trades_step", "num_passive_fills_step", "order_step_placed",
-                 "num_rejected_step"):
+        if f in _INT_FIELDS:
             return int(getattr(acc, f))
         raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        import decimal
+        f = _ALIAS.get(name, name)
+        vec, mk = self._env._vec, self._env._market
+        s = vec.get_state(mk)
+        acc = s.acc[self._idx]
+        if f in _DEC_FIELDS:
+            setattr(acc, f, K.decimal_to_dec(decimal.Decimal(value)))
+        elif f in _INT_FIELDS:
+            if int(value) != value:
+                raise ValueError(f"{name} is an integer count")
+            setattr(acc, f, int(value))
+        else:
+            raise AttributeError(name)
+        vec.set_state(mk, s)                             # (the dump holds the history oldest frame first; set_state re-bases the ring at slot 0)
 
 
 class _TraderView:
@@ -53,14 +83,54 @@ class _TraderView:
         self.acc = _AccountView(env, idx)
 
 
-class CDAEnv(_Base):
+class _ActionStage:
+    """Host staging of one step's actions for n markets: ONE pinned buffer [category | size_mean | size_sigma | price |
+    price_offset | present] filled through numpy views and moved with ONE host-to-device copy."""
+    _FIELDS = (("category", np.int32), ("size_mean", np.float32), ("size_sigma", np.float32), ("price", np.int32), ("price_offset", np.int32))
+
+    def __init__(self, n, a, device):
+        words = n * a
+        self.host = torch.zeros(5 * 4 * words + (words + 15) // 16 * 16, dtype=torch.uint8).pin_memory()
+        self.dev = torch.zeros_like(self.host, device=device)
+        hn = self.host.numpy()
+        self.np, self.t = {}, {}
+        for j, (k, dt) in enumerate(self._FIELDS):
+            self.np[k] = hn[j * 4 * words:(j + 1) * 4 * words].view(dt).reshape(n, a)
+            self.t[k] = self.dev[j * 4 * words:(j + 1) * 4 * words].view(torch.int32 if dt is np.int32 else torch.float32).view(n, a)
+        self.np["present"] = hn[20 * words:21 * words].reshape(n, a)
+        self.t["present"] = self.dev[20 * words:21 * words].view(n, a)
+
+    def clear(self):
+        self.host.zero_()
+        self.np["price_offset"][:] = 1                    # neutral 'join' (action_helper.py:256-258)
+
+    def upload(self):
+        self.dev.copy_(self.host, non_blocking=True)
+        return self.t
+
+
+def _jsonable(x):
+    """model_action as plain Python (info_helper.py:4-20 sanitises the echoed action for json.dumps): numpy scalars and
+    arrays become numbers and nested lists, containers are rebuilt around their sanitised members."""
+    if isinstance(x, dict):
+        return {k: _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (np.ndarray, np.generic)):
+        return np.asarray(x).tolist()
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    return x
+
+
+def _nan_none(x):
+    return None if x != x else float(x)
+
+
+class _DictSurface(_Base):
+    """What both facades share: config pickup, agent ids and spaces (continuousDoubleAuction_env.py:27-137)."""
     metadata = {"render.modes": ["human"]}
 
-    def __init__(self, config=None, device="cuda:0"):
-        super().__init__()
-        self.config = dict(config or {})
-        self._vec = CDAVecEnv(self.config, n_markets=1, device=device, with_info=True)
-        cfg = self._vec.config
+    def _init_surface(self, vec):
+        cfg = vec.config
         self.num_of_agents = int(cfg["num_of_agents"])
         self.max_step = int(cfg["max_step"])
         self.n_hist = int(cfg["n_hist"])
@@ -79,19 +149,97 @@ class CDAEnv(_Base):
         self.observation_spaces = {a: obs_space for a in agent_ids}
         act_space = _spaces.action_space()              # ONE shared Dict object, as in the reference
         self.action_spaces = {a: act_space for a in agent_ids}
+
+    def get_action_space(self, agent_id):
+        return self.action_spaces[agent_id]
+
+    def get_observation_space(self, agent_id):
+        return self.observation_spaces[agent_id]
+
+    def render(self):
+        return None
+
+    # ---- dict <-> array marshalling of ONE market ------------------------------------------------------------
+    def _encode(self, actions, cat, mean, sigma, price, off, present):
+        """One market's action dict -> row views of the [*, A] host arrays (action_helper.py:145-172, :241-283)."""
+        A = self.num_of_agents
+        for key, act in actions.items():
+            a = int(str(key).split("_")[1])
+            if not 0 <= a < A:
+                raise KeyError(key)
+            c = int(act["category"])
+            if not 0 <= c <= 8:
+                raise KeyError(c)                               # _CATEGORY_MAP lookup (action_helper.py:266)
+            present[a] = 1
+            cat[a] = c
+            mean[a] = np.float32(np.asarray(act["size_mean"], dtype=np.float32).reshape(-1)[0])
+            sigma[a] = np.float32(np.asarray(act["size_sigma"], dtype=np.float32).reshape(-1)[0])
+            if sigma[a] < 0:
+                raise ValueError("scale < 0")                   # numpy's Generator.normal
+            price[a] = int(act.get("price", 0))
+            off[a] = int(act.get("price_offset", 1))            # neutral 'join' (action_helper.py:256-258)
+
+    def _decode(self, i, actions, obs, rew, term, trunc, info):
+        """Market i's rows of the host copy -> the reference's five dicts (info_helper.py:30-116)."""
+        agents = self.agents
+        ob = obs[i]
+        nav = info["nav"][i].view(DEC_DTYPE).reshape(self.num_of_agents)
+        observations = {a: ob for a in agents}              # the SAME array object for every agent
+        rewards = {a: float(rew[i, k]) for k, a in enumerate(agents)}
+        terminateds = {a: False for a in agents}
+        truncateds = {a: False for a in agents}
+        terminateds["__all__"] = bool(term[i])
+        truncateds["__all__"] = bool(trunc[i])
+        lob = info["lob_actions"][i]
+        # env.LOB_actions (continuousDoubleAuction_env.py:284-285): the decoded orders in agent order, passes left out
+        lob_actions = [
+            {"ID": a, "side": ("bid", "ask")[int(row[0])], "type": ("market", "limit", "modify", "cancel")[int(row[1])],
+             "size": int(row[2]), "price": float(row[3])}
+            for a, row in zip(agents, lob) if row[0] >= 0]
+        infos, pass_agents, bankrupt = {}, set(), set()
+        last_price, bb, ba, sp = float(info["last_price"][i]), _nan_none(info["best_bid"][i]), _nan_none(info["best_ask"][i]), _nan_none(info["spread"][i])
+        for k, a in enumerate(agents):
+            nav_dec = K.dec_to_decimal(nav[k])
+            if nav_dec <= 0:
+                bankrupt.add(a)
+            if info["is_pass_action"][i, k]:
+                pass_agents.add(a)
+            d = {
+                "reward": rewards[a], "NAV": str(nav_dec), "num_trades": int(info["num_trades"][i, k]),
+                "net_position": int(info["net_position"][i, k]), "VWAP": float(info["vwap"][i, k]), "cash": float(info["cash"][i, k]),
+                "cash_on_hold": float(info["cash_on_hold"][i, k]), "position_val": float(info["position_val"][i, k]),
+                "drawdown": float(info["drawdown"][i, k]), "max_nav": float(info["max_nav"][i, k]),
+                "num_trades_step": int(info["num_trades_step"][i, k]),
+                "num_passive_fills_step": int(info["num_passive_fills_step"][i, k]),
+                "order_step_placed": int(info["order_step_placed"][i, k]), "num_rejected_step": int(info["num_rejected_step"][i, k]),
+                "is_pass_action": bool(info["is_pass_action"][i, k]),
+                "reward_terms": {n: float(info["reward_terms"][i, k, j]) for j, n in enumerate(_TERM_NAMES)},
+                "last_price": last_price, "best_bid": bb, "best_ask": ba, "spread": sp,
+            }
+            if actions is not None and a in actions:
+                d["model_action"] = _jsonable(actions[a])
+            infos[a] = d
+        return (observations, rewards, terminateds, truncateds, infos), lob_actions, pass_agents, bankrupt
+
+
+class CDAEnv(_DictSurface):
+    def __init__(self, config=None, device="cuda:0"):
+        super().__init__()
+        self.config = dict(config or {})
+        self._vec = CDAVecEnv(self.config, n_markets=1, device=device, with_info=True)
+        self._market = 0
+        self._init_surface(self._vec)
         self.traders = [_TraderView(self, i) for i in range(self.num_of_agents)]
         self.done_set = set()
         self.LOB_actions = None
         self.pass_agents = set()
         self.t_step = 0
         self.model_actions = None
-
-    # -- spaces -------------------------------------------------------------------------
-    def get_action_space(self, agent_id):
-        return self.action_spaces[agent_id]
-
-    def get_observation_space(self, agent_id):
-        return self.observation_spaces[agent_id]
+        self._seeded = False
+        A = self.num_of_agents
+        # host staging: ONE pinned buffer receives a whole step (obs | reward | flags | info) in one copy
+        self._host = torch.empty(self._vec.packed.numel(), dtype=torch.uint8).pin_memory()
+        self._stage = _ActionStage(1, A, self._vec.device)
 
     # -- diagnostics some reference tests read --------------------------------------------
     @property
@@ -119,6 +267,12 @@ class CDAEnv(_Base):
 
     # -- reset / step ---------------------------------------------------------------------
     def reset(self, *, seed=None, options=None):
+        """reset(seed=s): seeded episode.  reset(seed=None): the FIRST unseeded reset of an env draws a seed from OS entropy
+        (gymnasium's np_random does; several EnvRunners each constructing this env must not replay one stream), later
+        unseeded resets continue the stream (continuousDoubleAuction_env.py:186-188)."""
+        if seed is None and not self._seeded:
+            seed = _entropy_seed()
+        self._seeded = True
         obs = self._vec.reset(seed=None if seed is None else np.array([int(seed)], dtype=np.uint64))
         self.done_set = set()
         self.LOB_actions = None
@@ -130,83 +284,145 @@ class CDAEnv(_Base):
         return observations, infos
 
     def step(self, actions):
-        A = self.num_of_agents
-        cat = np.zeros(A, np.int32); mean = np.zeros(A, np.float32); sigma = np.zeros(A, np.float32)
-        price = np.zeros(A, np.int32); off = np.ones(A, np.int32); present = np.zeros(A, np.uint8)
-        for key, act in actions.items():
-            a = int(str(key).split("_")[1])
-            if not 0 <= a < A:
-                raise KeyError(key)
-            present[a] = 1
-            cat[a] = int(act["category"])
-            if not 0 <= cat[a] <= 8:
-                raise KeyError(int(act["category"]))           # _CATEGORY_MAP lookup (action_helper.py:266)
-            mean[a] = np.float32(np.asarray(act["size_mean"], dtype=np.float32).reshape(-1)[0])
-            sigma[a] = np.float32(np.asarray(act["size_sigma"], dtype=np.float32).reshape(-1)[0])
-            if sigma[a] < 0:
-                raise ValueError("scale < 0")                   # numpy's Generator.normal
-            price[a] = int(act.get("price", 0))
-            off[a] = int(act.get("price_offset", 1))            # neutral 'join' (action_helper.py:256-258)
+        st = self._stage
+        st.clear()
+        buf = st.np
+        self._encode(actions, buf["category"][0], buf["size_mean"][0], buf["size_sigma"][0], buf["price"][0], buf["price_offset"][0], buf["present"][0])
         self.model_actions = actions
-        obs_t, rew_t, term_t, trunc_t, info_t = self._vec.step(cat[None], mean[None], sigma[None], price[None], off[None],
-                                                               present[None])
-        ob = obs_t[0].cpu().numpy()
-        rew = rew_t[0].cpu().numpy()
-        info = {k: v[0].cpu().numpy() for k, v in info_t.items()}
-        nav = info["nav"].view(DEC_DTYPE).reshape(A)
-        obs = {a: ob for a in self.agents}
-        rewards = {a: float(rew[i]) for i, a in enumerate(self.agents)}
-        terminateds = {a: False for a in self.agents}
-        truncateds = {a: False for a in self.agents}
-        terminateds["__all__"] = bool(term_t[0].item())
-        truncateds["__all__"] = bool(trunc_t[0].item())
-        nn = lambda x: None if np.isnan(x) else float(x)       # noqa: E731
-        infos = {}
-        self.pass_agents = set()
-        # env.LOB_actions (continuousDoubleAuction_env.py:284-285): the decoded orders in agent order, passes left out
-        self.LOB_actions = [
-            {"ID": a, "side": ("bid", "ask")[int(row[0])], "type": ("market", "limit", "modify", "cancel")[int(row[1])],
-             "size": int(row[2]), "price": float(row[3])}
-            for a, row in zip(self.agents, info["lob_actions"]) if row[0] >= 0]
-        for i, a in enumerate(self.agents):
-            nav_dec = K.dec_to_decimal(nav[i])
-            if nav_dec <= 0:
-                self.done_set.add(a)
-            if info["is_pass_action"][i]:
-                self.pass_agents.add(a)
-            d = {
-                "reward": rewards[a], "NAV": str(nav_dec), "num_trades": int(info["num_trades"][i]),
-                "net_position": int(info["net_position"][i]), "VWAP": float(info["vwap"][i]), "cash": float(info["cash"][i]),
-                "cash_on_hold": float(info["cash_on_hold"][i]), "position_val": float(info["position_val"][i]),
-                "drawdown": float(info["drawdown"][i]), "max_nav": float(info["max_nav"][i]),
-                "num_trades_step": int(info["num_trades_step"][i]),
-                "num_passive_fills_step": int(info["num_passive_fills_step"][i]),
-                "order_step_placed": int(info["order_step_placed"][i]), "num_rejected_step": int(info["num_rejected_step"][i]),
-                "is_pass_action": bool(info["is_pass_action"][i]),
-                "reward_terms": {n: float(info["reward_terms"][i, j]) for j, n in enumerate(_TERM_NAMES)},
-                "last_price": float(info["last_price"]), "best_bid": nn(info["best_bid"]), "best_ask": nn(info["best_ask"]),
-                "spread": nn(info["spread"]),
-            }
-            if a in actions:
-                d["model_action"] = _plain(actions[a])
-            infos[a] = d
+        vec = self._vec
+        t = st.upload()                                        # ONE host-to-device copy of the step's actions
+        vec.step(t["category"], t["size_mean"], t["size_sigma"], t["price"], t["price_offset"], t["present"])
+        self._host.copy_(vec.packed)                           # the ONE device-to-host copy of the step (synchronous)
+        obs, rew, term, trunc, info = vec.unpack_host(self._host)
+        out, self.LOB_actions, self.pass_agents, bankrupt = self._decode(0, actions, obs.copy(), rew, term, trunc, info)
+        self.done_set |= bankrupt
         self.t_step += 1
-        return obs, rewards, terminateds, truncateds, infos
-
-    def render(self):
-        return None
+        return out
 
     def close(self):
         self._vec.close()
 
 
-def _plain(value):
-    if isinstance(value, np.ndarray):
-        return [_plain(v) for v in value.tolist()]
-    if isinstance(value, np.generic):
-        return value.item()
-    if isinstance(value, dict):
-        return {k: _plain(v) for k, v in value.items()}
-    if isinstance(value, (list, tuple)):
-        return [_plain(v) for v in value]
-    return value
+class CDAVecMultiAgentEnv(_DictSurface):
+    """N markets as N sub-envs of one object (the batched attach point).
+
+    Tensor API (no host round trip, everything is a VIEW of the env's output buffers):
+        obs, infos = env.reset_batch(seed=None)
+        obs, rewards, terminateds, truncateds, infos = env.step_batch(actions)
+      `actions`: {key: tensor [N, A]} for the five action keys (+ optional "present"), or {agent_id: {key: tensor [N]}}.
+      obs[agent] f32[N, n_hist*42] (the same tensor for every agent, as the reference hands every agent one array),
+      rewards[agent] f64[N] (column a of the [N, A] reward tensor), terminateds / truncateds [agent] all-False bool[N]
+      plus "__all__" bool[N], infos[agent][field] [N, ...] (column a of the SoA info tensors; "nav" as 16-byte decimal
+      triples, see CDAVecEnv.nav_decimals).
+    Vector protocol (lists of per-market dicts, the shape RLlib's vector env runners consume):
+        obs_list, info_list = env.reset(seed=None)
+        obs_list, rew_list, term_list, trunc_list, info_list = env.step(list_of_action_dicts)
+      one device-to-host copy per step for the whole batch; each market's dicts are what CDAEnv returns for it.
+    With config["auto_reset"] a finished market restarts in place (see include/cda.h); otherwise reset(mask=...).
+    """
+
+    def __init__(self, config=None, num_envs=1, device="cuda:0", with_info=True, groups=1):
+        super().__init__()
+        self.config = dict(config or {})
+        self.num_envs = int(num_envs)
+        self._vec = CDAVecEnv(self.config, n_markets=self.num_envs, device=device, with_info=with_info, groups=groups)
+        self._init_surface(self._vec)
+        self._seeded = False
+        N, A = self.num_envs, self.num_of_agents
+        self._false = torch.zeros(N, dtype=torch.bool, device=self._vec.device)
+        self._host = None
+        self._stage = None
+
+    @property
+    def vec(self):
+        """The underlying CDAVecEnv (flags(), nav_conservation(), get_state(i), ...)."""
+        return self._vec
+
+    # ---- tensor API -------------------------------------------------------------------------------------------
+    def _views(self, obs, rew, term, trunc, info):
+        agents = self.agents
+        observations = {a: obs for a in agents}
+        rewards = {a: rew[:, k] for k, a in enumerate(agents)}
+        terminateds = {a: self._false for a in agents}
+        truncateds = {a: self._false for a in agents}
+        terminateds["__all__"], truncateds["__all__"] = term, trunc
+        infos = {a: {} for a in agents}
+        for name, t in info.items():
+            per_agent = t.dim() >= 2 and t.shape[1] == self.num_of_agents and name not in ("last_price", "best_bid", "best_ask", "spread")
+            for k, a in enumerate(agents):
+                infos[a][name] = t[:, k] if per_agent else t
+        return observations, rewards, terminateds, truncateds, infos
+
+    def _seed_arg(self, seed):
+        if seed is None and not self._seeded:
+            seed = _entropy_seed()
+        self._seeded = True
+        if isinstance(seed, numbers.Integral):                      # market i gets SeedSequence(seed + i)
+            return (np.uint64(int(seed) & (2 ** 64 - 1)) + np.arange(self.num_envs, dtype=np.uint64)).astype(np.uint64)
+        return seed
+
+    def reset_batch(self, seed=None, mask=None):
+        obs = self._vec.reset(seed=self._seed_arg(seed), mask=mask)
+        return {a: obs for a in self.agents}, {a: {} for a in self.agents}
+
+    def step_batch(self, actions):
+        first = next(iter(actions.values()))
+        if isinstance(first, dict):                                 # {agent: {key: [N]}} -> {key: [N, A]}
+            missing = [a for a in self.agents if a not in actions]
+            present = None
+            if missing:
+                present = torch.zeros((self.num_envs, self.num_of_agents), dtype=torch.uint8, device=self._vec.device)
+            cols = {k: [] for k in ACTION_KEYS}
+            dts = {"category": torch.int32, "size_mean": torch.float32, "size_sigma": torch.float32, "price": torch.int32, "price_offset": torch.int32}
+            dev, n = self._vec.device, self.num_envs
+            for j, a in enumerate(self.agents):
+                act = actions.get(a)
+                if act is not None and present is not None:
+                    present[:, j] = 1
+                for k in ACTION_KEYS:
+                    if act is None:
+                        cols[k].append(torch.zeros(n, dtype=dts[k], device=dev))
+                    else:
+                        v = act.get(k, 1 if k == "price_offset" else 0) if k in ("price", "price_offset") else act[k]
+                        v = torch.as_tensor(v, device=dev).to(dts[k]).reshape(-1)
+                        cols[k].append(v.expand(n) if v.numel() == 1 else v.reshape(n))
+            actions = {k: torch.stack(cols[k], dim=1) for k in ACTION_KEYS}
+            if present is not None:
+                actions["present"] = present
+        obs, rew, term, trunc, info = self._vec.step(actions)
+        return self._views(obs, rew, term, trunc, info)
+
+    # ---- vector protocol: one sub-env per market --------------------------------------------------------------
+    def reset(self, *, seed=None, options=None, mask=None):
+        obs = self._vec.reset(seed=self._seed_arg(seed), mask=mask).cpu().numpy()
+        return [{a: obs[i] for a in self.agents} for i in range(self.num_envs)], [{a: {} for a in self.agents} for _ in range(self.num_envs)]
+
+    def step(self, action_dicts):
+        if len(action_dicts) != self.num_envs:
+            raise ValueError(f"need {self.num_envs} action dicts, one per market")
+        if not self._vec.with_info:
+            raise ValueError("the vector protocol builds info dicts: construct with with_info=True")
+        vec = self._vec
+        if self._stage is None:
+            self._stage = _ActionStage(self.num_envs, self.num_of_agents, vec.device)
+            self._host = torch.empty(vec.packed.numel(), dtype=torch.uint8).pin_memory()
+        st = self._stage
+        st.clear()
+        buf = st.np
+        for i, actions in enumerate(action_dicts):
+            self._encode(actions, buf["category"][i], buf["size_mean"][i], buf["size_sigma"][i], buf["price"][i], buf["price_offset"][i], buf["present"][i])
+        t = st.upload()                                            # ONE host-to-device copy of the batch's actions
+        vec.step(t["category"], t["size_mean"], t["size_sigma"], t["price"], t["price_offset"], t["present"])
+        vec.join()
+        self._host.copy_(vec.packed)                               # ONE device-to-host copy for the whole batch
+        obs, rew, term, trunc, info = vec.unpack_host(self._host)
+        obs = obs.copy()                                           # the caller keeps these rows; the staging buffer is reused
+        outs = ([], [], [], [], [])
+        for i, actions in enumerate(action_dicts):
+            five, _, _, _ = self._decode(i, actions, obs, rew, term, trunc, info)
+            for lst, x in zip(outs, five):
+                lst.append(x)
+        return outs
+
+    def close(self):
+        self._vec.close()

@@ -47,24 +47,32 @@ class CDAVecEnv:
         # step t+1 writes a different slab while step t's is still being read by an all-gather in flight.
         from .parallel import slab_layout, slab_views
         self.slab_layout = slab_layout(N, self.obs_dim, A)
-        self._slabs = torch.zeros((max(1, int(out_buffers)), self.slab_layout["bytes"]), dtype=torch.uint8, device=dev)
-        self._views = [slab_views(self._slabs[b], self.slab_layout) for b in range(self._slabs.shape[0])]
+        self.with_info = bool(with_info)
+        # ONE device allocation holds the output slab(s) and, behind them, every info tensor (16-byte aligned each):
+        # a host-side consumer (the dict facades) moves a whole step's outputs with a single D2H copy of `packed`.
+        B, sb = max(1, int(out_buffers)), self.slab_layout["bytes"]
+        self.info_layout, off = {}, B * sb
+        if self.with_info:
+            for name, ct, per_agent, dims in K.INFO_FIELDS:
+                shape = ((N, A) if per_agent else (N,)) + tuple(dims)
+                shape = shape + (16,) if ct is K.Dec else shape
+                dt = torch.uint8 if ct is K.Dec else _TORCH_OF[ct]
+                nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
+                self.info_layout[name] = (off, dt, shape, nbytes)
+                off += (nbytes + 15) // 16 * 16
+        self._all = torch.zeros(off, dtype=torch.uint8, device=dev)
+        self._slabs = self._all[:B * sb].view(B, sb)
+        self._views = [slab_views(self._slabs[b], self.slab_layout) for b in range(B)]
         self._out_ptrs = [tuple(t.data_ptr() for t in v) for v in self._views]
         self._step_call = lib().cda_step
         self._cur = 0
         self._bind_outputs()
-        self.with_info = bool(with_info)
         self.info = {}
         self._info_ptrs = K.InfoPtrs()
-        if self.with_info:
-            for name, ct, per_agent, dims in K.INFO_FIELDS:
-                shape = ((N, A) if per_agent else (N,)) + tuple(dims)
-                if ct is K.Dec:
-                    t = torch.zeros(shape + (16,), dtype=torch.uint8, device=dev)
-                else:
-                    t = torch.zeros(shape, dtype=_TORCH_OF[ct], device=dev)
-                self.info[name] = t
-                setattr(self._info_ptrs, name, t.data_ptr())
+        for name, (o, dt, shape, nbytes) in self.info_layout.items():
+            t = self._all[o:o + nbytes].view(dt).view(shape)
+            self.info[name] = t
+            setattr(self._info_ptrs, name, t.data_ptr())
         self._info_ref = C.byref(self._info_ptrs) if self.with_info else None
         # groups > 1: step() launches the batch as `groups` contiguous market groups, each an independent chain of
         # launches on its own stream (cda_step_groups).  Markets never interact, so nothing is lost - and a group's
@@ -86,6 +94,28 @@ class CDAVecEnv:
             self._fork_ev = torch.cuda.Event()
             self._join_ev = [torch.cuda.Event() for _ in range(self.groups)]
             self._need_fork = True
+
+    @property
+    def packed(self):
+        """uint8 view of everything a step writes: [output slab(s) | info tensors] (`slab_layout`, `info_layout`)."""
+        return self._all
+
+    def unpack_host(self, host):
+        """numpy views (no copies) into a HOST copy of `packed` (a uint8 numpy array or CPU tensor): the current
+        slab's (obs, reward, terminated, truncated) and the info dict."""
+        h = host.numpy() if isinstance(host, torch.Tensor) else host
+        lay, sb = self.slab_layout, self.slab_layout["bytes"]
+        base = self._cur * sb
+        n, od, a = lay["n"], lay["obs_dim"], lay["num_agents"]
+        obs = h[base + lay["obs"]: base + lay["obs"] + n * od * 4].view(np.float32).reshape(n, od)
+        rew = h[base + lay["reward"]: base + lay["reward"] + n * a * 8].view(np.float64).reshape(n, a)
+        term = h[base + lay["terminated"]: base + lay["terminated"] + n]
+        trunc = h[base + lay["truncated"]: base + lay["truncated"] + n]
+        info = {}
+        for name, (o, dt, shape, nbytes) in self.info_layout.items():
+            npdt = {torch.uint8: np.uint8, torch.int32: np.int32, torch.float64: np.float64}[dt]
+            info[name] = h[o:o + nbytes].view(npdt).reshape(shape)
+        return obs, rew, term, trunc, info
 
     def _bind_outputs(self):
         self.out_slab = self._slabs[self._cur]

@@ -99,7 +99,7 @@ def book_rows(lob):
     return out, len(rows_b), len(rows_a)
 
 
-def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None, reseed_at=None, presets=None):
+def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None, reseed_at=None, presets=None, dict_order=None):
     env = continuousDoubleAuctionEnv(dict(config))
     A = env.num_of_agents
     obs0, _ = env.reset(seed=seed)
@@ -140,7 +140,9 @@ def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None,
         env.set_agg_LOB()
         raw_pre = np.asarray(env.agg_LOB_raw, np.float32).copy()
         actions = {}
-        for a in range(A):
+        # dict_order: the reference assigns its RNG draws (and builds its arrival list) in the ITERATION order of this dict
+        # (action_helper.py:145-172); a non-ascending order is recorded as given, in the reference's own agent ids
+        for a in (range(A) if dict_order is None else dict_order):
             if present[a]:
                 actions[f"agent_{a}"] = {
                     "category": np.int64(cat[a]), "size_mean": np.array([mean[a]], np.float32),
@@ -224,6 +226,9 @@ def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None,
         resets=np.array(resets, np.int64).reshape(-1, 2),
         presets=np.array(preset_rows, np.int64).reshape(-1, 6),
     )
+    if dict_order is not None:
+        assert sorted(dict_order) == list(range(A))
+        rec["dict_order"] = np.array(dict_order, np.int32)
     nonint = sum(1 for s in acc_exp for v in s[:, 4] if v < -1)
     print(f"{name}: T={T} A={A} tape={L['tape_len'][-1]} max_orders={max(b[1] + b[2] for b in book_off)} "
           f"deep-exp NAVs={nonint} term={sum(L['term'])} rejected={int(np.array(cnt_l)[:, :, 3].sum())}")
@@ -274,6 +279,9 @@ def main():
     add("bigsize_aggr_s82", dict(base8, init_cash=50000000000, mkt_max_size=3000, limit_size_multiple=7), 82, 160, 7082, law="aggressive")
     add("floor_s83", dict(base4, initial_price_min=1, initial_price_max=3), 83, 192, 7083)
     add("long_s100", dict(base4, max_step=2048), 100, 2048, 7100)
+    # action dicts handed over in a fixed NON-ascending key order (all agents, and subsets of them)
+    add("perm_s91", dict(base4), 91, 160, 7091, dict_order=[2, 0, 3, 1])
+    add("perm8_s92", dict(base8), 92, 128, 7092, law="aggressive", present_p=0.7, dict_order=[5, 1, 7, 0, 3, 6, 2, 4])
     for name, rec in traces.items():
         np.savez_compressed(os.path.join(out_dir, f"trace_{name}.npz"), **rec)
     if only:

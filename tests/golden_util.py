@@ -25,12 +25,48 @@ def trace_names():
     return sorted(os.path.basename(p)[len("trace_"):-4] for p in glob.glob(os.path.join(GOLD, "trace_*.npz")))
 
 
-def load(name):
+def load(name, relabel=True):
     with np.load(os.path.join(GOLD, f"trace_{name}.npz")) as z:
         rec = {k: z[k] for k in z.files}
     rec["config"] = json.loads(str(rec["config"]))
     rec["name"] = name
+    if relabel and "dict_order" in rec:
+        rec = relabel_by_dict_order(rec)
     return rec
+
+
+_AGENT_AXIS1 = ["cat", "price", "off", "present", "mean", "sigma", "reward", "dec_type", "dec_side", "dec_size", "dec_price", "acc_sign",
+                "acc_exp", "acc_coeff", "net_position", "num_trades", "counters", "is_pass", "reward_terms", "info_floats"]
+
+
+def relabel_by_dict_order(rec):
+    """A trace cut with action dicts in the fixed key order `dict_order` (reference agent ids), restated in the build's
+    canonical labelling: the build always processes agents in ascending index order, so its agent k plays the part of
+    the reference's agent dict_order[k] (the k-th key the reference iterated).  All traders start identical, so this
+    is a pure renaming: per-agent columns are permuted, agent ids stored as VALUES (execution order, book owners,
+    done mask, presets) are mapped."""
+    order = np.asarray(rec["dict_order"], np.int64)
+    A = len(order)
+    inv = np.empty(A, np.int64)
+    inv[order] = np.arange(A)
+    out = dict(rec)
+    for k in _AGENT_AXIS1:
+        out[k] = rec[k][:, order]
+    ex = rec["exec_order"].copy()
+    ex[ex >= 0] = inv[ex[ex >= 0]]
+    out["exec_order"] = ex
+    book = rec["book"].copy()
+    book[:, 2] = inv[book[:, 2]]
+    out["book"] = book
+    dm = np.zeros_like(rec["done_mask"])
+    for old in range(A):
+        dm |= ((rec["done_mask"] >> old) & 1) << int(inv[old])
+    out["done_mask"] = dm
+    pre = rec["presets"].copy()
+    if len(pre):
+        pre[:, 1] = inv[pre[:, 1]]
+    out["presets"] = pre
+    return out
 
 
 def f32_bits(a):

@@ -21,3 +21,19 @@ def test_hip_matches_reference_goldens(key):
     assert steps > 0
     assert (env.flags() == 0).all()
     env.close()
+
+
+@pytest.mark.parametrize("name", ["perm_s91", "perm8_s92"])
+def test_dict_key_order_is_a_pure_relabelling_of_agents(name):
+    """See tests/test_oracle_golden.py: reference traces cut from action dicts in a fixed NON-ascending key order are
+    reproduced by the HIP path once agent k is read as the k-th key the reference iterated - and not otherwise."""
+    from hip_env import HipEnv
+    raw, ren = G.load(name, relabel=False), G.load(name)
+    env = HipEnv(ren["config"], n_markets=1)
+    assert G.run_group(env, [ren], state_every=4) == raw["cat"].shape[0]
+    assert (env.flags() == 0).all()
+    env.close()
+    env = HipEnv(raw["config"], n_markets=1)
+    with pytest.raises(AssertionError):
+        G.run_group(env, [raw], state_every=0)
+    env.close()
