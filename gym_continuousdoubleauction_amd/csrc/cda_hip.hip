@@ -584,6 +584,53 @@ __global__ void k_nav_conservation(const uint8_t* arena, Params P, double tol, d
     err_out[i] = e;
     if (viol_out) viol_out[i] = (uint8_t)(e > tol || ferr != 0);
 }
+// Structural invariants of every market, one thread per market (size-independent property check for the full-size runs):
+// the reference's OrderTree keeps each side sorted by price (ordertree.py:44-58), a book is never left crossed
+// (orderbook.py:162-194 matches before it rests), resting quantities are positive, cash_on_hold is exactly the value of
+// the trader's own resting orders (cash_processor.py:15-29 / :85-97 escrow and release) and every unit long is a unit
+// short (account.py:196-213).
+__global__ void k_check_invariants(const uint8_t* arena, Params P, uint32_t* out) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= P.n_markets) return;
+    const uint8_t* rec = arena + (size_t)i * (size_t)P.lay.stride;
+    const uint32_t* h = (const uint32_t*)rec;
+    const int32_t* bp = (const int32_t*)(rec + P.lay.book_off);
+    const Acc* acc = (const Acc*)(rec + P.lay.acc_off);
+    const int nb = (int)h[H_N_BIDS], na = (int)h[H_N_ASKS], A = P.cfg.num_agents;
+    uint32_t v = 0;
+    if (nb < 0 || na < 0 || nb + na > CAP) { out[i] = CDA_INV_BOOK_COUNT; return; }
+    long long held[CDA_MAX_AGENTS];
+    for (int a = 0; a < CDA_MAX_AGENTS; a++) held[a] = 0;
+    for (int sd = 0; sd < 2; sd++) {
+        const int n = sd == 0 ? nb : na;
+        for (int k = 0; k < n; k++) {
+            const int ph = book_phys(sd, k);
+            const int32_t p = bp[0 * CAP + ph], q = bp[1 * CAP + ph];
+            const int owner = bp[2 * CAP + ph] & 15;
+            if (q <= 0 || p <= 0) v |= CDA_INV_QTY;
+            if (owner >= A) v |= CDA_INV_OWNER; else held[owner] += (long long)p * (long long)q;
+            if (k > 0) {
+                const int pp = book_phys(sd, k - 1);
+                const int32_t prev = bp[0 * CAP + pp];
+                if (sd == 0 ? prev < p : prev > p) v |= sd == 0 ? CDA_INV_BIDS_SORTED : CDA_INV_ASKS_SORTED;
+            }
+        }
+    }
+    if (nb > 0 && na > 0 && bp[0 * CAP + book_phys(0, 0)] >= bp[0 * CAP + book_phys(1, 0)]) v |= CDA_INV_CROSSED;
+    long long net = 0;
+    for (int a = 0; a < A; a++) {
+        net += acc[a].net_position;
+        const cda_dec& hd = acc[a].hold;                                   // exact: hold * 10^-exp == held
+        u128 c = ((u128)hd.w[2] << 64) | ((u128)hd.w[1] << 32) | (u128)hd.w[0];
+        u128 want = (u128)(unsigned long long)held[a];
+        bool ok = !hd.sign || c == 0;
+        if (hd.exp <= 0 && hd.exp >= -18) { for (int k = 0; k < -hd.exp; k++) want *= 10u; ok = ok && c == want; }
+        else ok = false;
+        if (!ok) v |= CDA_INV_ESCROW;
+    }
+    if (net != 0) v |= CDA_INV_NET_POSITION;
+    out[i] = v;
+}
 __global__ void k_flags(uint8_t* arena, Params P, uint32_t* out) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i < P.n_markets) out[i] = ((const uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride))[H_FLAGS];
@@ -1055,6 +1102,14 @@ int cda_last_flags(cda_env* e, uint32_t* flags_out, void* stream) {
     if (!e || !flags_out) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_flags, dim3((unsigned)((e->P.n_markets + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->arena, e->P, flags_out);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+
+int cda_check_invariants(cda_env* e, uint32_t* violations_out, void* stream) {
+    if (!e || !violations_out) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_check_invariants, dim3((unsigned)((e->P.n_markets + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)e->arena, e->P, violations_out);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }

@@ -120,8 +120,10 @@ def _capture_policy_step(model, env, N, A):
     return g, (pobs, actions, logp, val, env_acts)
 
 
-def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True):
-    """On-device PPO over a CDAVecEnv-shaped env. Returns per-iteration stats (incl. agent-steps/s)."""
+def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, rollout_hook=None):
+    """On-device PPO over a CDAVecEnv-shaped env. Returns per-iteration stats (incl. agent-steps/s).
+    rollout_hook(iteration, step, env_actions, obs, reward, terminated, truncated): called after every env step with the
+    five [N,A] action tensors the policy produced and the step's output tensors (device tensors; clone what you keep)."""
     torch.manual_seed(seed)
     dev = env.obs.device
     N, A = env.n_markets, env.num_agents
@@ -148,11 +150,16 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
                 g.replay()                                           # reads env.obs (this step's observation)
                 pobs, actions, logp, val = pobs_s.clone(), tuple(x.clone() for x in actions_s), logp_s.clone(), val_s.clone()
                 o, r, term, trunc, _ = env.step(*env_acts_s)
+                if rollout_hook is not None:
+                    rollout_hook(it, len(buf_obs), env_acts_s, o, r, term, trunc)
             else:
                 pobs = env.obs.repeat_interleave(A, dim=0)           # every agent of a market sees the same vector
                 with torch.no_grad():
                     actions, logp, val = model.act(pobs)
-                o, r, term, trunc, _ = env.step(*to_env_actions(actions, N, A))
+                env_acts = to_env_actions(actions, N, A)
+                o, r, term, trunc, _ = env.step(*env_acts)
+                if rollout_hook is not None:
+                    rollout_hook(it, len(buf_obs), env_acts, o, r, term, trunc)
             done = (term | trunc)
             buf_obs.append(pobs); buf_act.append(actions); buf_logp.append(logp); buf_val.append(val)
             buf_rew.append((r.float() * reward_scale).reshape(-1)); buf_done.append(done.repeat_interleave(A).float())
@@ -184,11 +191,27 @@ def main(argv=None):
     p.add_argument("--horizon", type=int, default=64)
     p.add_argument("--iters", type=int, default=4)
     p.add_argument("--max-step", type=int, default=4096)
+    p.add_argument("--out", default=None, help="write a JSON summary (config, per-iteration stats, end-of-run env checks) to this file")
     args = p.parse_args(argv)
     from .vec_env import CDAVecEnv
     env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False, "auto_reset": True},
                     n_markets=args.markets, device="cuda:0", with_info=False)
-    train(env, iters=args.iters, horizon=args.horizon)
+    _, hist = train(env, iters=args.iters, horizon=args.horizon)
+    flags = env.flags()
+    _, bad = env.nav_conservation()
+    summary = {"metric": "agent-steps/sec end to end (rollout + PPO update), BASELINE configs[4]",
+               "config": {"workload": f"{args.markets} markets x {args.agents} agents, PyTorch-ROCm PPO policy in the loop (256x256 tanh actor and critic, "
+                                      f"4 epochs, 65536-sample minibatches), horizon {args.horizon}, {args.iters} iterations, auto_reset on",
+                          "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters},
+               "iterations": hist,
+               "value": sum(h["agent_steps"] for h in hist[1:] or hist) / sum(h["rollout_s"] + h["update_s"] for h in hist[1:] or hist),
+               "rollout_agent_steps_per_s": sum(h["agent_steps"] for h in hist[1:] or hist) / sum(h["rollout_s"] for h in hist[1:] or hist),
+               "unit": "agent-steps/s", "flagged_markets": int((flags != 0).sum().item()), "nav_conservation_violations": int(bad.sum().item()),
+               "invariant_violations": int((env.check_invariants() != 0).sum().item())}
+    print(json.dumps(summary))
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump(summary, fh, indent=1)
     env.close()
 
 

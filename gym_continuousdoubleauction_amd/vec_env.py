@@ -309,6 +309,16 @@ class CDAVecEnv:
             check(lib().cda_book_peak(self._h, p.data_ptr(), self._stream()), "cda_book_peak")
         return p
 
+    def check_invariants(self):
+        """Structural invariants of every market on the device (include/cda.h CDA_INV_*): int32[N] of violation bits, 0 = sides
+        sorted by price, book uncrossed, quantities positive, cash_on_hold == value of own resting orders, positions
+        net to zero."""
+        self.join()
+        v = torch.zeros(self.n_markets, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().cda_check_invariants(self._h, v.data_ptr(), self._stream()), "cda_check_invariants")
+        return v
+
     def nav_conservation(self, tolerance=1e-6):
         """The reference's end-of-episode invariant for every market, computed on the device in the ledger's own decimal
         arithmetic: (float(|sum of NAV - A * init_cash|) f64[N], violated bool[N])."""

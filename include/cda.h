@@ -255,6 +255,20 @@ int cda_last_flags(cda_env* env, uint32_t* flags_out, void* stream);
  * last reset.  The reference's OrderTree is unbounded (ordertree.py:5-58); this build holds CDA_BOOK_CAP. */
 int cda_book_peak(cda_env* env, int32_t* peak_out, void* stream);
 
+/* Structural invariants of every market -> u32[N] device buffer of CDA_INV_* bits (0 = all hold): sides sorted best
+ * price first (ordertree.py:44-58), book not crossed (orderbook.py:162-194), quantities positive,
+ * cash_on_hold == value of the trader's own resting orders, exactly (cash_processor.py:15-29, :85-97), positions net
+ * to zero (account.py:196-213).  A size-independent property check for runs too large to replay on the CPU. */
+#define CDA_INV_BIDS_SORTED   0x01u
+#define CDA_INV_ASKS_SORTED   0x02u
+#define CDA_INV_CROSSED       0x04u
+#define CDA_INV_QTY           0x08u
+#define CDA_INV_ESCROW        0x10u
+#define CDA_INV_NET_POSITION  0x20u
+#define CDA_INV_OWNER         0x80u
+#define CDA_INV_BOOK_COUNT    0x100u
+int cda_check_invariants(cda_env* env, uint32_t* violations_out, void* stream);
+
 /* Device self-tests of the ledger arithmetic and the RNG (host pointers; synchronous).
  * op: 0 add, 1 sub, 2 mul, 3 div, 4 cmp (result in out[i].w[0]: 0 lt, 1 eq, 2 gt), 5 to-double
  * (bits in out[i].w[0..1]). For mul/div `b` must be integer valued with coefficient < 2^32. */
