@@ -187,6 +187,25 @@ def main():
         e.reset(seed=seeds)
         return e
 
+    # Clock primer: an idle MI355X sits in a low-power state and needs tens of milliseconds of work before its engine clock
+    # is up; the driver's default run times 20 steps (~1 ms) right after start-up, which would measure the ramp, not the
+    # kernel.  A SCRATCH env (not the measured one) is stepped for ~PRIMER_MS first; the measured env then does exactly
+    # W untimed + K timed steps from its own reset.
+    primer_ms = float(os.environ.get("CDA_BENCH_PRIMER_MS", "40"))
+    primer_steps = 0
+    if primer_ms > 0 and not args.fused:
+        scratch = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=False, groups=groups)
+        scratch.reset(seed=seeds)
+        pa = scratch.random_actions_device(0, 64, action_seed=ACTION_SEED + 1, market_index_base=first_market)
+        t_end = time.perf_counter() + primer_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for i in range(64):
+                scratch.step(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i])
+            scratch.join()
+            torch.cuda.synchronize()
+            primer_steps += 64
+        scratch.close()
+        del pa
     env = make_env(args.info)
     # The action stream of the whole run, resident in HBM (20 B per agent-step: 350 MB for the default 1064 steps of
     # 4096 x 4); beyond MAX_RESIDENT steps the run cycles through the first MAX_RESIDENT (reported in `data`).
@@ -393,6 +412,7 @@ def main():
                                    + (f"; FUSED: {args.fused} steps per launch (cda_run_random)" if args.fused else ""),
                        "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info), "groups": env.groups,
                        "actions": f"cda_random_actions(seed {ACTION_SEED}, step, global market, agent), resident in HBM",
+                       "clock_primer": f"{primer_steps} untimed steps on a scratch env before the measured env's reset",
                        "gather_schedule": schedule_note, "gather_calibration": schedule_us,
                        "collective": ("all_gather(obs|reward|flags slab), " + ("overlapped with the next step on alternating streams" if overlap else "serial")) if gather else "none",
                        "flagged_markets": n_flagged, "peak_resting_orders": peak_orders},

@@ -15,11 +15,17 @@ import torch
 
 
 def shard_range(rank, world, n_total):
-    """Contiguous block partition of the market axis."""
-    if n_total % world != 0:
-        raise ValueError(f"n_markets_total={n_total} must be divisible by world size {world}")
+    """Contiguous block partition of the market axis: (first, count) of `rank`.  Every rank holds n_total // world
+    markets; a remainder goes to the LAST rank (the slab all-gather pads every shard to the largest one)."""
+    if not 0 <= rank < world or n_total < world:
+        raise ValueError(f"need 0 <= rank < world <= n_markets_total, got rank={rank} world={world} n_markets_total={n_total}")
     per = n_total // world
-    return rank * per, per
+    return rank * per, per + (n_total - per * world if rank == world - 1 else 0)
+
+
+def shard_pad(world, n_total):
+    """Markets of the largest shard (what every rank's slab is laid out for)."""
+    return n_total // world + n_total % world
 
 
 def global_seeds(seed_base, first, count):
@@ -109,6 +115,7 @@ class ShardedVecEnv:
         self.obs_dim = self.env.obs_dim
         self.num_agents = self.env.num_agents
         self._packed = None
+        self._padded = None
         self._gathered = None
         self.layout = slab_layout(self.n_local, self.obs_dim, self.num_agents)
         self._gbufs, self._gnext = [None, None], 0
@@ -126,10 +133,20 @@ class ShardedVecEnv:
         self._packed = pack_outputs(obs, reward, terminated, truncated, self._packed)
         if self.world == 1:
             return unpack_outputs(self._packed, self.obs_dim, self.num_agents)
+        n_pad, cols = shard_pad(self.world, self.n_total), self._packed.shape[1]
+        send = self._packed
+        if n_pad != self.n_local:           # uneven shards (the last rank holds the remainder): every contribution is padded to the largest
+            if self._padded is None:
+                self._padded = torch.zeros((n_pad, cols), dtype=torch.float32, device=send.device)
+            self._padded[:self.n_local].copy_(send)
+            send = self._padded
         if self._gathered is None:
-            self._gathered = torch.empty((self.n_total, self._packed.shape[1]), dtype=torch.float32, device=self._packed.device)
-        self.dist.all_gather_into_tensor(self._gathered, self._packed)
-        return unpack_outputs(self._gathered, self.obs_dim, self.num_agents)
+            self._gathered = torch.empty((self.world * n_pad, cols), dtype=torch.float32, device=send.device)
+        self.dist.all_gather_into_tensor(self._gathered, send)
+        g = self._gathered
+        if self.n_total % self.world:
+            g = torch.cat([g[r * n_pad: r * n_pad + shard_range(r, self.world, self.n_total)[1]] for r in range(self.world)], dim=0)
+        return unpack_outputs(g, self.obs_dim, self.num_agents)
 
     def gather_async(self, outputs=None):
         """Start the all-gather of this rank's output slab (the env's current one, i.e. the outputs of the
@@ -137,6 +154,8 @@ class ShardedVecEnv:
         handles may be outstanding; with a double-buffered env the caller's loop is
             step(t); h = gather_async(); prev.wait(); prev = h
         which lets gather(t) run under the kernel of step t+1."""
+        if self.n_total % self.world:
+            raise ValueError("the slab all-gather needs equal shards (n_markets_total divisible by the world size); use gather()")
         slab = getattr(self.env, "out_slab", None) if outputs is None else None
         if slab is None:                    # an env without slab-backed outputs: build the slab (copies)
             if outputs is None:

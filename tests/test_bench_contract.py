@@ -98,3 +98,17 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 48 and "all_gather" in d["config"]["collective"] and d["config"]["flagged_markets"] == 0
     assert "calibrated" in (d["config"]["gather_schedule"] or "") and "global 512 markets" in d["config"]["workload"]
     assert abs(d["value"] - 2 * 256 * 4 * 48 / (d["ms_per_step"] * 1e-3 * 48)) / d["value"] < 1e-6
+
+
+def test_rccl_refuses_two_ranks_on_one_device():
+    """Why the two-rank test above runs over gloo: RCCL (like NCCL) refuses a communicator with two ranks on one GPU, so the
+    multi-rank RCCL path cannot execute on a one-GPU box.  This pins the refusal (and its text, quoted in DESIGN §5): if a
+    future RCCL allows it, this test fails and the gloo stand-in should be replaced by the real transport."""
+    env = dict(os.environ, CDA_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CDA_BENCH_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8",
+                          "--warmup", "4", "--markets", "64", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0
+    assert "Duplicate GPU detected" in out.stderr, out.stderr[-1500:]

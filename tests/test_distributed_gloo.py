@@ -82,6 +82,53 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
+def _worker_uneven(rank, world, port, outdir, n_total):
+    """13 markets over 2 ranks: 6 + 7 (the last rank takes the remainder); the packed gather pads and trims."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv, shard_range
+    env = ShardedVecEnv(CFG, n_total, device=None, env_factory=lambda c, n, d: _OracleStepper(c, n, d))
+    assert (env.first, env.n_local) == shard_range(rank, world, n_total) == (rank * (n_total // world), n_total // world + (n_total % world if rank == world - 1 else 0))
+    env.reset(seed_base=1000)
+    rec = []
+    for t in range(8):
+        rng = np.random.default_rng(500 + t)
+        full = (rng.integers(0, 9, (n_total, A)).astype(np.int32), rng.uniform(-1, 1, (n_total, A)).astype(np.float32),
+                rng.uniform(0, 1, (n_total, A)).astype(np.float32), rng.integers(0, 10, (n_total, A)).astype(np.int32),
+                rng.integers(0, 3, (n_total, A)).astype(np.int32))
+        acts = [torch.from_numpy(x[env.first:env.first + env.n_local]) for x in full]
+        g = env.gather(*env.step(*acts)[:4])
+        assert g[0].shape[0] == n_total
+        rec.append([x.clone().numpy() for x in g])
+    with pytest.raises(ValueError):
+        env.gather_async(outputs=env.step(*acts)[:4])
+    if rank == 0:
+        np.savez(os.path.join(outdir, "uneven.npz"), obs=np.stack([r[0] for r in rec]), rew=np.stack([r[1] for r in rec]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_last_rank_takes_the_remainder(tmp_path):
+    n_total = 13
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_uneven, args=(2, port, str(tmp_path), n_total), nprocs=2, join=True)
+    got = np.load(tmp_path / "uneven.npz")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ref = _OracleStepper(CFG, n_total, None)
+    ref.reset(torch.arange(1000, 1000 + n_total, dtype=torch.int64))
+    for t in range(8):
+        rng = np.random.default_rng(500 + t)
+        full = (rng.integers(0, 9, (n_total, A)).astype(np.int32), rng.uniform(-1, 1, (n_total, A)).astype(np.float32),
+                rng.uniform(0, 1, (n_total, A)).astype(np.float32), rng.integers(0, 10, (n_total, A)).astype(np.int32),
+                rng.integers(0, 3, (n_total, A)).astype(np.int32))
+        obs, rew, _, _, _ = ref.step(*[torch.from_numpy(x) for x in full])
+        assert np.array_equal(got["obs"][t].view(np.uint32), obs.numpy().view(np.uint32)), t
+        assert np.array_equal(got["rew"][t].view(np.uint64), rew.numpy().view(np.uint64)), t
+
+
 def test_two_rank_shards_gather_to_the_single_process_result(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -47,8 +47,15 @@ def test_spaces_match_the_reference_contract():
 
 def test_shard_range_and_seeds():
     assert P.shard_range(0, 8, 16384) == (0, 2048) and P.shard_range(7, 8, 16384) == (14336, 2048)
+    # a size the world does not divide: equal blocks, the last rank takes the remainder; the shards tile the batch
+    assert [P.shard_range(r, 3, 10) for r in range(3)] == [(0, 3), (3, 3), (6, 4)] and P.shard_pad(3, 10) == 4
+    for world, n in ((8, 16384), (3, 10), (7, 100), (5, 5)):
+        parts = [P.shard_range(r, world, n) for r in range(world)]
+        assert parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1)) and sum(c for _, c in parts) == n
     with pytest.raises(ValueError):
-        P.shard_range(0, 3, 10)
+        P.shard_range(3, 3, 10)
+    with pytest.raises(ValueError):
+        P.shard_range(0, 4, 3)
     s = P.global_seeds(1000, 2048, 4)
     assert s.tolist() == [3048, 3049, 3050, 3051]
 
