@@ -18,7 +18,7 @@ SYMBOLS = [
     "cda_mark_to_mkt", "cda_get_state", "cda_set_state", "cda_get_raw_snapshot", "cda_last_flags",
     "cda_selftest_dec", "cda_selftest_rng", "cda_strerror", "cda_num_markets", "cda_obs_dim",
     "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host", "cda_nav_conservation",
-    "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants",
+    "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants", "cda_selftest_libm", "cda_selftest_libm_host",
 ]
 
 
@@ -49,6 +49,8 @@ def lib():
     L.cda_random_actions.argtypes = [u64, u64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.cda_book_peak.argtypes = [vp, vp, vp]
     L.cda_check_invariants.argtypes = [vp, vp, vp]
+    L.cda_selftest_libm.argtypes = [i32, i32, i32, vp, vp]
+    L.cda_selftest_libm_host.argtypes = [i32, i32, vp, vp]
     L.cda_run_random.argtypes = [vp, i32, u64, u64, vp, vp, vp, vp, vp, vp]
     L.cda_random_actions_host.argtypes = [u64, u64, i32, i32, i32, vp, vp, vp, vp, vp]
     L.cda_nav_conservation.argtypes = [vp, C.c_double, vp, vp, vp]

@@ -719,6 +719,10 @@ __global__ void k_selftest_dec(int op, int n, const cda_dec* a, const cda_dec* b
     }
     out[i] = o;
 }
+__global__ void k_selftest_libm(int op, int n, const double* x, double* y) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) y[i] = op == 0 ? glibc_log1p(x[i]) : (op == 1 ? glibc_exp(x[i]) : sqrt(x[i]));     // op 2: the IEEE square root of the observation's size rows
+}
 __global__ void k_selftest_rng(uint64_t seed, int lo, int hi, int n_steps, int n_normals, int perm_n,
                                int32_t* first_int, double* normals, int32_t* perms, uint64_t* final_state) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1130,6 +1134,30 @@ int cda_selftest_dec(int32_t device, int32_t op, int32_t n, const cda_dec* a_hos
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out_host, dout, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    return CDA_OK;
+}
+
+int cda_selftest_libm(int32_t device, int32_t op, int32_t n, const double* x_host, double* y_host) {
+    if (n < 0 || !x_host || !y_host || op < 0 || op > 2) return CDA_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CDA_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    if (n == 0) return CDA_OK;
+    double *dx = NULL, *dy = NULL;
+    const size_t bytes = (size_t)n * sizeof(double);
+    HIPCHK(hipMalloc((void**)&dx, bytes)); HIPCHK(hipMalloc((void**)&dy, bytes));
+    HIPCHK(hipMemcpy(dx, x_host, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest_libm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (int)op, (int)n, dx, dy);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(y_host, dy, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy);
+    return CDA_OK;
+}
+/* the SAME source compiled for the host: needs no GPU (the CPU suite checks the restatement against the machine's libm) */
+int cda_selftest_libm_host(int32_t op, int32_t n, const double* x_host, double* y_host) {
+    if (n < 0 || !x_host || !y_host || op < 0 || op > 1) return CDA_ERR_INVALID;
+    for (int32_t i = 0; i < n; i++) y_host[i] = op == 0 ? glibc_log1p(x_host[i]) : glibc_exp(x_host[i]);
     return CDA_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include "../../include/cda.h"
 #include "cda_dec.hpp"
+#include "cda_libm.hpp"
 
 #define CDA_ZIG_QUAL __device__ const
 #include "ziggurat_tables.h"
@@ -242,52 +243,6 @@ __device__ __forceinline__ uint32_t rng_interval(Mkt& m, uint32_t max) {
     do { v = rng_next32(m) & mask; } while (v > max);
     return v;
 }
-// log1p as glibc 2.35 computes it (sysdeps/ieee754/dbl-64/s_log1p.c: the fdlibm algorithm with the
-// split polynomial evaluation), restated so that the ziggurat tail `r + xx` of numpy - which calls the
-// host libm - is reproduced bit for bit on the device (checked against glibc on 2e7 inputs in the build
-// container; built with -ffp-contract=off).  Finite x > -1 only.
-__device__ __forceinline__ int32_t f64_hi(double x) { return (int32_t)((unsigned long long)__double_as_longlong(x) >> 32); }
-__device__ __forceinline__ double f64_set_hi(double x, int32_t h) {
-    unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    b = (b & 0xffffffffull) | ((unsigned long long)(uint32_t)h << 32);
-    return __longlong_as_double((long long)b);
-}
-__device__ __forceinline__ double glibc_log1p(double x) {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                 Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
-                 Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
-                 Lp7 = 1.479819860511658591e-01;
-    double hfsq, f = 0.0, c = 0.0, s, z, R, u;
-    int32_t k = 1, hx = f64_hi(x), hu = 0, ax = hx & 0x7fffffff;
-    if (hx < 0x3FDA827A) {
-        if (ax >= 0x3ff00000) return x == -1.0 ? -__longlong_as_double(0x7ff0000000000000LL) : __longlong_as_double(0x7ff8000000000000LL);
-        if (ax < 0x3e200000) return ax < 0x3c900000 ? x : x - x * x * 0.5;
-        if (hx > 0 || hx <= (int32_t)0xbfd2bec3) { k = 0; f = x; hu = 1; }
-    }
-    if (k != 0) {
-        if (hx < 0x43400000) {
-            u = 1.0 + x; hu = f64_hi(u); k = (hu >> 20) - 1023;
-            c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
-            c /= u;
-        } else { u = x; hu = f64_hi(u); k = (hu >> 20) - 1023; c = 0.0; }
-        hu &= 0x000fffff;
-        if (hu < 0x6a09e) u = f64_set_hi(u, hu | 0x3ff00000);
-        else { k += 1; u = f64_set_hi(u, hu | 0x3fe00000); hu = (0x00100000 - hu) >> 2; }
-        f = u - 1.0;
-    }
-    hfsq = 0.5 * f * f;
-    if (hu == 0) {
-        if (f == 0.0) { if (k == 0) return 0.0; c += k * ln2_lo; return k * ln2_hi + c; }
-        R = hfsq * (1.0 - 0.66666666666666666 * f);
-        if (k == 0) return f - R;
-        return k * ln2_hi - ((R - (k * ln2_lo + c)) - f);
-    }
-    s = f / (2.0 + f); z = s * s;
-    double R1 = z * Lp1, z2 = z * z, R2 = Lp2 + z * Lp3, z4 = z2 * z2, R3 = Lp4 + z * Lp5, z6 = z4 * z2, R4 = Lp6 + z * Lp7;
-    R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
-    if (k == 0) return f - (hfsq - s * (hfsq + R));
-    return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
-}
 // wi / ki: the two tables every draw reads (numpy's wi_double, ki_double).  k_step passes LDS copies (the index is data
 // dependent, so each draw pays the table latency in full: ~100 cycles from LDS instead of a scalar-cache / L2 round
 // trip); fi is only read on the rare wedge path and stays in global memory.
@@ -319,7 +274,7 @@ __device__ __forceinline__ double rng_std_normal(Mkt& m, const unsigned long lon
         } else {
             double f1 = __longlong_as_double((long long)cda_zig_fi_bits[idx - 1]);
             double f0 = __longlong_as_double((long long)cda_zig_fi_bits[idx]);
-            if ((f1 - f0) * rng_double(m) + f0 < exp(-0.5 * x * x)) return x;
+            if ((f1 - f0) * rng_double(m) + f0 < glibc_exp(-0.5 * x * x)) return x;
         }
     }
 }
@@ -865,13 +820,13 @@ __device__ __forceinline__ float snapshot_value(const Lds& L, const Mkt& m, int 
         else { const double q = (side ? raw - M : M - raw) / M; out = side ? -q : q; }
     } else {
         // lanes 40 (log M) and 41 (log1p of the spread in ticks) share ONE evaluation: M is a half-integer, M - 1 is exact, and
-        // float32(log1p(M - 1)) == float32(numpy.log(M)) for every M = k/2 up to 2^19 (checked exhaustively against numpy for
-        // k <= 2^20 in the build container); beyond that lane 40 falls back to log().  log1p(+0) = +0 covers the one-sided book.
+        // float32(log1p(M - 1)) == float32(numpy.log(M)) == float32(libm log(M)) for EVERY M = k/2 with k <= 2^25, i.e. for every
+        // mid of two prices below 2^24 ticks (the price clamp of step_market) - swept exhaustively by tools/sweep_libm.py, so
+        // there is no separate log().  log1p(+0) = +0 covers the one-sided book.
         double arg = 0.0;
-        bool in_domain = true;
-        if (j == 40) { arg = M - 1.0; in_domain = M <= 524288.0; }
+        if (j == 40) arg = M - 1.0;
         else if (two) { double st = (l1_ask - l1_bid) / (double)tick; arg = st > 0.0 ? st : 0.0; }
-        out = in_domain ? glibc_log1p(arg) : log(M);
+        out = glibc_log1p(arg);
     }
     return (float)out;
 }

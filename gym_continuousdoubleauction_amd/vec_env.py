@@ -356,3 +356,15 @@ def selftest_rng(seed, lo, hi, n_steps, n_normals, perm_n, device=0):
     check(lib().cda_selftest_rng(device, seed, lo, hi, n_steps, n_normals, perm_n, first.ctypes.data,
                                  normals.ctypes.data, perm_arg.ctypes.data, fs.ctypes.data), "cda_selftest_rng")
     return int(first[0]), normals, perm_arg[:, :perm_n], fs
+
+
+def selftest_libm(op, x, device=0):
+    """The restated libm function (op 0: log1p, 1: exp) on the DEVICE (device >= 0) or by the same source compiled for the
+    host (device=None; needs no GPU): float64 numpy in / out."""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.zeros_like(x)
+    if device is None:
+        check(lib().cda_selftest_libm_host(op, len(x), x.ctypes.data, y.ctypes.data), "cda_selftest_libm_host")
+    else:
+        check(lib().cda_selftest_libm(device, op, len(x), x.ctypes.data, y.ctypes.data), "cda_selftest_libm")
+    return y

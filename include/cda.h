@@ -281,6 +281,13 @@ int cda_selftest_rng(int32_t device, uint64_t seed, int32_t lo, int32_t hi, int3
                      double* normals_host /*[n_steps*n_normals]*/, int32_t* perms_host /*[n_steps*perm_n]*/,
                      uint64_t* final_state_host /*[6]: state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger*/);
 
+/* The restated libm functions numpy's generator calls on the host (csrc/cda_libm.hpp; op 0: log1p, glibc 2.35
+ * s_log1p.c; op 1: exp, glibc 2.35 e_exp.c as built with FMA; device only, op 2: the f64 square root the observation
+ * uses, which must be the correctly rounded IEEE one) evaluated on the device / by the same source compiled
+ * for the host (no GPU needed).  Host pointers; synchronous. */
+int cda_selftest_libm(int32_t device, int32_t op, int32_t n, const double* x_host, double* y_host);
+int cda_selftest_libm_host(int32_t op, int32_t n, const double* x_host, double* y_host);
+
 const char* cda_strerror(int status);
 int32_t cda_num_markets(const cda_env* env);
 int32_t cda_obs_dim(const cda_env* env);

@@ -1032,6 +1032,12 @@ int oracle_dec_op(int32_t op, int32_t n, const cda_dec* a, const cda_dec* b, cda
     }
     return CDA_OK;
 }
+/* the host's own libm (what numpy calls): op 0 log1p, 1 exp, 2 log - the yardstick of the restated functions in csrc/cda_libm.hpp */
+int oracle_libm(int32_t op, int64_t n, const double* x, double* y) {
+    if (!x || !y || op < 0 || op > 2) return CDA_ERR_INVALID;
+    for (int64_t i = 0; i < n; i++) y[i] = op == 0 ? log1p(x[i]) : (op == 1 ? exp(x[i]) : log(x[i]));
+    return CDA_OK;
+}
 int oracle_dec_str(const cda_dec* a, char* out, int32_t cap) {
     oracle_init();
     char s[128]; dec_to_str(dec_unpack(*a), s);

@@ -64,6 +64,8 @@ int oracle_last_flags(oracle_env* env, uint32_t* flags_out);
 /* op: 0 add, 1 sub, 2 mul, 3 div, 4 cmp (out.w[0] = 0 lt / 1 eq / 2 gt), 5 to-double (bits in w[0..1]) */
 int oracle_dec_op(int32_t op, int32_t n, const cda_dec* a, const cda_dec* b, cda_dec* out);
 int oracle_dec_str(const cda_dec* a, char* out, int32_t cap);
+/* the host's libm: op 0 log1p, 1 exp, 2 log */
+int oracle_libm(int32_t op, int64_t n, const double* x, double* y);
 /* final_state: [0..5] = state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger after the draws;
  * [6..9] = state_hi, state_lo, inc_hi, inc_lo right after seeding. */
 int oracle_rng(uint64_t seed, int32_t lo, int32_t hi, int32_t n_steps, int32_t n_normals, int32_t perm_n,

@@ -52,6 +52,7 @@ def lib():
         _lib.oracle_last_flags.argtypes = [vp, vp]
         _lib.oracle_dec_op.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
         _lib.oracle_dec_str.argtypes = [C.POINTER(K.Dec), C.c_char_p, C.c_int32]
+        _lib.oracle_libm.argtypes = [C.c_int32, C.c_int64, vp, vp]
         _lib.oracle_rng.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
     return _lib
 
@@ -204,3 +205,11 @@ def rng_schedule(seed, lo, hi, n_steps, n_normals, perm_n):
     rc = lib().oracle_rng(seed, lo, hi, n_steps, n_normals, perm_n, _ptr(first), _ptr(normals), _ptr(perms), _ptr(fs))
     assert rc == 0, rc
     return int(first[0]), normals, perms[:, :perm_n], fs
+
+
+def libm(op, x):
+    """The host's own libm (what numpy's generator calls): op 0 log1p, 1 exp, 2 log."""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.zeros_like(x)
+    assert lib().oracle_libm(op, x.size, _ptr(x), _ptr(y)) == 0
+    return y

@@ -84,6 +84,22 @@ def test_device_normal_slow_paths_match_numpy():
     assert np.array_equal(z.view(np.uint64), normals[0].view(np.uint64))
 
 
+def test_device_libm_restatements_equal_the_host_libm():
+    """glibc's log1p and exp as the DEVICE evaluates them (csrc/cda_libm.hpp) against the host's libm, bit for bit: the two
+    functions numpy's normal sampler calls outside its fast path, plus the observation's log(M) = log1p(M - 1) at float32."""
+    from gym_continuousdoubleauction_amd.vec_env import selftest_libm
+    rng = np.random.default_rng(8)
+    x = np.concatenate([-7.0 * rng.random(1_500_000), -0.01 * rng.random(300_000), 1024 * rng.random(200_000) - 512, np.array([0.0, -0.0, -1e-300, -6.676])])
+    assert np.array_equal(selftest_libm(1, x).view(np.uint64), O.libm(1, x).view(np.uint64))
+    x = np.concatenate([-rng.random(1_000_000), rng.random(500_000) * 1e6, np.array([0.0, 1.0, 2.0 ** 24])])
+    assert np.array_equal(selftest_libm(0, x).view(np.uint64), O.libm(0, x).view(np.uint64))
+    M = rng.integers(1, (1 << 25) + 1, 1_000_000).astype(np.float64) / 2
+    assert np.array_equal(selftest_libm(0, M - 1.0).astype(np.float32).view(np.uint32), np.log(M).astype(np.float32).view(np.uint32))
+    # the size rows: sqrt of an integer level volume (< 2^30, include/cda.h config bound) - every volume up to 2^22 and a sample above
+    v = np.concatenate([np.arange(1, (1 << 22) + 1, dtype=np.float64), rng.integers(1 << 22, 1 << 31, 3_000_000).astype(np.float64)])
+    assert np.array_equal(selftest_libm(2, v).view(np.uint64), np.sqrt(v).view(np.uint64))
+
+
 def test_device_float_conversion_near_rounding_boundaries():
     """float(Decimal) on the device has a certified double-double path and an exact integer path behind it.
     28-digit decimals that sit ON, next to and at graded distances from the midpoint of two adjacent doubles

@@ -66,17 +66,28 @@ def test_oracle_normal_slow_paths_match_numpy():
     assert np.array_equal(z.view(np.uint64), normals[0].view(np.uint64))
 
 
+def test_restated_libm_functions_equal_the_host_libm():
+    """csrc/cda_libm.hpp restates glibc's log1p (ziggurat tail) and exp (ziggurat wedge) for the device; the SAME source compiled
+    for the host is compared here with the machine's own libm - what numpy calls - bit for bit (exp: the FMA build glibc
+    selects on every current x86-64 CPU; domain |x| < 512, the wedge needs [-6.7, 0])."""
+    from gym_continuousdoubleauction_amd.vec_env import selftest_libm
+    rng = np.random.default_rng(5)
+    x = np.concatenate([-7.0 * rng.random(3_000_000), -0.01 * rng.random(1_000_000), 1024 * rng.random(1_000_000) - 512,
+                        np.array([0.0, -0.0, -1e-300, 1e-20, -1e-17, -6.676, -0.5])])
+    assert np.array_equal(selftest_libm(1, x, device=None).view(np.uint64), O.libm(1, x).view(np.uint64))
+    x = np.concatenate([-rng.random(2_000_000), rng.random(1_000_000) * 1e6, rng.random(500_000) * 1e-3, np.array([0.0, 1.0, 0.5, 2.0 ** 24])])
+    assert np.array_equal(selftest_libm(0, x, device=None).view(np.uint64), O.libm(0, x).view(np.uint64))
+
+
 def test_log_of_half_integer_mid_equals_log1p_form_at_float32():
-    """The device computes the observation's log(M) as log1p(M - 1) (one code path shared with the spread feature).
-    For the half-integer mids M = k/2 that is the same float32 as numpy.log(M) - checked here for k <= 2^18 against the
-    host libm (the device carries a restatement of glibc's log1p); the full device domain k <= 2^20 was checked once in the
-    build container."""
-    import ctypes
-    libm = ctypes.CDLL("libm.so.6")
-    libm.log1p.restype = ctypes.c_double
-    libm.log1p.argtypes = [ctypes.c_double]
-    k = np.arange(1, (1 << 18) + 1, dtype=np.float64)
+    """The device computes the observation's log(M) as log1p(M - 1) (one code path shared with the spread feature, no log()).
+    For the half-integer mids M = k/2 that is the same float32 as numpy.log(M) and as libm's log(M): every k <= 2^20 and a
+    two-million sample of k <= 2^25 (all mids of prices below 2^24 ticks) here; tools/sweep_libm.py swept all 2^25 once."""
+    from gym_continuousdoubleauction_amd.vec_env import selftest_libm
+    rng = np.random.default_rng(6)
+    k = np.concatenate([np.arange(1, (1 << 20) + 1, dtype=np.float64), rng.integers(1 << 20, (1 << 25) + 1, 2_000_000).astype(np.float64),
+                        np.array([float(1 << 25), float((1 << 25) - 1)])])
     M = k / 2
-    ref = np.log(M).astype(np.float32)
-    alt = np.array([libm.log1p(m - 1.0) for m in M], dtype=np.float64).astype(np.float32)
-    assert np.array_equal(ref.view(np.uint32), alt.view(np.uint32))
+    alt = selftest_libm(0, M - 1.0, device=None).astype(np.float32)
+    assert np.array_equal(np.log(M).astype(np.float32).view(np.uint32), alt.view(np.uint32))
+    assert np.array_equal(O.libm(2, M).astype(np.float32).view(np.uint32), alt.view(np.uint32))
