@@ -11,7 +11,8 @@ SNAPSHOT_DIM = 42
 RAW_DIM = 40
 MAX_HIST = 16
 MAX_AGENTS = 16
-BOOK_CAP = 256
+BOOK_CAP = 256          # default book pool (resting orders per market, both sides together)
+BOOK_CAP_MAX = 512      # the larger compiled pool; sizes the parity-dump arrays
 MAX_GROUPS = 16
 NUM_REWARD_TERMS = 5
 
@@ -30,7 +31,7 @@ class Config(C.Structure):
         ("init_cash", C.c_int64),
         ("initial_price_min", C.c_int32), ("initial_price_max", C.c_int32),
         ("min_size", C.c_int32), ("mkt_max_size", C.c_int32), ("limit_size_multiple", C.c_int32),
-        ("auto_reset", C.c_int32),
+        ("auto_reset", C.c_int32), ("book_capacity", C.c_int32),
         ("order_penalty", C.c_double), ("trade_penalty", C.c_double), ("drawdown_penalty", C.c_double),
         ("passive_bonus", C.c_double), ("loss_multiplier", C.c_double),
     ]
@@ -94,7 +95,7 @@ class MarketState(C.Structure):
         ("last_price", C.c_int32), ("has_trade", C.c_int32), ("last_trade_price", C.c_int32),
         ("done_mask", C.c_uint32), ("flags", C.c_uint32),
         ("n_bids", C.c_int32), ("n_asks", C.c_int32),
-        ("bids", Order * BOOK_CAP), ("asks", Order * BOOK_CAP),
+        ("bids", Order * BOOK_CAP_MAX), ("asks", Order * BOOK_CAP_MAX),
         ("acc", AccountState * MAX_AGENTS),
         ("hist", C.c_float * (MAX_HIST * SNAPSHOT_DIM)),
     ]
@@ -127,7 +128,8 @@ def make_config(config=None):
 
     Unknown keys raise; missing keys take the reference's standalone defaults."""
     cfg = dict(ENV_DEFAULTS)
-    cfg["auto_reset"] = False            # extension of this build (include/cda.h), not a reference key
+    cfg["auto_reset"] = False            # extensions of this build (include/cda.h), not reference keys
+    cfg["book_capacity"] = 0             # 0 = by agent count (256 up to 8 agents, 512 above); or 256 / 512
     for k, v in (config or {}).items():
         if k not in cfg:
             raise KeyError(f"unknown env config key {k!r}; known: {sorted(cfg)}")
@@ -149,6 +151,7 @@ def make_config(config=None):
     c.mkt_max_size = int(cfg["mkt_max_size"])
     c.limit_size_multiple = int(cfg["limit_size_multiple"])
     c.auto_reset = 1 if cfg["auto_reset"] else 0
+    c.book_capacity = int(cfg["book_capacity"])
     c.order_penalty = float(cfg["order_penalty"])
     c.trade_penalty = float(cfg["trade_penalty"])
     c.drawdown_penalty = float(cfg["drawdown_penalty"])

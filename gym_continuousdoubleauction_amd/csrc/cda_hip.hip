@@ -60,101 +60,15 @@ __device__ __forceinline__ void vec_finish(void* dst, const void* src, int nbyte
     for (int i = lane + WAVE; i < n16; i += WAVE) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
     for (int w = (n16 << 2) + lane; w < (nbytes >> 2); w += WAVE) reinterpret_cast<uint32_t*>(dst)[w] = reinterpret_cast<const uint32_t*>(src)[w];
 }
-// The market record is loaded in two halves so that a kernel can put its per-workgroup table setup (global loads, LDS
-// writes, one __syncthreads) BETWEEN them: every request of the record is in flight while the tables are being staged.
-struct MarketPrefetch { uint32_t hv; BookPrefetch book; VecPrefetch acc, hist; };
-template <bool WITH_HIST>
-__device__ __forceinline__ MarketPrefetch load_market_issue(const MarketPtrs& mp, const Params& P, int lane) {
-    MarketPrefetch q;
-    q.hv = load_header_word(mp.hdr, lane);                 // all the requests are in flight together
-    q.book = prefetch_book(mp.book, lane);
-    q.acc = vec_prefetch(mp.acc, P.cfg.num_agents * (int)sizeof(Acc), lane);
-    q.hist.has = false; q.hist.v = make_uint4(0u, 0u, 0u, 0u);
-    // k_step: the observation's history ring rides along, so that phase 6 does not pay an HBM round trip of its own
-    if (WITH_HIST) q.hist = vec_prefetch(mp.hist, P.cfg.n_hist * CDA_SNAPSHOT_DIM * 4, lane);
-    return q;
-}
-template <bool WITH_HIST>
-__device__ __forceinline__ void load_market_finish(const MarketPtrs& mp, const Params& P, Lds& L, Mkt& m, const MarketPrefetch& q, int lane) {
-    const int acc_bytes = P.cfg.num_agents * (int)sizeof(Acc), hist_bytes = P.cfg.n_hist * CDA_SNAPSHOT_DIM * 4;
-    decode_header(q.hv, m);
-    finish_book_load(mp.book, q.book, L.book, m, lane);
-    vec_finish(&L.acc[0], mp.acc, acc_bytes, q.acc, lane);
-    if (WITH_HIST) vec_finish(lds_hist(L, P.cfg.num_agents), mp.hist, hist_bytes, q.hist, lane);
-    if (m.levels_valid && lane >= H_LEVELS && lane < H_LEVELS + 4 * CDA_K_ROWS) (&L.lvl_px[0][0])[lane - H_LEVELS] = (int32_t)q.hv;
-    CDA_WSYNC();
-}
-template <bool WITH_HIST = false>
-__device__ __forceinline__ void load_market(const MarketPtrs& mp, const Params& P, Lds& L, Mkt& m, int lane) {
-    const MarketPrefetch q = load_market_issue<WITH_HIST>(mp, P, lane);
-    load_market_finish<WITH_HIST>(mp, P, L, m, q, lane);
-}
-// the level aggregation currently in LDS describes the book as it is being stored: keep it for the next step
-__device__ __forceinline__ void store_levels(const MarketPtrs& mp, const Lds& L, int lane) {
-    if (lane >= H_LEVELS && lane < H_LEVELS + 4 * CDA_K_ROWS) mp.hdr[lane] = (uint32_t)(&L.lvl_px[0][0])[lane - H_LEVELS];
-}
-__device__ __forceinline__ void store_market(const MarketPtrs& mp, const Params& P, Lds& L, const Mkt& m, int lane) {
-    CDA_WSYNC();
-    store_header(mp.hdr, m, lane);
-    store_book(mp.book, L.book, m, lane);
-    {
-        const int n16 = P.cfg.num_agents * (int)(sizeof(Acc) / 16);
-        for (int i = lane; i < n16; i += WAVE) reinterpret_cast<uint4*>(mp.acc)[i] = reinterpret_cast<const uint4*>(&L.acc[0])[i];
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // reset
 // ------------------------------------------------------------------------------------------
 // dynamic LDS of a workgroup: [decimal power-of-ten table (640 B)] [k_step only: ziggurat wi, ki (4 KB), PCG jump table (512 B)] [wave 0 image] ...
 constexpr int ZIG_LDS_BYTES = (2 * 256 + PCG_JUMP_WORDS64) * 8;
-__device__ __forceinline__ Lds& wave_lds(const Params& P, int wave, int extra = 0) {
-    return *reinterpret_cast<Lds*>(cda_smem + DEC_TABLE_BYTES + extra + (size_t)wave * (size_t)lds_bytes_per_wave(P.cfg.num_agents, P.cfg.n_hist));
-}
 __device__ __forceinline__ void zig_tables_init() {       // every thread of the workgroup, before the first __syncthreads
     unsigned long long* t = reinterpret_cast<unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
     for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) { t[i] = cda_zig_wi_bits[i]; t[256 + i] = cda_zig_ki[i]; }
     for (int i = (int)threadIdx.x; i < PCG_JUMP_WORDS64; i += (int)blockDim.x) t[512 + i] = reinterpret_cast<const unsigned long long*>(&PCG_JUMP)[i];
-}
-
-__global__ __launch_bounds__(64 * CDA_WPB) void k_reset(uint8_t* arena, Params P, const uint64_t* seeds, const uint8_t* mask, float* obs_out, int first_market, int end_market) {
-    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
-    int mi = first_market + (int)blockIdx.x * CDA_WPB + wave;
-    if (mi >= end_market) return;
-    if (mask && !mask[mi]) return;
-    Lds& L = wave_lds(P, wave);
-    MarketPtrs mp = market_ptrs(arena, P, mi);
-    Mkt m;
-    load_header(mp.hdr, m, lane);
-    if (seeds) { rng_seed(m, seeds[mi]); m.seeded = 1; }
-    else if (!m.seeded) { rng_seed(m, (uint64_t)mi); m.seeded = 1; }
-    m.nb = 0; m.na = 0;
-    m.t_step = 0; m.lob_time = 0; m.next_oid = 0; m.has_trade = 0; m.last_trade_price = 0; m.done_mask = 0; m.flags = 0;
-    m.peak_orders = 0;
-    m.last_price = rng_integers(m, P.cfg.initial_price_min, P.cfg.initial_price_max);
-    int A = P.cfg.num_agents;
-    if (lane < A) {                                     // Account.reset_acc (account/account.py:55-82)
-        Acc& a = L.acc[lane];
-        uint32_t f = 0;
-        D cash = d_from_i64(P.cfg.init_cash), z = d_zero();
-        st_dec(a.cash, cash, f); st_dec(a.hold, z, f); st_dec(a.posval, z, f); st_dec(a.vwap, z, f);
-        st_dec(a.nav, cash, f); st_dec(a.prev_nav, cash, f); st_dec(a.max_nav, cash, f);
-        a.net_position = 0; a.num_trades = 0; a.num_trades_step = 0; a.num_passive_fills_step = 0;
-        a.order_step_placed = 0; a.num_rejected_step = 0; a.pad[0] = 0; a.pad[1] = 0;
-    }
-    aggregate_levels(L, m, lane);
-    int H = P.cfg.n_hist;
-    if (lane < CDA_SNAPSHOT_DIM) {
-        float v = snapshot_value(L, m, P.cfg.tick_size, lane);
-        for (int h = 0; h < H; h++) {
-            mp.hist[h * CDA_SNAPSHOT_DIM + lane] = v;
-            if (obs_out) obs_out[(size_t)mi * (size_t)(H * CDA_SNAPSHOT_DIM) + (size_t)(h * CDA_SNAPSHOT_DIM + lane)] = v;
-        }
-    }
-    m.hist_head = 0;
-    m.levels_valid = 1;                                   // aggregate_levels above ran on the (empty) book
-    store_market(mp, P, L, m, lane);
-    store_levels(mp, L, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -181,267 +95,9 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 #define PH_MARK(ph, i) do {} while (0)
 #endif
 struct LaneAction { int cat, level, off; float mean, sigma; bool pres; };     // lane a: agent a's action words (unclamped)
-
-// phases 1-5: everything of a step that changes the market.  Returns the mask of agents that passed.
-__device__ __forceinline__ uint32_t step_market(Lds& L, Mkt& m, const Params& P, const unsigned long long* zig_wi, const unsigned long long* zig_ki,
-                                                const LaneAction& in, unsigned long long* ph, int lane) {
-    const int A = P.cfg.num_agents, tick = P.cfg.tick_size;
-    // 1. pre-step snapshot (continuousDoubleAuction_env.py:274): prices of ALL orders resolve against it.  It equals the
-    //    post-step aggregation of the previous step, which travels in the header; recomputed only when a test hook,
-    //    set_state or reset touched the book in between.
-    if (!m.levels_valid) aggregate_levels(L, m, lane);
-    PH_MARK(ph, 2);
-    // 2. set_actions (exchg/action_helper.py:145-172, :241-283): one normal per present agent, in agent order; lane a
-    //    decodes agent a.  Every agent's normal is first computed SPECULATIVELY in its own lane: the k-th present agent
-    //    jumps the LCG ahead by k + 1 and takes the ziggurat's first candidate.  If every lane accepted (95 % of the steps at
-    //    4 agents) those ARE the sequential draws; otherwise the draws are redone one after the other, wave-uniform.
-    uint32_t act_mask = 0, pass_mask = 0;
-    {
-        const bool pres = in.pres;
-        const uint64_t pm = __ballot(pres);
-        if (pm) {
-            double z = 0.0;
-            {
-                const int k = __popcll(pm & ((1ull << lane) - 1ull));             // draws that precede this agent's
-                const u128 sj = pcg_jump_state(zig_ki + 256, k & (CDA_MAX_AGENTS - 1), m.rng_state, m.rng_inc);
-                const bool ok = zig_first_candidate(pcg_output(sj), zig_wi, zig_ki, &z);
-                if (__ballot(pres && !ok) == 0) {
-                    const int last = 63 - __clzll(pm);                             // its state is the stream's state after all draws
-                    uint32_t w0 = (uint32_t)sj, w1 = (uint32_t)(sj >> 32), w2 = (uint32_t)(sj >> 64), w3 = (uint32_t)(sj >> 96);
-                    w0 = (uint32_t)__builtin_amdgcn_readlane((int)w0, last); w1 = (uint32_t)__builtin_amdgcn_readlane((int)w1, last);
-                    w2 = (uint32_t)__builtin_amdgcn_readlane((int)w2, last); w3 = (uint32_t)__builtin_amdgcn_readlane((int)w3, last);
-                    m.rng_state = ((u128)w3 << 96) | ((u128)w2 << 64) | ((u128)w1 << 32) | (u128)w0;
-                } else {
-                    for (int a = 0; a < A; a++) {
-                        if (!((pm >> a) & 1ull)) continue;
-                        double za = rng_std_normal(m, zig_wi, zig_ki);
-                        if (lane == a) z = za;
-                    }
-                }
-            }
-            bool ovf = false;
-            int side = S_NONE;
-            if (pres) {
-                int cat = clampi(in.cat, 0, 8);
-                float mean = clampf(in.mean, -1.0f, 1.0f), sigma = clampf(in.sigma, 0.0f, 1.0f);
-                int level = clampi(in.level, 0, CDA_K_ROWS - 1), off = clampi(in.off, 0, 2) - 1;
-                side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
-                int type = cat == 0 ? T_MARKET : ((cat - 1) & 3);
-                float locf = (type == T_MARKET ? P.mkt_mul : P.lim_mul) * mean;      // float32 product (numpy NEP 50)
-                double prod = (double)sigma * z;
-                double sample = (double)locf + prod;                                   // built with -ffp-contract=off
-                double rs = rint(fabs(sample));
-                if (rs > 1.0e9) { rs = 1.0e9; ovf = true; }
-                int32_t size = (int32_t)rs + P.cfg.min_size;
-                int32_t pr = -1;
-                if (type != T_MARKET) {                                                // _set_price (action_helper.py:341-397)
-                    int32_t p = L.lvl_px[side == S_BID ? 0 : 1][level];
-                    if (side == S_BID) pr = (p == 0 ? m.last_price - (level + 1) * tick : p) + off * tick;
-                    else pr = (p == 0 ? m.last_price + (level + 1) * tick : p) - off * tick;
-                    if (pr < tick) pr = tick;
-                    if (pr >= (1 << 24)) { pr = (1 << 24) - 1; ovf = true; }
-                }
-                L.act_tsp[lane] = type | (side << 2) | ((pr + 1) << 4);
-                L.act_size[lane] = size;
-            }
-            act_mask = (uint32_t)__ballot(pres && side != S_NONE);
-            pass_mask = (uint32_t)__ballot(pres && side == S_NONE);
-            // two or more market orders: this step will most likely sweep - take the head start now (see match())
-            if (__popcll(__ballot(pres && side != S_NONE && (L.act_tsp[lane] & 3) == T_MARKET)) >= 2) __builtin_amdgcn_s_setprio(1);
-            if (__ballot(ovf)) m.flags |= CDA_FLAG_INT_OVERFLOW;
-        }
-        CDA_WSYNC();
-    }
-    PH_MARK(ph, 3);
-    // 3. rand_exec_seq (action_helper.py:174-199): Fisher-Yates over the n non-pass orders, nibble-packed
-    m.fills = 0;
-    int n_acts = __popc(act_mask);
-    uint64_t perm = 0xFEDCBA9876543210ull;
-    for (int i = n_acts - 1; i >= 1; i--) {
-        int j = (int)rng_interval(m, (uint32_t)i);
-        uint64_t vi = (perm >> (4 * i)) & 0xFull, vj = (perm >> (4 * j)) & 0xFull;
-        perm &= ~((0xFull << (4 * i)) | (0xFull << (4 * j)));
-        perm |= (vj << (4 * i)) | (vi << (4 * j));
-    }
-    PH_MARK(ph, 4);
-    // 4. do_actions (action_helper.py:201-239): sequential, order dependent
-    for (int i = 0; i < n_acts; i++) {
-        int k = (int)((perm >> (4 * i)) & 0xFull);
-        uint32_t mk = act_mask;
-        for (int s = 0; s < k; s++) mk &= mk - 1;                             // drop k lowest set bits
-        int tr = __ffs((int)mk) - 1;
-        int32_t tsp = L.act_tsp[tr], size = L.act_size[tr];
-        place_order<true>(L, m, tr, tsp & 3, (tsp >> 2) & 3, size, (tsp >> 4) - 1, lane);     // mark_to_mkt below rewrites position_val
-    }
-    PH_MARK(ph, 5);
-    // 5. mark_to_mkt
-    mark_to_mkt(L, m, A, lane);
-    PH_MARK(ph, 6);
-    return pass_mask;
-}
-
-// phase 7, Reward_Helper.set_reward (exchg/reward_helper.py:35-102) and Done_Helper.set_done (done_helper.py:3-18) for
-// lane a < A.  The two float(Decimal) conversions of the reward are independent: the owner lane converts nav - prev_nav
-// while its helper lane (a + 16) converts max_nav - nav, in the same instruction stream.
 struct StepReward { double r, t0, t1, t2, t3, t4, drawdown, max_nav; bool bankrupt; };
-// WITH_MAX_NAV (info outputs): a third lane (a + 32) converts max_nav itself through the same call site, so the info
-// tensor float(max_nav) costs no conversion of its own.
-__device__ __forceinline__ StepReward step_reward(Lds& L, const Params& P, uint32_t& ferr, int lane, bool with_max_nav = false) {
-    const int A = P.cfg.num_agents;
-    StepReward o; o.r = o.t0 = o.t1 = o.t2 = o.t3 = o.t4 = o.drawdown = o.max_nav = 0.0; o.bankrupt = false;
-    double conv = 0.0;
-    if (lane_acc(lane) < A && lane_grp(lane) < (with_max_nav ? 3 : 2)) {
-        const Acc& a = L.acc[lane_acc(lane)];
-        const int g = lane_grp(lane);
-        const bool own = g == 0;
-        D nav = ld_dec(a.nav), mx = ld_dec(a.max_nav);
-        D x = own ? nav : mx, y = own ? ld_dec(a.prev_nav) : nav;
-        D df = d_sub(x, y);                                  // ONE call site each, so owner and helpers stay converged
-        if (g == 2) df = mx;
-        if (g != 1 || d_sgn(df) > 0) conv = d_to_double(df, &ferr);
-    }
-    const double conv_helper = __shfl(conv, (lane + 16) & 63, WAVE);
-    o.max_nav = __shfl(conv, (lane + 32) & 63, WAVE);
-    if (lane < A) {
-        const Acc& a = L.acc[lane];
-        double nav_change = conv;
-        double nav_term = nav_change * (nav_change < 0 ? P.cfg.loss_multiplier : 1.0);
-        o.drawdown = conv_helper;
-        o.t0 = nav_term;
-        o.t1 = -(P.cfg.order_penalty * (double)a.order_step_placed);
-        o.t2 = -(P.cfg.trade_penalty * (double)a.num_trades_step);
-        o.t3 = -(P.cfg.drawdown_penalty * o.drawdown);
-        o.t4 = P.cfg.passive_bonus * (double)a.num_passive_fills_step;
-        double r = 0.0; r += o.t0; r += o.t1; r += o.t2; r += o.t3; r += o.t4;   // left to right (reward_helper.py:92-94)
-        o.r = r;
-        o.bankrupt = d_sgn(ld_dec(a.nav)) <= 0;
-    }
-    return o;
-}
 __device__ __forceinline__ void clear_step_counters(Acc& a) {          // exchg_helper.py:116-120
     a.num_trades_step = 0; a.num_passive_fills_step = 0; a.order_step_placed = 0; a.num_rejected_step = 0;
-}
-
-__global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_step(uint8_t* arena, Params P, StepArgs S) {
-    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
-    int mi = S.first_market + (int)blockIdx.x * CDA_WPB + wave;
-    const bool live = mi < S.end_market;      // (a workgroup's surplus waves still take part in the table setup)
-    MarketPtrs mp = market_ptrs(arena, P, live ? mi : 0);
-    MarketPrefetch mq;
-    if (live) mq = load_market_issue<true>(mp, P, lane);    // the record's requests fly while the tables are staged
-    zig_tables_init();
-    dec_tables_init();                        // workgroup-wide (one __syncthreads), before any early exit
-    if (!live) return;
-    Lds& L = wave_lds(P, wave, ZIG_LDS_BYTES);
-    const unsigned long long* zig_wi = reinterpret_cast<const unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
-    const unsigned long long* zig_ki = zig_wi + 256;
-    Mkt m;
-    const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
-    unsigned long long* ph = nullptr;
-#ifdef CDA_PHASE_TIMING
-    for (int i = 0; i < 24; i++) m.tacc[i] = 0;
-    ph = S.phase_cycles ? S.phase_cycles + (size_t)mi * 40 : nullptr;
-#endif
-    PH_MARK(ph, 0);
-    load_market_finish<true>(mp, P, L, m, mq, lane);
-    PH_MARK(ph, 1);
-    LaneAction in;
-    {
-        const size_t ab = (size_t)mi * (size_t)A;
-        in.pres = lane < A && (!S.present || S.present[ab + lane]);
-        in.cat = 0; in.level = 0; in.off = 0; in.mean = 0.0f; in.sigma = 0.0f;
-        if (in.pres) {
-            in.cat = S.category[ab + lane]; in.mean = S.size_mean[ab + lane]; in.sigma = S.size_sigma[ab + lane];
-            in.level = S.price[ab + lane]; in.off = S.price_offset[ab + lane];
-        }
-    }
-    const uint32_t pass_mask = step_market(L, m, P, zig_wi, zig_ki, in, ph, lane);
-    // 6. prep_next_state (state_helper.py:80-92): new frame, history ring, stacked observation
-    aggregate_levels(L, m, lane);
-    {
-        size_t ob = (size_t)mi * (size_t)(H * CDA_SNAPSHOT_DIM);
-        if (lane < CDA_SNAPSHOT_DIM) {
-            float v = snapshot_value(L, m, tick, lane);
-            int head = m.hist_head;                       // slot of the oldest frame = the one to overwrite
-            const float* hist = lds_hist(L, A);           // staged by load_market
-            for (int j = 0; j < H - 1; j++) {
-                int slot = head + 1 + j; if (slot >= H) slot -= H;
-                S.obs_out[ob + (size_t)(j * CDA_SNAPSHOT_DIM + lane)] = hist[slot * CDA_SNAPSHOT_DIM + lane];
-            }
-            S.obs_out[ob + (size_t)((H - 1) * CDA_SNAPSHOT_DIM + lane)] = v;
-            mp.hist[head * CDA_SNAPSHOT_DIM + lane] = v;
-        }
-        m.hist_head = m.hist_head + 1 >= H ? 0 : m.hist_head + 1;
-    }
-    PH_MARK(ph, 7);
-    // 7. set_step_outputs (exchg_helper.py:93-124)
-    uint32_t ferr = 0;
-    const StepReward rw = step_reward(L, P, ferr, lane, S.has_info != 0);
-    if (S.has_info) {                                                          // Info_Helper.set_info (info_helper.py:30-116)
-        // the four float(Decimal) fields of an account are converted by four lanes (a, a+16, a+32, a+48) through ONE call site
-        const cda_info_ptrs& I = S.info;
-        const int al = lane_acc(lane), g = lane_grp(lane);
-        if (al < A) {
-            const Acc& a = L.acc[al];
-            const cda_dec& src = g == 0 ? a.vwap : (g == 1 ? a.cash : (g == 2 ? a.hold : a.posval));
-            double* dst = g == 0 ? I.vwap : (g == 1 ? I.cash : (g == 2 ? I.cash_on_hold : I.position_val));
-            const double v = d_to_double(ld_dec(src), &ferr);
-            if (dst) dst[(size_t)mi * (size_t)A + (size_t)al] = v;
-        }
-    }
-    if (lane < A) {
-        Acc& a = L.acc[lane];
-        size_t ix = (size_t)mi * (size_t)A + (size_t)lane;
-        S.reward_out[ix] = rw.r;
-        if (S.has_info) {
-            const cda_info_ptrs& I = S.info;
-            if (I.nav) I.nav[ix] = a.nav;
-            if (I.num_trades) I.num_trades[ix] = a.num_trades;
-            if (I.net_position) I.net_position[ix] = a.net_position;
-            if (I.drawdown) I.drawdown[ix] = rw.drawdown;
-            if (I.max_nav) I.max_nav[ix] = rw.max_nav;
-            if (I.num_trades_step) I.num_trades_step[ix] = a.num_trades_step;
-            if (I.num_passive_fills_step) I.num_passive_fills_step[ix] = a.num_passive_fills_step;
-            if (I.order_step_placed) I.order_step_placed[ix] = a.order_step_placed;
-            if (I.num_rejected_step) I.num_rejected_step[ix] = a.num_rejected_step;
-            if (I.is_pass_action) I.is_pass_action[ix] = (uint8_t)((pass_mask >> lane) & 1u);
-            if (I.reward_terms) { double* rt = I.reward_terms + ix * 5; rt[0] = rw.t0; rt[1] = rw.t1; rt[2] = rw.t2; rt[3] = rw.t3; rt[4] = rw.t4; }
-            if (I.lob_actions) {                                               // decoded orders as the env keeps them (agent order, passes left out)
-                int32_t* la = I.lob_actions + ix * 4;
-                const int32_t tsp = L.act_tsp[lane];
-                const bool has = in.pres && !((pass_mask >> lane) & 1u);
-                la[0] = has ? ((tsp >> 2) & 3) : -1; la[1] = has ? (tsp & 3) : -1; la[2] = has ? L.act_size[lane] : -1; la[3] = has ? (tsp >> 4) - 1 : -1;
-            }
-        }
-        clear_step_counters(a);
-    }
-    if (__ballot(ferr != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
-    m.done_mask |= (uint32_t)__ballot(rw.bankrupt);
-    if (lane == 0) {
-        if (S.has_info) {
-            const cda_info_ptrs& I = S.info;
-            double bb = m.nb ? (double)L.book.price[0][0] : __longlong_as_double(0x7ff8000000000000LL);
-            double ba = m.na ? (double)L.book.price[1][0] : __longlong_as_double(0x7ff8000000000000LL);
-            if (I.last_price) I.last_price[mi] = (double)m.last_price;
-            if (I.best_bid) I.best_bid[mi] = bb;
-            if (I.best_ask) I.best_ask[mi] = ba;
-            if (I.spread) I.spread[mi] = (m.nb && m.na) ? ba - bb : __longlong_as_double(0x7ff8000000000000LL);
-        }
-        // Done_Helper.set_all_done (done_helper.py:20-54)
-        const bool term = __popc(m.done_mask) == A, trunc = m.t_step + 1 >= P.cfg.max_step;
-        S.terminated_out[mi] = (uint8_t)term;
-        S.truncated_out[mi] = (uint8_t)trunc;
-        if (S.done_out) S.done_out[mi] = (uint8_t)(term || trunc);
-    }
-    m.t_step += 1;
-    m.levels_valid = 1;                                   // lvl_px/lvl_sz hold the post-step aggregation (phase 6)
-    PH_MARK(ph, 8);
-    store_market(mp, P, L, m, lane);
-    store_levels(mp, L, lane);
-    PH_MARK(ph, 9);
-#ifdef CDA_PHASE_TIMING
-    if (ph && lane == 0) for (int i = 0; i < 24; i++) ph[10 + i] = m.tacc[i];
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -451,124 +107,19 @@ struct RunArgs {
     int32_t n_steps; uint64_t seed, market_base;
     float* obs_out; double* return_out; uint8_t* terminated_out; uint8_t* truncated_out; int32_t* steps_out;
 };
-__global__ __launch_bounds__(64 * CDA_WPB, CDA_MIN_WAVES) void k_run_random(uint8_t* arena, Params P, RunArgs R) {
-    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    int mi = (int)blockIdx.x * CDA_WPB + wave;
-    zig_tables_init();
-    dec_tables_init();
-    if (mi >= P.n_markets) return;
-    Lds& L = wave_lds(P, wave, ZIG_LDS_BYTES);
-    const unsigned long long* zig_wi = reinterpret_cast<const unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
-    const unsigned long long* zig_ki = zig_wi + 256;
-    MarketPtrs mp = market_ptrs(arena, P, mi);
-    Mkt m;
-    const int A = P.cfg.num_agents, H = P.cfg.n_hist, tick = P.cfg.tick_size;
-#ifdef CDA_PHASE_TIMING
-    for (int i = 0; i < 24; i++) m.tacc[i] = 0;
-#endif
-    load_market<true>(mp, P, L, m, lane);
-    float* hist = lds_hist(L, A);                           // the history ring stays in LDS for the whole episode
-    int32_t* hist_raw = reinterpret_cast<int32_t*>(hist);
-    double ret = 0.0;
-    int steps = 0;
-    bool term = false, trunc = false;
-    for (int it = 0; it < R.n_steps; it++) {
-        LaneAction in;
-        in.pres = lane < A; in.cat = 0; in.level = 0; in.off = 0; in.mean = 0.0f; in.sigma = 0.0f;
-        if (in.pres) cda_random_action(R.seed, R.market_base + (uint64_t)mi, (uint32_t)m.t_step, (uint32_t)lane, &in.cat, &in.mean, &in.sigma, &in.level, &in.off);
-        step_market(L, m, P, zig_wi, zig_ki, in, nullptr, lane);
-        aggregate_levels(L, m, lane);
-        // Nobody reads the observation while the episode runs: the ring keeps the RAW frame (the 2 x 2 x 10 level
-        // aggregation and last_price, 41 integers) and the normalisation (f64 divisions, square roots, log, log1p) is
-        // done after the loop, for the at most n_hist frames that are still in the window.
-        if (lane < 4 * CDA_K_ROWS) hist_raw[m.hist_head * CDA_SNAPSHOT_DIM + lane] = (&L.lvl_px[0][0])[lane];
-        else if (lane == 4 * CDA_K_ROWS) hist_raw[m.hist_head * CDA_SNAPSHOT_DIM + lane] = m.last_price;
-        m.hist_head = m.hist_head + 1 >= H ? 0 : m.hist_head + 1;
-        uint32_t ferr = 0;
-        const StepReward rw = step_reward(L, P, ferr, lane);
-        if (lane < A) { ret += rw.r; clear_step_counters(L.acc[lane]); }
-        if (__ballot(ferr != 0)) m.flags |= CDA_FLAG_DEC_DOMAIN;
-        m.done_mask |= (uint32_t)__ballot(rw.bankrupt);
-        term = __popc(m.done_mask) == A; trunc = m.t_step + 1 >= P.cfg.max_step;
-        m.t_step += 1;
-        m.levels_valid = 1;
-        steps += 1;
-        CDA_WSYNC();
-        if (term || trunc) break;
-    }
-    {   // normalise the raw frames of this launch that are still in the window, oldest first: the newest one is converted
-        // last, which leaves L.lvl_* / m.last_price describing the current book again
-        const int n_raw = steps < H ? steps : H;
-        const int32_t last_price_now = m.last_price;
-        for (int k = 0; k < n_raw; k++) {
-            int slot = m.hist_head - n_raw + k; if (slot < 0) slot += H;
-            CDA_WSYNC();
-            if (lane < 4 * CDA_K_ROWS) (&L.lvl_px[0][0])[lane] = hist_raw[slot * CDA_SNAPSHOT_DIM + lane];
-            m.last_price = hist_raw[slot * CDA_SNAPSHOT_DIM + 4 * CDA_K_ROWS];
-            CDA_WSYNC();
-            float v = 0.0f;
-            if (lane < CDA_SNAPSHOT_DIM) v = snapshot_value(L, m, tick, lane);
-            CDA_WSYNC();
-            if (lane < CDA_SNAPSHOT_DIM) hist[slot * CDA_SNAPSHOT_DIM + lane] = v;
-        }
-        m.last_price = last_price_now;
-        CDA_WSYNC();
-    }
-    if (R.obs_out && lane < CDA_SNAPSHOT_DIM) {             // oldest frame first; hist_head is the oldest slot
-        const size_t ob = (size_t)mi * (size_t)(H * CDA_SNAPSHOT_DIM);
-        for (int j = 0; j < H; j++) {
-            int slot = m.hist_head + j; if (slot >= H) slot -= H;
-            R.obs_out[ob + (size_t)(j * CDA_SNAPSHOT_DIM + lane)] = hist[slot * CDA_SNAPSHOT_DIM + lane];
-        }
-    }
-    if (R.return_out && lane < A) R.return_out[(size_t)mi * (size_t)A + (size_t)lane] = ret;
-    if (lane == 0) {
-        if (R.terminated_out) R.terminated_out[mi] = (uint8_t)term;
-        if (R.truncated_out) R.truncated_out[mi] = (uint8_t)trunc;
-        if (R.steps_out) R.steps_out[mi] = steps;
-    }
-    store_market(mp, P, L, m, lane);
-    copy_words((uint32_t*)mp.hist, (const uint32_t*)hist, H * CDA_SNAPSHOT_DIM, lane);
-    store_levels(mp, L, lane);
-}
 
-// ------------------------------------------------------------------------------------------
-// test hooks and small kernels
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_place_order(uint8_t* arena, Params P, int mi, int tr, int type, int side, int size, int price) {
-    Lds& lds1 = wave_lds(P, 0);
-    int lane = lane_id();
-    dec_tables_init();
-    MarketPtrs mp = market_ptrs(arena, P, mi);
-    Mkt m;
-    load_market(mp, P, lds1, m, lane);
-    place_order<false>(lds1, m, tr, type, side, size, price, lane);
-    m.levels_valid = 0;                                   // the cached aggregation no longer describes the book
-    store_market(mp, P, lds1, m, lane);
-}
-__global__ __launch_bounds__(64) void k_mark_to_mkt(uint8_t* arena, Params P, int mi) {
-    Lds& lds1 = wave_lds(P, 0);
-    int lane = lane_id();
-    dec_tables_init();
-    MarketPtrs mp = market_ptrs(arena, P, mi);
-    Mkt m;
-    load_market(mp, P, lds1, m, lane);
-    mark_to_mkt(lds1, m, P.cfg.num_agents, lane);
-    store_market(mp, P, lds1, m, lane);
-}
-__global__ __launch_bounds__(64 * CDA_WPB) void k_raw_snapshot(uint8_t* arena, Params P, float* raw_out) {
-    int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave index pinned to an SGPR: market pointers and counts become scalar
-    int mi = (int)blockIdx.x * CDA_WPB + wave;
-    if (mi >= P.n_markets) return;
-    Lds& L = wave_lds(P, wave);
-    MarketPtrs mp = market_ptrs(arena, P, mi);
-    Mkt m;
-    load_header(mp.hdr, m, lane);
-    load_book(mp.book, L.book, m, lane);
-    CDA_WSYNC();
-    aggregate_levels(L, m, lane);
-    if (lane < CDA_RAW_DIM) raw_out[(size_t)mi * CDA_RAW_DIM + (size_t)lane] = raw_value(L, lane);
-}
+// ---- the market-wave kernels, one build per book capacity ------------------------------------------------
+#define CDA_CAP 256
+#define CDA_CAPNS cap256
+#include "cda_kernels.inc"
+#undef CDA_CAP
+#undef CDA_CAPNS
+#define CDA_CAP 512
+#define CDA_CAPNS cap512
+#include "cda_kernels.inc"
+#undef CDA_CAP
+#undef CDA_CAPNS
+
 // Sum-of-NAV conservation check, one thread per market (callbk/league_based_self_play_callback.py:679-704)
 __global__ void k_nav_conservation(const uint8_t* arena, Params P, double tol, double* err_out, uint8_t* viol_out) {
     dec_tables_init();
@@ -589,7 +140,8 @@ __global__ void k_nav_conservation(const uint8_t* arena, Params P, double tol, d
 // (orderbook.py:162-194 matches before it rests), resting quantities are positive, cash_on_hold is exactly the value of
 // the trader's own resting orders (cash_processor.py:15-29 / :85-97 escrow and release) and every unit long is a unit
 // short (account.py:196-213).
-__global__ void k_check_invariants(const uint8_t* arena, Params P, uint32_t* out) {
+__host__ __device__ static inline int book_phys_rt(int cap, int s, int i) { return s == 0 ? i : cap - 1 - i; }     // cda_book.inc book_phys with a run-time capacity
+__global__ void k_check_invariants(const uint8_t* arena, Params P, int CAP, uint32_t* out) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= P.n_markets) return;
     const uint8_t* rec = arena + (size_t)i * (size_t)P.lay.stride;
@@ -604,19 +156,19 @@ __global__ void k_check_invariants(const uint8_t* arena, Params P, uint32_t* out
     for (int sd = 0; sd < 2; sd++) {
         const int n = sd == 0 ? nb : na;
         for (int k = 0; k < n; k++) {
-            const int ph = book_phys(sd, k);
+            const int ph = book_phys_rt(CAP, sd, k);
             const int32_t p = bp[0 * CAP + ph], q = bp[1 * CAP + ph];
             const int owner = bp[2 * CAP + ph] & 15;
             if (q <= 0 || p <= 0) v |= CDA_INV_QTY;
             if (owner >= A) v |= CDA_INV_OWNER; else held[owner] += (long long)p * (long long)q;
             if (k > 0) {
-                const int pp = book_phys(sd, k - 1);
+                const int pp = book_phys_rt(CAP, sd, k - 1);
                 const int32_t prev = bp[0 * CAP + pp];
                 if (sd == 0 ? prev < p : prev > p) v |= sd == 0 ? CDA_INV_BIDS_SORTED : CDA_INV_ASKS_SORTED;
             }
         }
     }
-    if (nb > 0 && na > 0 && bp[0 * CAP + book_phys(0, 0)] >= bp[0 * CAP + book_phys(1, 0)]) v |= CDA_INV_CROSSED;
+    if (nb > 0 && na > 0 && bp[0 * CAP + book_phys_rt(CAP, 0, 0)] >= bp[0 * CAP + book_phys_rt(CAP, 1, 0)]) v |= CDA_INV_CROSSED;
     long long net = 0;
     for (int a = 0; a < A; a++) {
         net += acc[a].net_position;
@@ -745,6 +297,7 @@ __global__ void k_selftest_rng(uint64_t seed, int lo, int hi, int n_steps, int n
 struct cda_env {
     Params P;
     int device;
+    int cap;                 // book capacity of this env: 256 or 512 (selects the cap256:: / cap512:: kernels)
     uint8_t* arena;
     size_t arena_bytes;
     uint8_t* done_buf;       // auto_reset: u8[N] behind the market records - terminated | truncated of the last step
@@ -775,6 +328,7 @@ const char* cda_strerror(int status) {
 int cda_default_config(cda_config* c) {
     if (!c) return CDA_ERR_INVALID;
     memset(c, 0, sizeof *c);
+    c->book_capacity = 0;
     c->num_agents = 5; c->max_step = 64; c->n_hist = 4; c->tick_size = 1; c->init_cash = 1000000;
     c->initial_price_min = 10; c->initial_price_max = 100; c->min_size = 1; c->mkt_max_size = 100; c->limit_size_multiple = 10;
     c->order_penalty = 0.1; c->trade_penalty = 0.05; c->drawdown_penalty = 0.2; c->passive_bonus = 0.1; c->loss_multiplier = 1.5;
@@ -787,18 +341,26 @@ static int cfg_ok(const cda_config* c) {
     if (c->tick_size != 1) return CDA_ERR_UNSUPPORTED;
     if (c->initial_price_max < c->initial_price_min || c->initial_price_min < 0) return CDA_ERR_INVALID;
     if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;
-    // Sizes are int32 on the device and a price level sums up to CDA_BOOK_CAP of them: the largest decodable size is
+    // Sizes are int32 on the device and a price level sums up to CDA_BOOK_CAP_MAX of them: the largest decodable size is
     // (mkt_max_size * limit_size_multiple - min_size) / 2 * |mean| + sigma * z + min_size, clamped at 1e9 (flagged).  Keep
     // the configured scale itself well inside int32 so that neither the product nor a level sum can wrap silently.
-    if ((int64_t)c->mkt_max_size * (int64_t)c->limit_size_multiple + (int64_t)c->min_size > (int64_t)(1 << 30) / CDA_BOOK_CAP) return CDA_ERR_INVALID;
+    if ((int64_t)c->mkt_max_size * (int64_t)c->limit_size_multiple + (int64_t)c->min_size > (int64_t)(1 << 30) / CDA_BOOK_CAP_MAX) return CDA_ERR_INVALID;
     if (c->max_step < 1) return CDA_ERR_INVALID;
+    if (c->book_capacity != 0 && c->book_capacity != 256 && c->book_capacity != 512) return CDA_ERR_INVALID;
     if (c->init_cash > (1LL << 62) || c->init_cash < -(1LL << 62)) return CDA_ERR_INVALID;
     if (c->auto_reset != 0 && c->auto_reset != 1) return CDA_ERR_INVALID;
     return CDA_OK;
 }
 
+// launch the capacity variant of a market-wave kernel that matches the env
+#define LAUNCH_CAP(e, kern, grid, block, smem, stream, ...) do { \
+    if ((e)->cap == 512) hipLaunchKernelGGL(cda::cap512::kern, grid, block, smem, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(cda::cap256::kern, grid, block, smem, stream, __VA_ARGS__); } while (0)
 static dim3 grid_for(int n) { return dim3((unsigned)((n + CDA_WPB - 1) / CDA_WPB)); }
-static size_t smem_for(const Params& P, int waves) { return (size_t)DEC_TABLE_BYTES + (size_t)waves * (size_t)lds_bytes_per_wave(P.cfg.num_agents, P.cfg.n_hist); }
+static size_t smem_for(const cda_env* e, int waves) {
+    const int per = e->cap == 512 ? cda::cap512::lds_bytes_per_wave(e->P.cfg.num_agents, e->P.cfg.n_hist) : cda::cap256::lds_bytes_per_wave(e->P.cfg.num_agents, e->P.cfg.n_hist);
+    return (size_t)DEC_TABLE_BYTES + (size_t)waves * (size_t)per;
+}
 
 int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env** out) {
     if (!cfg || !out || n_markets < 1) return CDA_ERR_INVALID;
@@ -810,6 +372,9 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     cda_env* e = (cda_env*)calloc(1, sizeof *e);
     if (!e) return CDA_ERR_NOMEM;
     e->device = device;
+    // book capacity: as asked, else by the agent count (census, profiles/r02: random agents hold up to 83 / 129 / 235 resting
+    // orders per market at 4 / 8 / 16 agents over 4096 steps; the flip-heavy law overflows 256 at 16 agents)
+    e->cap = cfg->book_capacity ? cfg->book_capacity : (cfg->num_agents <= 8 ? 256 : 512);
     Params& P = e->P;
     P.cfg = *cfg; P.n_markets = n_markets;
     P.mkt_mul = (float)((double)(cfg->mkt_max_size - cfg->min_size) / 2.0);
@@ -817,7 +382,7 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     int off = HEADER_BYTES;
     P.lay.acc_off = off; off += cfg->num_agents * (int)sizeof(Acc);
     P.lay.hist_off = off; off += cfg->n_hist * CDA_SNAPSHOT_DIM * 4; off = (off + 15) & ~15;
-    P.lay.book_off = off; off += BOOK_BYTES;
+    P.lay.book_off = off; off += e->cap * BOOK_FIELDS * 4;
     P.lay.stride = (off + 255) & ~255;
     const size_t records = (size_t)P.lay.stride * (size_t)n_markets;
     e->arena_bytes = records + (((size_t)n_markets + 255) & ~(size_t)255);
@@ -844,7 +409,7 @@ static int range_ok(const cda_env* e, int32_t first, int32_t n) { return first >
 int cda_reset_range(cda_env* e, int32_t first_market, int32_t n_markets, const uint64_t* seeds, const uint8_t* mask, float* obs_out, void* stream) {
     if (!e || !range_ok(e, first_market, n_markets)) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_reset, grid_for(n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out,
+    LAUNCH_CAP(e, k_reset, grid_for(n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out,
                        (int)first_market, (int)(first_market + n_markets));
     HIPCHK(hipGetLastError());
     return CDA_OK;
@@ -858,10 +423,10 @@ int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs
 static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0, hipStream_t stream) {
     StepArgs S = S0;
     S.first_market = first; S.end_market = first + n;
-    hipLaunchKernelGGL(k_step, grid_for(n), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, stream, e->arena, e->P, S);
+    LAUNCH_CAP(e, k_step, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, stream, e->arena, e->P, S);
     HIPCHK(hipGetLastError());
     if (e->P.cfg.auto_reset) {            // same stream: every market-wave of it exits at once unless its episode just ended
-        hipLaunchKernelGGL(k_reset, grid_for(n), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), stream, e->arena, e->P,
+        LAUNCH_CAP(e, k_reset, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), stream, e->arena, e->P,
                            (const uint64_t*)NULL, (const uint8_t*)e->done_buf, S.obs_out, (int)first, (int)(first + n));
         HIPCHK(hipGetLastError());
     }
@@ -937,7 +502,7 @@ int cda_run_random(cda_env* e, int32_t n_steps, uint64_t action_seed, uint64_t m
     R.n_steps = n_steps; R.seed = action_seed; R.market_base = market_index_base;
     R.obs_out = obs_out; R.return_out = episode_return_out; R.terminated_out = terminated_out; R.truncated_out = truncated_out;
     R.steps_out = steps_taken_out;
-    hipLaunchKernelGGL(k_run_random, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, R);
+    LAUNCH_CAP(e, k_run_random, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, R);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -988,7 +553,7 @@ int cda_place_order(cda_env* e, int32_t market, int32_t trader, int32_t type, in
     if (type < 0 || type > 3 || side < 0 || side > 1 || size < 1) return CDA_ERR_INVALID;
     if (type != 0 && price < 1) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_place_order, dim3(1), dim3(64), smem_for(e->P, 1), 0, e->arena, e->P, market, trader, type, side, size, price);
+    LAUNCH_CAP(e, k_place_order, dim3(1), dim3(64), smem_for(e, 1), 0, e->arena, e->P, market, trader, type, side, size, price);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return CDA_OK;
@@ -996,7 +561,7 @@ int cda_place_order(cda_env* e, int32_t market, int32_t trader, int32_t type, in
 int cda_mark_to_mkt(cda_env* e, int32_t market) {
     if (!e || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_mark_to_mkt, dim3(1), dim3(64), smem_for(e->P, 1), 0, e->arena, e->P, market);
+    LAUNCH_CAP(e, k_mark_to_mkt, dim3(1), dim3(64), smem_for(e, 1), 0, e->arena, e->P, market);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return CDA_OK;
@@ -1006,6 +571,7 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     const Params& P = e->P;
+    const int CAP = e->cap;
     uint8_t* rec = (uint8_t*)malloc((size_t)P.lay.stride);
     if (!rec) return CDA_ERR_NOMEM;
     HIPCHK(hipDeviceSynchronize());
@@ -1027,7 +593,7 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
         int n = sd == 0 ? s->n_bids : s->n_asks;
         for (int i = 0; i < n && i < CAP; i++) {
             cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
-            const int ph = book_phys(sd, i);
+            const int ph = book_phys_rt(CAP, sd, i);
             o->price = bp[0 * CAP + ph]; o->qty = bp[1 * CAP + ph]; o->owner = bp[2 * CAP + ph] & 15;
             o->order_id = (int32_t)((uint32_t)bp[2 * CAP + ph] >> 4); o->timestamp = bp[3 * CAP + ph];
         }
@@ -1053,9 +619,10 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
 
 int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
-    if (s->n_bids < 0 || s->n_asks < 0 || s->n_bids + s->n_asks > CAP) return CDA_ERR_INVALID;
+    if (s->n_bids < 0 || s->n_asks < 0 || s->n_bids + s->n_asks > e->cap) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     const Params& P = e->P;
+    const int CAP = e->cap;
     uint8_t* rec = (uint8_t*)calloc(1, (size_t)P.lay.stride);
     if (!rec) return CDA_ERR_NOMEM;
     uint32_t* h = (uint32_t*)rec;
@@ -1074,7 +641,7 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
         for (int i = 0; i < n; i++) {
             const cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
             if (o->owner < 0 || o->owner >= CDA_MAX_AGENTS || o->order_id < 0 || o->order_id >= (1 << 27)) { free(rec); return CDA_ERR_INVALID; }
-            const int ph = book_phys(sd, i);
+            const int ph = book_phys_rt(CAP, sd, i);
             bp[0 * CAP + ph] = o->price; bp[1 * CAP + ph] = o->qty; bp[2 * CAP + ph] = (int32_t)(((uint32_t)o->order_id << 4) | (uint32_t)o->owner); bp[3 * CAP + ph] = o->timestamp;
         }
     }
@@ -1098,7 +665,7 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
 int cda_get_raw_snapshot(cda_env* e, float* raw_out, void* stream) {
     if (!e || !raw_out) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_raw_snapshot, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e->P, CDA_WPB), (hipStream_t)stream, e->arena, e->P, raw_out);
+    LAUNCH_CAP(e, k_raw_snapshot, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), (hipStream_t)stream, e->arena, e->P, raw_out);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -1113,7 +680,7 @@ int cda_last_flags(cda_env* e, uint32_t* flags_out, void* stream) {
 int cda_check_invariants(cda_env* e, uint32_t* violations_out, void* stream) {
     if (!e || !violations_out) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_check_invariants, dim3((unsigned)((e->P.n_markets + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)e->arena, e->P, violations_out);
+    hipLaunchKernelGGL(k_check_invariants, dim3((unsigned)((e->P.n_markets + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)e->arena, e->P, e->cap, violations_out);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -1213,6 +780,7 @@ int cda_debug_dec_calls(unsigned long long* host8, int reset) {
 }
 #endif
 
+int32_t cda_book_capacity(const cda_env* e) { return e ? e->cap : 0; }
 int32_t cda_num_markets(const cda_env* e) { return e ? e->P.n_markets : 0; }
 int32_t cda_obs_dim(const cda_env* e) { return e ? e->P.cfg.n_hist * CDA_SNAPSHOT_DIM : 0; }
 int64_t cda_state_bytes_per_market(const cda_env* e) { return e ? (int64_t)e->P.lay.stride : 0; }

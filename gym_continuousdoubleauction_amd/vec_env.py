@@ -40,6 +40,7 @@ class CDAVecEnv:
         h = C.c_void_p()
         check(lib().cda_create(C.byref(self.cfg_struct), self.n_markets, self.device_index, C.byref(h)), "cda_create")
         self._h = h
+        self.book_capacity = int(lib().cda_book_capacity(h))     # 256 or 512 resting orders per market (config['book_capacity'])
         N, A, dev = self.n_markets, self.num_agents, self.device
         # The per-step outputs of one launch live in ONE contiguous slab (obs | reward | terminated | truncated),
         # so a multi-GPU caller hands them to its peers with a single collective and no packing pass

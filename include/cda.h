@@ -35,9 +35,8 @@ extern "C" {
 #define CDA_RAW_DIM       40            /* agg_LOB_raw: state_helper.py:159-160 */
 #define CDA_MAX_HIST      16            /* n_hist upper bound of this build (reference default 4) */
 #define CDA_MAX_AGENTS    16            /* agents per market upper bound of this build */
-#ifndef CDA_BOOK_CAP
-#define CDA_BOOK_CAP      256           /* resting orders per market, both sides together (reference: unbounded) */
-#endif
+#define CDA_BOOK_CAP      256           /* default book pool: resting orders per market, both sides together (reference: unbounded) */
+#define CDA_BOOK_CAP_MAX  512           /* the larger compiled pool (cda_config.book_capacity); sizes the parity-dump arrays */
 #define CDA_NUM_REWARD_TERMS 5          /* reward_helper.py:75-81 */
 #define CDA_MAX_GROUPS    16            /* cda_step_groups: concurrent market groups per env */
 
@@ -51,7 +50,7 @@ typedef enum cda_status {
 } cda_status;
 
 /* Per-market sticky flag bits reported by cda_last_flags. */
-#define CDA_FLAG_BOOK_OVERFLOW   0x1u   /* a rest was dropped: the market already held CDA_BOOK_CAP orders */
+#define CDA_FLAG_BOOK_OVERFLOW   0x1u   /* a rest was dropped: the market's book pool was full */
 #define CDA_FLAG_INT_OVERFLOW    0x2u   /* a size/position/price left the int32 / 2^24 domain */
 #define CDA_FLAG_DEC_DOMAIN      0x4u   /* a ledger value left the 28-digit / exponent domain */
 
@@ -75,6 +74,10 @@ typedef struct cda_config {
                                     reset(seed=None) semantics (the RNG stream continues, continuousDoubleAuction_env.py:186-188);
                                     its obs row then holds the NEW episode's first observation, reward / flags / info are the
                                     finished step's */
+    int32_t book_capacity;       /* extension: resting orders a market can hold, both sides together (the reference's OrderTree is
+                                    unbounded, ordertree.py:5-58).  256 or 512 (two compiled builds of the market kernels); 0 = by agent
+                                    count: 256 up to 8 agents, 512 above.  A rest that does not fit is dropped and flagged
+                                    (CDA_FLAG_BOOK_OVERFLOW), never silently */
     double  order_penalty;       /* 0.1  */
     double  trade_penalty;       /* 0.05 */
     double  drawdown_penalty;    /* 0.2  */
@@ -145,8 +148,8 @@ typedef struct cda_market_state {
     uint32_t done_mask;           /* env.done_set as a bit mask */
     uint32_t flags;
     int32_t  n_bids, n_asks;
-    cda_order bids[CDA_BOOK_CAP]; /* queue order: best price first, FIFO inside a level */
-    cda_order asks[CDA_BOOK_CAP];
+    cda_order bids[CDA_BOOK_CAP_MAX]; /* queue order: best price first, FIFO inside a level */
+    cda_order asks[CDA_BOOK_CAP_MAX];
     cda_account_state acc[CDA_MAX_AGENTS];
     float    hist[CDA_MAX_HIST * CDA_SNAPSHOT_DIM];  /* oldest frame first */
 } cda_market_state;
@@ -252,7 +255,7 @@ int cda_get_raw_snapshot(cda_env* env, float* raw_out, void* stream);
 /* Per-market sticky flags u32[N] -> device buffer. */
 int cda_last_flags(cda_env* env, uint32_t* flags_out, void* stream);
 /* Book census i32[N] -> device buffer: the most resting orders (both sides together) each market has held since its
- * last reset.  The reference's OrderTree is unbounded (ordertree.py:5-58); this build holds CDA_BOOK_CAP. */
+ * last reset.  The reference's OrderTree is unbounded (ordertree.py:5-58); this build holds cda_book_capacity(env). */
 int cda_book_peak(cda_env* env, int32_t* peak_out, void* stream);
 
 /* Structural invariants of every market -> u32[N] device buffer of CDA_INV_* bits (0 = all hold): sides sorted best
@@ -290,6 +293,7 @@ int cda_selftest_libm_host(int32_t op, int32_t n, const double* x_host, double* 
 
 const char* cda_strerror(int status);
 int32_t cda_num_markets(const cda_env* env);
+int32_t cda_book_capacity(const cda_env* env);   /* 256 or 512: the pool this env was built with */
 int32_t cda_obs_dim(const cda_env* env);
 /* Bytes the arena keeps per market in HBM. */
 int64_t cda_state_bytes_per_market(const cda_env* env);

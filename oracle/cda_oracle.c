@@ -399,7 +399,7 @@ typedef struct {
 struct oracle_env {
     cda_config cfg;
     int32_t n;
-    int32_t book_cap;          /* CDA_BOOK_CAP (the product's capacity) unless oracle_set_book_cap changed it; 0 = unbounded */
+    int32_t book_cap;          /* the product's capacity (cda_create's rule) unless oracle_set_book_cap changed it; 0 = unbounded */
     float mkt_mul, lim_mul;
     market_t* m;
 };
@@ -423,7 +423,7 @@ static void side_remove(side_t* sd, int idx) {
 /* OrderTree.insert_order (orderbook/ordertree.py:44-58): tail of its price level */
 static int side_insert(market_t* m, int s, order_t o) {
     side_t* sd = &m->side[s]; const side_t* other = &m->side[s ^ 1];
-    if (m->book_cap > 0 && sd->n + other->n >= m->book_cap) return 0;       /* the product's capacity (CDA_BOOK_CAP resting orders per market) when mirrored */
+    if (m->book_cap > 0 && sd->n + other->n >= m->book_cap) return 0;       /* the product's pool (256 or 512 resting orders per market) when mirrored */
     if (sd->n == sd->alloc) { sd->alloc = sd->alloc ? 2 * sd->alloc : 64; sd->o = (order_t*)realloc(sd->o, (size_t)sd->alloc * sizeof(order_t)); if (!sd->o) abort(); }
     int pos = 0;
     while (pos < sd->n && better_or_equal(s, sd->o[pos].price, o.price)) pos++;
@@ -819,6 +819,7 @@ static int cfg_ok(const cda_config* c) {
     if (c->tick_size != 1) return CDA_ERR_UNSUPPORTED;
     if (c->initial_price_max < c->initial_price_min) return CDA_ERR_INVALID;
     if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;
+    if (c->book_capacity != 0 && c->book_capacity != CDA_BOOK_CAP && c->book_capacity != CDA_BOOK_CAP_MAX) return CDA_ERR_INVALID;
     return CDA_OK;
 }
 
@@ -828,7 +829,8 @@ int oracle_create(const cda_config* cfg, int32_t n_markets, oracle_env** out) {
     int rc = cfg_ok(cfg); if (rc) return rc;
     oracle_env* e = (oracle_env*)calloc(1, sizeof *e);
     if (!e) return CDA_ERR_NOMEM;
-    e->cfg = *cfg; e->n = n_markets; e->book_cap = CDA_BOOK_CAP;
+    e->cfg = *cfg; e->n = n_markets;
+    e->book_cap = cfg->book_capacity ? cfg->book_capacity : (cfg->num_agents <= 8 ? CDA_BOOK_CAP : CDA_BOOK_CAP_MAX);   /* the product's rule (cda_create) */
     e->mkt_mul = (float)((double)(cfg->mkt_max_size - cfg->min_size) / 2.0);
     e->lim_mul = (float)((double)((int64_t)cfg->mkt_max_size * (int64_t)cfg->limit_size_multiple - (int64_t)cfg->min_size) / 2.0);
     e->m = (market_t*)calloc((size_t)n_markets, sizeof(market_t));
@@ -841,7 +843,7 @@ int oracle_destroy(oracle_env* e) {
     if (e) { for (int i = 0; i < e->n; i++) { free(e->m[i].side[0].o); free(e->m[i].side[1].o); } free(e->m); free(e); }
     return CDA_OK;
 }
-/* 0 = unbounded book (the reference); CDA_BOOK_CAP (default) mirrors the product's capacity and its overflow flag */
+/* 0 = unbounded book (the reference); 256 / 512 mirror the product's pools and their overflow flag */
 int oracle_set_book_cap(oracle_env* e, int32_t cap) {
     if (!e || cap < 0) return CDA_ERR_INVALID;
     e->book_cap = cap;
@@ -957,7 +959,7 @@ int oracle_get_state(oracle_env* e, int32_t market, cda_market_state* s) {
     s->last_price = m->last_price; s->has_trade = m->has_trade; s->last_trade_price = m->last_trade_price;
     s->done_mask = m->done_mask; s->flags = m->flags;
     s->n_bids = m->side[0].n; s->n_asks = m->side[1].n;
-    for (int sd = 0; sd < 2; sd++) for (int i = 0; i < m->side[sd].n && i < CDA_BOOK_CAP; i++) {   /* (an unbounded book's tail beyond the struct's capacity is not dumped) */
+    for (int sd = 0; sd < 2; sd++) for (int i = 0; i < m->side[sd].n && i < CDA_BOOK_CAP_MAX; i++) {   /* (an unbounded book's tail beyond the struct's capacity is not dumped) */
         cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i]; const order_t* q = &m->side[sd].o[i];
         o->price = q->price; o->qty = q->qty; o->owner = q->owner; o->order_id = q->order_id; o->timestamp = q->timestamp;
     }
@@ -975,8 +977,9 @@ int oracle_get_state(oracle_env* e, int32_t market, cda_market_state* s) {
 }
 int oracle_set_state(oracle_env* e, int32_t market, const cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->n) return CDA_ERR_INVALID;
-    if (s->n_bids < 0 || s->n_asks < 0 || s->n_bids + s->n_asks > CDA_BOOK_CAP) return CDA_ERR_INVALID;
+    if (s->n_bids < 0 || s->n_asks < 0 || s->n_bids > CDA_BOOK_CAP_MAX || s->n_asks > CDA_BOOK_CAP_MAX) return CDA_ERR_INVALID;
     market_t* m = &e->m[market];
+    if (m->book_cap > 0 && s->n_bids + s->n_asks > m->book_cap) return CDA_ERR_INVALID;
     m->rng.state = ((u128)s->rng_state_hi << 64) | s->rng_state_lo; m->rng.inc = ((u128)s->rng_inc_hi << 64) | s->rng_inc_lo;
     m->rng.has_uint32 = s->rng_has_uint32; m->rng.uinteger = s->rng_uinteger; m->seeded = 1;
     m->t_step = s->t_step; m->lob_time = s->lob_time; m->next_order_id = s->next_order_id;

@@ -116,3 +116,45 @@ def test_config_scale_beyond_int32_level_sums_is_refused():
     with pytest.raises(CDAError):
         CDAVecEnv({"num_of_agents": 2, "mkt_max_size": 1 << 20, "limit_size_multiple": 64, "is_render": False}, 1)
     CDAVecEnv({"num_of_agents": 2, "mkt_max_size": 100000, "limit_size_multiple": 20, "is_render": False}, 1).close()
+
+
+def test_book_capacity_variants_512_pool_for_many_agents():
+    """Two compiled pools (cda_config.book_capacity): 16 agents get 512 resting orders per market by default - the flip-heavy law
+    overflows 256 within a few thousand steps (profiles/r02 census) - and the larger build is bit-identical to the oracle and, while
+    nothing overflows, to the 256 build."""
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    import oracle_lib as O
+    n, a, steps = 96, 16, 160
+    cfg = {"num_of_agents": a, "init_cash": 1000000, "max_step": 4096, "is_render": False}
+    big, small, ora = CDAVecEnv(cfg, n), CDAVecEnv(dict(cfg, book_capacity=256), n), O.OracleEnv(cfg, n)
+    assert big.book_capacity == 512 and small.book_capacity == 256
+    seeds = np.arange(77, 77 + n, dtype=np.uint64)
+    big.reset(seed=seeds); small.reset(seed=seeds); ora.reset(seeds)
+    rng = np.random.default_rng(4)
+    for t in range(steps):
+        # the flip-heavy law of tests/golden/make_goldens.py
+        acts = (rng.choice([1, 2, 2, 5, 6, 6, 3, 7, 4, 8], (n, a)).astype(np.int32), rng.uniform(-0.05, 0.05, (n, a)).astype(np.float32),
+                rng.uniform(0, 1, (n, a)).astype(np.float32), rng.integers(0, 3, (n, a)).astype(np.int32), rng.choice([1, 2, 2], (n, a)).astype(np.int32))
+        ob, rb, *_ = big.step(*acts)
+        small.step(*acts)
+        oo, orw, *_ = ora.step(*acts)
+        assert np.array_equal(ob.cpu().numpy().view(np.uint32), oo.view(np.uint32)) and np.array_equal(rb.cpu().numpy().view(np.uint64), orw.view(np.uint64)), t
+    assert (big.flags() == 0).all() and (big.check_invariants() == 0).all()
+    assert np.array_equal(big.book_peak().cpu().numpy(), ora.book_peak())
+    clear = (small.flags() == 0).cpu().numpy()
+    for i in range(n):
+        assert bytes(big.get_state(i)) == bytes(ora.get_state(i)), i
+        if clear[i]:
+            assert bytes(small.get_state(i)) == bytes(big.get_state(i)), i
+    # a 4-agent env on the 512 pool equals the default 256 one
+    c4 = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 64, "is_render": False}
+    x, y = CDAVecEnv(c4, 64), CDAVecEnv(dict(c4, book_capacity=512), 64)
+    x.reset(seed=5); y.reset(seed=5)
+    for t in range(48):
+        acts = x.random_actions(t, action_seed=8)
+        rx, ry = x.step(*acts), y.step(*acts)
+        assert torch.equal(rx[0], ry[0]) and torch.equal(rx[1], ry[1])
+    assert all(bytes(x.get_state(i)) == bytes(y.get_state(i)) for i in range(0, 64, 7))
+    for e in (big, small, ora, x, y):
+        e.close()

@@ -61,8 +61,22 @@ def test_unbounded_book_equals_the_capped_one_while_no_overflow_is_flagged():
     for i in np.nonzero(clear)[0]:
         assert bytes(cap.get_state(int(i))) == bytes(unb.get_state(int(i)))
     assert (unb.flags() & K.FLAG_BOOK_OVERFLOW == 0).all()
-    assert (unb.book_peak() >= cap.book_peak()).all() and cap.book_peak().max() <= K.BOOK_CAP
+    assert (unb.book_peak() >= cap.book_peak()).all() and cap.book_peak().max() <= K.BOOK_CAP_MAX      # 16 agents: the 512-order pool
     cap.close(); unb.close()
+
+
+def test_capacity_follows_the_agent_count_or_the_config_key():
+    for cfg, want in (({"num_of_agents": 8}, K.BOOK_CAP), ({"num_of_agents": 9}, K.BOOK_CAP_MAX), ({"num_of_agents": 4, "book_capacity": 512}, 512),
+                      ({"num_of_agents": 16, "book_capacity": 256}, 256)):
+        e = O.OracleEnv(dict(cfg, init_cash=10 ** 12, is_render=False), 1)
+        e.reset(np.array([1], np.uint64))
+        for i in range(want + 5):
+            e.place_order(0, 0, K.T_LIMIT, K.S_BID, 1, 5 + i)
+        assert sum(e.book_size(0)) == want and e.flags()[0] & K.FLAG_BOOK_OVERFLOW
+        e.close()
+    import pytest
+    with pytest.raises(RuntimeError):
+        O.OracleEnv({"num_of_agents": 4, "book_capacity": 300, "is_render": False}, 1)
 
 
 def test_unbounded_book_holds_more_than_the_product_pool():
