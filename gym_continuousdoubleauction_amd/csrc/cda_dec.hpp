@@ -193,6 +193,22 @@ template <int NL> __device__ __forceinline__ uint32_t w_div_small(WN<NL>& x, uin
     }
     return rem;
 }
+// the same with the running remainder seeded by the caller (rem0 < d): continues a long division below its top limb
+template <int NL> __device__ __forceinline__ uint32_t w_div_small_seeded(WN<NL>& x, uint32_t d, double rd, uint32_t rem0) {
+    uint32_t rem = rem0;
+    #pragma unroll
+    for (int i = NL - 1; i >= 0; i--) {
+        const double cur = __builtin_fma((double)rem, 4294967296.0, (double)x.w[i]);
+        uint32_t q = (uint32_t)(cur * rd);
+        int32_t r = (int32_t)(x.w[i] - q * d);
+        const bool lo = r < 0;
+        q -= lo ? 1u : 0u; r += lo ? (int32_t)d : 0;
+        const bool hi = r >= (int32_t)d;
+        q += hi ? 1u : 0u; r -= hi ? (int32_t)d : 0;
+        x.w[i] = q; rem = (uint32_t)r;
+    }
+    return rem;
+}
 template <int NL> __device__ __forceinline__ int w_bits(const WN<NL>& a) {
     int b = 0;
     #pragma unroll
@@ -296,7 +312,15 @@ __device__ __noinline__ D d_round_mid(int sign, u128 r, int exp) {      // a LEA
         drop = 9;
     }
     uint32_t pw = lds_pow10(drop)[0];
-    uint32_t rem = w_div_small(x, pw, lds_rcp10(drop));
+    // r < 10^(28 + drop), so the quotient is below 10^28 < 2^94: its top limb is zero and the top limb of r (< 10^drop, or the
+    // division could not come out below 2^96) is simply the first partial remainder - three limb steps instead of four
+    uint32_t rem;
+    {
+        const double rd = lds_rcp10(drop);
+        WN<3> lo; lo.w[0] = x.w[0]; lo.w[1] = x.w[1]; lo.w[2] = x.w[2];
+        rem = w_div_small_seeded(lo, pw, rd, x.w[3]);
+        x.w[0] = lo.w[0]; x.w[1] = lo.w[1]; x.w[2] = lo.w[2]; x.w[3] = 0;
+    }
     // 10^27 = 0x033b2e3c_9fd0803c_e8000000
     const bool full = x.w[2] > 0x033b2e3cu || (x.w[2] == 0x033b2e3cu && (x.w[1] > 0x9fd0803cu || (x.w[1] == 0x9fd0803cu && x.w[0] >= 0xe8000000u)));
     if (!full) {                                                // r has nd_hi - 1 digits: one digit fewer to drop
@@ -551,6 +575,10 @@ __device__ __noinline__ D d_div_inexact_leaf(D a, uint32_t n) { // a LEAF (no ca
     return d_make(0, 0, 0, D_NOT_HANDLED, 0);
 }
 __device__ __forceinline__ D d_div_u32(D a, uint32_t n) {
+    if (a.w2 == 0) {        // a short dividend - a position built at ONE price, the usual case early in an episode: mostly an exact
+        WN<2> x; x.w[0] = a.w0; x.w[1] = a.w1;          // quotient, which the inexact leaf would only hand on to the general routine
+        if (w_div_u32(x, n) == 0) return d_make(x.w[0], x.w[1], 0, a.exp, a.sign);     // coefficient / n at the ideal exponent (also 0 / n)
+    }
     D r = d_div_inexact_leaf(a, n);
     if (r.exp == D_NOT_HANDLED) r = d_div_general(a, n);
     return r;

@@ -83,7 +83,15 @@ struct StepArgs {
     cda_info_ptrs info; int has_info;
     int first_market, end_market;       // this launch steps the markets [first_market, end_market); every array argument is the full [N, ...] one
     unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,40] cycle stamps
+    int dbg_skip;                       // debug builds only (CDA_DEBUG_SKIP): phases to leave out (tools/fixed_cost_probe.py); results are then wrong
 };
+#ifdef CDA_DEBUG_SKIP
+#define CDA_DBG_HAS(S, bit) (((S).dbg_skip & (bit)) != 0)
+#define CDA_DBG_SKIP(S, bit, stmt) do { if (CDA_DBG_HAS(S, bit)) stmt; } while (0)
+#else
+#define CDA_DBG_HAS(S, bit) false
+#define CDA_DBG_SKIP(S, bit, stmt) do {} while (0)
+#endif
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { if (!(v >= lo)) return lo; if (!(v <= hi)) return hi; return v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -239,6 +247,14 @@ __global__ void k_opbench(int op, int iters, const cda_dec* a, const cda_dec* b,
     st_dec(sink[0], x, f); sink[1].w[0] = (uint32_t)iacc + (uint32_t)__double_as_longlong(dacc);
 }
 
+// debug (tools/clock_probe.py): shader-clock cycles (s_memtime) against the constant 100 MHz counter over a spin
+__global__ void k_clock_probe(int iters, unsigned long long* out) {
+    unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    unsigned int x = threadIdx.x;
+    for (int i = 0; i < iters; i++) x = x * 1664525u + 1013904223u;
+    unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = x; }
+}
 // PMC calibration (tools/profile_gpu.sh): known byte counts in THIS library's access pattern (4 B per lane,
 // coalesced) so that FETCH_SIZE / WRITE_SIZE can be converted to bytes (MI355X_MICROARCH.md, HBM section).
 __global__ void k_calib_read(const uint32_t* p, size_t n, uint32_t* out) {
@@ -304,6 +320,7 @@ struct cda_env {
 };
 
 static thread_local char g_err[256] = "";
+static int g_dbg_skip = 0;                          // debug (CDA_DEBUG_SKIP builds)
 static unsigned long long* g_phase_cycles = NULL;   // debug (CDA_PHASE_TIMING builds): device buffer [N,40]
 static int hip_fail(hipError_t e, const char* what) {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
@@ -441,6 +458,7 @@ static int fill_step_args(cda_env* e, StepArgs& S, const int32_t* category, cons
     S.present = present; S.obs_out = obs_out; S.reward_out = reward_out; S.terminated_out = terminated_out; S.truncated_out = truncated_out;
     if (info_out) { S.info = *info_out; S.has_info = 1; } else { memset(&S.info, 0, sizeof S.info); S.has_info = 0; }
     S.phase_cycles = g_phase_cycles;
+    S.dbg_skip = g_dbg_skip;
     S.done_out = e->P.cfg.auto_reset ? e->done_buf : NULL;
     S.first_market = 0; S.end_market = e->P.n_markets;
     return CDA_OK;
@@ -770,8 +788,15 @@ int cda_debug_calib(void* dev_buf, size_t n_bytes, int mode, void* stream) {
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
+/* debug hook (not in include/cda.h): enqueue the clock probe on `stream`; out: device u64[3] = shader cycles, 100 MHz ticks, sink */
+int cda_debug_clock_probe(int iters, unsigned long long* dev_out, void* stream) {
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, iters, dev_out);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
 /* debug hook (not in include/cda.h): device buffer [N,40] of cycle stamps, used by tools/phase_timing.py */
 void cda_debug_set_phase_buffer(unsigned long long* dev_buf) { g_phase_cycles = dev_buf; }
+/* debug hook (not in include/cda.h; CDA_DEBUG_SKIP builds): leave phases of k_step out to price them (wrong results) */
+void cda_debug_set_skip(int mask) { g_dbg_skip = mask; }
 #ifdef CDA_DEC_COUNTERS
 int cda_debug_dec_calls(unsigned long long* host8, int reset) {
     if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(cda::g_dec_calls), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;

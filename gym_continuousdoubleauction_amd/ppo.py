@@ -81,7 +81,9 @@ def gae(rew, val, last_val, done, gamma=0.99, lam=0.95):
     return adv, adv + val
 
 
-def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch=65536, clip=0.2, vf_coef=0.5, ent_coef=0.01):
+def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch=65536, clip=0.2, vf_coef=0.5, ent_coef=0.01, amp=False):
+    """amp: run the two MLPs' matrix products of the update in bfloat16 on the MFMA units (torch.autocast; softmax / log-prob /
+    losses stay float32, parameters and Adam state stay float32) - the update is the learner-bound 80 % of an iteration."""
     B = obs.shape[0]
     adv = (adv - adv.mean()) / (adv.std() + 1e-8)
     stats = {}
@@ -89,7 +91,9 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
         perm = torch.randperm(B, device=obs.device)
         for s in range(0, B, minibatch):
             idx = perm[s:s + minibatch]
-            logp, ent, v = model.evaluate(obs[idx], tuple(x[idx] for x in actions))
+            with torch.autocast(obs.device.type, dtype=torch.bfloat16, enabled=amp):
+                logp, ent, v = model.evaluate(obs[idx], tuple(x[idx] for x in actions))
+            logp, ent, v = logp.float(), ent.float(), v.float()
             ratio = (logp - logp_old[idx]).exp()
             pg = -torch.min(ratio * adv[idx], ratio.clamp(1 - clip, 1 + clip) * adv[idx]).mean()
             vl = (v - ret[idx]).pow(2).mean()
@@ -120,12 +124,13 @@ def _capture_policy_step(model, env, N, A):
     return g, (pobs, actions, logp, val, env_acts)
 
 
-def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, rollout_hook=None):
+def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, rollout_hook=None, amp=None):
     """On-device PPO over a CDAVecEnv-shaped env. Returns per-iteration stats (incl. agent-steps/s).
     rollout_hook(iteration, step, env_actions, obs, reward, terminated, truncated): called after every env step with the
     five [N,A] action tensors the policy produced and the step's output tensors (device tensors; clone what you keep)."""
     torch.manual_seed(seed)
     dev = env.obs.device
+    amp = (dev.type == "cuda") if amp is None else bool(amp)
     N, A = env.n_markets, env.num_agents
     model = ActorCritic(env.obs_dim).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=lr, fused=dev.type == "cuda")     # one kernel per step instead of one per tensor
@@ -173,7 +178,7 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
         flat = lambda xs: torch.cat(xs, 0)                         # noqa: E731
         acts = tuple(flat([b[i] for b in buf_act]) for i in range(4))
         t_roll = time.perf_counter()
-        stats = ppo_update(model, opt, flat(buf_obs), acts, flat(buf_logp), adv.reshape(-1), ret.reshape(-1), epochs=epochs)
+        stats = ppo_update(model, opt, flat(buf_obs), acts, flat(buf_logp), adv.reshape(-1), ret.reshape(-1), epochs=epochs, amp=amp)
         if dev.type == "cuda":
             torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -191,18 +196,19 @@ def main(argv=None):
     p.add_argument("--horizon", type=int, default=64)
     p.add_argument("--iters", type=int, default=4)
     p.add_argument("--max-step", type=int, default=4096)
+    p.add_argument("--fp32-update", action="store_true", help="PPO update in float32 instead of bfloat16 autocast")
     p.add_argument("--out", default=None, help="write a JSON summary (config, per-iteration stats, end-of-run env checks) to this file")
     args = p.parse_args(argv)
     from .vec_env import CDAVecEnv
     env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False, "auto_reset": True},
                     n_markets=args.markets, device="cuda:0", with_info=False)
-    _, hist = train(env, iters=args.iters, horizon=args.horizon)
+    _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update)
     flags = env.flags()
     _, bad = env.nav_conservation()
     summary = {"metric": "agent-steps/sec end to end (rollout + PPO update), BASELINE configs[4]",
                "config": {"workload": f"{args.markets} markets x {args.agents} agents, PyTorch-ROCm PPO policy in the loop (256x256 tanh actor and critic, "
                                       f"4 epochs, 65536-sample minibatches), horizon {args.horizon}, {args.iters} iterations, auto_reset on",
-                          "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters},
+                          "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters, "update_dtype": "float32" if args.fp32_update else "bfloat16 autocast (float32 parameters, Adam state, softmax and losses)"},
                "iterations": hist,
                "value": sum(h["agent_steps"] for h in hist[1:] or hist) / sum(h["rollout_s"] + h["update_s"] for h in hist[1:] or hist),
                "rollout_agent_steps_per_s": sum(h["agent_steps"] for h in hist[1:] or hist) / sum(h["rollout_s"] for h in hist[1:] or hist),

@@ -8,7 +8,9 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 200 --warmup 16 --no-cpu-baseline"
+# one timed leg, no clock primer: every k_step dispatch of the run belongs to the measured env (two concurrent group chains)
+export CDA_BENCH_PRIMER_MS=0
+BENCH="python $R/bench.py --steps 200 --warmup 16 --no-cpu-baseline --no-info-leg ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $BENCH > /dev/null 2> $OUT/pmc_write.err

@@ -66,12 +66,40 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
                     vals.append(float(row["Counter_Value"]))
         if vals:
             res[ctr] = sum(vals) / len(vals)
+import re
+meta = {}
+for f in find("", "trace_bench.json"):
+    try:
+        with open(f) as fh:
+            line = [ln for ln in fh if ln.startswith("{")][-1]
+        b = json.loads(line)
+        meta = {"markets": b["config"]["markets_per_gpu"], "agents": b["config"]["agents"], "info": b["config"]["info_outputs"],
+                "groups": b["config"]["groups"], "markets_per_launch": b["roofline"]["markets_per_launch"]}
+    except Exception as ex:  # noqa: BLE001
+        print("no bench line in the trace pass:", ex)
+insts = {}
+for sub in ("pmc_sq", "pmc_sq2", "pmc_sq3"):
+    for f in find(sub, "*counter_collection.csv"):
+        acc, cnt = defaultdict(float), defaultdict(int)
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "k_step" in row.get("Kernel_Name", ""):
+                    acc[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
+        for k in acc:
+            insts[k] = acc[k] / cnt[k]
 if res and calib:
     fetch_b = res.get("FETCH_SIZE", 0) * calib.get("FETCH_SIZE", 1024)
     write_b = res.get("WRITE_SIZE", 0) * calib.get("WRITE_SIZE", 1024)
-    out_json = {"kernel": "k_step", "workload": "bench.py default (4096 markets x 4 agents)", "fetch_counter": res.get("FETCH_SIZE"),
-                "write_counter": res.get("WRITE_SIZE"), "bytes_per_fetch_unit": calib.get("FETCH_SIZE"), "bytes_per_write_unit": calib.get("WRITE_SIZE"),
-                "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b, "hbm_bytes_per_launch": fetch_b + write_b}
-    print("k_step HBM traffic per launch (calibrated):", json.dumps(out_json))
-    with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+    mpl = meta.get("markets_per_launch") or 4096
+    issued = sum(insts.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"))
+    out_json = dict(meta, kernel="k_step", workload=f"bench.py, {meta.get('markets')} markets x {meta.get('agents')} agents, {meta.get('groups')} group chain(s), info {meta.get('info')}",
+                    fetch_counter=res.get("FETCH_SIZE"), write_counter=res.get("WRITE_SIZE"), bytes_per_fetch_unit=calib.get("FETCH_SIZE"),
+                    bytes_per_write_unit=calib.get("WRITE_SIZE"), fetch_bytes_per_launch=fetch_b, write_bytes_per_launch=write_b,
+                    hbm_bytes_per_launch=fetch_b + write_b, hbm_bytes_per_market_step=(fetch_b + write_b) / mpl,
+                    wave_insts_per_market_step=issued / mpl, valu_insts_per_market_step=insts.get("SQ_INSTS_VALU", 0.0) / mpl,
+                    salu_insts_per_market_step=insts.get("SQ_INSTS_SALU", 0.0) / mpl, lds_insts_per_market_step=insts.get("SQ_INSTS_LDS", 0.0) / mpl,
+                    active_inst_any_over_wave_cycles=(insts.get("SQ_ACTIVE_INST_ANY", 0.0) / insts["SQ_WAVE_CYCLES"]) if insts.get("SQ_WAVE_CYCLES") else None,
+                    wait_any_over_wave_cycles=(insts.get("SQ_WAIT_ANY", 0.0) / insts["SQ_WAVE_CYCLES"]) if insts.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in insts else None)
+    print("k_step HBM traffic and issue picture per launch (calibrated):", json.dumps(out_json))
+    with open(os.path.join(out, "pmc_latest.json"), "w") as fh:
         json.dump(out_json, fh, indent=1)
