@@ -37,6 +37,7 @@ ALG_BYTES_PER_AGENT = 324
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 GPU_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: peak engine clock
 N_SIMD = 1024               # 256 CUs x 4 SIMDs
+VALU_CYCLES = 2.0           # MI355X_MICROARCH.md: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
 ACTION_SEED = 2024          # bench_seed
 SEED_BASE = 1000            # market i is seeded SeedSequence(1000 + i)
 CONFIGS = {"c3": (4096, 4), "c4": (2048, 8)}
@@ -397,7 +398,7 @@ def main():
                 traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, calibrated; per market-step x markets of one launch)"
                 cycles = elapsed / K * GPU_CLOCK_GHZ * 1e9                     # device cycles per step of the whole batch
                 issue_frac = pmc["wave_insts_per_market_step"] * N / (N_SIMD * cycles)
-                valu_busy = 4.0 * pmc["valu_insts_per_market_step"] * N / (N_SIMD * cycles)
+                valu_busy = VALU_CYCLES * pmc["valu_insts_per_market_step"] * N / (N_SIMD * cycles)
         except Exception:  # noqa: BLE001
             pass
         out = {
