@@ -106,6 +106,12 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
     return {k: float(v) for k, v in stats.items()}          # one host sync per update, not one per minibatch
 
 
+def _join(env):
+    """A groups > 1 env leaves each group's outputs on that group's stream: this loop consumes them on the current one."""
+    if getattr(env, "groups", 1) > 1:
+        env.join()
+
+
 def _capture_policy_step(model, env, N, A):
     """HIP graph of: observation broadcast -> policy/value forward -> sampling -> env action tensors."""
     side = torch.cuda.Stream()
@@ -155,6 +161,7 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
                 g.replay()                                           # reads env.obs (this step's observation)
                 pobs, actions, logp, val = pobs_s.clone(), tuple(x.clone() for x in actions_s), logp_s.clone(), val_s.clone()
                 o, r, term, trunc, _ = env.step(*env_acts_s)
+                _join(env)
                 if rollout_hook is not None:
                     rollout_hook(it, len(buf_obs), env_acts_s, o, r, term, trunc)
             else:
@@ -163,6 +170,7 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
                     actions, logp, val = model.act(pobs)
                 env_acts = to_env_actions(actions, N, A)
                 o, r, term, trunc, _ = env.step(*env_acts)
+                _join(env)
                 if rollout_hook is not None:
                     rollout_hook(it, len(buf_obs), env_acts, o, r, term, trunc)
             done = (term | trunc)
