@@ -1,12 +1,20 @@
-// cda_hip.hip - kernels + the C-ABI of include/cda.h (gfx950 only; no CPU fallback, no shims).
+// cda_hip.hip - the C-ABI of include/cda.h and the kernels that do not own a market-wave (gfx950 only; no CPU fallback, no shims).
 //
-// Kernels (all: one wave64 per market, WPB markets per workgroup, no inter-wave communication):
-//   k_reset         reset(seed)            continuousDoubleAuction_env.py:175-231
-//   k_step          step(actions)          continuousDoubleAuction_env.py:265-309  <- the hot kernel
-//   k_place_order   Trader.place_order     agent/trader.py:49-106   (test hook, 1 market)
-//   k_mark_to_mkt   Exchg_Helper.mark_to_mkt                         (test hook, 1 market)
-//   k_raw_snapshot  agg_LOB_raw            exchg/state_helper.py:159-160
-//   k_selftest_dec / k_selftest_rng        device self-tests of the ledger arithmetic and the RNG
+// File map of csrc/:
+//   cda_dec.hpp      28-digit decimal ledger arithmetic (Python Decimal semantics)
+//   cda_libm.hpp     glibc's log1p / exp restated (what numpy's normal sampler calls on the host)
+//   cda_market.hpp   everything of a market-wave that does not depend on the book capacity: record header, accounts, numpy RNG
+//   cda_book.inc     the pooled order book, matching, ledger functions, observation - compiled once per book capacity
+//   cda_kernels.inc  the market-wave kernels (all: one wave64 per market, WPB markets per workgroup, no inter-wave
+//                    communication), included below for CAP = 256 (cda::cap256) and CAP = 512 (cda::cap512):
+//                      k_reset         reset(seed)            continuousDoubleAuction_env.py:175-231
+//                      k_step          step(actions)          continuousDoubleAuction_env.py:265-309  <- the hot kernel
+//                      k_run_random    CDA_rand.run_random    CDA_rand.py:40-85
+//                      k_place_order   Trader.place_order     agent/trader.py:49-106   (test hook, 1 market)
+//                      k_mark_to_mkt   Exchg_Helper.mark_to_mkt                         (test hook, 1 market)
+//                      k_raw_snapshot  agg_LOB_raw            exchg/state_helper.py:159-160
+//   here             k_init_arena, k_random_actions, k_nav_conservation, k_check_invariants, k_flags, k_book_peak, self-tests,
+//                    debug probes, and the host side: arena, capacity dispatch, every extern "C" entry point
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
