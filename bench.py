@@ -16,7 +16,7 @@ include/cda_random_agents.h keyed (2024, step, GLOBAL market index, agent) - the
 reference (train/model/model_handler.py:38-53).  The whole stream is generated on the device before the timed region
 (cda_random_actions), so every input is resident in HBM; the cpu_baseline leg replays the SAME stream.
 
-On one GPU the batch is stepped as `--groups` (default 2) contiguous market groups, each a chain of k_step launches on
+On one GPU the batch is stepped as `--groups` (default 4; 2 for runs shorter than 200 steps) contiguous market groups, each a chain of k_step launches on
 its own stream (cda_step_groups): markets never interact, so the batch-wide barrier of a single launch is not part of
 the reference's semantics, and a group's slowest market then overlaps the other group's work.
 
@@ -52,7 +52,7 @@ def parse():
                    "c4: 2048 x 8 per GPU (the per-GPU share of BASELINE configs[3], 16384 x 8 over 8 GPUs)")
     p.add_argument("--markets", type=int, default=None, help="markets per GPU (overrides --config)")
     p.add_argument("--agents", type=int, default=None)
-    p.add_argument("--groups", type=int, default=None, help="concurrent market groups per GPU (default 2; 1 with the all-gather)")
+    p.add_argument("--groups", type=int, default=None, help="concurrent market groups per GPU (default 4, 2 below 200 timed steps; 1 with the all-gather)")
     p.add_argument("--info", action="store_true", help="headline run WITH the info tensors (a14); otherwise info-on is timed as a second leg")
     p.add_argument("--no-info-leg", action="store_true", help="skip the second (info tensors on) timed leg")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the obs/reward all-gather")
@@ -173,7 +173,9 @@ def main():
     total_steps = W + 2 * CAL + K
     max_step = max(4096, total_steps + 1)                          # no truncation inside the run
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
-    groups = args.groups if args.groups is not None else (1 if (gather or args.fused) else 2)
+    # default number of group chains: 4 pays once the chains are long (433 M vs 417 M at 1000 steps), 2 when the whole timed
+    # region is a few dozen steps and the staggered start / drain of four chains is a visible share of it (384 M vs 372 M at 20)
+    groups = args.groups if args.groups is not None else (1 if (gather or args.fused) else (4 if K >= 200 else 2))
     groups = max(1, min(groups, N))
     if gather and groups != 1:
         raise SystemExit("the all-gather schedule steps the shard as one launch: use --groups 1")
@@ -319,8 +321,7 @@ def main():
         """K steps of env `e` bracketed by barrier + synchronize; returns (elapsed s, [per-launch kernel ms per stream])."""
         if use_dist:
             dist.barrier()
-        e.join()
-        torch.cuda.synchronize()
+        e.sync()                                                   # device-wide: the group streams are idle too, no stream edges needed
         # HIP events on the stream(s) the kernel is launched on.  groups == 1, N == 1: one pair on torch's current stream
         # (== the stream handed to cda_step) brackets the K back-to-back launches, kernel_ms = span / K.  groups > 1: one
         # pair per group stream, each bracketing that group's K launches.  N > 1 with the all-gather: collectives and
@@ -333,8 +334,6 @@ def main():
             timed.update({first_t + t: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for t in range(0, K, EV_STRIDE)})
         elif with_events:
             lanes = e.group_streams if e.groups > 1 else [torch.cuda.current_stream(device)]
-            if e.groups > 1:
-                e.fork()
             evs = [(s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in lanes]
         t0 = time.perf_counter()
         for s, a, _ in evs:
@@ -343,8 +342,7 @@ def main():
             one_step(e, first_t + t)
         for s, _, b in evs:
             b.record(s)
-        e.join()
-        torch.cuda.synchronize()
+        e.sync()                                                   # barrier + synchronize on both sides of the K steps (every stream of the device)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -393,9 +391,10 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)
-            if (pmc.get("markets"), pmc.get("agents"), bool(pmc.get("info")), pmc.get("groups")) == (N, A, bool(args.info), env.groups) and not args.fused and not gather:
+            if (pmc.get("markets"), pmc.get("agents"), bool(pmc.get("info"))) == (N, A, bool(args.info)) and not args.fused and not gather:
                 traffic = pmc["hbm_bytes_per_market_step"] * markets_per_launch[0]
-                traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, calibrated; per market-step x markets of one launch)"
+                traffic_src = (f"profiles/pmc_latest.json (rocprofv3 --pmc, calibrated; per market-step figure of a {pmc.get('groups')}-chain run "
+                               "x markets of one launch)")
                 cycles = elapsed / K * GPU_CLOCK_GHZ * 1e9                     # device cycles per step of the whole batch
                 issue_frac = pmc["wave_insts_per_market_step"] * N / (N_SIMD * cycles)
                 valu_busy = VALU_CYCLES * pmc["valu_insts_per_market_step"] * N / (N_SIMD * cycles)

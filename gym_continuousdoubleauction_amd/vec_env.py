@@ -177,6 +177,14 @@ class CDAVecEnv:
             s.wait_event(self._fork_ev)
         self._need_fork = False
 
+    def sync(self):
+        """Host-side barrier: wait until the device has finished everything enqueued on ANY stream (the group streams included).
+        Afterwards no stream has pending work, so the next step() needs no fork and a consumer needs no join - unlike join(),
+        this puts no dependency edge into any stream."""
+        torch.cuda.synchronize(self.device)
+        if self.groups > 1:
+            self._need_fork = False
+
     def join(self):
         """Order the caller's current stream after every group's last step, so that the outputs can be consumed there;
         the next step() forks again.  A caller that pipelines per group works inside `torch.cuda.stream(group_streams[g])`

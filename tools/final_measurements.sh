@@ -10,6 +10,7 @@ cd $R
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command.json 2>/dev/null
 python bench.py --groups 1 --no-cpu-baseline > $O/bench_groups1.json 2>/dev/null
+python bench.py --groups 2 --no-cpu-baseline > $O/bench_groups2.json 2>/dev/null
 python bench.py --config c4 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null
 python bench.py --fused 64 --steps 1024 --warmup 64 --no-cpu-baseline > $O/bench_fused.json 2>/dev/null
 python bench.py --force-gather --no-cpu-baseline --steps 400 > $O/bench_forcegather_one_rank.json 2>/dev/null
