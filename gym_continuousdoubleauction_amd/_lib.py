@@ -34,6 +34,10 @@ def lib():
         raise CDAError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
             f"`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    # PyTorch-ROCm ships its own HIP runtime.  It must be in the process BEFORE this library resolves libamdhip64: loaded the
+    # other way round, the system runtime this library would pull in and torch's copy both initialise, and hipGetDeviceCount
+    # then reports no device (seen as "cda_create failed (-2)" when build() ran before smoke() in one interpreter).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     L.cda_default_config.argtypes = [C.POINTER(K.Config)]
