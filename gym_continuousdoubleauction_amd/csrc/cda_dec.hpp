@@ -58,6 +58,14 @@ constexpr Pow5Tab make_pow5() {
     for (int k = 0; k < 56; k++) { t.lo[k] = (uint64_t)v; t.hi[k] = (uint64_t)(v >> 64); v *= 5; }
     return t;
 }
+struct Rcp10Tab { double v[10]; };
+constexpr Rcp10Tab make_rcp10() {
+    Rcp10Tab t{};
+    double p = 1.0;
+    for (int k = 0; k < 10; k++) { t.v[k] = 1.0 / p; p *= 10.0; }          // 10^k exact in binary64; one correctly rounded division each
+    return t;
+}
+__device__ const Rcp10Tab RCP10 = make_rcp10();
 __device__ const Pow10Tab POW10 = make_pow10();     // global memory: only the wide path reads it
 __device__ const Pow5Tab POW5 = make_pow5();
 
@@ -80,7 +88,7 @@ __device__ __forceinline__ void dec_tables_init() {
     if ((uint32_t)(uintptr_t)cda_smem != 0u) __builtin_trap();          // see lds_pow10()
     uint32_t* t = reinterpret_cast<uint32_t*>(cda_smem);
     for (int i = (int)threadIdx.x; i < DEC_LDS_POW * 4; i += (int)blockDim.x) t[i] = POW10.v[i >> 2][i & 3];
-    if (threadIdx.x < 10) reinterpret_cast<double*>(cda_smem + DEC_RCP_OFF)[threadIdx.x] = 1.0 / (double)POW10.v[threadIdx.x][0];
+    if (threadIdx.x < 10) reinterpret_cast<double*>(cda_smem + DEC_RCP_OFF)[threadIdx.x] = RCP10.v[threadIdx.x];      // RN(1 / 10^k), folded at compile time
     __syncthreads();
 }
 
@@ -246,6 +254,12 @@ __device__ __forceinline__ D d_from_i64(int64_t v) {
 __device__ __forceinline__ D d_from_u32(uint32_t v) { return d_make(v, 0, 0, 0, 0); }
 // a tick price as the book holds it: Decimal(str(float(p))) = Decimal('p.0') (orderbook.py:52,239)
 __device__ __forceinline__ D d_price(int32_t p) { uint64_t a = (uint64_t)(uint32_t)p * 10u; return d_make((uint32_t)a, (uint32_t)(a >> 32), 0, -1, 0); }
+// Decimal('p.0') * n for a tick price p < 2^24 and an integer n < 2^31 (order and trade values, orderbook.py:52,239 with
+// trader.py:312): always exact - the coefficient 10 * p * n stays below 2^59 - so no generic 128-bit product, no 10^28 test
+__device__ __forceinline__ D d_price_times(int32_t p, uint32_t n) {
+    const uint64_t c = (uint64_t)(uint32_t)p * 10u * (uint64_t)n;
+    return d_make((uint32_t)c, (uint32_t)(c >> 32), 0, -1, 0);
+}
 __device__ __forceinline__ bool d_is_zero(const D& a) { return (a.w0 | a.w1 | a.w2) == 0; }
 template <int NL> __device__ __forceinline__ WN<NL> d_wide(const D& a) { return w_from3<NL>(a.w0, a.w1, a.w2); }
 __device__ __forceinline__ D d_neg(D a) { a.sign ^= 1; return a; }
