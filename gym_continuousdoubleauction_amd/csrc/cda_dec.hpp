@@ -464,21 +464,24 @@ constexpr int D_NOT_HANDLED = -0x40000000;                      // exponent sent
 // transfer - a 28-digit cash, a short cash_on_hold - run the same instructions.  Anything that does not fit the shape, or
 // would need rounding, is handed back (exp == D_NOT_HANDLED) to the general addition.
 __device__ __noinline__ D d_add_order_value(D field, D v) {
+    // Straight-line on purpose: sum and both differences are formed and the result SELECTED - every `if` on per-lane data
+    // costs an exec-mask save / branch / restore, and the two lanes of a transfer (cash: 28 digits, hold: short) would take
+    // different arms anyway.
     const int diff = v.exp - field.exp;
     const u128 co = d_c128(field);
-    const bool shape = (v.w1 | v.w2) == 0 && v.w0 != 0 && diff >= 0 && diff <= 28 &&
-                       (co == 0 || (((bits128(co) - 1) * 1233) >> 12) >= diff - 1);     // no _normalize replacement (see d_add_mid)
-    D bad = d_make(0, 0, 0, D_NOT_HANDLED, 0);
-    if (!shape) return bad;
-    const u128 ct = mul_u32_pow10_lds(v.w0, diff);
-    u128 r; int rs;
-    if (field.sign != v.sign && co != 0) {
-        if (ct == co) return d_make(0, 0, 0, field.exp, 0);
-        const bool vg = ct > co;
-        r = vg ? ct - co : co - ct; rs = vg ? v.sign : field.sign;
-    } else { r = ct + co; rs = co == 0 ? v.sign : field.sign; }        // a zero field only lends its exponent (Decimal.__add__, `if not self`)
-    if (!(r < p28_128())) return bad;
-    return d_from128(r, field.exp, rs);
+    const bool fz = co == 0;
+    const int dcl = diff < 0 ? 0 : (diff > 28 ? 28 : diff);                            // a valid table index whatever the shape
+    const bool shape = (v.w1 | v.w2) == 0 && v.w0 != 0 && diff == dcl &&
+                       (fz || (((bits128(co) - 1) * 1233) >> 12) >= diff - 1);           // no _normalize replacement (see d_add_mid)
+    const u128 ct = mul_u32_pow10_lds(v.w0, dcl);
+    const bool same = field.sign == v.sign || fz;                                       // a zero field only lends its exponent (Decimal.__add__, `if not self`)
+    const bool vg = ct > co;
+    const u128 sum = ct + co, dv = ct - co, df = co - ct;
+    const u128 r = same ? sum : (vg ? dv : df);
+    int rs = same ? (fz ? v.sign : field.sign) : (vg ? v.sign : field.sign);
+    rs = r == 0 ? 0 : rs;                                                               // equal magnitudes, opposite signs: +0 at the field's exponent
+    const bool ok = shape && r < p28_128();
+    return d_make(ok ? (uint32_t)r : 0u, ok ? (uint32_t)(r >> 32) : 0u, ok ? (uint32_t)(r >> 64) : 0u, ok ? field.exp : D_NOT_HANDLED, ok ? rs : 0);
 }
 
 // ---- multiplication: Decimal.__mul__ (_pydecimal.py:1267) for b = (+) m * 10^mexp with m < 2^32 ----

@@ -86,6 +86,9 @@ struct Mkt {
     int32_t nb, na;              // resting orders per side (two scalars: a dynamically indexed array would force Mkt into scratch)
     int32_t seeded, hist_head, levels_valid;
     int32_t peak_orders;         // census: see H_PEAK_ORDERS
+#ifdef CDA_DEBUG_SKIP
+    int32_t dbg;                 // debug: pieces of the order phase to leave out (tools/inst_count.sh); results are then wrong
+#endif
     int32_t fills;               // fills settled in the current step (issue priority of this wave grows with it)
 #ifdef CDA_PHASE_TIMING
     unsigned long long tacc[24];    // debug: cycles in approval / find / match+settle / insert+remove / escrow+cancel, fills, ...; 14..20: inside a fill
@@ -111,6 +114,11 @@ struct Mkt {
 #define TACC_BEGIN() do {} while (0)
 #define TACC_END(m, i) do {} while (0)
 #define TACC_COUNT(m, i, n) do {} while (0)
+#endif
+#ifdef CDA_DEBUG_SKIP
+#define CDA_MKT_DBG(m, bit) (((m).dbg & (bit)) != 0)
+#else
+#define CDA_MKT_DBG(m, bit) false
 #endif
 __device__ __forceinline__ int mkt_n(const Mkt& m, int s) { return s == 0 ? m.nb : m.na; }
 __device__ __forceinline__ void mkt_set_n(Mkt& m, int s, int v) { if (s == 0) m.nb = v; else m.na = v; }
@@ -268,6 +276,9 @@ __device__ __forceinline__ void decode_header(uint32_t v, Mkt& m) {
     m.nb = (int32_t)RL(H_N_BIDS); m.na = (int32_t)RL(H_N_ASKS);
     m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD); m.levels_valid = (int32_t)RL(H_LEVELS_VALID);
     m.peak_orders = (int32_t)RL(H_PEAK_ORDERS);
+#ifdef CDA_DEBUG_SKIP
+    m.dbg = 0;
+#endif
     m.fills = 0;
     #undef RL
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: instruction counts per market-step by phase (skip masks, every agent passes) and by action category.
 R=${GRAFT_REPO_ROOT:-$PWD}
-export TMPDIR=/tmp CDA_HIP_LIB=$R/build_tmp/dbgskip.so
+export TMPDIR=/tmp CDA_HIP_LIB=$R/build_tmp/dbgskip.so     # hipcc <flags of __graft_entry__> -DCDA_DEBUG_SKIP
 cd /tmp
 run() {  # mask cat tag
   rm -rf /tmp/ic; mkdir -p /tmp/ic
@@ -20,3 +20,8 @@ run 0 2 "all bid limit"
 run 0 3 "all bid modify"
 run 0 4 "all bid cancel"
 run 0 1 "all bid market"
+run 256 9 "uniform random: - approval"
+run 512 9 "uniform random: - cash / hold transfers"
+run 1024 9 "uniform random: - own-order lookup (every limit order new)"
+run 4096 9 "uniform random: - fill settlement"
+run 4864 9 "uniform random: - approval - transfers - settlement"
