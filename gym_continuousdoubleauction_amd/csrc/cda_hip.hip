@@ -58,8 +58,7 @@ __device__ __forceinline__ MarketPtrs market_ptrs(uint8_t* arena, const Params& 
 struct VecPrefetch { uint4 v; bool has; };
 __device__ __forceinline__ VecPrefetch vec_prefetch(const void* src, int nbytes, int lane) {
     VecPrefetch p; p.has = lane < (nbytes >> 4);
-    p.v = make_uint4(0u, 0u, 0u, 0u);
-    if (p.has) p.v = reinterpret_cast<const uint4*>(src)[lane];
+    p.v = reinterpret_cast<const uint4*>(src)[p.has ? lane : 0];     // every lane requests (nbytes >= 16): no branch, hence no wait, around the load
     return p;
 }
 __device__ __forceinline__ void vec_finish(void* dst, const void* src, int nbytes, const VecPrefetch& p, int lane) {   // 16-byte aligned, nbytes % 4 == 0
@@ -77,6 +76,36 @@ __device__ __forceinline__ void zig_tables_init() {       // every thread of the
     unsigned long long* t = reinterpret_cast<unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
     for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) { t[i] = cda_zig_wi_bits[i]; t[256 + i] = cda_zig_ki[i]; }
     for (int i = (int)threadIdx.x; i < PCG_JUMP_WORDS64; i += (int)blockDim.x) t[512 + i] = reinterpret_cast<const unsigned long long*>(&PCG_JUMP)[i];
+}
+
+// The same staging for a 64 * CDA_WPB = 256-thread workgroup, in two halves: stage_tables_issue() only REQUESTS this thread's
+// table words (five independent loads in one basic block), stage_tables_commit() writes them to LDS and holds the
+// workgroup's one __syncthreads.  k_step issues the table requests first, then the market record's and the actions', and
+// commits in between: the wait for the (L2-resident) tables then leaves the record's HBM round trip in flight instead of
+// paying for it once per table, which is what separate load / wait / store loops did.
+struct TablePrefetch { unsigned long long wi, ki, jump; double rcp; uint32_t pow10; };
+static_assert(PCG_JUMP_WORDS64 <= 64 * CDA_WPB && DEC_LDS_POW * 4 <= 64 * CDA_WPB && 64 * CDA_WPB == 256, "one table word of each kind per thread");
+__device__ __forceinline__ TablePrefetch stage_tables_issue() {
+    const int t = (int)threadIdx.x;
+    TablePrefetch q;
+    const int tj = t < PCG_JUMP_WORDS64 ? t : PCG_JUMP_WORDS64 - 1, tp = t < DEC_LDS_POW * 4 ? t : DEC_LDS_POW * 4 - 1;   // clamped: no branch around a load
+    q.wi = cda_zig_wi_bits[t]; q.ki = cda_zig_ki[t];
+    q.jump = reinterpret_cast<const unsigned long long*>(&PCG_JUMP)[tj];
+    q.pow10 = POW10.v[tp >> 2][tp & 3];
+    q.rcp = RCP10.v[t < 10 ? t : 9];
+    return q;
+}
+__device__ __forceinline__ void stage_tables_commit(const TablePrefetch& q) {
+    if ((uint32_t)(uintptr_t)cda_smem != 0u) __builtin_trap();          // see lds_pow10()
+    const int t = (int)threadIdx.x;
+    unsigned long long* z = reinterpret_cast<unsigned long long*>(cda_smem + DEC_TABLE_BYTES);
+    z[t] = q.wi; z[256 + t] = q.ki;
+    // clamped indices again: the surplus threads rewrite the last word with the same value - a store under a condition would
+    // let the compiler sink its LOAD into the conditional block, behind the record's requests
+    z[512 + (t < PCG_JUMP_WORDS64 ? t : PCG_JUMP_WORDS64 - 1)] = q.jump;
+    reinterpret_cast<uint32_t*>(cda_smem)[t < DEC_LDS_POW * 4 ? t : DEC_LDS_POW * 4 - 1] = q.pow10;
+    reinterpret_cast<double*>(cda_smem + DEC_RCP_OFF)[t < 10 ? t : 9] = q.rcp;           // RN(1 / 10^k), folded at compile time
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
