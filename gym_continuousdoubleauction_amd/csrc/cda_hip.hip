@@ -320,6 +320,12 @@ __global__ void k_selftest_dec(int op, int n, const cda_dec* a, const cda_dec* b
         case 2: { D r = d_mul_u32(x, yc, y.exp); r.sign ^= y.sign; st_dec(o, r, f); break; }
         case 3: { D r = d_div_u32(x, yc); r.sign ^= y.sign; st_dec(o, r, f); break; }
         case 4: o.w[0] = (uint32_t)(d_cmp(x, y) + 1); break;
+        case 6: {                                       // the transfer leaf: x + y, pad = 1 when the leaf itself produced it
+            D r = d_add_order_value(x, y);
+            const bool handled = r.exp != D_NOT_HANDLED;
+            if (!handled) r = d_add(x, y);
+            st_dec(o, r, f); o.pad = handled ? 1u : 0u; break;
+        }
         default: { double d = d_to_double(x, &f); unsigned long long bits = (unsigned long long)__double_as_longlong(d); o.w[0] = (uint32_t)bits; o.w[1] = (uint32_t)(bits >> 32); o.w[2] = f; break; }
     }
     out[i] = o;
@@ -477,7 +483,8 @@ int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs
 static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0, hipStream_t stream) {
     StepArgs S = S0;
     S.first_market = first; S.end_market = first + n;
-    LAUNCH_CAP(e, k_step, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, stream, e->arena, e->P, S);
+    if (S.has_info) LAUNCH_CAP(e, k_step<true>, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, stream, e->arena, e->P, S);
+    else LAUNCH_CAP(e, k_step<false>, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, stream, e->arena, e->P, S);
     HIPCHK(hipGetLastError());
     if (e->P.cfg.auto_reset) {            // same stream: every market-wave of it exits at once unless its episode just ended
         LAUNCH_CAP(e, k_reset, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), stream, e->arena, e->P,
@@ -741,7 +748,7 @@ int cda_check_invariants(cda_env* e, uint32_t* violations_out, void* stream) {
 }
 
 int cda_selftest_dec(int32_t device, int32_t op, int32_t n, const cda_dec* a_host, const cda_dec* b_host, cda_dec* out_host) {
-    if (n < 0 || !a_host || !out_host || op < 0 || op > 5) return CDA_ERR_INVALID;
+    if (n < 0 || !a_host || !out_host || op < 0 || op > 6) return CDA_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CDA_ERR_NO_DEVICE;
     HIPCHK(hipSetDevice(device));

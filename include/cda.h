@@ -274,7 +274,9 @@ int cda_check_invariants(cda_env* env, uint32_t* violations_out, void* stream);
 
 /* Device self-tests of the ledger arithmetic and the RNG (host pointers; synchronous).
  * op: 0 add, 1 sub, 2 mul, 3 div, 4 cmp (result in out[i].w[0]: 0 lt, 1 eq, 2 gt), 5 to-double
- * (bits in out[i].w[0..1]). For mul/div `b` must be integer valued with coefficient < 2^32. */
+ * (bits in out[i].w[0..1]). For mul/div `b` must be integer valued with coefficient < 2^32.
+ * 6 = a + b through the cash / cash_on_hold transfer leaf with the general addition as its fallback
+ * (out[i].pad = 1 when the leaf itself produced the result). */
 int cda_selftest_dec(int32_t device, int32_t op, int32_t n, const cda_dec* a_host, const cda_dec* b_host,
                      cda_dec* out_host);
 /* Draw, on the device, the env's RNG schedule for one seed: one integers(lo,hi+1), then `n_steps`

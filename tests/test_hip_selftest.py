@@ -132,3 +132,42 @@ def test_device_float_conversion_near_rounding_boundaries():
         if got != bits or int(out[i]["w"][2]) != 0:
             bad.append((v, hex(bits), hex(got)))
     assert not bad, (len(bad), bad[:5])
+
+
+def _order_value(rng):
+    """'p.0' * n as the ledger forms it: coefficient 10 * p * n, exponent -1."""
+    p, n = rng.randint(1, 5000), rng.randint(1, 20000)
+    return D(p) * D(n) * D("1.0")
+
+
+def test_transfer_leaf_matches_cpython():
+    """op 6: field + order value through d_add_order_value (cash / cash_on_hold transfers), any field - positive, negative, zero
+    with an exponent of its own, short or 28 digits - and a share of operands the leaf must hand back to the general addition."""
+    from gym_continuousdoubleauction_amd.vec_env import selftest_dec
+    rng = random.Random(606)
+    A, B = [], []
+    for i in range(30000):
+        r = rng.random()
+        if r < 0.35:                                   # a cash that went through a division: 28 digits around 1e6
+            f = (D(rng.randint(1, 2 * 10 ** 6)) + D(rng.randint(0, 10 ** 21)).scaleb(-21)) * 1
+        elif r < 0.55:                                 # a cash_on_hold: short, exponent -1
+            f = D(rng.randint(0, 10 ** 7)).scaleb(-1)
+        elif r < 0.65:                                 # zero with an exponent
+            f = D((rng.randint(0, 1), (0,), rng.randint(-27, 0)))
+        else:
+            f = rnd_dec(rng)
+        if rng.random() < 0.3:
+            f = -f
+        v = _order_value(rng) if rng.random() < 0.85 else rnd_dec(rng)
+        if rng.random() < 0.5:
+            v = -v
+        if rng.random() < 0.03:
+            v = -f                                      # exact cancellation (whatever the shape)
+        A.append(f); B.append(v)
+    a, b = O.dec_array(A), O.dec_array(B)
+    out = selftest_dec(6, a, b)
+    bad = [(A[i], B[i], A[i] + B[i], K.dec_to_decimal(out[i])) for i in range(len(A)) if K.dec_to_decimal(out[i]).as_tuple() != (A[i] + B[i]).as_tuple()]
+    assert not bad, bad[:5]
+    ref = O.dec_op(0, a, b)                          # and the CPU oracle's addition, field by field (`pad` carries the leaf's flag here)
+    assert all(np.array_equal(out[k], ref[k]) for k in ("w", "exp", "sign"))
+    assert 0.25 < float(out["pad"].mean()) < 0.99      # both the leaf and its fallback were exercised

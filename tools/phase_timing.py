@@ -30,7 +30,7 @@ L.cda_debug_set_phase_buffer(C.c_void_p(buf.data_ptr()))
 g = torch.Generator(device="cuda:0"); g.manual_seed(1)
 names = ["load", "snapshot_pre", "decode+rng", "shuffle", "orders", "mtm", "snapshot_post+obs", "reward/info", "store"]
 acc = np.zeros(9); span = 0.0
-tot_all = []; worst = None; sub = np.zeros(24); sub_worst = None
+tot_all = []; worst = None; sub = np.zeros(24); sub_worst = None; sub_slow = np.zeros(24); ph_slow = np.zeros(9)
 T, W = 300, 200
 calls = (C.c_ulonglong * 8)()
 if COUNTERS:
@@ -53,6 +53,7 @@ for t in range(W + T):
         tw = d.sum(axis=1)
         tot_all.append(tw)
         i = int(tw.argmax())
+        sub_slow += b[i, 10:34]; ph_slow += d[i]
         if worst is None or tw[i] > worst[0]:
             worst = (tw[i], d[i].copy(), t, i); sub_worst = b[i, 10:34].copy()
 acc /= T
@@ -68,10 +69,12 @@ print("max over the 4096 waves of one step: mean %.0f  (min %.0f, max %.0f)" % (
 print("slowest wave seen: %.0f cycles at step %d market %d; phases:" % (worst[0], worst[2], worst[3]), dict(zip(names, worst[1].astype(int).tolist())))
 
 subn = ["approval", "find_own", "match+settle", "insert/remove(after match)", "cancel/escrow/other", "fills",
-        "book_remove/in-place", "release transfer", "escrow transfer", "x9", "n_modify", "n_escrow", "x12", "x13",
-        "fill:prep(mode,tv)", "fill:stage1 mul", "fill:stage2 select", "fill:stage2 add", "fill:stage3", "fill:tail(sync,ballots)", "fills with lane 0 involved", "x21", "x22", "x23"]
+        "book_remove/in-place", "release transfer", "escrow transfer", "x9", "n_modify", "n_escrow", "lane-0 fills in mode 0", "x13",
+        "fill:prep(mode,tv)", "fill:stage1 mul", "fill:stage2 select", "fill:stage2 add", "fill:stage3 (modes 1, 2)", "fill:tail(sync,ballots)", "fills with lane 0 involved", "lane-0 fills in mode 3/4", "fill:stage3 (covered)", "fill:stage3 (neutral)"]
 print("orders phase breakdown, mean per wave per step:", {n: round(v / T, 1) for n, v in zip(subn, sub)})
 print("orders phase breakdown, slowest wave:", dict(zip(subn, sub_worst.astype(int).tolist())))
+print("the slowest wave of each step, averaged over the steps - phases:", dict(zip(names, (ph_slow / T).astype(int).tolist())))
+print("  its orders phase:", {n: round(v / T, 1) for n, v in zip(subn, sub_slow)})
 
 if not COUNTERS:
     sys.exit(0)
