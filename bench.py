@@ -18,7 +18,9 @@ reference (train/model/model_handler.py:38-53).  The whole stream is generated o
 
 On one GPU the batch is stepped as `--groups` (default 4; 2 for runs shorter than 200 steps) contiguous market groups, each a chain of k_step launches on
 its own stream (cda_step_groups): markets never interact, so the batch-wide barrier of a single launch is not part of
-the reference's semantics, and a group's slowest market then overlaps the other group's work.
+the reference's semantics, and a group's slowest market then overlaps the other group's work.  `roofline.kernel_ms` comes from
+HIP event pairs on the group streams themselves: on every chain, or (`--event-lanes one`, the default below 200 timed steps)
+on the first chain only - a timing event pair costs each stream ~7 us, which a 0.7-ms run notices.
 
 Prints ONE JSON line on rank 0; see the fields `roofline` and `cpu_baseline` in DESIGN.md.
 """
@@ -53,6 +55,8 @@ def parse():
     p.add_argument("--markets", type=int, default=None, help="markets per GPU (overrides --config)")
     p.add_argument("--agents", type=int, default=None)
     p.add_argument("--groups", type=int, default=None, help="concurrent market groups per GPU (default 4, 2 below 200 timed steps; 1 with the all-gather)")
+    p.add_argument("--event-lanes", choices=["all", "one"], default=None,
+                   help="HIP event pairs on every group stream, or on the first one only (default: all, one below 200 timed steps)")
     p.add_argument("--info", action="store_true", help="headline run WITH the info tensors (a14); otherwise info-on is timed as a second leg")
     p.add_argument("--no-info-leg", action="store_true", help="skip the second (info tensors on) timed leg")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the obs/reward all-gather")
@@ -175,6 +179,7 @@ def main():
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
     # default number of group chains: 4 pays once the chains are long (433 M vs 417 M at 1000 steps), 2 when the whole timed
     # region is a few dozen steps and the staggered start / drain of four chains is a visible share of it (384 M vs 372 M at 20)
+    event_lanes = args.event_lanes or ("all" if K >= 200 else "one")
     groups = args.groups if args.groups is not None else (1 if (gather or args.fused) else (4 if K >= 200 else 2))
     groups = max(1, min(groups, N))
     if gather and groups != 1:
@@ -334,6 +339,8 @@ def main():
             timed.update({first_t + t: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for t in range(0, K, EV_STRIDE)})
         elif with_events:
             lanes = e.group_streams if e.groups > 1 else [torch.cuda.current_stream(device)]
+            if event_lanes == "one":
+                lanes = lanes[:1]
             evs = [(s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in lanes]
         t0 = time.perf_counter()
         for s, a, _ in evs:
@@ -377,8 +384,10 @@ def main():
         total_agent_steps = float(world) * N * A * K
         value = total_agent_steps / elapsed
         B = ALG_BYTES_CONST + ALG_BYTES_PER_AGENT * A                         # algorithmic bytes per market-step
-        n_lanes = max(1, len(kernel_ms_lanes))
         markets_per_launch = [c for _, c in env.group_ranges] if env.groups > 1 else [N]
+        if len(kernel_ms_lanes) == 1 and len(markets_per_launch) > 1:          # one chain timed: the others run the same launches
+            kernel_ms_lanes = kernel_ms_lanes * len(markets_per_launch)
+        n_lanes = max(1, len(kernel_ms_lanes))
         # `achieved`: algorithmic bytes of one launch / that launch's duration.  With G concurrent group chains G launches are
         # in flight at any time; the aggregate rate of the device is the sum over the concurrent launches.
         per_launch_gbps = [B * m / (ms * 1e-3) / 1e9 for m, ms in zip(markets_per_launch, kernel_ms_lanes)]

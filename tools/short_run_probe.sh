@@ -1,8 +1,10 @@
-mkdir -p gpurun_out/short
-p() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f M  wall %.2f us  kern %.2f us  info %.1f M' % (d['value']/1e6, d['ms_per_step']*1e3, d['roofline']['kernel_ms']*1e3, (d.get('value_with_info') or 0)/1e6))"; }
-for rep in 1 2; do
-echo "== default"; python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | p
-echo "== HSA_ENABLE_INTERRUPT=0"; HSA_ENABLE_INTERRUPT=0 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | p
+#!/bin/bash
+# Run ON THE GPU BOX: the driver's command (20 timed steps) for a few chain counts, twice each.
+# Usage: tools/short_run_probe.sh [extra bench.py args]
+R=${GRAFT_REPO_ROOT:-$PWD}
+p() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f M  wall %.2f us  kernel %.2f us  with info %.1f M' % (d['value']/1e6, d['ms_per_step']*1e3, d['roofline']['kernel_ms']*1e3, (d.get('value_with_info') or 0)/1e6))"; }
+for g in 2 3 4; do
+  for rep in 1 2; do
+    echo -n "groups $g: "; python $R/bench.py --gpus 1 --steps 20 --warmup 5 --groups $g --no-cpu-baseline "$@" 2>/dev/null | tail -1 | p
+  done
 done
-for g in 1 3 4; do echo "== groups $g"; python bench.py --gpus 1 --steps 20 --warmup 5 --groups $g 2>/dev/null | tail -1 | p; done
-echo "== HSA_ENABLE_INTERRUPT=0 groups 4"; HSA_ENABLE_INTERRUPT=0 python bench.py --gpus 1 --steps 20 --warmup 5 --groups 4 2>/dev/null | tail -1 | p
