@@ -25,6 +25,7 @@ on the first chain only - a timing event pair costs each stream ~7 us, which a 0
 Prints ONE JSON line on rank 0; see the fields `roofline` and `cpu_baseline` in DESIGN.md.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -40,6 +41,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 GPU_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: peak engine clock
 N_SIMD = 1024               # 256 CUs x 4 SIMDs
 VALU_CYCLES = 2.0           # MI355X_MICROARCH.md: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
+PG_TIMEOUT = datetime.timedelta(seconds=240)      # a collective that never completes must fail the run, not hang it (the default is 10 minutes)
 ACTION_SEED = 2024          # bench_seed
 SEED_BASE = 1000            # market i is seeded SeedSequence(1000 + i)
 CONFIGS = {"c3": (4096, 4), "c4": (2048, 8)}
@@ -157,9 +159,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"), timeout=PG_TIMEOUT)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=PG_TIMEOUT)
     n_gpus = world
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -288,9 +290,9 @@ def main():
         torch.cuda.synchronize()
         dist.destroy_process_group()
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=PG_TIMEOUT)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=PG_TIMEOUT)
         env.close()
         env = make_env(args.info)
         torch.cuda.synchronize()
