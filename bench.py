@@ -210,7 +210,7 @@ def main():
         t_end = time.perf_counter() + primer_ms * 1e-3
         while time.perf_counter() < t_end:
             for i in range(64):
-                scratch.step(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i])
+                scratch.step(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], pipelined=True)
             scratch.join()
             torch.cuda.synchronize()
             primer_steps += 64
@@ -245,7 +245,7 @@ def main():
             ev = timed.get(t)
             if ev:
                 ev[0].record()
-            e.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+            e.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i], pipelined=True)
             if ev:
                 ev[1].record()
             if gather:
@@ -258,7 +258,7 @@ def main():
             ev = timed.get(t)
             if ev:
                 ev[0].record(cur)
-            e.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i])
+            e.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i], pipelined=True)
             if ev:
                 ev[1].record(cur)
             step_done[t & 1].record(cur)

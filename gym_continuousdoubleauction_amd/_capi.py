@@ -11,8 +11,8 @@ SNAPSHOT_DIM = 42
 RAW_DIM = 40
 MAX_HIST = 16
 MAX_AGENTS = 16
-BOOK_CAP = 256          # default book pool (resting orders per market, both sides together)
-BOOK_CAP_MAX = 512      # the larger compiled pool; sizes the parity-dump arrays
+BOOK_CAP = 256          # default LDS book tile (the top of a market's book, both sides together)
+BOOK_CAP_MAX = 512      # the larger compiled tile; sizes the arrays of the fixed-size parity dump (MarketState)
 MAX_GROUPS = 16
 NUM_REWARD_TERMS = 5
 
@@ -31,7 +31,7 @@ class Config(C.Structure):
         ("init_cash", C.c_int64),
         ("initial_price_min", C.c_int32), ("initial_price_max", C.c_int32),
         ("min_size", C.c_int32), ("mkt_max_size", C.c_int32), ("limit_size_multiple", C.c_int32),
-        ("auto_reset", C.c_int32), ("book_capacity", C.c_int32),
+        ("auto_reset", C.c_int32), ("book_capacity", C.c_int32), ("book_spill", C.c_int32),
         ("order_penalty", C.c_double), ("trade_penalty", C.c_double), ("drawdown_penalty", C.c_double),
         ("passive_bonus", C.c_double), ("loss_multiplier", C.c_double),
     ]
@@ -129,7 +129,9 @@ def make_config(config=None):
     Unknown keys raise; missing keys take the reference's standalone defaults."""
     cfg = dict(ENV_DEFAULTS)
     cfg["auto_reset"] = False            # extensions of this build (include/cda.h), not reference keys
-    cfg["book_capacity"] = 0             # 0 = by agent count (256 up to 8 agents, 512 above); or 256 / 512
+    cfg["book_capacity"] = 0             # LDS book tile: 0 = by agent count (256 up to 8 agents, 512 above); or 256 / 512
+    cfg["book_spill"] = 0                # HBM spill ring, orders per side: 0 = automatic (num_agents * max_step: never overflows inside an
+    #                                      episode), n > 0 = at least n, -1 = no HBM tier (a rest beyond the tile is dropped and flagged)
     for k, v in (config or {}).items():
         if k not in cfg:
             raise KeyError(f"unknown env config key {k!r}; known: {sorted(cfg)}")
@@ -152,6 +154,7 @@ def make_config(config=None):
     c.limit_size_multiple = int(cfg["limit_size_multiple"])
     c.auto_reset = 1 if cfg["auto_reset"] else 0
     c.book_capacity = int(cfg["book_capacity"])
+    c.book_spill = int(cfg["book_spill"])
     c.order_penalty = float(cfg["order_penalty"])
     c.trade_penalty = float(cfg["trade_penalty"])
     c.drawdown_penalty = float(cfg["drawdown_penalty"])

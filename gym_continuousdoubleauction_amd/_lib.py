@@ -19,6 +19,7 @@ SYMBOLS = [
     "cda_selftest_dec", "cda_selftest_rng", "cda_strerror", "cda_num_markets", "cda_obs_dim",
     "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host", "cda_nav_conservation",
     "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants", "cda_selftest_libm", "cda_selftest_libm_host", "cda_book_capacity",
+    "cda_get_book", "cda_book_spill",
 ]
 
 
@@ -70,6 +71,8 @@ def lib():
     L.cda_strerror.restype = C.c_char_p
     L.cda_num_markets.argtypes = [vp]
     L.cda_book_capacity.argtypes = [vp]
+    L.cda_book_spill.argtypes = [vp]
+    L.cda_get_book.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
     L.cda_obs_dim.argtypes = [vp]
     L.cda_state_bytes_per_market.argtypes = [vp]
     L.cda_state_bytes_per_market.restype = i64

@@ -44,12 +44,17 @@ using namespace cda;
 // ------------------------------------------------------------------------------------------
 struct MarketPtrs {
     uint32_t* hdr; uint32_t* acc; float* hist; int32_t* book;
+    int32_t* spill;          // the market's HBM tier (cda_book.inc): int32 hdr[16], then the two sides' rings
 };
+// arena = [N market records][done_buf: N bytes, padded to 256][N spill regions]
+__host__ __device__ static inline size_t spill_region_bytes(int32_t spill_cap) { return spill_cap > 0 ? 64 + (size_t)spill_cap * 2 * BOOK_FIELDS * 4 : 0; }
+__host__ __device__ static inline size_t spill_arena_off(const Params& P) { return (size_t)P.n_markets * (size_t)P.lay.stride + (((size_t)P.n_markets + 255) & ~(size_t)255); }
 __device__ __forceinline__ MarketPtrs market_ptrs(uint8_t* arena, const Params& P, int mi) {
     uint8_t* rec = arena + (size_t)mi * (size_t)P.lay.stride;
     MarketPtrs r;
     r.hdr = (uint32_t*)rec; r.acc = (uint32_t*)(rec + P.lay.acc_off);
     r.hist = (float*)(rec + P.lay.hist_off); r.book = (int32_t*)(rec + P.lay.book_off);
+    r.spill = (int32_t*)(arena + spill_arena_off(P) + (size_t)mi * spill_region_bytes(P.lay.spill_cap));
     return r;
 }
 // One 16-byte request per lane moves the accounts (36 lanes at 4 agents) and the history ring (42 lanes at n_hist 4):
@@ -139,7 +144,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 #else
 #define PH_MARK(ph, i) do {} while (0)
 #endif
-struct LaneAction { int cat, level, off; float mean, sigma; bool pres; };     // lane a: agent a's action words (unclamped)
+struct LaneAction { int cat, level, off; float mean, sigma; bool pres; int ord; };     // lane a: agent a's action words (unclamped); ord: its place in the caller's dict
 struct StepReward { double r, t0, t1, t2, t3, t4, drawdown, max_nav; bool bankrupt; };
 __device__ __forceinline__ void clear_step_counters(Acc& a) {          // exchg_helper.py:116-120
     a.num_trades_step = 0; a.num_passive_fills_step = 0; a.order_step_placed = 0; a.num_rejected_step = 0;
@@ -186,34 +191,53 @@ __global__ void k_nav_conservation(const uint8_t* arena, Params P, double tol, d
 // the trader's own resting orders (cash_processor.py:15-29 / :85-97 escrow and release) and every unit long is a unit
 // short (account.py:196-213).
 __host__ __device__ static inline int book_phys_rt(int cap, int s, int i) { return s == 0 ? i : cap - 1 - i; }     // cda_book.inc book_phys with a run-time capacity
+// order i of side sd of a market, wherever it lives: the first `tile_n` orders in the record's tile, the rest in the spill ring
+struct BookView {
+    const int32_t* tile; const int32_t* spill; int cap, spill_cap; int tile_n[2], tail_n[2], tail_base[2];
+    __host__ __device__ int total(int sd) const { return tile_n[sd] + tail_n[sd]; }
+    __host__ __device__ int32_t get(int sd, int f, int i) const {
+        if (i < tile_n[sd]) return tile[f * cap + book_phys_rt(cap, sd, i)];
+        const uint32_t sl = (uint32_t)(tail_base[sd] + (i - tile_n[sd])) & (uint32_t)(spill_cap - 1);
+        return spill[16 + (size_t)(sd * BOOK_FIELDS + f) * (size_t)spill_cap + sl];
+    }
+};
+__host__ __device__ static inline BookView book_view(const uint32_t* h, const int32_t* tile, const int32_t* spill, int cap, int spill_cap) {
+    BookView v;
+    v.tile = tile; v.spill = spill; v.cap = cap; v.spill_cap = spill_cap;
+    v.tile_n[0] = (int)h[H_N_BIDS]; v.tile_n[1] = (int)h[H_N_ASKS];
+    for (int sd = 0; sd < 2; sd++) {
+        const bool has = spill_cap > 0 && (h[H_STATUS] & (uint32_t)(ST_TAIL_BID << sd)) != 0;
+        v.tail_n[sd] = has ? spill[sd] : 0; v.tail_base[sd] = has ? spill[2 + sd] : 0;
+    }
+    return v;
+}
 __global__ void k_check_invariants(const uint8_t* arena, Params P, int CAP, uint32_t* out) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= P.n_markets) return;
     const uint8_t* rec = arena + (size_t)i * (size_t)P.lay.stride;
     const uint32_t* h = (const uint32_t*)rec;
-    const int32_t* bp = (const int32_t*)(rec + P.lay.book_off);
     const Acc* acc = (const Acc*)(rec + P.lay.acc_off);
-    const int nb = (int)h[H_N_BIDS], na = (int)h[H_N_ASKS], A = P.cfg.num_agents;
+    const int A = P.cfg.num_agents;
+    const BookView bv = book_view(h, (const int32_t*)(rec + P.lay.book_off), (const int32_t*)(arena + spill_arena_off(P) + (size_t)i * spill_region_bytes(P.lay.spill_cap)), CAP, P.lay.spill_cap);
     uint32_t v = 0;
-    if (nb < 0 || na < 0 || nb + na > CAP) { out[i] = CDA_INV_BOOK_COUNT; return; }
+    if (bv.tile_n[0] < 0 || bv.tile_n[1] < 0 || bv.tile_n[0] + bv.tile_n[1] > CAP || bv.tail_n[0] < 0 || bv.tail_n[1] < 0 ||
+        bv.tail_n[0] > P.lay.spill_cap || bv.tail_n[1] > P.lay.spill_cap) { out[i] = CDA_INV_BOOK_COUNT; return; }
+    if ((bv.tail_n[0] > 0 && bv.tile_n[0] == 0) || (bv.tail_n[1] > 0 && bv.tile_n[1] == 0)) v |= CDA_INV_BOOK_COUNT;   // the top of a side is always in its tile
     long long held[CDA_MAX_AGENTS];
     for (int a = 0; a < CDA_MAX_AGENTS; a++) held[a] = 0;
     for (int sd = 0; sd < 2; sd++) {
-        const int n = sd == 0 ? nb : na;
+        const int n = bv.total(sd);
+        int32_t prev = 0;
         for (int k = 0; k < n; k++) {
-            const int ph = book_phys_rt(CAP, sd, k);
-            const int32_t p = bp[0 * CAP + ph], q = bp[1 * CAP + ph];
-            const int owner = bp[2 * CAP + ph] & 15;
+            const int32_t p = bv.get(sd, 0, k), q = bv.get(sd, 1, k);
+            const int owner = bv.get(sd, 2, k) & 15;
             if (q <= 0 || p <= 0) v |= CDA_INV_QTY;
             if (owner >= A) v |= CDA_INV_OWNER; else held[owner] += (long long)p * (long long)q;
-            if (k > 0) {
-                const int pp = book_phys_rt(CAP, sd, k - 1);
-                const int32_t prev = bp[0 * CAP + pp];
-                if (sd == 0 ? prev < p : prev > p) v |= sd == 0 ? CDA_INV_BIDS_SORTED : CDA_INV_ASKS_SORTED;
-            }
+            if (k > 0 && (sd == 0 ? prev < p : prev > p)) v |= sd == 0 ? CDA_INV_BIDS_SORTED : CDA_INV_ASKS_SORTED;
+            prev = p;
         }
     }
-    if (nb > 0 && na > 0 && bp[0 * CAP + book_phys_rt(CAP, 0, 0)] >= bp[0 * CAP + book_phys_rt(CAP, 1, 0)]) v |= CDA_INV_CROSSED;
+    if (bv.total(0) > 0 && bv.total(1) > 0 && bv.get(0, 0, 0) >= bv.get(1, 0, 0)) v |= CDA_INV_CROSSED;
     long long net = 0;
     for (int a = 0; a < A; a++) {
         net += acc[a].net_position;
@@ -400,11 +424,13 @@ static int cfg_ok(const cda_config* c) {
     if (c->n_hist < 1 || c->n_hist > CDA_MAX_HIST) return CDA_ERR_INVALID;
     if (c->tick_size != 1) return CDA_ERR_UNSUPPORTED;
     if (c->initial_price_max < c->initial_price_min || c->initial_price_min < 0) return CDA_ERR_INVALID;
+    if (c->initial_price_max >= (1 << 24)) return CDA_ERR_INVALID;      // prices live below 2^24 ticks (the clamp of step_market; the libm sweeps cover exactly that domain)
     if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;
     // Sizes are int32 on the device and a price level sums up to CDA_BOOK_CAP_MAX of them: the largest decodable size is
     // (mkt_max_size * limit_size_multiple - min_size) / 2 * |mean| + sigma * z + min_size, clamped at 1e9 (flagged).  Keep
     // the configured scale itself well inside int32 so that neither the product nor a level sum can wrap silently.
     if ((int64_t)c->mkt_max_size * (int64_t)c->limit_size_multiple + (int64_t)c->min_size > (int64_t)(1 << 30) / CDA_BOOK_CAP_MAX) return CDA_ERR_INVALID;
+    if (c->book_spill < -1 || c->book_spill > CDA_SPILL_MAX) return CDA_ERR_INVALID;
     if (c->max_step < 1) return CDA_ERR_INVALID;
     if (c->book_capacity != 0 && c->book_capacity != 256 && c->book_capacity != 512) return CDA_ERR_INVALID;
     if (c->init_cash > (1LL << 62) || c->init_cash < -(1LL << 62)) return CDA_ERR_INVALID;
@@ -444,8 +470,24 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     P.lay.hist_off = off; off += cfg->n_hist * CDA_SNAPSHOT_DIM * 4; off = (off + 15) & ~15;
     P.lay.book_off = off; off += e->cap * BOOK_FIELDS * 4;
     P.lay.stride = (off + 255) & ~255;
+    // HBM tier of the book: a ring of spill_cap orders per side behind every market's tile.  Automatic size: a side gains at
+    // most one resting order per agent and step, so num_agents * max_step (+ the tile) can never be exceeded inside an episode -
+    // the unbounded OrderTree of the reference (ordertree.py:5-58), priced in HBM: 32 B per order slot and market, untouched
+    // (not even paged in) by a market whose book fits its tile.  Halved while the rings would take more than a quarter of the
+    // device's free memory.
+    P.lay.spill_cap = 0;
+    if (cfg->book_spill >= 0) {
+        int64_t want = cfg->book_spill > 0 ? (int64_t)cfg->book_spill : (int64_t)cfg->num_agents * (int64_t)cfg->max_step;
+        if (cfg->book_spill == 0 && want < 1024) want = 1024;
+        int64_t capv = CDA_SPILL_MIN;
+        while (capv < want && capv < CDA_SPILL_MAX) capv <<= 1;
+        size_t free_b = 0, total_b = 0;
+        if (cfg->book_spill == 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (capv > 1024 && spill_region_bytes((int32_t)capv) * (size_t)n_markets > free_b / 4) capv >>= 1;
+        P.lay.spill_cap = (int32_t)capv;
+    }
     const size_t records = (size_t)P.lay.stride * (size_t)n_markets;
-    e->arena_bytes = records + (((size_t)n_markets + 255) & ~(size_t)255);
+    e->arena_bytes = spill_arena_off(P) + spill_region_bytes(P.lay.spill_cap) * (size_t)n_markets;
     hipError_t he = hipMalloc((void**)&e->arena, e->arena_bytes);
     if (he != hipSuccess) { free(e); return he == hipErrorOutOfMemory ? CDA_ERR_NOMEM : hip_fail(he, "hipMalloc"); }
     e->done_buf = e->arena + records;
@@ -481,14 +523,20 @@ int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs
 
 // one launch of k_step (+ the auto-reset pass) over [first, first + n) on `stream`; arguments validated by the callers
 static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0, hipStream_t stream) {
-    StepArgs S = S0;
-    S.first_market = first; S.end_market = first + n;
-    if (S.has_info) LAUNCH_CAP(e, k_step<true>, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, stream, e->arena, e->P, S);
-    else LAUNCH_CAP(e, k_step<false>, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, stream, e->arena, e->P, S);
+    const size_t smem = smem_for(e, CDA_WPB) + ZIG_LDS_BYTES;
+    if (e->cap == 512) {
+        cda::cap512::StepKernArgs K; K.arena = e->arena; K.P = e->P; K.S = S0; K.S.first_market = first; K.S.end_market = first + n;
+        if (K.S.has_info) hipLaunchKernelGGL(cda::cap512::k_step<true>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
+        else hipLaunchKernelGGL(cda::cap512::k_step<false>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
+    } else {
+        cda::cap256::StepKernArgs K; K.arena = e->arena; K.P = e->P; K.S = S0; K.S.first_market = first; K.S.end_market = first + n;
+        if (K.S.has_info) hipLaunchKernelGGL(cda::cap256::k_step<true>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
+        else hipLaunchKernelGGL(cda::cap256::k_step<false>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
+    }
     HIPCHK(hipGetLastError());
     if (e->P.cfg.auto_reset) {            // same stream: every market-wave of it exits at once unless its episode just ended
         LAUNCH_CAP(e, k_reset, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), stream, e->arena, e->P,
-                           (const uint64_t*)NULL, (const uint8_t*)e->done_buf, S.obs_out, (int)first, (int)(first + n));
+                           (const uint64_t*)NULL, (const uint8_t*)e->done_buf, S0.obs_out, (int)first, (int)(first + n));
         HIPCHK(hipGetLastError());
     }
     return CDA_OK;
@@ -531,6 +579,7 @@ int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const 
 }
 
 void cda_group_range(int32_t n_markets, int32_t n_groups, int32_t group, int32_t* first_out, int32_t* count_out) {
+    if (n_groups < 1 || group < 0 || group >= n_groups || n_markets < 0) { if (first_out) *first_out = 0; if (count_out) *count_out = 0; return; }
     const int64_t lo = (int64_t)n_markets * group / n_groups, hi = (int64_t)n_markets * (group + 1) / n_groups;
     if (first_out) *first_out = (int32_t)lo;
     if (count_out) *count_out = (int32_t)(hi - lo);
@@ -564,7 +613,8 @@ int cda_run_random(cda_env* e, int32_t n_steps, uint64_t action_seed, uint64_t m
     R.n_steps = n_steps; R.seed = action_seed; R.market_base = market_index_base;
     R.obs_out = obs_out; R.return_out = episode_return_out; R.terminated_out = terminated_out; R.truncated_out = truncated_out;
     R.steps_out = steps_taken_out;
-    LAUNCH_CAP(e, k_run_random, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, e->arena, e->P, R);
+    if (e->cap == 512) { cda::cap512::RunKernArgs K; K.arena = e->arena; K.P = e->P; K.R = R; hipLaunchKernelGGL(cda::cap512::k_run_random, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, K); }
+    else { cda::cap256::RunKernArgs K; K.arena = e->arena; K.P = e->P; K.R = R; hipLaunchKernelGGL(cda::cap256::k_run_random, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, K); }
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -629,11 +679,56 @@ int cda_mark_to_mkt(cda_env* e, int32_t market) {
     return CDA_OK;
 }
 
+// one side of a market's book in queue order -> out[0 .. min(n, max_orders)); `rec` = host copy of the market record
+static int read_book_side(cda_env* e, int32_t market, const uint8_t* rec, int sd, cda_order* out, int32_t max_orders, int32_t* n_out) {
+    const Params& P = e->P;
+    const uint32_t* h = (const uint32_t*)rec;
+    const int32_t* tile = (const int32_t*)(rec + P.lay.book_off);
+    int32_t shdr[16] = {0};
+    const bool has_tail = P.lay.spill_cap > 0 && (h[H_STATUS] & (uint32_t)(ST_TAIL_BID << sd)) != 0;
+    const uint8_t* sp = e->arena + spill_arena_off(P) + (size_t)market * spill_region_bytes(P.lay.spill_cap);
+    if (has_tail) HIPCHK(hipMemcpy(shdr, sp, sizeof shdr, hipMemcpyDeviceToHost));
+    const int tile_n = (int)(sd == 0 ? h[H_N_BIDS] : h[H_N_ASKS]), tail_n = has_tail ? shdr[sd] : 0, base = shdr[2 + sd];
+    if (tile_n < 0 || tile_n > e->cap || tail_n < 0 || tail_n > P.lay.spill_cap) return CDA_ERR_INVALID;
+    *n_out = tile_n + tail_n;
+    int32_t* ring = NULL;
+    const int want_tail = max_orders > tile_n ? (tail_n < max_orders - tile_n ? tail_n : max_orders - tile_n) : 0;
+    if (want_tail > 0) {                                 // the side's four ring arrays, whole (a dump is not a hot path)
+        const size_t bytes = (size_t)BOOK_FIELDS * (size_t)P.lay.spill_cap * 4;
+        ring = (int32_t*)malloc(bytes);
+        if (!ring) return CDA_ERR_NOMEM;
+        hipError_t he = hipMemcpy(ring, sp + 64 + (size_t)sd * bytes, bytes, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) { free(ring); return hip_fail(he, "hipMemcpy D2H (spill ring)"); }
+    }
+    for (int i = 0; i < tile_n + want_tail && i < max_orders; i++) {
+        int32_t f[BOOK_FIELDS];
+        for (int k = 0; k < BOOK_FIELDS; k++) {
+            if (i < tile_n) f[k] = tile[k * e->cap + book_phys_rt(e->cap, sd, i)];
+            else f[k] = ring[(size_t)k * (size_t)P.lay.spill_cap + ((uint32_t)(base + (i - tile_n)) & (uint32_t)(P.lay.spill_cap - 1))];
+        }
+        out[i].price = f[0]; out[i].qty = f[1]; out[i].owner = f[2] & 15; out[i].order_id = (int32_t)((uint32_t)f[2] >> 4); out[i].timestamp = f[3];
+    }
+    free(ring);
+    return CDA_OK;
+}
+int cda_get_book(cda_env* e, int32_t market, int32_t side, cda_order* orders_out_host, int32_t max_orders, int32_t* n_out_host) {
+    if (!e || market < 0 || market >= e->P.n_markets || side < 0 || side > 1 || max_orders < 0 || (max_orders > 0 && !orders_out_host) || !n_out_host) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    const Params& P = e->P;
+    uint8_t* rec = (uint8_t*)malloc((size_t)P.lay.stride);
+    if (!rec) return CDA_ERR_NOMEM;
+    HIPCHK(hipDeviceSynchronize());
+    hipError_t he = hipMemcpy(rec, e->arena + (size_t)market * (size_t)P.lay.stride, (size_t)P.lay.stride, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { free(rec); return hip_fail(he, "hipMemcpy D2H"); }
+    int rc = read_book_side(e, market, rec, side, orders_out_host, max_orders, n_out_host);
+    free(rec);
+    return rc;
+}
+
 int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     const Params& P = e->P;
-    const int CAP = e->cap;
     uint8_t* rec = (uint8_t*)malloc((size_t)P.lay.stride);
     if (!rec) return CDA_ERR_NOMEM;
     HIPCHK(hipDeviceSynchronize());
@@ -649,16 +744,13 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
     s->t_step = (int32_t)h[H_T_STEP]; s->lob_time = (int32_t)h[H_LOB_TIME]; s->next_order_id = (int32_t)h[H_NEXT_OID];
     s->last_price = (int32_t)h[H_LAST_PRICE]; s->has_trade = (int32_t)h[H_HAS_TRADE]; s->last_trade_price = (int32_t)h[H_LAST_TRADE_PRICE];
     s->done_mask = h[H_DONE_MASK]; s->flags = h[H_FLAGS];
-    s->n_bids = (int32_t)h[H_N_BIDS]; s->n_asks = (int32_t)h[H_N_ASKS];
-    const int32_t* bp = (const int32_t*)(rec + P.lay.book_off);
-    for (int sd = 0; sd < 2; sd++) {
-        int n = sd == 0 ? s->n_bids : s->n_asks;
-        for (int i = 0; i < n && i < CAP; i++) {
-            cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
-            const int ph = book_phys_rt(CAP, sd, i);
-            o->price = bp[0 * CAP + ph]; o->qty = bp[1 * CAP + ph]; o->owner = bp[2 * CAP + ph] & 15;
-            o->order_id = (int32_t)((uint32_t)bp[2 * CAP + ph] >> 4); o->timestamp = bp[3 * CAP + ph];
+    {
+        int32_t nn[2] = {0, 0};
+        for (int sd = 0; sd < 2; sd++) {
+            int rc = read_book_side(e, market, rec, sd, sd == 0 ? s->bids : s->asks, CDA_BOOK_CAP_MAX, &nn[sd]);
+            if (rc) { free(rec); return rc; }
         }
+        s->n_bids = nn[0]; s->n_asks = nn[1];              // the true lengths; the arrays hold the first CDA_BOOK_CAP_MAX of each side
     }
     const Acc* ap = (const Acc*)(rec + P.lay.acc_off);
     for (int a = 0; a < P.cfg.num_agents; a++) {
@@ -679,15 +771,71 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
     return CDA_OK;
 }
 
+/* The book is restored from the struct's arrays (up to CDA_BOOK_CAP_MAX orders per side: what does not fit the LDS tile goes
+ * to the HBM spill ring).  A state whose side is LONGER than the arrays (a dump of a big book) can only be put back onto the
+ * market it came from: if both lengths equal the market's current ones its book is left in place and everything else is
+ * restored (get_state -> edit accounts -> set_state round trips on any book); otherwise CDA_ERR_INVALID. */
 int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
-    if (s->n_bids < 0 || s->n_asks < 0 || s->n_bids + s->n_asks > e->cap) return CDA_ERR_INVALID;
+    if (s->n_bids < 0 || s->n_asks < 0) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     const Params& P = e->P;
     const int CAP = e->cap;
+    HIPCHK(hipDeviceSynchronize());
     uint8_t* rec = (uint8_t*)calloc(1, (size_t)P.lay.stride);
     if (!rec) return CDA_ERR_NOMEM;
     uint32_t* h = (uint32_t*)rec;
+    uint8_t* dev_rec = e->arena + (size_t)market * (size_t)P.lay.stride;
+    uint8_t* dev_spill = e->arena + spill_arena_off(P) + (size_t)market * spill_region_bytes(P.lay.spill_cap);
+    const bool keep_book = s->n_bids > CDA_BOOK_CAP_MAX || s->n_asks > CDA_BOOK_CAP_MAX;
+    int32_t* bp = (int32_t*)(rec + P.lay.book_off);
+    if (keep_book) {
+        hipError_t he = hipMemcpy(rec, dev_rec, (size_t)P.lay.stride, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) { free(rec); return hip_fail(he, "hipMemcpy D2H"); }
+        int32_t shdr[16] = {0};
+        if (P.lay.spill_cap > 0 && (h[H_STATUS] & ST_TAIL_ANY)) {
+            he = hipMemcpy(shdr, dev_spill, sizeof shdr, hipMemcpyDeviceToHost);
+            if (he != hipSuccess) { free(rec); return hip_fail(he, "hipMemcpy D2H"); }
+        }
+        const int cur_b = (int)h[H_N_BIDS] + ((h[H_STATUS] & ST_TAIL_BID) ? shdr[0] : 0), cur_a = (int)h[H_N_ASKS] + ((h[H_STATUS] & ST_TAIL_ASK) ? shdr[1] : 0);
+        if (cur_b != s->n_bids || cur_a != s->n_asks) { free(rec); return CDA_ERR_INVALID; }
+        h[H_STATUS] &= ~(uint32_t)ST_LEVELS_VALID;
+    } else {
+        // tile / tail split of a restored book: everything in the tile when it fits, else the tile is shared evenly
+        int tb = s->n_bids, ta = s->n_asks;
+        if (tb + ta > CAP) {
+            tb = s->n_bids < CAP / 2 ? s->n_bids : CAP / 2;
+            ta = s->n_asks < CAP - tb ? s->n_asks : CAP - tb;
+            tb = s->n_bids < CAP - ta ? s->n_bids : CAP - ta;
+        }
+        const int tail_n[2] = {s->n_bids - tb, s->n_asks - ta}, tile_n[2] = {tb, ta};
+        if (tail_n[0] > P.lay.spill_cap || tail_n[1] > P.lay.spill_cap) { free(rec); return CDA_ERR_INVALID; }
+        h[H_N_BIDS] = (uint32_t)tb; h[H_N_ASKS] = (uint32_t)ta;
+        h[H_STATUS] = (tail_n[0] > 0 ? ST_TAIL_BID : 0) | (tail_n[1] > 0 ? ST_TAIL_ASK : 0);
+        int32_t* ring = NULL;
+        const size_t side_bytes = (size_t)BOOK_FIELDS * (size_t)P.lay.spill_cap * 4;
+        if (tail_n[0] > 0 || tail_n[1] > 0) { ring = (int32_t*)calloc(1, 2 * side_bytes); if (!ring) { free(rec); return CDA_ERR_NOMEM; } }
+        for (int sd = 0; sd < 2; sd++) {
+            const int n = sd == 0 ? s->n_bids : s->n_asks;
+            for (int i = 0; i < n; i++) {
+                const cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
+                if (o->owner < 0 || o->owner >= P.cfg.num_agents || o->order_id < 0 || o->order_id >= (1 << 27)) { free(rec); free(ring); return CDA_ERR_INVALID; }
+                const int32_t f[BOOK_FIELDS] = {o->price, o->qty, (int32_t)(((uint32_t)o->order_id << 4) | (uint32_t)o->owner), o->timestamp};
+                for (int k = 0; k < BOOK_FIELDS; k++) {
+                    if (i < tile_n[sd]) bp[k * CAP + book_phys_rt(CAP, sd, i)] = f[k];
+                    else ring[((size_t)sd * BOOK_FIELDS + (size_t)k) * (size_t)P.lay.spill_cap + (size_t)(i - tile_n[sd])] = f[k];
+                }
+            }
+        }
+        if (ring) {
+            const int32_t shdr[16] = {tail_n[0], tail_n[1], 0, 0};
+            hipError_t he = hipMemcpy(dev_spill, shdr, sizeof shdr, hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipMemcpy(dev_spill + 64, ring, 2 * side_bytes, hipMemcpyHostToDevice);
+            free(ring);
+            if (he != hipSuccess) { free(rec); return hip_fail(he, "hipMemcpy H2D (spill ring)"); }
+        }
+        h[H_PEAK_ORDERS] = (uint32_t)(s->n_bids + s->n_asks);
+    }
     h[H_RNG_STATE_LO] = (uint32_t)s->rng_state_lo; h[H_RNG_STATE_LO + 1] = (uint32_t)(s->rng_state_lo >> 32);
     h[H_RNG_STATE_HI] = (uint32_t)s->rng_state_hi; h[H_RNG_STATE_HI + 1] = (uint32_t)(s->rng_state_hi >> 32);
     h[H_RNG_INC_LO] = (uint32_t)s->rng_inc_lo; h[H_RNG_INC_LO + 1] = (uint32_t)(s->rng_inc_lo >> 32);
@@ -695,18 +843,8 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
     h[H_HAS_U32] = s->rng_has_uint32; h[H_UINTEGER] = s->rng_uinteger;
     h[H_T_STEP] = (uint32_t)s->t_step; h[H_LOB_TIME] = (uint32_t)s->lob_time; h[H_NEXT_OID] = (uint32_t)s->next_order_id;
     h[H_LAST_PRICE] = (uint32_t)s->last_price; h[H_HAS_TRADE] = (uint32_t)s->has_trade; h[H_LAST_TRADE_PRICE] = (uint32_t)s->last_trade_price;
-    h[H_DONE_MASK] = s->done_mask; h[H_FLAGS] = s->flags; h[H_N_BIDS] = (uint32_t)s->n_bids; h[H_N_ASKS] = (uint32_t)s->n_asks;
-    h[H_SEEDED] = 1; h[H_HIST_HEAD] = 0; h[H_LEVELS_VALID] = 0;
-    int32_t* bp = (int32_t*)(rec + P.lay.book_off);
-    for (int sd = 0; sd < 2; sd++) {
-        int n = sd == 0 ? s->n_bids : s->n_asks;
-        for (int i = 0; i < n; i++) {
-            const cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i];
-            if (o->owner < 0 || o->owner >= CDA_MAX_AGENTS || o->order_id < 0 || o->order_id >= (1 << 27)) { free(rec); return CDA_ERR_INVALID; }
-            const int ph = book_phys_rt(CAP, sd, i);
-            bp[0 * CAP + ph] = o->price; bp[1 * CAP + ph] = o->qty; bp[2 * CAP + ph] = (int32_t)(((uint32_t)o->order_id << 4) | (uint32_t)o->owner); bp[3 * CAP + ph] = o->timestamp;
-        }
-    }
+    h[H_DONE_MASK] = s->done_mask; h[H_FLAGS] = s->flags;
+    h[H_SEEDED] = 1; h[H_HIST_HEAD] = 0;
     Acc* ap = (Acc*)(rec + P.lay.acc_off);
     for (int a = 0; a < P.cfg.num_agents; a++) {
         const cda_account_state* o = &s->acc[a];
@@ -717,8 +855,7 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
         ap[a].order_step_placed = o->order_step_placed; ap[a].num_rejected_step = o->num_rejected_step;
     }
     memcpy(rec + P.lay.hist_off, s->hist, sizeof(float) * (size_t)P.cfg.n_hist * CDA_SNAPSHOT_DIM);
-    hipError_t he = hipDeviceSynchronize();
-    if (he == hipSuccess) he = hipMemcpy(e->arena + (size_t)market * (size_t)P.lay.stride, rec, (size_t)P.lay.stride, hipMemcpyHostToDevice);
+    hipError_t he = hipMemcpy(dev_rec, rec, (size_t)P.lay.stride, hipMemcpyHostToDevice);
     free(rec);
     if (he != hipSuccess) return hip_fail(he, "hipMemcpy H2D");
     return CDA_OK;
@@ -850,6 +987,7 @@ int cda_debug_dec_calls(unsigned long long* host8, int reset) {
 #endif
 
 int32_t cda_book_capacity(const cda_env* e) { return e ? e->cap : 0; }
+int32_t cda_book_spill(const cda_env* e) { return e ? e->P.lay.spill_cap : 0; }
 int32_t cda_num_markets(const cda_env* e) { return e ? e->P.n_markets : 0; }
 int32_t cda_obs_dim(const cda_env* e) { return e ? e->P.cfg.n_hist * CDA_SNAPSHOT_DIM : 0; }
 int64_t cda_state_bytes_per_market(const cda_env* e) { return e ? (int64_t)e->P.lay.stride : 0; }

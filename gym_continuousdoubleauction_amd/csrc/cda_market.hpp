@@ -46,13 +46,18 @@ enum { S_BID = 0, S_ASK = 1, S_NONE = 2 };
 enum {
     H_RNG_STATE_LO = 0, H_RNG_STATE_HI = 2, H_RNG_INC_LO = 4, H_RNG_INC_HI = 6, H_HAS_U32 = 8, H_UINTEGER = 9,
     H_T_STEP = 10, H_LOB_TIME = 11, H_NEXT_OID = 12, H_LAST_PRICE = 13, H_HAS_TRADE = 14, H_LAST_TRADE_PRICE = 15,
-    H_DONE_MASK = 16, H_FLAGS = 17, H_N_BIDS = 18, H_N_ASKS = 19, H_SEEDED = 20, H_HIST_HEAD = 21, H_LEVELS_VALID = 22,
+    H_DONE_MASK = 16, H_FLAGS = 17, H_N_BIDS = 18, H_N_ASKS = 19, H_SEEDED = 20, H_HIST_HEAD = 21,
+    H_STATUS = 22,            // ST_* bits below (bit 0 used to be the whole word: "levels valid")
     H_PEAK_ORDERS = 23,       // most resting orders (both sides together) the market has held since its last reset (cda_book_peak)
     H_LEVELS = 24,            // 40 words: the top-10 aggregation (lvl_px[2][10], lvl_sz[2][10]) of the book as stored,
                               // so that the next step's pre-step snapshot is a copy instead of a scan (valid flag above)
     H_WORDS = 64
 };
 constexpr int HEADER_BYTES = H_WORDS * 4;   // 256: one coalesced load per wave
+// H_STATUS bits.  H_N_BIDS / H_N_ASKS count the orders of a side that live in the record's book TILE (the LDS-staged top of
+// the book); a side whose ST_TAIL bit is set continues in the market's HBM spill ring (cda_book.inc), otherwise the tile is
+// the whole side - the only case the hot path ever sees.
+enum { ST_LEVELS_VALID = 1, ST_TAIL_BID = 2, ST_TAIL_ASK = 4, ST_TAIL_ANY = 6 };
 
 struct Acc {                     // 144 B, 16-byte aligned; lane a owns account a
     cda_dec cash, hold, posval, vwap, nav, prev_nav, max_nav;     // 7 x 16 B
@@ -68,6 +73,7 @@ __device__ __forceinline__ int oo_pack(int32_t oid, int owner) { return (int32_t
 
 struct Layout {                  // byte offsets inside a market record
     int32_t acc_off, hist_off, book_off, stride;
+    int32_t spill_cap;           // orders per side the market's HBM spill ring holds (a power of two; 0 = no HBM tier)
 };
 
 struct Params {
@@ -84,7 +90,7 @@ struct Mkt {
     int32_t t_step, lob_time, next_oid, last_price, has_trade, last_trade_price;
     uint32_t done_mask, flags;
     int32_t nb, na;              // resting orders per side (two scalars: a dynamically indexed array would force Mkt into scratch)
-    int32_t seeded, hist_head, levels_valid;
+    int32_t seeded, hist_head, status;   // status: ST_* bits (cached level aggregation valid; which sides continue in the HBM spill ring)
     int32_t peak_orders;         // census: see H_PEAK_ORDERS
 #ifdef CDA_DEBUG_SKIP
     int32_t dbg;                 // debug: pieces of the order phase to leave out (tools/inst_count.sh); results are then wrong
@@ -122,6 +128,7 @@ struct Mkt {
 #endif
 __device__ __forceinline__ int mkt_n(const Mkt& m, int s) { return s == 0 ? m.nb : m.na; }
 __device__ __forceinline__ void mkt_set_n(Mkt& m, int s, int v) { if (s == 0) m.nb = v; else m.na = v; }
+__device__ __forceinline__ bool mkt_has_tail(const Mkt& m, int s) { return (m.status & (ST_TAIL_BID << s)) != 0; }
 
 __device__ __forceinline__ D ld_dec(const cda_dec& p) { return d_make(p.w[0], p.w[1], p.w[2], (int)p.exp, (int)p.sign); }
 __device__ __forceinline__ void st_dec(cda_dec& p, const D& d, uint32_t& flags) {
@@ -274,7 +281,7 @@ __device__ __forceinline__ void decode_header(uint32_t v, Mkt& m) {
     m.last_price = (int32_t)RL(H_LAST_PRICE); m.has_trade = (int32_t)RL(H_HAS_TRADE); m.last_trade_price = (int32_t)RL(H_LAST_TRADE_PRICE);
     m.done_mask = RL(H_DONE_MASK); m.flags = RL(H_FLAGS);
     m.nb = (int32_t)RL(H_N_BIDS); m.na = (int32_t)RL(H_N_ASKS);
-    m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD); m.levels_valid = (int32_t)RL(H_LEVELS_VALID);
+    m.seeded = (int32_t)RL(H_SEEDED); m.hist_head = (int32_t)RL(H_HIST_HEAD); m.status = (int32_t)RL(H_STATUS);
     m.peak_orders = (int32_t)RL(H_PEAK_ORDERS);
 #ifdef CDA_DEBUG_SKIP
     m.dbg = 0;
@@ -293,7 +300,7 @@ __device__ __forceinline__ void store_header(uint32_t* hp, const Mkt& m, int lan
         hp[H_LAST_PRICE] = (uint32_t)m.last_price; hp[H_HAS_TRADE] = (uint32_t)m.has_trade; hp[H_LAST_TRADE_PRICE] = (uint32_t)m.last_trade_price;
         hp[H_DONE_MASK] = m.done_mask; hp[H_FLAGS] = m.flags;
         hp[H_N_BIDS] = (uint32_t)m.nb; hp[H_N_ASKS] = (uint32_t)m.na;
-        hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head; hp[H_LEVELS_VALID] = (uint32_t)m.levels_valid;
+        hp[H_SEEDED] = (uint32_t)m.seeded; hp[H_HIST_HEAD] = (uint32_t)m.hist_head; hp[H_STATUS] = (uint32_t)m.status;
         hp[H_PEAK_ORDERS] = (uint32_t)m.peak_orders;
     }
 }

@@ -13,8 +13,9 @@ Same constructor config keys and defaults (config/env_defaults.json:8-27), `agen
 (obs, rewards, terminateds, truncateds, infos) dicts keyed "agent_i" (+ "__all__").  The env state lives on the GPU;
 these classes only marshal dicts <-> tensors.
 
-One deliberate canonicalisation: the reference assigns its per-agent RNG draws in the caller's dict
-iteration order; here agents are always processed in ascending index order.
+The reference assigns its per-agent RNG draws - and builds the arrival list it shuffles - in the ITERATION order of the caller's
+action dict (exchg/action_helper.py:164-170).  So do these facades: the order travels to the kernel in cda_step's `present`
+array (0 = not in the dict, else 1 + position in it), and `LOB_actions` lists the decoded orders in that order too.
 """
 import numbers
 
@@ -163,14 +164,14 @@ class _DictSurface(_Base):
     def _encode(self, actions, cat, mean, sigma, price, off, present):
         """One market's action dict -> row views of the [*, A] host arrays (action_helper.py:145-172, :241-283)."""
         A = self.num_of_agents
-        for key, act in actions.items():
+        for pos, (key, act) in enumerate(actions.items()):
             a = int(str(key).split("_")[1])
             if not 0 <= a < A:
                 raise KeyError(key)
             c = int(act["category"])
             if not 0 <= c <= 8:
                 raise KeyError(c)                               # _CATEGORY_MAP lookup (action_helper.py:266)
-            present[a] = 1
+            present[a] = 1 + pos                                # the dict's iteration order decides who draws which normal (:164-170)
             cat[a] = c
             mean[a] = np.float32(np.asarray(act["size_mean"], dtype=np.float32).reshape(-1)[0])
             sigma[a] = np.float32(np.asarray(act["size_sigma"], dtype=np.float32).reshape(-1)[0])
@@ -191,11 +192,13 @@ class _DictSurface(_Base):
         terminateds["__all__"] = bool(term[i])
         truncateds["__all__"] = bool(trunc[i])
         lob = info["lob_actions"][i]
-        # env.LOB_actions (continuousDoubleAuction_env.py:284-285): the decoded orders in agent order, passes left out
+        # env.LOB_actions (continuousDoubleAuction_env.py:284-285): the decoded orders in the order of the action dict, passes left out
+        index = {a: k for k, a in enumerate(agents)}
+        listed = [a for a in actions if a in index] if actions is not None else agents
         lob_actions = [
             {"ID": a, "side": ("bid", "ask")[int(row[0])], "type": ("market", "limit", "modify", "cancel")[int(row[1])],
              "size": int(row[2]), "price": float(row[3])}
-            for a, row in zip(agents, lob) if row[0] >= 0]
+            for a, row in ((a, lob[index[a]]) for a in listed) if row[0] >= 0]
         infos, pass_agents, bankrupt = {}, set(), set()
         last_price, bb, ba, sp = float(info["last_price"][i]), _nan_none(info["best_bid"][i]), _nan_none(info["best_ask"][i]), _nan_none(info["spread"][i])
         for k, a in enumerate(agents):
@@ -368,9 +371,11 @@ class CDAVecMultiAgentEnv(_DictSurface):
     def step_batch(self, actions):
         first = next(iter(actions.values()))
         if isinstance(first, dict):                                 # {agent: {key: [N]}} -> {key: [N, A]}
-            missing = [a for a in self.agents if a not in actions]
+            # `present` carries the dict's iteration order (0 = absent, else 1 + position): needed when agents are missing or the
+            # keys do not come in ascending agent order
+            order = [a for a in actions if a in self._agent_ids]
             present = None
-            if missing:
+            if order != self.agents:
                 present = torch.zeros((self.num_envs, self.num_of_agents), dtype=torch.uint8, device=self._vec.device)
             cols = {k: [] for k in ACTION_KEYS}
             dts = {"category": torch.int32, "size_mean": torch.float32, "size_sigma": torch.float32, "price": torch.int32, "price_offset": torch.int32}
@@ -378,7 +383,7 @@ class CDAVecMultiAgentEnv(_DictSurface):
             for j, a in enumerate(self.agents):
                 act = actions.get(a)
                 if act is not None and present is not None:
-                    present[:, j] = 1
+                    present[:, j] = 1 + order.index(a)
                 for k in ACTION_KEYS:
                     if act is None:
                         cols[k].append(torch.zeros(n, dtype=dts[k], device=dev))
@@ -389,7 +394,7 @@ class CDAVecMultiAgentEnv(_DictSurface):
             actions = {k: torch.stack(cols[k], dim=1) for k in ACTION_KEYS}
             if present is not None:
                 actions["present"] = present
-        obs, rew, term, trunc, info = self._vec.step(actions)
+        obs, rew, term, trunc, info = self._vec.step(actions)      # (groups > 1: forked from and joined back into the caller's stream)
         return self._views(obs, rew, term, trunc, info)
 
     # ---- vector protocol: one sub-env per market --------------------------------------------------------------
@@ -413,7 +418,6 @@ class CDAVecMultiAgentEnv(_DictSurface):
             self._encode(actions, buf["category"][i], buf["size_mean"][i], buf["size_sigma"][i], buf["price"][i], buf["price_offset"][i], buf["present"][i])
         t = st.upload()                                            # ONE host-to-device copy of the batch's actions
         vec.step(t["category"], t["size_mean"], t["size_sigma"], t["price"], t["price_offset"], t["present"])
-        vec.join()
         self._host.copy_(vec.packed)                               # ONE device-to-host copy for the whole batch
         obs, rew, term, trunc, info = vec.unpack_host(self._host)
         obs = obs.copy()                                           # the caller keeps these rows; the staging buffer is reused

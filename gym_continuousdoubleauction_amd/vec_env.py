@@ -40,7 +40,8 @@ class CDAVecEnv:
         h = C.c_void_p()
         check(lib().cda_create(C.byref(self.cfg_struct), self.n_markets, self.device_index, C.byref(h)), "cda_create")
         self._h = h
-        self.book_capacity = int(lib().cda_book_capacity(h))     # 256 or 512 resting orders per market (config['book_capacity'])
+        self.book_capacity = int(lib().cda_book_capacity(h))     # LDS book tile: 256 or 512 resting orders per market (config['book_capacity'])
+        self.book_spill = int(lib().cda_book_spill(h))           # HBM spill ring behind it: orders per side (config['book_spill']; 0 = none)
         N, A, dev = self.n_markets, self.num_agents, self.device
         # The per-step outputs of one launch live in ONE contiguous slab (obs | reward | terminated | truncated),
         # so a multi-GPU caller hands them to its peers with a single collective and no packing pass
@@ -206,8 +207,15 @@ class CDAVecEnv:
         t = t.reshape(self.n_markets, self.num_agents)
         return t.contiguous()
 
-    def step(self, category, size_mean=None, size_sigma=None, price=None, price_offset=None, present=None):
-        """One env step for all markets.  `category` may also be a dict holding the five action tensors."""
+    def step(self, category, size_mean=None, size_sigma=None, price=None, price_offset=None, present=None, pipelined=False):
+        """One env step for all markets.  `category` may also be a dict holding the five action tensors.  `present` u8[N,A]
+        (optional): 0 = the agent is not in this step's action dict; non-zero values also carry the dict's iteration order
+        (agents are processed by ascending value, ties by agent index - see include/cda.h).
+
+        groups > 1: the launches go to the group streams.  By default the step is ordered AFTER everything enqueued on the caller's
+        current stream (the tensors a policy just wrote) and the caller's stream AFTER the step (fork + join: one event edge each
+        way), so it composes like any other stream-ordered op.  pipelined=True leaves both edges out: the caller orders things
+        itself (fork() / join() / sync(), or per-group work on group_streams[g]) - what bench.py's free-running loop does."""
         if isinstance(category, dict):
             d = category
             present = d.get("present", present)
@@ -222,7 +230,7 @@ class CDAVecEnv:
             self._cur = (self._cur + 1) % len(self._views)
             self._bind_outputs()
         if self.groups > 1:
-            if self._need_fork:
+            if self._need_fork or not pipelined:
                 self.fork()
             fn = self._groups_call
             call = (self._h, self.groups, cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
@@ -239,7 +247,12 @@ class CDAVecEnv:
                 rc = fn(*call)
         if rc != 0:
             check(rc, "cda_step")
-        self._keep = (cat, sm, ss, pr, po, ps)      # keep inputs alive until the async kernel has consumed them
+        # keep the inputs of the last TWO steps alive: a pipelined caller may have step t still reading them on a group stream
+        # when step t+1 is enqueued (the caching allocator would otherwise hand the memory out again on the caller's stream)
+        self._keep_prev = getattr(self, "_keep", None)
+        self._keep = (cat, sm, ss, pr, po, ps)
+        if self.groups > 1 and not pipelined:
+            self.join()
         return self.obs, self.reward, self._term.view(torch.bool), self._trunc.view(torch.bool), self.info
 
     def run_random(self, n_steps, action_seed=0, market_index_base=0):
@@ -291,6 +304,19 @@ class CDAVecEnv:
         torch.cuda.synchronize(self.device)
         check(lib().cda_get_state(self._h, market, C.byref(s)), "cda_get_state")
         return s
+
+    def get_book(self, market=0, side=None):
+        """One market's book, whole, in queue order (best price first, FIFO inside a level): int32 [n, 5] rows of
+        (price, qty, owner, order_id, timestamp); side 0 bids, 1 asks, None = (bids, asks).  Unlike get_state() this is
+        not limited to the first BOOK_CAP_MAX orders of a side."""
+        if side is None:
+            return self.get_book(market, 0), self.get_book(market, 1)
+        torch.cuda.synchronize(self.device)
+        n = C.c_int32()
+        check(lib().cda_get_book(self._h, market, side, None, 0, C.byref(n)), "cda_get_book")
+        buf = (K.Order * max(n.value, 1))()
+        check(lib().cda_get_book(self._h, market, side, C.cast(buf, C.c_void_p), n.value, C.byref(n)), "cda_get_book")
+        return np.ctypeslib.as_array(buf).view(np.int32).reshape(-1, 5)[: n.value].copy()
 
     def set_state(self, market, state):
         torch.cuda.synchronize(self.device)

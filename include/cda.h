@@ -35,8 +35,10 @@ extern "C" {
 #define CDA_RAW_DIM       40            /* agg_LOB_raw: state_helper.py:159-160 */
 #define CDA_MAX_HIST      16            /* n_hist upper bound of this build (reference default 4) */
 #define CDA_MAX_AGENTS    16            /* agents per market upper bound of this build */
-#define CDA_BOOK_CAP      256           /* default book pool: resting orders per market, both sides together (reference: unbounded) */
-#define CDA_BOOK_CAP_MAX  512           /* the larger compiled pool (cda_config.book_capacity); sizes the parity-dump arrays */
+#define CDA_BOOK_CAP      256           /* default LDS book tile: the top of a market's book, both sides together (cda_config.book_capacity) */
+#define CDA_BOOK_CAP_MAX  512           /* the larger compiled tile; also sizes the arrays of the fixed-size parity dump (cda_market_state) */
+#define CDA_SPILL_MIN     64            /* smallest / largest HBM spill ring per side (cda_config.book_spill, a power of two) */
+#define CDA_SPILL_MAX     (1 << 20)
 #define CDA_NUM_REWARD_TERMS 5          /* reward_helper.py:75-81 */
 #define CDA_MAX_GROUPS    16            /* cda_step_groups: concurrent market groups per env */
 
@@ -50,7 +52,7 @@ typedef enum cda_status {
 } cda_status;
 
 /* Per-market sticky flag bits reported by cda_last_flags. */
-#define CDA_FLAG_BOOK_OVERFLOW   0x1u   /* a rest was dropped: the market's book pool was full */
+#define CDA_FLAG_BOOK_OVERFLOW   0x1u   /* a rest was dropped: the market's book (LDS tile + HBM spill ring) was full */
 #define CDA_FLAG_INT_OVERFLOW    0x2u   /* a size/position/price left the int32 / 2^24 domain */
 #define CDA_FLAG_DEC_DOMAIN      0x4u   /* a ledger value left the 28-digit / exponent domain */
 
@@ -74,10 +76,15 @@ typedef struct cda_config {
                                     reset(seed=None) semantics (the RNG stream continues, continuousDoubleAuction_env.py:186-188);
                                     its obs row then holds the NEW episode's first observation, reward / flags / info are the
                                     finished step's */
-    int32_t book_capacity;       /* extension: resting orders a market can hold, both sides together (the reference's OrderTree is
-                                    unbounded, ordertree.py:5-58).  256 or 512 (two compiled builds of the market kernels); 0 = by agent
-                                    count: 256 up to 8 agents, 512 above.  A rest that does not fit is dropped and flagged
-                                    (CDA_FLAG_BOOK_OVERFLOW), never silently */
+    int32_t book_capacity;       /* extension: size of the LDS-staged book TILE, the top of a market's book, both sides together:
+                                    256 or 512 resting orders (two compiled builds of the market kernels); 0 = by agent count: 256 up
+                                    to 8 agents, 512 above.  What does not fit the tile lives in the HBM spill ring below */
+    int32_t book_spill;          /* extension: resting orders PER SIDE a market can hold in HBM behind its tile (the reference's
+                                    OrderTree is unbounded, ordertree.py:5-58).  0 = automatic: num_agents * max_step rounded up to a
+                                    power of two (at least 1024) - a side cannot grow faster than one order per agent and step, so
+                                    no order is ever dropped inside an episode; n > 0: rounded up to a power of two in
+                                    [CDA_SPILL_MIN, CDA_SPILL_MAX]; -1: no HBM tier (the round-1/2 behaviour: the tile is the whole
+                                    book).  A rest that fits neither is dropped and flagged (CDA_FLAG_BOOK_OVERFLOW), never silently */
     double  order_penalty;       /* 0.1  */
     double  trade_penalty;       /* 0.05 */
     double  drawdown_penalty;    /* 0.2  */
@@ -138,6 +145,8 @@ typedef struct cda_account_state {
     int32_t num_trades_step, num_passive_fills_step, order_step_placed, num_rejected_step;
 } cda_account_state;
 
+/* The dump holds the first CDA_BOOK_CAP_MAX orders of each side; n_bids / n_asks are the TRUE counts (they may be larger:
+ * cda_get_book reads a side of any length). */
 typedef struct cda_market_state {
     uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;  /* numpy PCG64 */
     uint32_t rng_has_uint32, rng_uinteger;
@@ -249,13 +258,20 @@ int cda_mark_to_mkt(cda_env* env, int32_t market);
 int cda_get_state(cda_env* env, int32_t market, cda_market_state* out_host);
 int cda_set_state(cda_env* env, int32_t market, const cda_market_state* in_host);
 
+/* One side of one market's book, whole, in queue order (best price first, FIFO inside a level; ordertree.py / orderlist.py):
+ * up to max_orders orders -> orders_out_host (host), the side's true length -> n_out_host.  side: 0 bids, 1 asks.  Synchronous. */
+int cda_get_book(cda_env* env, int32_t market, int32_t side, cda_order* orders_out_host, int32_t max_orders, int32_t* n_out_host);
+/* Orders per side the HBM spill ring of this env holds (0 = no HBM tier). */
+int32_t cda_book_spill(const cda_env* env);
+
 /* Pre-step raw top-10 snapshot agg_LOB_raw f32[N,40] (state_helper.py:159-160) -> device buffer. */
 int cda_get_raw_snapshot(cda_env* env, float* raw_out, void* stream);
 
 /* Per-market sticky flags u32[N] -> device buffer. */
 int cda_last_flags(cda_env* env, uint32_t* flags_out, void* stream);
 /* Book census i32[N] -> device buffer: the most resting orders (both sides together) each market has held since its
- * last reset.  The reference's OrderTree is unbounded (ordertree.py:5-58); this build holds cda_book_capacity(env). */
+ * last reset.  The reference's OrderTree is unbounded (ordertree.py:5-58); this build holds cda_book_capacity(env) in the
+ * LDS tile and cda_book_spill(env) per side behind it in HBM. */
 int cda_book_peak(cda_env* env, int32_t* peak_out, void* stream);
 
 /* Structural invariants of every market -> u32[N] device buffer of CDA_INV_* bits (0 = all hold): sides sorted best
@@ -295,7 +311,7 @@ int cda_selftest_libm_host(int32_t op, int32_t n, const double* x_host, double* 
 
 const char* cda_strerror(int status);
 int32_t cda_num_markets(const cda_env* env);
-int32_t cda_book_capacity(const cda_env* env);   /* 256 or 512: the pool this env was built with */
+int32_t cda_book_capacity(const cda_env* env);   /* 256 or 512: the LDS tile this env was built with */
 int32_t cda_obs_dim(const cda_env* env);
 /* Bytes the arena keeps per market in HBM. */
 int64_t cda_state_bytes_per_market(const cda_env* env);

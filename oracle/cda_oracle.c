@@ -711,8 +711,19 @@ static void market_step(const struct oracle_env* e, market_t* m, int mi,
     /* 2. set_actions (action_helper.py:145-172, :241-283) */
     act_t acts[CDA_MAX_AGENTS]; int na = 0; uint32_t pass_mask = 0;
     if (info && info->lob_actions) for (int k = 0; k < 4 * A; k++) info->lob_actions[(size_t)mi * (size_t)A * 4 + (size_t)k] = -1;
-    for (int a = 0; a < A; a++) {
-        if (present && !present[a]) continue;
+    /* The reference walks the caller's action dict in ITS iteration order (action_helper.py:164-170): one normal per key in that
+     * order, and the arrival list handed to the shuffle is built in that order too.  `present[a]` carries it: 0 = agent a is
+     * not in the dict, otherwise agents are visited by ascending present[a] (1 + position in the dict), ties - e.g. a plain
+     * 0 / 1 mask - by ascending agent index. */
+    int visit[CDA_MAX_AGENTS], nv = 0;
+    for (int a = 0; a < A; a++) if (!present || present[a]) visit[nv++] = a;
+    if (present) for (int i = 1; i < nv; i++) {                       /* stable insertion sort by present[] */
+        int v = visit[i], j = i;
+        while (j > 0 && present[visit[j - 1]] > present[v]) { visit[j] = visit[j - 1]; j--; }
+        visit[j] = v;
+    }
+    for (int vi = 0; vi < nv; vi++) {
+        const int a = visit[vi];
         int cat = clampi(category[a], 0, 8);
         int side = cat == 0 ? S_NONE : (cat <= 4 ? S_BID : S_ASK);
         int type = cat == 0 ? T_MARKET : (cat - 1) & 3;
@@ -820,6 +831,7 @@ static int cfg_ok(const cda_config* c) {
     if (c->initial_price_max < c->initial_price_min) return CDA_ERR_INVALID;
     if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;
     if (c->book_capacity != 0 && c->book_capacity != CDA_BOOK_CAP && c->book_capacity != CDA_BOOK_CAP_MAX) return CDA_ERR_INVALID;
+    if (c->book_spill < -1 || c->book_spill > CDA_SPILL_MAX) return CDA_ERR_INVALID;
     return CDA_OK;
 }
 
@@ -830,7 +842,9 @@ int oracle_create(const cda_config* cfg, int32_t n_markets, oracle_env** out) {
     oracle_env* e = (oracle_env*)calloc(1, sizeof *e);
     if (!e) return CDA_ERR_NOMEM;
     e->cfg = *cfg; e->n = n_markets;
-    e->book_cap = cfg->book_capacity ? cfg->book_capacity : (cfg->num_agents <= 8 ? CDA_BOOK_CAP : CDA_BOOK_CAP_MAX);   /* the product's rule (cda_create) */
+    /* the reference's book is unbounded (ordertree.py:5-58) and so is the product's with its HBM tier; only an env built
+     * WITHOUT that tier (book_spill = -1) holds just its tile, which the oracle then mirrors together with the overflow flag */
+    e->book_cap = cfg->book_spill >= 0 ? 0 : (cfg->book_capacity ? cfg->book_capacity : (cfg->num_agents <= 8 ? CDA_BOOK_CAP : CDA_BOOK_CAP_MAX));
     e->mkt_mul = (float)((double)(cfg->mkt_max_size - cfg->min_size) / 2.0);
     e->lim_mul = (float)((double)((int64_t)cfg->mkt_max_size * (int64_t)cfg->limit_size_multiple - (int64_t)cfg->min_size) / 2.0);
     e->m = (market_t*)calloc((size_t)n_markets, sizeof(market_t));
@@ -975,22 +989,27 @@ int oracle_get_state(oracle_env* e, int32_t market, cda_market_state* s) {
     memcpy(s->hist, m->hist, sizeof(float) * (size_t)e->cfg.n_hist * CDA_SNAPSHOT_DIM);
     return CDA_OK;
 }
+/* same rule as cda_set_state: a side longer than the struct's arrays can only go back onto the market it was dumped from
+ * (both lengths equal the market's: the book stays in place) */
 int oracle_set_state(oracle_env* e, int32_t market, const cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->n) return CDA_ERR_INVALID;
-    if (s->n_bids < 0 || s->n_asks < 0 || s->n_bids > CDA_BOOK_CAP_MAX || s->n_asks > CDA_BOOK_CAP_MAX) return CDA_ERR_INVALID;
+    if (s->n_bids < 0 || s->n_asks < 0) return CDA_ERR_INVALID;
     market_t* m = &e->m[market];
+    const int keep_book = s->n_bids > CDA_BOOK_CAP_MAX || s->n_asks > CDA_BOOK_CAP_MAX;
+    if (keep_book && (s->n_bids != m->side[0].n || s->n_asks != m->side[1].n)) return CDA_ERR_INVALID;
     if (m->book_cap > 0 && s->n_bids + s->n_asks > m->book_cap) return CDA_ERR_INVALID;
     m->rng.state = ((u128)s->rng_state_hi << 64) | s->rng_state_lo; m->rng.inc = ((u128)s->rng_inc_hi << 64) | s->rng_inc_lo;
     m->rng.has_uint32 = s->rng_has_uint32; m->rng.uinteger = s->rng_uinteger; m->seeded = 1;
     m->t_step = s->t_step; m->lob_time = s->lob_time; m->next_order_id = s->next_order_id;
     m->last_price = s->last_price; m->has_trade = s->has_trade; m->last_trade_price = s->last_trade_price;
     m->done_mask = s->done_mask; m->flags = s->flags;
-    for (int sd = 0; sd < 2; sd++) {
+    for (int sd = 0; sd < 2 && !keep_book; sd++) {
         const int need = sd == 0 ? s->n_bids : s->n_asks; side_t* q = &m->side[sd];
         if (q->alloc < need) { q->alloc = need; q->o = (order_t*)realloc(q->o, (size_t)need * sizeof(order_t)); if (!q->o) abort(); }
         q->n = need;
     }
-    for (int sd = 0; sd < 2; sd++) for (int i = 0; i < m->side[sd].n; i++) {
+    if (!keep_book && m->side[0].n + m->side[1].n > m->peak_orders) m->peak_orders = m->side[0].n + m->side[1].n;
+    for (int sd = 0; sd < 2 && !keep_book; sd++) for (int i = 0; i < m->side[sd].n; i++) {
         const cda_order* o = sd == 0 ? &s->bids[i] : &s->asks[i]; order_t* q = &m->side[sd].o[i];
         q->price = o->price; q->qty = o->qty; q->owner = o->owner; q->order_id = o->order_id; q->timestamp = o->timestamp;
     }
@@ -1003,6 +1022,17 @@ int oracle_set_state(oracle_env* e, int32_t market, const cda_market_state* s) {
         q->order_step_placed = o->order_step_placed; q->num_rejected_step = o->num_rejected_step;
     }
     memcpy(m->hist, s->hist, sizeof(float) * (size_t)e->cfg.n_hist * CDA_SNAPSHOT_DIM);
+    return CDA_OK;
+}
+/* one whole side in queue order (cda_get_book) */
+int oracle_get_book(oracle_env* e, int32_t market, int32_t side, cda_order* out, int32_t max_orders, int32_t* n_out) {
+    if (!e || market < 0 || market >= e->n || side < 0 || side > 1 || max_orders < 0 || !n_out) return CDA_ERR_INVALID;
+    const side_t* sd = &e->m[market].side[side];
+    *n_out = sd->n;
+    for (int i = 0; i < sd->n && i < max_orders; i++) {
+        const order_t* q = &sd->o[i];
+        out[i].price = q->price; out[i].qty = q->qty; out[i].owner = q->owner; out[i].order_id = q->order_id; out[i].timestamp = q->timestamp;
+    }
     return CDA_OK;
 }
 int oracle_get_raw_snapshot(oracle_env* e, float* raw_out) {

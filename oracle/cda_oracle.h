@@ -47,13 +47,14 @@ int oracle_run_range(oracle_env* env, int32_t first, int32_t count, int32_t n_st
 int oracle_run_random_range(oracle_env* env, int32_t first, int32_t count, int32_t step0, int32_t n_steps,
                             uint64_t action_seed, uint64_t market_index_base,
                             float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out);
-/* Book capacity mirrored by the oracle: the product's rule by default (cda_config.book_capacity; 256 up to 8 agents, 512
- * above - with its overflow flag);
- * 0 = unbounded, as the reference's OrderTree (ordertree.py:5-58).  oracle_book_peak: most resting orders each market
+/* Book capacity of the oracle: 0 = unbounded, as the reference's OrderTree (ordertree.py:5-58) - the default, and what the
+ * product is with its HBM tier; an env created with cda_config.book_spill = -1 (the product without that tier) mirrors the
+ * tile pool (cda_config.book_capacity; 256 up to 8 agents, 512 above) with its overflow flag.  oracle_book_peak: most resting orders each market
  * has held since its last reset; oracle_book_size: current orders per side (get_state dumps at most CDA_BOOK_CAP_MAX per side). */
 int oracle_set_book_cap(oracle_env* env, int32_t cap);
 int oracle_book_peak(oracle_env* env, int32_t* peak_out /* [N] */);
 int oracle_book_size(oracle_env* env, int32_t market, int32_t* n_bids, int32_t* n_asks);
+int oracle_get_book(oracle_env* env, int32_t market, int32_t side, cda_order* out, int32_t max_orders, int32_t* n_out);
 int oracle_place_order(oracle_env* env, int32_t market, int32_t trader, int32_t type, int32_t side,
                        int32_t size, int32_t price);
 int oracle_mark_to_mkt(oracle_env* env, int32_t market);

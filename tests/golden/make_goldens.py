@@ -39,7 +39,13 @@ def dec_triple(d):
     return sign, coeff, exp
 
 
-def sample_actions(rng, A, law):
+def sample_actions(rng, A, law, t=0):
+    if law == "trend_waves":   # the "trend" law below, its direction reversed every 384 steps (sides swapped: 1 <-> 5, 2 <-> 6, ...):
+        # the orders one wave leaves behind are swept, modified and cancelled by the next, far beyond the top of the book
+        cat, mean, sigma, price, off = sample_actions(rng, A, "trend")
+        if (t // 384) % 2 == 1:
+            cat = np.where(cat == 0, 0, np.where(cat <= 4, cat + 4, cat - 4)).astype(np.int32)
+        return cat, mean, sigma, price, off
     if law == "uniform":       # RandomRLModule / spaces.sample() law (train/model/model_handler.py:38-53)
         cat = rng.integers(0, 9, A)
         price = rng.integers(0, 10, A)
@@ -58,6 +64,13 @@ def sample_actions(rng, A, law):
         off = rng.choice([0, 2], A)
         mean = rng.choice(np.array([-1.0, 1.0, 0.0], np.float32), A)
         sigma = rng.choice(np.array([0.0, 1.0], np.float32), A)
+    elif law == "trend":       # a drifting market that leaves resting orders behind: bids keep improving by a tick, market buys
+        # lift the asks, few cancels - the book outgrows any fixed pool (hundreds of price levels, > 1000 resting orders)
+        cat = rng.choice([2, 2, 2, 2, 2, 6, 6, 6, 1, 1, 1, 5, 3, 7, 4, 8, 0], A)
+        price = rng.choice([0, 0, 0, 1, 2, 5, 9], A)
+        off = rng.choice([2, 2, 1, 0], A)
+        mean = (rng.uniform(-0.004, 0.004, A)).astype(np.float32)
+        sigma = rng.uniform(0, 1, A).astype(np.float32)
     else:
         raise ValueError(law)
     return cat.astype(np.int32), mean, sigma, price.astype(np.int32), off.astype(np.int32)
@@ -99,7 +112,9 @@ def book_rows(lob):
     return out, len(rows_b), len(rows_a)
 
 
-def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None, reseed_at=None, presets=None, dict_order=None):
+def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None, reseed_at=None, presets=None, dict_order=None, book_every=1):
+    """book_every > 1: the book dump (thousands of orders in the big-book traces) is kept for every book_every-th step and the
+    last one only; `book_off[t] = (-1, n_bids, n_asks)` for the others (the counts are always recorded)."""
     env = continuousDoubleAuctionEnv(dict(config))
     A = env.num_of_agents
     obs0, _ = env.reset(seed=seed)
@@ -135,14 +150,24 @@ def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None,
             o, _ = env.reset(seed=reseed_at[t])
             resets.append((t, -1 if reseed_at[t] is None else reseed_at[t]))
             rec[f"reset_obs_{t}"] = o["agent_0"].copy()
-        cat, mean, sigma, price, off = sample_actions(rng, A, law)
+        cat, mean, sigma, price, off = sample_actions(rng, A, law, t)
         present = np.ones(A, np.uint8) if present_p is None else (rng.uniform(0, 1, A) < present_p).astype(np.uint8)
         env.set_agg_LOB()
         raw_pre = np.asarray(env.agg_LOB_raw, np.float32).copy()
         actions = {}
         # dict_order: the reference assigns its RNG draws (and builds its arrival list) in the ITERATION order of this dict
         # (action_helper.py:145-172); a non-ascending order is recorded as given, in the reference's own agent ids
-        for a in (range(A) if dict_order is None else dict_order):
+        if isinstance(dict_order, str):             # "shuffle": a different key order every step
+            order_t = [int(x) for x in rng.permutation(A)]
+        else:
+            order_t = list(range(A)) if dict_order is None else list(dict_order)
+        if dict_order is not None:                  # recorded as cda_step's `present` carries it: 1 + position in the dict, 0 = absent
+            pos = 0
+            for a in order_t:
+                if present[a]:
+                    pos += 1
+                    present[a] = pos
+        for a in order_t:
             if present[a]:
                 actions[f"agent_{a}"] = {
                     "category": np.int64(cat[a]), "size_mean": np.array([mean[a]], np.float32),
@@ -209,7 +234,10 @@ def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None,
             dm |= 1 << int(aid.split("_")[1])
         L["done_mask"].append(dm); L["t_step"].append(env.t_step)
         rows, nb, na = book_rows(lob)
-        book_off.append((len(book_all), nb, na)); book_all.extend(rows)
+        if t % book_every == 0 or t == T - 1:
+            book_off.append((len(book_all), nb, na)); book_all.extend(rows)
+        else:
+            book_off.append((-1, nb, na))
         st = env.np_random.bit_generator.state
         rng_l.append(np.array([st["state"]["state"] >> 64, st["state"]["state"] & (2 ** 64 - 1), st["has_uint32"],
                                st["uinteger"] if st["has_uint32"] else 0], np.uint64))
@@ -226,9 +254,11 @@ def run_trace(name, config, seed, T, action_seed, law="uniform", present_p=None,
         resets=np.array(resets, np.int64).reshape(-1, 2),
         presets=np.array(preset_rows, np.int64).reshape(-1, 6),
     )
-    if dict_order is not None:
+    if dict_order is not None and not isinstance(dict_order, str):
         assert sorted(dict_order) == list(range(A))
         rec["dict_order"] = np.array(dict_order, np.int32)
+    if dict_order is not None:
+        rec["ordered"] = np.array(1)                # `present` holds ranks, not a 0 / 1 mask
     nonint = sum(1 for s in acc_exp for v in s[:, 4] if v < -1)
     print(f"{name}: T={T} A={A} tape={L['tape_len'][-1]} max_orders={max(b[1] + b[2] for b in book_off)} "
           f"deep-exp NAVs={nonint} term={sum(L['term'])} rejected={int(np.array(cnt_l)[:, :, 3].sum())}")
@@ -282,6 +312,16 @@ def main():
     # action dicts handed over in a fixed NON-ascending key order (all agents, and subsets of them)
     add("perm_s91", dict(base4), 91, 160, 7091, dict_order=[2, 0, 3, 1])
     add("perm8_s92", dict(base8), 92, 128, 7092, law="aggressive", present_p=0.7, dict_order=[5, 1, 7, 0, 3, 6, 2, 4])
+    # ... and in an order that changes every step (all agents / subsets, 4 and 8 agents)
+    add("permshuf_s93", dict(base4), 93, 160, 7093, dict_order="shuffle")
+    add("permshuf8_s94", dict(base8), 94, 128, 7094, law="aggressive", present_p=0.75, dict_order="shuffle")
+    # books far beyond any fixed pool (the reference's OrderTree is unbounded, ordertree.py:5-58): a drifting market leaves
+    # thousands of resting orders behind; in the second trace the drift reverses every 384 steps, so sweeps, modifies and
+    # cancels reach deep into what the previous wave left.  (seeds found with tests/golden/find_big_book_seed.py)
+    add("bigbook_s201", dict(base16, max_step=1280), 201, 1280, 7401, law="trend", book_every=64)                 # ~3000 resting bids (tile: 512)
+    add("bigbook_waves_s205", dict(base16, max_step=1280), 205, 1280, 7405, law="trend_waves", book_every=64)     # ~850 orders, both sides deep
+    add("bigbook8_waves_s203", dict(base8, max_step=1280), 203, 1280, 7403, law="trend_waves", book_every=64)     # tile 256
+    add("bigbook4_s201", dict(base4, max_step=1280), 201, 1280, 7401, law="trend", book_every=64)                 # tile 256, 4 agents
     for name, rec in traces.items():
         np.savez_compressed(os.path.join(out_dir, f"trace_{name}.npz"), **rec)
     if only:

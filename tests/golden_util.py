@@ -25,12 +25,21 @@ def trace_names():
     return sorted(os.path.basename(p)[len("trace_"):-4] for p in glob.glob(os.path.join(GOLD, "trace_*.npz")))
 
 
-def load(name, relabel=True):
+def load(name, relabel=False):
+    """A trace as recorded.  Where the reference was handed its action dicts in a non-ascending key order, `present` carries that
+    order the way cda_step takes it: 0 = absent, else 1 + the agent's position in the dict (action_helper.py:164-170 walks the
+    dict).  relabel=True (fixed-order traces only): the same episode restated with agent k = the k-th key, in ascending order."""
     with np.load(os.path.join(GOLD, f"trace_{name}.npz")) as z:
         rec = {k: z[k] for k in z.files}
     rec["config"] = json.loads(str(rec["config"]))
     rec["name"] = name
-    if relabel and "dict_order" in rec:
+    if "dict_order" in rec and "ordered" not in rec:      # (the two round-2 fixtures keep a 0 / 1 mask plus the fixed order)
+        order = np.asarray(rec["dict_order"], np.int64)
+        pos = np.empty(len(order), np.int64)
+        pos[order] = np.arange(len(order))
+        rec["present_mask"] = rec["present"].copy()
+        rec["present"] = np.where(rec["present"] != 0, 1 + pos[None, :], 0).astype(np.uint8)
+    if relabel:
         rec = relabel_by_dict_order(rec)
     return rec
 
@@ -52,6 +61,7 @@ def relabel_by_dict_order(rec):
     out = dict(rec)
     for k in _AGENT_AXIS1:
         out[k] = rec[k][:, order]
+    out["present"] = (out["present"] != 0).astype(np.uint8)     # ascending order now: a plain mask
     ex = rec["exec_order"].copy()
     ex[ex >= 0] = inv[ex[ex >= 0]]
     out["exec_order"] = ex
@@ -93,7 +103,7 @@ def _eq(what, got, exp, ctx):
         raise AssertionError(f"{ctx}: {what} mismatch\n got {got!r}\n exp {exp!r}")
 
 
-def check_state(state, rec, t, A, ctx, n_hist):
+def check_state(state, rec, t, A, ctx, n_hist, book=None):
     """Compare a MarketState dump with the golden record after step t."""
     _eq("lob_time", state.lob_time, rec["lob_time"][t], ctx)
     _eq("next_order_id", state.next_order_id, rec["next_order_id"][t], ctx)
@@ -107,10 +117,15 @@ def check_state(state, rec, t, A, ctx, n_hist):
     off, nb, na = (int(x) for x in rec["book_off"][t])
     _eq("n_bids", state.n_bids, nb, ctx)
     _eq("n_asks", state.n_asks, na, ctx)
-    gb = np.array([[o.price, o.qty, o.owner, o.order_id, o.timestamp] for o in state.bids[:nb]], np.int32).reshape(-1, 5)
-    ga = np.array([[o.price, o.qty, o.owner, o.order_id, o.timestamp] for o in state.asks[:na]], np.int32).reshape(-1, 5)
-    _eq("bids", gb, rec["book"][off:off + nb], ctx)
-    _eq("asks", ga, rec["book"][off + nb:off + nb + na], ctx)
+    if off >= 0:                          # (the big-book traces keep the dump for every 64th step only)
+        if book is not None:              # the whole sides (get_book): a MarketState holds the first BOOK_CAP_MAX orders of a side only
+            gb, ga = book
+        else:
+            assert nb <= K.BOOK_CAP_MAX and na <= K.BOOK_CAP_MAX, "this trace needs env.get_book"
+            gb = np.array([[o.price, o.qty, o.owner, o.order_id, o.timestamp] for o in state.bids[:nb]], np.int32).reshape(-1, 5)
+            ga = np.array([[o.price, o.qty, o.owner, o.order_id, o.timestamp] for o in state.asks[:na]], np.int32).reshape(-1, 5)
+        _eq("bids", gb, rec["book"][off:off + nb], ctx)
+        _eq("asks", ga, rec["book"][off + nb:off + nb + na], ctx)
     r = rec["rng"][t]
     _eq("rng_state", [state.rng_state_hi, state.rng_state_lo], r[:2], ctx)
     if not any(rt <= t and rs >= 0 for (rt, rs) in rec["resets"]):   # a re-seed changes the increment
@@ -236,5 +251,7 @@ def run_group(env, recs, state_every=1, trace_getter=None, max_steps=None):
                 if got != exp:
                     raise AssertionError(f"{ctx}: info.nav agent {a} got {got} exp {exp}")
             if state_every and (t % state_every == 0 or t == r["cat"].shape[0] - 1):
-                check_state(env.get_state(i), r, t, A, ctx, n_hist)
+                st = env.get_state(i)
+                big = (st.n_bids > K.BOOK_CAP_MAX or st.n_asks > K.BOOK_CAP_MAX) and r["book_off"][t][0] >= 0
+                check_state(st, r, t, A, ctx, n_hist, book=env.get_book(i) if big else None)
     return T

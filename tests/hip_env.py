@@ -28,6 +28,9 @@ class HipEnv:
     def get_state(self, i):
         return self.env.get_state(i)
 
+    def get_book(self, i=0, side=None):
+        return self.env.get_book(i, side)
+
     def set_state(self, i, s):
         self.env.set_state(i, s)
 

@@ -44,6 +44,7 @@ def lib():
         _lib.oracle_set_book_cap.argtypes = [vp, C.c_int32]
         _lib.oracle_book_peak.argtypes = [vp, vp]
         _lib.oracle_book_size.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        _lib.oracle_get_book.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
         _lib.oracle_place_order.argtypes = [vp] + [C.c_int32] * 6
         _lib.oracle_mark_to_mkt.argtypes = [vp, C.c_int32]
         _lib.oracle_get_state.argtypes = [vp, C.c_int32, C.POINTER(K.MarketState)]
@@ -150,6 +151,16 @@ class OracleEnv:
         nb, na = C.c_int32(), C.c_int32()
         assert lib().oracle_book_size(self.h, market, C.byref(nb), C.byref(na)) == 0
         return nb.value, na.value
+
+    def get_book(self, market=0, side=None):
+        """int32 [n, 5] rows (price, qty, owner, order_id, timestamp) of one whole side in queue order; side None = (bids, asks)."""
+        if side is None:
+            return self.get_book(market, 0), self.get_book(market, 1)
+        n = C.c_int32()
+        assert lib().oracle_get_book(self.h, market, side, None, 0, C.byref(n)) == 0
+        buf = (K.Order * max(n.value, 1))()
+        assert lib().oracle_get_book(self.h, market, side, C.cast(buf, C.c_void_p), n.value, C.byref(n)) == 0
+        return np.ctypeslib.as_array(buf).view(np.int32).reshape(-1, 5)[: n.value].copy()
 
     def place_order(self, market, trader, type_, side, size, price):
         rc = lib().oracle_place_order(self.h, market, trader, type_, side, size, price)

@@ -151,3 +151,70 @@ def test_facade_steps_per_second_are_reported(capsys):
     with capsys.disabled():
         print(f"\n[facade] CDAEnv {one:,.0f} env-steps/s; CDAVecMultiAgentEnv(256) {many:,.0f} env-steps/s (dict protocol); reference 2,260")
     assert one > 0 and many > 0
+
+
+@pytest.mark.parametrize("name", ["perm_s91", "permshuf8_s94"])
+def test_dict_facade_walks_the_action_dict_in_its_iteration_order(name):
+    """CDAEnv.step(action_dict): the reference draws one normal per key IN THE DICT'S ORDER and shuffles the arrival list built
+    in that order (exchg/action_helper.py:164-170).  Golden traces the reference produced from dicts in a non-ascending (perm)
+    or per-step shuffled (permshuf) key order, replayed through the dict facade with the dicts rebuilt in the recorded order:
+    observations, rewards and env.LOB_actions (ids in dict order) match; with sorted keys they do not."""
+    import golden_util as G
+    from gym_continuousdoubleauction_amd import CDAEnv
+    rec = G.load(name)
+    A, T = rec["cat"].shape[1], 60
+
+    def run(sort_keys):
+        env = CDAEnv(rec["config"])
+        env.reset(seed=int(rec["seed"]))
+        for t in range(T):
+            pres = rec["present"][t]
+            order = sorted((a for a in range(A) if pres[a]), key=(lambda a: a) if sort_keys else (lambda a: pres[a]))
+            acts = {f"agent_{a}": {"category": np.int64(rec["cat"][t, a]), "size_mean": np.array([rec["mean"][t, a]], np.float32),
+                                   "size_sigma": np.array([rec["sigma"][t, a]], np.float32), "price": np.int64(rec["price"][t, a]),
+                                   "price_offset": np.int64(rec["off"][t, a])} for a in order}
+            obs, rew, *_ = env.step(acts)
+            if not np.array_equal(obs["agent_0"].view(np.uint32), rec["obs"][t].view(np.uint32)):
+                env.close()
+                return t
+            assert [x["ID"] for x in env.LOB_actions] == [f"agent_{a}" for a in order if rec["dec_type"][t, a] != -9]
+            assert all(np.float64(rew[f"agent_{a}"]).view(np.uint64) == rec["reward"][t, a].view(np.uint64) for a in range(A))
+        env.close()
+        return T
+    assert run(False) == T
+    assert run(True) < T
+
+
+def test_groups_step_batch_is_stream_ordered_like_any_other_op():
+    """with groups > 1 the launches go to the group streams; by default a step is ordered after the caller's stream
+    (the action tensors it just wrote) and the caller's stream after the step.  A policy-in-the-loop pattern - actions computed
+    on the caller's stream right before step_batch, outputs consumed right after - equals groups = 1 bit for bit."""
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecMultiAgentEnv
+    n, a = 2048, 4
+    cfg = dict(CFG, max_step=400)
+    g1, g4 = CDAVecMultiAgentEnv(cfg, num_envs=n, groups=1), CDAVecMultiAgentEnv(cfg, num_envs=n, groups=4)
+    o1, _ = g1.reset_batch(seed=7)
+    o4, _ = g4.reset_batch(seed=7)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    acc1 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    acc4 = torch.zeros_like(acc1)
+    for t in range(60):
+        # fresh tensors every step (the allocator recycles them), derived from the previous observation like a policy's would be
+        seedish = (o1["agent_0"][:, -2:].abs().sum(dim=1, keepdim=True) * 1000).to(torch.int64)
+        cat = ((torch.randint(0, 9, (n, a), generator=gen, device="cuda") + seedish) % 9).to(torch.int32)
+        batch = {"category": cat, "size_mean": torch.rand((n, a), generator=gen, device="cuda") * 2 - 1,
+                 "size_sigma": torch.rand((n, a), generator=gen, device="cuda"),
+                 "price": torch.randint(0, 10, (n, a), generator=gen, device="cuda", dtype=torch.int32),
+                 "price_offset": torch.randint(0, 3, (n, a), generator=gen, device="cuda", dtype=torch.int32)}
+        o1, r1, *_ = g1.step_batch({k: v.clone() for k, v in batch.items()})
+        o4, r4, *_ = g4.step_batch(batch)
+        del batch, cat
+        junk = torch.full((n, a), 7, dtype=torch.int32, device="cuda")          # would land in a just-freed action tensor
+        acc1 += r1["agent_0"]; acc4 += r4["agent_0"]                             # consumed on the caller's stream, no explicit join
+        assert torch.equal(o1["agent_0"], o4["agent_0"]), t
+        del junk
+    assert torch.equal(acc1, acc4)
+    assert (g4.vec.flags() == 0).all()
+    g1.close(); g4.close()

@@ -104,10 +104,11 @@ def test_market_results_do_not_depend_on_the_batch():
 
 
 def test_book_capacity_overflow_is_flagged_not_silent():
-    """More than CDA_BOOK_CAP resting orders on one side: the extra rest is dropped and the market flagged."""
+    """An env built WITHOUT the HBM tier (book_spill = -1: the tile is the whole book): more than CDA_BOOK_CAP resting orders -
+    the extra rest is dropped and the market flagged."""
     from hip_env import HipEnv
     import oracle_lib as O
-    cfg = {"num_of_agents": 2, "init_cash": 10 ** 9, "max_step": 64, "is_render": False}
+    cfg = {"num_of_agents": 2, "init_cash": 10 ** 9, "max_step": 64, "is_render": False, "book_spill": -1}
     env, ora = HipEnv(cfg, 1), O.OracleEnv(cfg, 1)
     for e in (env, ora):
         e.reset(np.array([3], np.uint64))

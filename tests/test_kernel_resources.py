@@ -3,6 +3,7 @@ market-waves per SIMD: 512 / 128 VGPRs; a change that pushes it over that, or in
 scratch traffic to every decimal operation - both cost more than any instruction they save (optimisation log)."""
 import os
 import re
+import shutil
 import subprocess
 import sys
 
@@ -11,9 +12,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
 def _kernels():
+    """metadata of every kernel + the disassembled body of every function of the built library"""
     import __graft_entry__ as G
     from kernel_resources import code_object
     so = G.build_hip()
@@ -21,6 +24,7 @@ def _kernels():
     try:
         open(co, "wb").write(code_object(so))
         notes = subprocess.run([READELF, "--notes", co], capture_output=True, text=True, check=True).stdout
+        asm = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
     finally:
         if os.path.exists(co):
             os.remove(co)
@@ -29,22 +33,36 @@ def _kernels():
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
         out[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
                      for k in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
-    return out
+    bodies, cur = {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            cur = bodies.setdefault(m.group(1), [])
+        elif cur is not None and line.strip():
+            cur.append(line)
+    return out, bodies
 
 
-@pytest.mark.skipif(not os.path.exists(READELF), reason="needs the ROCm LLVM tools")
+@pytest.mark.skipif(not (os.path.exists(READELF) and os.path.exists(OBJDUMP) and shutil.which(os.environ.get("HIPCC", "hipcc"))),
+                    reason="needs hipcc and the ROCm LLVM tools")
 def test_step_kernels_keep_four_waves_per_simd_and_spill_no_vgpr():
-    ks = _kernels()
+    ks, bodies = _kernels()
     steps = {n: v for n, v in ks.items() if "k_stepILb" in n}
-    assert len(steps) == 4, sorted(ks)                     # two book capacities x with / without info tensors
+    assert len(steps) == 4, sorted(ks)                     # two book tiles x with / without info tensors
     for n, v in steps.items():
+        # the metadata is the maximum over the call graph: it includes the out-of-line general step (slow_step), which is free to
+        # spill - what must hold is the occupancy (128 VGPRs = four waves per SIMD) and a HOT body without scratch traffic: at most
+        # the one save / restore pair the compiler puts around the call of slow_step, on the branch a BASELINE market never takes
         assert v["vgpr_count"] <= 128, (n, v)
-        assert v["vgpr_spill_count"] == 0, (n, v)
-        assert v["private_segment_fixed_size"] <= 128, (n, v)
+        body = bodies[n]
+        scratch = [i for i, l in enumerate(body) if "scratch_" in l]
+        assert len(scratch) <= 2, (n, len(scratch))
+        calls = [i for i, l in enumerate(body) if "s_swappc" in l]
+        for i in scratch:
+            assert min(abs(i - c) for c in calls) <= 4, (n, body[i])
     for cap in ("cap256", "cap512"):
-        plain = next(v for n, v in steps.items() if cap in n and "ILb0" in n)
-        info = next(v for n, v in steps.items() if cap in n and "ILb1" in n)
-        assert plain["sgpr_spill_count"] < info["sgpr_spill_count"], (cap, plain, info)   # the info-less instance carries no info pointers
+        slow = [n for n in bodies if cap in n and "slow_step" in n]
+        assert len(slow) == 2, slow                          # the general build exists once per info variant, out of line
     for n, v in ks.items():
         if "k_run_random" in n or "k_reset" in n:                 # (the episode kernel keeps more state live and spills a few VGPRs)
             assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 16, (n, v)

@@ -1,5 +1,6 @@
-"""CPU: the oracle's book is unbounded like the reference's OrderTree (ordertree.py:5-58) unless told to mirror the
-product's pool of CDA_BOOK_CAP orders; its random-agent runner replays include/cda_random_agents.h."""
+"""CPU: the oracle's book is unbounded like the reference's OrderTree (ordertree.py:5-58) - and like the product's, with its
+HBM tier - unless the env is built WITHOUT that tier (`book_spill = -1`), in which case it mirrors the product's tile pool
+of CDA_BOOK_CAP orders and its overflow flag; its random-agent runner replays include/cda_random_agents.h."""
 import ctypes as C
 
 import numpy as np
@@ -50,8 +51,7 @@ def test_run_random_equals_stepping_the_same_stream():
 def test_unbounded_book_equals_the_capped_one_while_no_overflow_is_flagged():
     n, a, steps = 16, 16, 300
     cfg = {"num_of_agents": a, "init_cash": 10 ** 8, "max_step": 10000, "is_render": False}
-    cap, unb = O.OracleEnv(cfg, n), O.OracleEnv(cfg, n)
-    unb.set_book_cap(0)
+    cap, unb = O.OracleEnv(dict(cfg, book_spill=-1), n), O.OracleEnv(cfg, n)
     seeds = np.arange(900, 900 + n, dtype=np.uint64)
     cap.reset(seeds); unb.reset(seeds)
     cap.run_random(0, steps, action_seed=5)
@@ -68,7 +68,7 @@ def test_unbounded_book_equals_the_capped_one_while_no_overflow_is_flagged():
 def test_capacity_follows_the_agent_count_or_the_config_key():
     for cfg, want in (({"num_of_agents": 8}, K.BOOK_CAP), ({"num_of_agents": 9}, K.BOOK_CAP_MAX), ({"num_of_agents": 4, "book_capacity": 512}, 512),
                       ({"num_of_agents": 16, "book_capacity": 256}, 256)):
-        e = O.OracleEnv(dict(cfg, init_cash=10 ** 12, is_render=False), 1)
+        e = O.OracleEnv(dict(cfg, init_cash=10 ** 12, is_render=False, book_spill=-1), 1)
         e.reset(np.array([1], np.uint64))
         for i in range(want + 5):
             e.place_order(0, 0, K.T_LIMIT, K.S_BID, 1, 5 + i)
@@ -81,12 +81,13 @@ def test_capacity_follows_the_agent_count_or_the_config_key():
 
 def test_unbounded_book_holds_more_than_the_product_pool():
     cfg = {"num_of_agents": 2, "init_cash": 10 ** 12, "max_step": 10000, "is_render": False}
-    cap, unb = O.OracleEnv(cfg, 1), O.OracleEnv(cfg, 1)
-    unb.set_book_cap(0)
+    cap, unb = O.OracleEnv(dict(cfg, book_spill=-1), 1), O.OracleEnv(cfg, 1)
     for e in (cap, unb):
         e.reset(np.array([1], np.uint64))
         for i in range(K.BOOK_CAP + 40):                       # distinct prices: every limit order rests as a new order
             e.place_order(0, 0, K.T_LIMIT, K.S_BID, 1, 5 + i)
     assert sum(cap.book_size(0)) == K.BOOK_CAP and cap.flags()[0] & K.FLAG_BOOK_OVERFLOW
     assert sum(unb.book_size(0)) == K.BOOK_CAP + 40 and unb.flags()[0] == 0 and unb.book_peak()[0] == K.BOOK_CAP + 40
+    bids, asks = unb.get_book(0)
+    assert bids.shape == (K.BOOK_CAP + 40, 5) and asks.shape == (0, 5) and (np.diff(bids[:, 0]) < 0).all()      # best price first
     cap.close(); unb.close()

@@ -21,18 +21,25 @@ def test_oracle_matches_reference_goldens(key):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["perm_s91", "perm8_s92"])
-def test_dict_key_order_is_a_pure_relabelling_of_agents(name):
-    """The reference hands its RNG draws out in the ITERATION order of the action dict (action_helper.py:145-172); the
-    build always works in ascending agent order.  For traces the reference produced from dicts in a fixed non-ascending
-    key order: replayed as recorded they must NOT match (the order matters), renamed so that agent k is the k-th key
-    the reference iterated they match bit for bit (it is only a renaming)."""
-    raw, ren = G.load(name, relabel=False), G.load(name)
-    assert list(raw["dict_order"]) != sorted(raw["dict_order"])
-    env = O.OracleEnv(ren["config"], n_markets=1)
-    assert G.run_group(env, [ren], state_every=1, trace_getter=lambda: env.trace) == raw["cat"].shape[0]
+@pytest.mark.parametrize("name", ["perm_s91", "perm8_s92", "permshuf_s93", "permshuf8_s94"])
+def test_dict_key_order_is_honoured(name):
+    """The reference hands its RNG draws out - and builds the arrival list it shuffles - in the ITERATION order of the action
+    dict (action_helper.py:164-170).  These traces were cut with dicts in a fixed non-ascending key order (perm*) or in a new
+    random order every step (permshuf*); `present` carries the order (0 = absent, else 1 + position in the dict).  They replay
+    bit for bit AS RECORDED (the parametrised test above does that too); with the order thrown away (a plain 0 / 1 mask) they
+    must NOT - the order matters; and a fixed order is a pure renaming of identical traders: restated with agent k = the k-th
+    key, in ascending order, the episode matches again."""
+    rec = G.load(name)
+    env = O.OracleEnv(rec["config"], n_markets=1)
+    assert G.run_group(env, [rec], state_every=1, trace_getter=lambda: env.trace) == rec["cat"].shape[0]
     env.close()
-    env = O.OracleEnv(raw["config"], n_markets=1)
+    flat = dict(rec, present=(rec["present"] != 0).astype(rec["present"].dtype))
+    env = O.OracleEnv(rec["config"], n_markets=1)
     with pytest.raises(AssertionError):
-        G.run_group(env, [raw], state_every=1)
+        G.run_group(env, [flat], state_every=1)
     env.close()
+    if "dict_order" in rec:
+        ren = G.load(name, relabel=True)
+        env = O.OracleEnv(ren["config"], n_markets=1)
+        assert G.run_group(env, [ren], state_every=1, trace_getter=lambda: env.trace) == rec["cat"].shape[0]
+        env.close()
