@@ -16,11 +16,27 @@ include/cda_random_agents.h keyed (2024, step, GLOBAL market index, agent) - the
 reference (train/model/model_handler.py:38-53).  The whole stream is generated on the device before the timed region
 (cda_random_actions), so every input is resident in HBM; the cpu_baseline leg replays the SAME stream.
 
-On one GPU the batch is stepped as `--groups` (default 4; 2 for runs shorter than 200 steps) contiguous market groups, each a chain of k_step launches on
-its own stream (cda_step_groups): markets never interact, so the batch-wide barrier of a single launch is not part of
-the reference's semantics, and a group's slowest market then overlaps the other group's work.  `roofline.kernel_ms` comes from
-HIP event pairs on the group streams themselves: on every chain, or (`--event-lanes one`, the default below 200 timed steps)
-on the first chain only - a timing event pair costs each stream ~7 us, which a 0.7-ms run notices.
+The batch is stepped as `--groups` (default 4; 2 for runs shorter than 200 steps) contiguous market groups, each a chain of
+k_step launches on its own stream (cda_step_groups): markets never interact, so the batch-wide barrier of a single launch is
+not part of the reference's semantics, and a group's slowest market then overlaps the other groups' work.
+
+What the line reports (one MI355X):
+  value / ms_per_step        the HEADLINE leg: step() WITH every info tensor of Info_Helper.set_info (the
+                             reference's step() always builds info) inside the timed region, group chains free-running
+                             (resident actions, nobody consumes the outputs between steps).  For K < 200 the K-step leg is
+                             run `timed_repeats.n` (5) times back to back, each bracketed by barrier + synchronize, and
+                             `value` is the MEDIAN leg (min / median / max in `timed_repeats`): a 0.8-ms window is
+                             otherwise a coin flip.
+  value_without_info         the same with no info tensors (a learner that asks for none)
+  value_one_launch           info on, the whole batch as ONE launch per step (--groups 1)
+  value_ordered_per_step     info on, group chains, every step ordered after the caller's stream and the caller's stream
+                             after it (CDAVecEnv.step's default: what a policy-in-the-loop consumer pays)
+  roofline                   HIP event pairs on the chains' own streams around the k_step launches of the headline leg;
+                             `traffic` / `issue_frac` only when a committed PMC pass of exactly this shape exists
+                             (profiles/pmc/<markets>x<agents>_info<0|1>_g<groups>.json)
+N > 1 (one rank per GPU): every chain also hands its markets' compact records (newest frame | reward | flags) to all ranks with
+its OWN all-gather on its OWN stream and communicator and rebuilds the learner-side arrays there (parallel.py); the timed
+region contains all of it.
 
 Prints ONE JSON line on rank 0; see the fields `roofline` and `cpu_baseline` in DESIGN.md.
 """
@@ -56,15 +72,15 @@ def parse():
                    "c4: 2048 x 8 per GPU (the per-GPU share of BASELINE configs[3], 16384 x 8 over 8 GPUs)")
     p.add_argument("--markets", type=int, default=None, help="markets per GPU (overrides --config)")
     p.add_argument("--agents", type=int, default=None)
-    p.add_argument("--groups", type=int, default=None, help="concurrent market groups per GPU (default 4, 2 below 200 timed steps; 1 with the all-gather)")
+    p.add_argument("--groups", type=int, default=None, help="concurrent market groups per GPU (default 4, 2 below 200 timed steps)")
     p.add_argument("--event-lanes", choices=["all", "one"], default=None,
                    help="HIP event pairs on every group stream, or on the first one only (default: all, one below 200 timed steps)")
-    p.add_argument("--info", action="store_true", help="headline run WITH the info tensors (a14); otherwise info-on is timed as a second leg")
-    p.add_argument("--no-info-leg", action="store_true", help="skip the second (info tensors on) timed leg")
-    p.add_argument("--no-gather", action="store_true", help="N>1: skip the obs/reward all-gather")
-    p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each step's all-gather before the next launch")
+    p.add_argument("--repeats", type=int, default=None, help="timed K-step legs run back to back (default 5 below 200 timed steps, else 1); value = the median leg")
+    p.add_argument("--no-info", action="store_true", help="headline leg WITHOUT the info tensors (then value_with_info is the extra)")
+    p.add_argument("--no-extra-legs", action="store_true", help="skip value_without_info / value_one_launch / value_ordered_per_step")
+    p.add_argument("--no-gather", action="store_true", help="N>1: skip the hand-back (records all-gather + rebuild)")
     p.add_argument("--force-gather", action="store_true",
-                   help="run the N>1 code path (process group + all-gather) even with one rank; diagnostics")
+                   help="run the N>1 code path (process group, per-chain all-gather, rebuild) even with one rank; diagnostics")
     p.add_argument("--fused", type=int, default=0, metavar="T",
                    help="not the headline run: T steps per launch through cda_run_random (random agents sampled in the kernel, "
                         "market state resident in LDS across steps, no per-step barrier between markets)")
@@ -82,6 +98,25 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def physical_cores():
+    try:
+        ids = set()
+        with open("/proc/cpuinfo") as fh:
+            phys = core = None
+            for ln in fh:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        ids.add((phys, core))
+                    phys = core = None
+        return len(ids) or "?"
+    except OSError:
+        return "?"
 
 
 def cpu_baseline(markets, agents, budget_s, max_step, first_market):
@@ -126,9 +161,22 @@ def cpu_baseline(markets, agents, budget_s, max_step, first_market):
     steps1 = int(max(8, min(max_step - 1, 0.2 * budget_s / max(dt1 / 4, 1e-6))))
     dt1, _ = timed(n1, 1, steps1)
     value1 = n1 * agents * steps1 / dt1
-    return {"value": value, "unit": "agent-steps/s", "cores": used, "kind": "port", "value_1thread": value1, "cpu_model": cpu_model(),
+    return {"value": value, "unit": "agent-steps/s", "cores": used, "cores_note": f"{used} hardware threads ({physical_cores()} physical cores, SMT)",
+            "kind": "port", "value_1thread": value1, "cpu_model": cpu_model(),
             "sample": f"{n} markets x {agents} agents x steps 0..{steps - 1} of the GPU leg's action stream ({dt:.1f} s wall), C oracle, "
                       f"{used} threads, obs+reward outputs only; 1 thread: {n1} markets x {steps1} steps ({dt1:.1f} s)"}
+
+
+def pmc_entry(n, a, info, groups):
+    """A committed PMC pass (tools/profile_gpu.sh -> profiles/pmc/...) of EXACTLY this shape, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc", f"{n}x{a}_info{int(bool(info))}_g{groups}.json")) as fh:
+            pmc = json.load(fh)
+        if (pmc.get("markets"), pmc.get("agents"), bool(pmc.get("info")), pmc.get("groups")) == (n, a, bool(info), groups):
+            return pmc
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def main():
@@ -141,6 +189,8 @@ def main():
             port = sk.getsockname()[1]
         os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    import statistics
+
     import torch
     import torch.distributed as dist
 
@@ -167,6 +217,7 @@ def main():
     torch.cuda.set_device(device)
 
     from gym_continuousdoubleauction_amd import CDAVecEnv
+    from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv, handback_stride
 
     N, A = CONFIGS[args.config]
     N = args.markets if args.markets is not None else N
@@ -175,32 +226,51 @@ def main():
     if args.fused and (args.steps % args.fused or args.warmup % args.fused):
         raise SystemExit("--fused T needs --steps and --warmup to be multiples of T")
     gather = use_dist and not args.no_gather and not args.fused
-    CAL = 32 if gather and not args.no_overlap else 0             # untimed steps of each all-gather schedule (calibration)
-    total_steps = W + 2 * CAL + K
+    R = max(1, args.repeats if args.repeats is not None else (5 if K < 200 and not args.fused else 1))
+    total_steps = W + R * K
     max_step = max(4096, total_steps + 1)                          # no truncation inside the run
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
-    # default number of group chains: 4 pays once the chains are long (433 M vs 417 M at 1000 steps), 2 when the whole timed
-    # region is a few dozen steps and the staggered start / drain of four chains is a visible share of it (384 M vs 372 M at 20)
+    # default number of group chains: 4 pays once the chains are long, 2 when the whole timed region is a few dozen steps and the
+    # staggered start / drain of four chains is a visible share of it (profiles/r02)
     event_lanes = args.event_lanes or ("all" if K >= 200 else "one")
-    groups = args.groups if args.groups is not None else (1 if (gather or args.fused) else (4 if K >= 200 else 2))
+    groups = args.groups if args.groups is not None else (1 if args.fused else (4 if K >= 200 else 2))
     groups = max(1, min(groups, N))
-    if gather and groups != 1:
-        raise SystemExit("the all-gather schedule steps the shard as one launch: use --groups 1")
     first_market = rank * N                           # global market index -> seed and action key, independent of the GPU count
     seeds = (SEED_BASE + first_market + torch.arange(N, dtype=torch.int64)).numpy().astype("uint64")
+    headline_info = not args.no_info
 
-    def make_env(with_info):
-        # N > 1: the per-step outputs (obs | reward | flags: one contiguous slab written by k_step itself) are all-gathered
-        # over xGMI with ONE collective per step and no packing pass; the env rotates two slabs, so the gather of step t
-        # runs underneath the kernel of step t+1.
-        e = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=with_info, out_buffers=2 if gather else 1, groups=groups)
-        e.reset(seed=seeds)
-        return e
+    class Leg:
+        """One measured env: `groups` chains, info on / off, optionally the N > 1 hand-back, free-running or ordered per step."""
+
+        def __init__(self, with_info, n_groups, handback=False, ordered=False):
+            self.with_info, self.ordered, self.handback = with_info, ordered, handback
+            if handback:
+                self.sh = ShardedVecEnv(cfg, world * N, device=str(device), groups=n_groups, handback=True,
+                                        env_factory=lambda c, n, d, g: CDAVecEnv(c, n_markets=n, device=d, with_info=with_info, groups=g, handback=True))
+                self.env = self.sh.env
+                self.sh.reset(seed_base=SEED_BASE)
+            else:
+                self.sh = None
+                self.env = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=with_info, groups=n_groups)
+                self.env.reset(seed=seeds)
+
+        def step(self, t):
+            i = t % period
+            if args.fused:
+                if t % args.fused == 0:
+                    self.env.run_random(args.fused, action_seed=ACTION_SEED, market_index_base=first_market)
+            elif self.sh is not None:
+                self.sh.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i], pipelined=True)
+            else:
+                self.env.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i], pipelined=not self.ordered)
+
+        def close(self):
+            (self.sh or self.env).close()
 
     # Clock primer: an idle MI355X sits in a low-power state and needs tens of milliseconds of work before its engine clock
     # is up; the driver's default run times 20 steps (~1 ms) right after start-up, which would measure the ramp, not the
-    # kernel.  A SCRATCH env (not the measured one) is stepped for ~PRIMER_MS first; the measured env then does exactly
-    # W untimed + K timed steps from its own reset.
+    # kernel.  A SCRATCH env (not a measured one) is stepped for ~PRIMER_MS first; every measured env then does exactly
+    # W untimed + R x K timed steps from its own reset.
     primer_ms = float(os.environ.get("CDA_BENCH_PRIMER_MS", "40"))
     primer_steps = 0
     if primer_ms > 0 and not args.fused:
@@ -216,216 +286,140 @@ def main():
             primer_steps += 64
         scratch.close()
         del pa
-    env = make_env(args.info)
     # The action stream of the whole run, resident in HBM (20 B per agent-step: 350 MB for the default 1064 steps of
     # 4096 x 4); beyond MAX_RESIDENT steps the run cycles through the first MAX_RESIDENT (reported in `data`).
     MAX_RESIDENT = 4096
     period = min(total_steps, MAX_RESIDENT)
-    acts = None if args.fused else env.random_actions_device(0, period, action_seed=ACTION_SEED, market_index_base=first_market)
-    if gather:
-        gathered = [torch.empty(world * env.slab_layout["bytes"], dtype=torch.uint8, device=device) for _ in range(2)]
-    # N > 1, overlapped: two streams alternate.  Stream X runs step t and then its all-gather (a synchronous collective
-    # stays on the caller's stream); stream Y runs step t+1 as soon as ONE event says step t is done (the market state
-    # dependency), i.e. underneath gather t.  Step t+2 is back on X behind gather t, which is also what protects the
-    # slab gather t reads.  One cross-stream edge per step (~12 us on this platform, tools/host_overhead.py) instead of
-    # the two that an async_op collective on RCCL's own stream costs.
-    overlap = gather and not args.no_overlap
-    if overlap:
-        streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
-        step_done = [torch.cuda.Event(), torch.cuda.Event()]
-    timed = {}                                                 # global step index -> (start, end) timing events
+    acts = None
+    if not args.fused:
+        gen = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=False)
+        acts = gen.random_actions_device(0, period, action_seed=ACTION_SEED, market_index_base=first_market)
+        torch.cuda.synchronize()
+        gen.close()
 
-    def one_step(e, t):
-        i = t % period
-        if args.fused:
-            if t % args.fused == 0:
-                e.run_random(args.fused, action_seed=ACTION_SEED, market_index_base=first_market)
-            return
-        if not overlap:
-            ev = timed.get(t)
-            if ev:
-                ev[0].record()
-            e.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i], pipelined=True)
-            if ev:
-                ev[1].record()
-            if gather:
-                dist.all_gather_into_tensor(gathered[t & 1], e.out_slab)
-            return
-        cur = streams[t & 1]
-        with torch.cuda.stream(cur):
-            if t > 0:
-                cur.wait_event(step_done[(t - 1) & 1])
-            ev = timed.get(t)
-            if ev:
-                ev[0].record(cur)
-            e.step(acts[0][i], acts[1][i], acts[2][i], acts[3][i], acts[4][i], pipelined=True)
-            if ev:
-                ev[1].record(cur)
-            step_done[t & 1].record(cur)
-            dist.all_gather_into_tensor(gathered[t & 1], e.out_slab)
-
-    def agree(flag):
-        """N > 1: every rank must take the same branch (a rank-local decision would deadlock the next collective)."""
-        if not use_dist:
-            return flag
-        v = torch.tensor([1.0 if flag else 0.0], device=device)
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
-        return bool(v.item() > 0)
-
-    torch.cuda.synchronize()                                   # reset and the action stream are complete before any side stream starts
-    failed = False
-    try:
+    def run_leg(leg, with_events):
+        """W untimed steps, then R legs of EXACTLY K steps, each bracketed by barrier + synchronize on both sides (max over ranks).
+        Returns ([elapsed s per leg], [kernel ms per launch per timed stream])."""
+        e = leg.env
         for t in range(W):
-            one_step(env, t)
-        torch.cuda.synchronize()
-    except Exception as ex:  # noqa: BLE001 - the overlapped schedule could not be exercised on a multi-GPU node before the driver's run
-        if not overlap:
-            raise
-        print(f"[bench] rank {rank}: overlapped all-gather failed in warm-up ({ex})", file=sys.stderr)
-        failed = True
-    if overlap and agree(failed):
-        # a collective that raised leaves the process group unusable: rebuild it, then every rank takes the serial schedule
-        print("[bench] falling back to the serial all-gather schedule on a fresh process group", file=sys.stderr)
-        overlap, CAL = False, 0
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=PG_TIMEOUT)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=PG_TIMEOUT)
-        env.close()
-        env = make_env(args.info)
-        torch.cuda.synchronize()
-        for t in range(W):
-            one_step(env, t)
-        torch.cuda.synchronize()
-    # Which all-gather schedule is faster depends on what the transfer costs on THIS node's links against ~12 us of stream
-    # dependency per step; nothing could measure that before the driver's multi-GPU run, so both are timed for a few
-    # (untimed) steps and every rank adopts the one whose slowest rank is faster.
-    T0 = W                                                     # global index of the first timed step
-    schedule_note, schedule_us = None, None
-    if gather and overlap:
-        took = []
-        for mode in (False, True):
-            overlap = mode
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-            c0 = time.perf_counter()
-            for t in range(CAL):
-                one_step(env, T0 + t)
-            torch.cuda.synchronize()
-            took.append(time.perf_counter() - c0)
-            T0 += CAL
-        tk = torch.tensor(took, dtype=torch.float64, device=device)
-        dist.all_reduce(tk, op=dist.ReduceOp.MAX)
-        took = [float(x) for x in tk.tolist()]
-        overlap = took[1] <= took[0]
-        schedule_us = {"serial_us_per_step": took[0] / CAL * 1e6, "overlapped_us_per_step": took[1] / CAL * 1e6}
-        schedule_note = f"calibrated over {CAL} steps each: serial {took[0] / CAL * 1e6:.1f} us/step, overlapped {took[1] / CAL * 1e6:.1f} us/step"
-
-    def timed_leg(e, first_t, with_events):
-        """K steps of env `e` bracketed by barrier + synchronize; returns (elapsed s, [per-launch kernel ms per stream])."""
-        if use_dist:
-            dist.barrier()
-        e.sync()                                                   # device-wide: the group streams are idle too, no stream edges needed
-        # HIP events on the stream(s) the kernel is launched on.  groups == 1, N == 1: one pair on torch's current stream
-        # (== the stream handed to cda_step) brackets the K back-to-back launches, kernel_ms = span / K.  groups > 1: one
-        # pair per group stream, each bracketing that group's K launches.  N > 1 with the all-gather: collectives and
-        # stream dependencies sit between launches, so single launches get their own pair - every EV_STRIDE-th one only,
-        # a timing event pair costs ~7 us of stream time (tools/host_overhead.py).
-        per_launch = gather
+            leg.step(t)
+        lanes = (e.group_streams if e.groups > 1 else [torch.cuda.current_stream(device)])
+        if event_lanes == "one":
+            lanes = lanes[:1]
+        # HIP events on the stream(s) the kernel is launched on.  Without the hand-back one pair per stream brackets that chain's K
+        # back-to-back launches (kernel_ms = span / K).  With it, collectives and the rebuild sit between a chain's launches, so
+        # single launches of the first chain get their own pair - every EV_STRIDE-th step only, a pair costs ~7 us of stream time.
         EV_STRIDE = 16
-        evs = []
-        if with_events and per_launch:
-            timed.update({first_t + t: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for t in range(0, K, EV_STRIDE)})
-        elif with_events:
-            lanes = e.group_streams if e.groups > 1 else [torch.cuda.current_stream(device)]
-            if event_lanes == "one":
-                lanes = lanes[:1]
-            evs = [(s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in lanes]
-        t0 = time.perf_counter()
-        for s, a, _ in evs:
-            a.record(s)
-        for t in range(K):
-            one_step(e, first_t + t)
-        for s, _, b in evs:
-            b.record(s)
-        e.sync()                                                   # barrier + synchronize on both sides of the K steps (every stream of the device)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        if not with_events:
-            return elapsed, []
-        if per_launch:
-            return elapsed, [sum(a.elapsed_time(b) for a, b in timed.values()) / len(timed)]
-        return elapsed, [a.elapsed_time(b) / K for _, a, b in evs]
+        took, kms = [], []
+        for r in range(R):
+            base = W + r * K
+            spans, singles = [], []
+            if use_dist:
+                dist.barrier()
+            e.sync()                                               # device-wide: every stream is idle, no stream edges needed
+            if with_events and not leg.handback:
+                spans = [(s, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in lanes]
+            t0 = time.perf_counter()
+            for s, a, _ in spans:
+                a.record(s)
+            for t in range(K):
+                if with_events and leg.handback and t % EV_STRIDE == 0:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(lanes[0])
+                    e.step(acts[0][(base + t) % period], acts[1][(base + t) % period], acts[2][(base + t) % period], acts[3][(base + t) % period],
+                           acts[4][(base + t) % period], pipelined=True)
+                    b.record(lanes[0])
+                    leg.sh.handback()
+                    singles.append((a, b))
+                else:
+                    leg.step(base + t)
+            for s, _, b in spans:
+                b.record(s)
+            e.sync()                                               # barrier + synchronize on both sides of the K steps (every stream of the device)
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            if use_dist:
+                tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                elapsed = float(tt.item())
+            took.append(elapsed)
+            if spans:
+                kms.append([a.elapsed_time(b) / K for _, a, b in spans])
+            elif singles:
+                kms.append([sum(a.elapsed_time(b) for a, b in singles) / len(singles)])
+        return took, kms
 
-    elapsed, kernel_ms_lanes = timed_leg(env, T0, True)
-    flags = env.flags()
-    n_flagged = int((flags != 0).sum().item())
+    torch.cuda.synchronize()
+    head = Leg(headline_info, groups, handback=gather)
+    took, kms = run_leg(head, True)
+    env = head.env
+    n_flagged = int((env.flags() != 0).sum().item())
     peak_orders = int(env.book_peak().max().item())
+    tile, spill = env.book_capacity, env.book_spill
+    head_groups, head_ranges = env.groups, list(env.group_ranges)
+    head.close()
 
-    # second leg, one rank only: the same K steps with every info tensor of Info_Helper.set_info (row a14) emitted inside the
-    # timed region - the reference's step() always builds info - or, with --info, the info-less leg.
-    other = None
-    if world == 1 and not args.no_info_leg and not args.fused and not gather:
-        env2 = make_env(not args.info)
-        for t in range(W):
-            one_step(env2, t)
-        e2, _ = timed_leg(env2, W, False)
-        other = {"elapsed": e2, "flagged": int((env2.flags() != 0).sum().item())}
-        env2.close()
+    extras = {}
+    if world == 1 and not args.no_extra_legs and not args.fused and not gather:
+        def extra(name, **kw):
+            leg = Leg(**kw)
+            tk, _ = run_leg(leg, False)
+            extras[name] = {"elapsed": statistics.median(tk), "flagged": int((leg.env.flags() != 0).sum().item())}
+            leg.close()
+        extra("with_info" if not headline_info else "without_info", with_info=not headline_info, n_groups=groups)
+        if groups != 1:
+            extra("one_launch", with_info=headline_info, n_groups=1)
+            extra("ordered_per_step", with_info=headline_info, n_groups=groups, ordered=True)
 
     if rank == 0:
         total_agent_steps = float(world) * N * A * K
+        elapsed = statistics.median(took)
         value = total_agent_steps / elapsed
         B = ALG_BYTES_CONST + ALG_BYTES_PER_AGENT * A                         # algorithmic bytes per market-step
-        markets_per_launch = [c for _, c in env.group_ranges] if env.groups > 1 else [N]
-        if len(kernel_ms_lanes) == 1 and len(markets_per_launch) > 1:          # one chain timed: the others run the same launches
-            kernel_ms_lanes = kernel_ms_lanes * len(markets_per_launch)
-        n_lanes = max(1, len(kernel_ms_lanes))
+        markets_per_launch = [c for _, c in head_ranges] if head_groups > 1 else [N]
+        lanes_ms = [statistics.mean(x) for x in zip(*kms)] if kms else []     # per timed stream, averaged over the repeats
+        if len(lanes_ms) == 1 and len(markets_per_launch) > 1:                 # one chain timed: the others run the same launches
+            lanes_ms = lanes_ms * len(markets_per_launch)
+        n_lanes = max(1, len(lanes_ms))
         # `achieved`: algorithmic bytes of one launch / that launch's duration.  With G concurrent group chains G launches are
         # in flight at any time; the aggregate rate of the device is the sum over the concurrent launches.
-        per_launch_gbps = [B * m / (ms * 1e-3) / 1e9 for m, ms in zip(markets_per_launch, kernel_ms_lanes)]
+        per_launch_gbps = [B * m / (ms * 1e-3) / 1e9 for m, ms in zip(markets_per_launch, lanes_ms)]
         achieved = sum(per_launch_gbps)
-        kernel_ms = sum(kernel_ms_lanes) / n_lanes
-        # HBM bytes and issued wave-instructions per market-step from the PMC passes (rocprofv3 --pmc, each counter group in
-        # its own run; FETCH_SIZE / WRITE_SIZE calibrated on known byte counts by tools/profile_gpu.sh): committed
-        # measurements of THIS workload and build, not live - reported only for the shape they were taken on.
+        kernel_ms = sum(lanes_ms) / n_lanes if lanes_ms else None
+        # HBM bytes and issued wave-instructions per market-step from committed PMC passes of EXACTLY this shape (markets, agents,
+        # info, chains) - rocprofv3 --pmc, each counter group in its own run, FETCH_SIZE / WRITE_SIZE calibrated on known byte
+        # counts (tools/profile_gpu.sh); null otherwise.
         traffic = traffic_src = issue_frac = valu_busy = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
-                pmc = json.load(fh)
-            if (pmc.get("markets"), pmc.get("agents"), bool(pmc.get("info"))) == (N, A, bool(args.info)) and not args.fused and not gather:
-                traffic = pmc["hbm_bytes_per_market_step"] * markets_per_launch[0]
-                traffic_src = (f"profiles/pmc_latest.json (rocprofv3 --pmc, calibrated; per market-step figure of a {pmc.get('groups')}-chain run "
-                               "x markets of one launch)")
-                cycles = elapsed / K * GPU_CLOCK_GHZ * 1e9                     # device cycles per step of the whole batch
-                issue_frac = pmc["wave_insts_per_market_step"] * N / (N_SIMD * cycles)
-                valu_busy = VALU_CYCLES * pmc["valu_insts_per_market_step"] * N / (N_SIMD * cycles)
-        except Exception:  # noqa: BLE001
-            pass
+        pmc = None if (args.fused or gather) else pmc_entry(N, A, headline_info, head_groups)
+        if pmc:
+            traffic = pmc["hbm_bytes_per_market_step"] * markets_per_launch[0]
+            traffic_src = f"profiles/pmc/{N}x{A}_info{int(headline_info)}_g{head_groups}.json (rocprofv3 --pmc, calibrated; this build, this shape)"
+            cycles = elapsed / K * GPU_CLOCK_GHZ * 1e9                         # device cycles per step of the whole batch
+            issue_frac = pmc["wave_insts_per_market_step"] * N / (N_SIMD * cycles)
+            valu_busy = VALU_CYCLES * pmc["valu_insts_per_market_step"] * N / (N_SIMD * cycles)
+        shape = ("BASELINE configs[2]" if (N, A) == CONFIGS["c3"] else "per-GPU share of BASELINE configs[3]" if (N, A) == CONFIGS["c4"] else "custom shape")
+        how = "FUSED episodes (cda_run_random)" if args.fused else (
+            f"step() {'with every info tensor (row a14)' if headline_info else 'without info tensors'}, {head_groups} free-running group chain(s)"
+            + (", per-chain hand-back of the new frame | reward | flags to every rank" if gather else ""))
         out = {
-            "metric": "agent-steps/sec (whole node), 4 agents x N parallel markets",
+            "metric": f"agent-steps/sec (whole node), 4 agents x N parallel markets; {how}",
             "value": value, "unit": "agent-steps/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+dec28+f64",
             "data": "synthetic" + ("" if total_steps <= MAX_RESIDENT or args.fused else f" (action stream cycles with period {MAX_RESIDENT} steps)"),
-            "config": {"workload": f"{N} markets x {A} random agents per GPU ({'BASELINE configs[2]' if (N, A) == CONFIGS['c3'] else 'per-GPU share of BASELINE configs[3]' if (N, A) == CONFIGS['c4'] else 'custom shape'}); "
-                                   f"book pool of 256 resting orders per market shared by both sides (= 128 per side on average; "
-                                   f"the reference is unbounded; most held by any market in this run: {peak_orders}); global {world * N} markets"
+            "timed_repeats": {"n": R, "ms_per_step": [x / K * 1e3 for x in took], "min": min(took) / K * 1e3, "median": elapsed / K * 1e3,
+                              "max": max(took) / K * 1e3, "value_is": "the median leg" if R > 1 else "the one leg"},
+            "config": {"workload": f"{N} markets x {A} random agents per GPU ({shape}); unbounded book: LDS tile of {tile} resting orders per market "
+                                   f"(the top of the book, both sides) + HBM spill ring of {spill} per side (the reference's OrderTree is unbounded; "
+                                   f"most held by any market in this run: {peak_orders}); global {world * N} markets"
                                    + (f"; FUSED: {args.fused} steps per launch (cda_run_random)" if args.fused else ""),
-                       "markets_per_gpu": N, "agents": A, "info_outputs": bool(args.info), "groups": env.groups,
+                       "markets_per_gpu": N, "agents": A, "info_outputs": bool(headline_info), "groups": head_groups,
                        "actions": f"cda_random_actions(seed {ACTION_SEED}, step, global market, agent), resident in HBM",
-                       "clock_primer": f"{primer_steps} untimed steps on a scratch env before the measured env's reset",
-                       "gather_schedule": schedule_note, "gather_calibration": schedule_us,
-                       "collective": ("all_gather(obs|reward|flags slab), " + ("overlapped with the next step on alternating streams" if overlap else "serial")) if gather else "none",
+                       "clock_primer": f"{primer_steps} untimed steps on a scratch env before the measured envs' resets",
+                       "collective": (f"{head_groups} all_gather_into_tensor per step (one per chain, own stream + communicator) of {handback_stride(A)}-B records "
+                                      f"(newest frame | reward | flags), rebuilt into [global markets, ...] arrays by cda_handback_unpack") if gather else "none",
                        "flagged_markets": n_flagged, "peak_resting_orders": peak_orders},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -434,19 +428,16 @@ def main():
                          "algorithmic_bytes_per_launch": B * markets_per_launch[0], "achieved_per_launch": per_launch_gbps[0] if per_launch_gbps else None,
                          "issue_frac": issue_frac, "valu_busy_frac": valu_busy},
         }
-        if other is not None:
-            v2 = total_agent_steps / other["elapsed"]
-            key = "without_info" if args.info else "with_info"
-            out[f"value_{key}"] = v2
-            out[f"ms_per_step_{key}"] = other["elapsed"] / K * 1e3
-            out["config"][f"flagged_markets_{key}"] = other["flagged"]
+        for name, ex in extras.items():
+            out[f"value_{name}"] = total_agent_steps / ex["elapsed"]
+            out[f"ms_per_step_{name}"] = ex["elapsed"] / K * 1e3
+            out["config"][f"flagged_markets_{name}"] = ex["flagged"]
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, A, args.cpu_seconds, max_step, first_market)
             except Exception as ex:  # noqa: BLE001 - the baseline is a reported extra, never the measured path
                 out["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(out))
-    env.close()
     if use_dist:
         dist.destroy_process_group()
 

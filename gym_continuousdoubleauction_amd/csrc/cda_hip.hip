@@ -124,6 +124,7 @@ struct StepArgs {
     uint8_t* done_out;                  // auto_reset only: terminated | truncated, the mask of the k_reset launch that follows
     cda_info_ptrs info; int has_info;
     int first_market, end_market;       // this launch steps the markets [first_market, end_market); every array argument is the full [N, ...] one
+    uint8_t* handback; int32_t handback_stride;   // cda_set_handback: compact per-market records of what is new this step (NULL = off)
     unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,40] cycle stamps
     int dbg_skip;                       // debug builds only (CDA_DEBUG_SKIP): phases to leave out (tools/fixed_cost_probe.py); results are then wrong
 };
@@ -280,6 +281,30 @@ __global__ void k_random_actions(uint64_t seed, uint64_t market_base, int step0,
         cda_random_action(seed, market_base + (uint64_t)mk, (uint32_t)(step0 + (int)t), (uint32_t)a, &category[ix], &size_mean[ix], &size_sigma[ix], &price[ix], &price_offset[ix]);
     }
 }
+// receiving side of the hand-back: one wave per record.  Lane l < 42 holds column l of every frame of its row in registers, so
+// the shift by one frame has no read-after-write hazard; restarted rows are filled with the new frame.
+__global__ __launch_bounds__(256) void k_handback_unpack(const uint8_t* rec, int n_seg, int seg_records, long long seg_row_stride, long long row0, int A, int H, int stride,
+                                                          float* obs_full, double* reward_full, uint8_t* term_full, uint8_t* trunc_full) {
+    const long long r = (long long)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = (int)(threadIdx.x & 63);
+    if (r >= (long long)n_seg * seg_records) return;
+    const uint8_t* p = rec + (size_t)r * (size_t)stride;
+    const size_t row = (size_t)(row0 + (r / seg_records) * seg_row_stride + (r % seg_records));
+    const uint8_t* fl = p + CDA_SNAPSHOT_DIM * 4 + A * 8;
+    const bool restarted = fl[2] != 0;
+    if (lane < CDA_SNAPSHOT_DIM) {
+        float* o = obs_full + row * (size_t)(H * CDA_SNAPSHOT_DIM);
+        const float nf = reinterpret_cast<const float*>(p)[lane];
+        float keep[CDA_MAX_HIST];
+        #pragma unroll
+        for (int h = 1; h < CDA_MAX_HIST; h++) keep[h] = h < H ? o[h * CDA_SNAPSHOT_DIM + lane] : 0.0f;
+        #pragma unroll
+        for (int h = 1; h < CDA_MAX_HIST; h++) if (h < H) o[(h - 1) * CDA_SNAPSHOT_DIM + lane] = restarted ? nf : keep[h];
+        o[(H - 1) * CDA_SNAPSHOT_DIM + lane] = nf;
+    }
+    if (lane < A) reward_full[row * (size_t)A + (size_t)lane] = reinterpret_cast<const double*>(p + CDA_SNAPSHOT_DIM * 4)[lane];
+    if (lane == 0) { term_full[row] = fl[0]; trunc_full[row] = fl[1]; }
+}
 __global__ void k_book_peak(const uint8_t* arena, Params P, int32_t* out) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i < P.n_markets) out[i] = (int32_t)((const uint32_t*)(arena + (size_t)i * (size_t)P.lay.stride))[H_PEAK_ORDERS];
@@ -384,7 +409,9 @@ struct cda_env {
     uint8_t* arena;
     size_t arena_bytes;
     uint8_t* done_buf;       // auto_reset: u8[N] behind the market records - terminated | truncated of the last step
+    uint8_t* handback;       // cda_set_handback: caller-owned [N, handback_stride(A)] bytes, or NULL
 };
+static inline int32_t handback_stride_of(int32_t num_agents) { return (CDA_SNAPSHOT_DIM * 4 + num_agents * 8 + 3 + 7) & ~7; }
 
 static thread_local char g_err[256] = "";
 static int g_dbg_skip = 0;                          // debug (CDA_DEBUG_SKIP builds)
@@ -512,7 +539,7 @@ int cda_reset_range(cda_env* e, int32_t first_market, int32_t n_markets, const u
     if (!e || !range_ok(e, first_market, n_markets)) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     LAUNCH_CAP(e, k_reset, grid_for(n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out,
-                       (int)first_market, (int)(first_market + n_markets));
+                       (int)first_market, (int)(first_market + n_markets), e->handback, handback_stride_of(e->P.cfg.num_agents), 0);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -536,7 +563,8 @@ static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0,
     HIPCHK(hipGetLastError());
     if (e->P.cfg.auto_reset) {            // same stream: every market-wave of it exits at once unless its episode just ended
         LAUNCH_CAP(e, k_reset, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), stream, e->arena, e->P,
-                           (const uint64_t*)NULL, (const uint8_t*)e->done_buf, S0.obs_out, (int)first, (int)(first + n));
+                           (const uint64_t*)NULL, (const uint8_t*)e->done_buf, S0.obs_out, (int)first, (int)(first + n),
+                           e->handback, handback_stride_of(e->P.cfg.num_agents), 1);
         HIPCHK(hipGetLastError());
     }
     return CDA_OK;
@@ -552,6 +580,7 @@ static int fill_step_args(cda_env* e, StepArgs& S, const int32_t* category, cons
     S.phase_cycles = g_phase_cycles;
     S.dbg_skip = g_dbg_skip;
     S.done_out = e->P.cfg.auto_reset ? e->done_buf : NULL;
+    S.handback = e->handback; S.handback_stride = handback_stride_of(e->P.cfg.num_agents);
     S.first_market = 0; S.end_market = e->P.n_markets;
     return CDA_OK;
 }
@@ -639,6 +668,32 @@ int cda_random_actions(uint64_t action_seed, uint64_t market_index_base, int32_t
     const size_t blocks = (total + 255) / 256;
     hipLaunchKernelGGL(k_random_actions, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream, action_seed, market_index_base,
                        (int)step0, (int)n_steps, (int)n_markets, (int)num_agents, category, size_mean, size_sigma, price, price_offset);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+
+int32_t cda_handback_stride(int32_t num_agents) { return num_agents >= 1 && num_agents <= CDA_MAX_AGENTS ? handback_stride_of(num_agents) : 0; }
+int cda_set_handback(cda_env* e, void* records_dev) {
+    if (!e) return CDA_ERR_INVALID;
+    e->handback = (uint8_t*)records_dev;
+    return CDA_OK;
+}
+int cda_handback_unpack(const void* records_dev, int32_t n_segments, int32_t seg_records, int64_t seg_row_stride, int64_t row0,
+                        int32_t num_agents, int32_t n_hist,
+                        float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full, void* stream) {
+    if (!records_dev || n_segments < 0 || seg_records < 0 || seg_row_stride < 0 || row0 < 0) return CDA_ERR_INVALID;
+    if (num_agents < 1 || num_agents > CDA_MAX_AGENTS || n_hist < 1 || n_hist > CDA_MAX_HIST) return CDA_ERR_INVALID;
+    if (!obs_full || !reward_full || !terminated_full || !truncated_full) return CDA_ERR_INVALID;
+    const int64_t count = (int64_t)n_segments * seg_records;
+    if (count == 0) return CDA_OK;
+    if (count > (int64_t)1 << 30) return CDA_ERR_INVALID;
+    int dev = 0;                                          // the launch goes to the device that owns the destination (a C caller may sit on another one)
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, obs_full) == hipSuccess) dev = at.device;
+    HIPCHK(hipSetDevice(dev));
+    hipLaunchKernelGGL(k_handback_unpack, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)records_dev, (int)n_segments,
+                       (int)seg_records, (long long)seg_row_stride, (long long)row0, (int)num_agents, (int)n_hist, (int)handback_stride_of(num_agents),
+                       obs_full, reward_full, terminated_full, truncated_full);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }

@@ -4,12 +4,18 @@ RCCL on ROCm, "gloo" in the CPU tests).
 Markets are fully independent (each owns its book, accounts and RNG - SURVEY §8e), so the simulation
 needs NO collective: rank r steps the contiguous block [r*N/G, (r+1)*N/G).  Seeds derive from the GLOBAL
 market index, so results do not depend on the GPU count.  The only exchange is the hand-back of the
-per-market outputs to a central learner: ONE all-gather per step of the env's output slab
-(obs f32[n,obs_dim] | reward f64[n,A] | terminated u8[n] | truncated u8[n], the bytes `k_step` itself
-wrote - no packing pass).  On the fully connected xGMI node each rank pushes its shard directly to its 7
-peers, so the gather is per-link bound (2.9 MB per rank at 4096 x 4: ~50 us at ~55 GB/s per link); it
-is issued asynchronously (`gather_async`) and overlaps the NEXT step's kernel, whose outputs go to the
-other slab of a double-buffered env.  `gather()` is the simple synchronous packed variant for any env.
+per-market outputs to a central learner, and of those only what is NEW each step travels: of the n_hist x 42
+observation that is the newest frame, so a market hands back ONE compact record - f32 frame[42] | f64 reward[A] |
+terminated | truncated | restarted, 208 B at 4 agents instead of the 706 B of observation + reward + flags
+(`cda_set_handback`, include/cda.h) - and the receiving side rebuilds the stacked observation (shift by one frame,
+append; `cda_handback_unpack`, one launch).
+
+`ShardedVecEnv` steps its shard as the env's group chains (CDAVecEnv(groups=G): G independent chains of k_step launches
+on G streams) and every chain carries ITS OWN collective: on stream g, k_step(group g, t) -> all_gather(records of group g)
+-> unpack -> k_step(group g, t+1) ..., with one communicator per chain, so no dependency edge ever crosses streams and a
+chain's transfer runs underneath the other chains' kernels.  On the fully connected xGMI node each rank pushes a group's
+records (1024 markets x 208 B = 213 KB at 4096 x 4, G = 4) directly to its 7 peers, one link each.
+`gather()` is the simple synchronous packed variant (whole observations) for any env and uneven shards.
 """
 import torch
 
@@ -57,22 +63,6 @@ def slab_views(slab, lay):
     return obs, rew, term, trunc
 
 
-class GatherHandle:
-    """An all-gather in flight.  wait() orders the caller's CURRENT stream after it (no host sync on a
-    GPU) and returns per-rank views [world, n_local, ...] into the gathered buffer: obs, reward,
-    terminated (bool), truncated (bool).  `.reshape(world * n_local, ...)` flattens them (one copy)."""
-
-    def __init__(self, work, gathered, lay):
-        self.work, self.gathered, self.lay = work, gathered, lay
-
-    def wait(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
-        obs, rew, term, trunc = slab_views(self.gathered, self.lay)
-        return obs, rew, term != 0, trunc != 0
-
-
 def pack_outputs(obs, reward, terminated, truncated, out=None):
     """[n, obs_dim] f32, [n, A] f64, [n] bool, [n] bool -> [n, obs_dim + 2A + 2] f32 (bit-preserving)."""
     n, od = obs.shape
@@ -95,38 +85,119 @@ def unpack_outputs(packed, obs_dim, num_agents):
     return obs, reward, terminated, truncated
 
 
+def handback_stride(num_agents):
+    """bytes of one hand-back record (cda_handback_stride): f32 frame[42] | f64 reward[A] | u8 terminated, truncated, restarted | pad to 8"""
+    return (42 * 4 + num_agents * 8 + 3 + 7) // 8 * 8
+
+
+def _hip_unpack(records, n_segments, seg_records, seg_row_stride, row0, num_agents, n_hist, obs, reward, term, trunc):
+    """the product's receiving side: one launch of cda_handback_unpack on the CURRENT stream"""
+    from ._lib import check, lib
+    check(lib().cda_handback_unpack(records.data_ptr(), int(n_segments), int(seg_records), int(seg_row_stride), int(row0), int(num_agents), int(n_hist),
+                                    obs.data_ptr(), reward.data_ptr(), term.data_ptr(), trunc.data_ptr(),
+                                    torch.cuda.current_stream(obs.device).cuda_stream), "cda_handback_unpack")
+
+
 class ShardedVecEnv:
-    """This rank's shard of a global batch of `n_markets_total` markets.
+    """This rank's shard of a global batch of `n_markets_total` markets, and - with `handback=True` - the learner-side arrays
+    of the WHOLE batch on this rank's device, refreshed every step from the all-gathered hand-back records:
 
-    env_factory(config, n_local, device) builds the local stepper (default: the HIP CDAVecEnv on this
-    rank's GPU; the CPU tests inject a stand-in with the same interface)."""
+        obs f32[n_total, n_hist*42], reward f64[n_total, A], terminated / truncated u8[n_total]     (`.full`)
 
-    def __init__(self, config, n_markets_total, device=None, env_factory=None, dist=None):
+    env_factory(config, n_local, device, groups) builds the local stepper (default: the HIP CDAVecEnv on this rank's GPU with
+    `groups` chains and hand-back records; the CPU tests inject a stand-in with the same interface) and `unpack` the receiving
+    side (default: the HIP kernel behind cda_handback_unpack; the CPU tests inject a restatement)."""
+
+    def __init__(self, config, n_markets_total, device=None, env_factory=None, dist=None, groups=1, handback=False, unpack=None):
         import torch.distributed as tdist
         self.dist = dist or tdist
         self.rank = self.dist.get_rank() if self.dist.is_initialized() else 0
         self.world = self.dist.get_world_size() if self.dist.is_initialized() else 1
         self.n_total = int(n_markets_total)
         self.first, self.n_local = shard_range(self.rank, self.world, self.n_total)
+        self.use_handback = bool(handback)
+        if self.use_handback and self.n_total % self.world:
+            raise ValueError("the hand-back path needs equal shards (n_markets_total divisible by the world size); use gather()")
         if env_factory is None:
             from .vec_env import CDAVecEnv
-            env_factory = lambda cfg, n, dev: CDAVecEnv(cfg, n_markets=n, device=dev, with_info=False, out_buffers=2)   # noqa: E731
-        self.env = env_factory(config, self.n_local, device)
+            env_factory = lambda cfg, n, dev, g: CDAVecEnv(cfg, n_markets=n, device=dev, with_info=False, groups=g, handback=self.use_handback)   # noqa: E731
+        self.env = env_factory(config, self.n_local, device, int(groups))
         self.obs_dim = self.env.obs_dim
         self.num_agents = self.env.num_agents
+        self.n_hist = self.obs_dim // 42
         self._packed = None
         self._padded = None
         self._gathered = None
         self.layout = slab_layout(self.n_local, self.obs_dim, self.num_agents)
-        self._gbufs, self._gnext = [None, None], 0
+        self.full = None
+        if self.use_handback:
+            self._unpack = unpack or _hip_unpack
+            rec = self.env.handback
+            dev = rec.device
+            self.group_ranges = list(getattr(self.env, "group_ranges", None) or [(0, self.n_local)])
+            self.group_streams = list(getattr(self.env, "group_streams", None) or [])
+            stride = rec.shape[1]
+            # one communicator per chain: collectives of different chains may then be in flight at the same time, each on its own stream
+            self._pgs = [self.dist.new_group(ranks=list(range(self.world))) if self.world > 1 else None for _ in self.group_ranges]
+            self._gbuf = [torch.zeros((self.world, cnt, stride), dtype=torch.uint8, device=dev) for _, cnt in self.group_ranges]
+            self.full = (torch.zeros((self.n_total, self.obs_dim), dtype=torch.float32, device=dev),
+                         torch.zeros((self.n_total, self.num_agents), dtype=torch.float64, device=dev),
+                         torch.zeros(self.n_total, dtype=torch.uint8, device=dev), torch.zeros(self.n_total, dtype=torch.uint8, device=dev))
+
+    # ------------------------------------------------------------------ the hand-back
+    def _stream_ctx(self, g):
+        if self.group_streams:
+            return torch.cuda.stream(self.group_streams[g])
+        import contextlib
+        return contextlib.nullcontext()
+
+    def _handback_group(self, g):
+        """on chain g's stream: all-gather the chain's records, then one unpack launch into the full arrays"""
+        first, cnt = self.group_ranges[g]
+        mine = self.env.handback[first:first + cnt]
+        buf = self._gbuf[g]
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=self._pgs[g])
+        else:
+            buf[0].copy_(mine)
+        self._unpack(buf, self.world, cnt, self.n_local, first, self.num_agents, self.n_hist, *self.full)
+
+    def handback(self):
+        """Enqueue the hand-back of the step (or reset) just enqueued: per chain, on the chain's own stream.  `full` is complete
+        for chain g's rows when its stream gets there; join() orders the caller's stream after all of them."""
+        for g in range(len(self.group_ranges)):
+            with self._stream_ctx(g):
+                self._handback_group(g)
+
+    def join(self):
+        if hasattr(self.env, "join"):
+            self.env.join()
 
     def reset(self, seed_base=0):
-        seeds = global_seeds(seed_base, self.first, self.n_local)
-        return self.env.reset(seed=seeds)
+        """seed_base = s: global market i is seeded s + i; None: every market keeps its RNG stream (reset(seed=None))."""
+        obs = self.env.reset(seed=None if seed_base is None else global_seeds(seed_base, self.first, self.n_local))
+        if self.use_handback:               # the reset wrote `restarted` records: the full observation restarts from them
+            if self.group_streams:
+                self.env.fork()
+            self.handback()
+            self.join()
+        return obs
 
-    def step(self, category, size_mean, size_sigma, price, price_offset, present=None):
-        """Actions for THIS rank's markets ([n_local, A]); returns the local outputs."""
-        return self.env.step(category, size_mean, size_sigma, price, price_offset, present)
+    def step(self, category, size_mean, size_sigma, price, price_offset, present=None, pipelined=False):
+        """Actions for THIS rank's markets ([n_local, A]); returns the local outputs.  With hand-back the full arrays follow on the
+        chains' streams; pipelined=True leaves the fork / join with the caller's stream out (see CDAVecEnv.step)."""
+        if not self.use_handback:
+            return self.env.step(category, size_mean, size_sigma, price, price_offset, present)
+        if self.group_streams:
+            if not pipelined:
+                self.env.fork()             # the chains start after whatever the caller's stream holds (the actions a policy just wrote)
+            out = self.env.step(category, size_mean, size_sigma, price, price_offset, present, pipelined=True)
+        else:
+            out = self.env.step(category, size_mean, size_sigma, price, price_offset, present)
+        self.handback()
+        if not pipelined:
+            self.join()
+        return out
 
     def gather(self, obs, reward, terminated, truncated):
         """All-gather the per-market outputs of every rank -> global (obs, reward, terminated, truncated)."""
@@ -147,32 +218,6 @@ class ShardedVecEnv:
         if self.n_total % self.world:
             g = torch.cat([g[r * n_pad: r * n_pad + shard_range(r, self.world, self.n_total)[1]] for r in range(self.world)], dim=0)
         return unpack_outputs(g, self.obs_dim, self.num_agents)
-
-    def gather_async(self, outputs=None):
-        """Start the all-gather of this rank's output slab (the env's current one, i.e. the outputs of the
-        step just enqueued; or a slab built from `outputs` for an env without one) and return a GatherHandle.  Two gathered buffers rotate, so at most two
-        handles may be outstanding; with a double-buffered env the caller's loop is
-            step(t); h = gather_async(); prev.wait(); prev = h
-        which lets gather(t) run under the kernel of step t+1."""
-        if self.n_total % self.world:
-            raise ValueError("the slab all-gather needs equal shards (n_markets_total divisible by the world size); use gather()")
-        slab = getattr(self.env, "out_slab", None) if outputs is None else None
-        if slab is None:                    # an env without slab-backed outputs: build the slab (copies)
-            if outputs is None:
-                raise ValueError("this env has no output slab: pass outputs=(obs, reward, terminated, truncated)")
-            slab = torch.zeros(self.layout["bytes"], dtype=torch.uint8, device=outputs[0].device)
-            for dst, src in zip(slab_views(slab, self.layout), outputs):
-                dst.copy_(src.to(dst.dtype))
-        b = self._gnext
-        self._gnext ^= 1
-        if self._gbufs[b] is None:
-            self._gbufs[b] = torch.zeros((self.world, self.layout["bytes"]), dtype=torch.uint8, device=slab.device)
-        g = self._gbufs[b]
-        if self.world == 1:
-            g[0].copy_(slab)
-            return GatherHandle(None, g, self.layout)
-        work = self.dist.all_gather_into_tensor(g.view(-1), slab, async_op=True)
-        return GatherHandle(work, g, self.layout)
 
     def close(self):
         self.env.close()

@@ -23,7 +23,7 @@ class CDAVecEnv:
     """Batched env.  Tensors: actions [N,A]; obs f32[N, n_hist*42]; reward f64[N,A];
     terminated/truncated bool[N] (the reference's "__all__" flags); info = dict of SoA tensors."""
 
-    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True, out_buffers=1, groups=1):
+    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True, out_buffers=1, groups=1, handback=False):
         self.cfg_struct, self.config = K.make_config(config)
         self.n_markets = int(n_markets)
         self.num_agents = self.cfg_struct.num_agents
@@ -76,6 +76,13 @@ class CDAVecEnv:
             self.info[name] = t
             setattr(self._info_ptrs, name, t.data_ptr())
         self._info_ref = C.byref(self._info_ptrs) if self.with_info else None
+        # handback: every step / reset also writes ONE compact record per market of what is new (newest frame | reward | flags; see
+        # cda_set_handback in include/cda.h) - what a multi-GPU caller all-gathers instead of the whole observation (parallel.py)
+        self.handback = None
+        if handback:
+            self.handback_stride = int(lib().cda_handback_stride(A))
+            self.handback = torch.zeros((N, self.handback_stride), dtype=torch.uint8, device=dev)
+            check(lib().cda_set_handback(h, self.handback.data_ptr()), "cda_set_handback")
         # groups > 1: step() launches the batch as `groups` contiguous market groups, each an independent chain of
         # launches on its own stream (cda_step_groups).  Markets never interact, so nothing is lost - and a group's
         # slowest market no longer stalls the markets of the other groups.  See group_streams / join().

@@ -217,6 +217,28 @@ int cda_step_groups(cda_env* env, int32_t n_groups,
 /* markets of group `group` of `n_groups`: [first, first + count) with first = N*group/n_groups (integer division) */
 void cda_group_range(int32_t n_markets, int32_t n_groups, int32_t group, int32_t* first_out, int32_t* count_out);
 
+/* The hand-back to a central learner (north_star: "RCCL all-gather over xGMI only for the observation/reward tensors handed
+ * back to the learner"; the reference hands step()'s return value to RLlib in-process, train/train.py:509-518).  Of a market's
+ * n_hist x 42 observation only the newest frame is new each step, so what has to travel is ONE compact record per market:
+ *
+ *     f32 frame[42]   the newest observation frame (state_helper.py:94-111 appends it to the history)
+ *     f64 reward[A]
+ *     u8  terminated, truncated      the "__all__" flags
+ *     u8  restarted                   1: the observation restarts from `frame` (reset / auto-reset: all n_hist frames equal it)
+ *     padding to cda_handback_stride(A) bytes (a multiple of 8)
+ *
+ * cda_set_handback(env, records): from now on every step (and reset) ALSO writes records[market] (device, [N, stride] bytes;
+ * NULL switches it off).  The records of a contiguous market range are contiguous, so a group chain hands its own range to
+ * the collective where the kernel left it.  cda_handback_unpack is the receiving side, for ANY process (it needs no env):
+ * n_segments x seg_records records (an all-gathered buffer: one segment per rank), record k of segment s belonging to row
+ * row0 + s * seg_row_stride + k of the learner's full arrays - the observation row is shifted by one frame and the new frame
+ * appended (or, restarted, all frames set), reward / flags rows are overwritten.  One launch. */
+int32_t cda_handback_stride(int32_t num_agents);
+int cda_set_handback(cda_env* env, void* records_dev);
+int cda_handback_unpack(const void* records_dev, int32_t n_segments, int32_t seg_records, int64_t seg_row_stride, int64_t row0,
+                        int32_t num_agents, int32_t n_hist,
+                        float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full, void* stream);
+
 /* Replaces CDA_rand.run_random (CDA_rand.py:40-85): every market plays uniform random agents (the law and the
  * counter-based sampler of include/cda_random_agents.h, keyed by action_seed, market_index_base + market, the
  * market's own step counter and the agent) for up to n_steps steps, stopping early at its episode's end

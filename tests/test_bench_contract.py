@@ -31,19 +31,46 @@ def test_bench_json_contract():
     assert abs(r["achieved"] - 2 * r["achieved_per_launch"]) / r["achieved"] < 0.2
     assert abs(r["achieved_per_launch"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved_per_launch"] < 0.2
     assert "issue_frac" in r and "valu_busy_frac" in r
-    # row a14 inside the timed region: the info-on figure sits next to the headline
-    assert d["config"]["info_outputs"] is False and 0 < d["value_with_info"] <= d["value"] * 1.05 and d["ms_per_step_with_info"] > 0
-    assert d["config"]["flagged_markets"] == 0 and d["config"]["flagged_markets_with_info"] == 0
+    # the HEADLINE has row a14 (every info tensor of Info_Helper.set_info) inside the timed region and says so;
+    # the info-less figure, the one-launch figure and the ordered-per-step figure sit next to it
+    assert d["config"]["info_outputs"] is True and "info tensor" in d["metric"] and "free-running" in d["metric"]
+    assert d["value_without_info"] >= d["value"] * 0.9 and d["ms_per_step_without_info"] > 0
+    assert d["value_one_launch"] > 0 and d["value_ordered_per_step"] > 0 and d["value_ordered_per_step"] <= d["value"] * 1.1
+    assert d["config"]["flagged_markets"] == 0 and d["config"]["flagged_markets_without_info"] == 0
+    # (ii): traffic / issue_frac come from a committed PMC pass of EXACTLY this shape or are null - 512 markets has none
+    assert r["traffic"] is None and r["issue_frac"] is None and r["traffic_source"] is None
+    # (iii): below 200 timed steps the K-step leg runs five times back to back; value is the median leg
+    tr = d["timed_repeats"]
+    assert tr["n"] == 5 and len(tr["ms_per_step"]) == 5 and tr["min"] <= tr["median"] <= tr["max"] and tr["median"] == d["ms_per_step"]
+    assert "unbounded book" in d["config"]["workload"] and "HBM spill ring" in d["config"]["workload"]
     assert "cda_random_actions" in d["config"]["actions"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "agent-steps/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert c["value_1thread"] > 0 and isinstance(c["cpu_model"], str) and c["cpu_model"]
-    assert "GPU leg's action stream" in c["sample"]
+    assert "GPU leg's action stream" in c["sample"] and "hardware threads" in c["cores_note"] and "physical cores" in c["cores_note"]
+
+
+def test_bench_traffic_only_from_a_pmc_pass_of_the_same_shape():
+    """the committed PMC passes (profiles/pmc/) carry the shape they were taken on in their name and body; bench.py reports
+    roofline.traffic for exactly that shape - here: the driver's command, 4096 x 4, info on, two chains"""
+    import glob
+    passes = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc", "*.json")))
+    assert passes, "no PMC pass committed under profiles/pmc/"
+    for f in passes:
+        p = json.load(open(f))
+        assert os.path.basename(f) == f"{p['markets']}x{p['agents']}_info{int(bool(p['info']))}_g{p['groups']}.json"
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                                   "--no-extra-legs"], cwd=ROOT, stderr=subprocess.DEVNULL, text=True, timeout=600)
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    have = os.path.exists(os.path.join(ROOT, "profiles", "pmc", "4096x4_info1_g2.json"))
+    assert (d["roofline"]["traffic"] is not None) == have
+    if have:
+        assert "4096x4_info1_g2" in d["roofline"]["traffic_source"] and 0 < d["roofline"]["issue_frac"] < 1
 
 
 def test_bench_named_config_c4_and_single_group():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup", "8", "--config", "c4", "--groups", "1",
-                                   "--no-cpu-baseline", "--no-info-leg"], cwd=ROOT, stderr=subprocess.DEVNULL, text=True, timeout=600)
+                                   "--no-cpu-baseline", "--no-extra-legs"], cwd=ROOT, stderr=subprocess.DEVNULL, text=True, timeout=600)
     d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
     assert d["config"]["markets_per_gpu"] == 2048 and d["config"]["agents"] == 8 and "configs[3]" in d["config"]["workload"]
     assert d["config"]["groups"] == 1 and d["roofline"]["concurrent_launches"] == 1 and d["config"]["flagged_markets"] == 0
@@ -52,20 +79,19 @@ def test_bench_named_config_c4_and_single_group():
 
 
 def test_bench_multi_gpu_code_path_on_one_rank():
-    """The N>1 path of bench.py (RCCL process group, double-buffered output slabs, asynchronous all-gather
-    overlapped with the next launch) with a single rank - what the driver launches under torchrun at N>1."""
+    """The N>1 path of bench.py (RCCL process group, one communicator + all-gather of the hand-back records per group chain,
+    the rebuild of the learner-side arrays) with a single rank - what the driver launches under torchrun at N>1."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", LOCAL_RANK="0",
                WORLD_SIZE="1")
-    for extra in ([], ["--no-overlap"]):
+    for extra in ([], ["--groups", "1"]):
         out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--markets",
                                        "512", "--no-cpu-baseline", "--force-gather"] + extra, cwd=ROOT, env=env,
                                       stderr=subprocess.STDOUT, text=True, timeout=600)
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, out[-2000:]
         d = json.loads(lines[0])
-        assert d["n_gpus"] == 1 and d["value"] > 1e6 and "all_gather" in d["config"]["collective"]
-        if not extra:                                    # the calibrated schedule figures are reported even with one rank
-            assert d["config"]["gather_calibration"]["serial_us_per_step"] > 0 and d["config"]["gather_calibration"]["overlapped_us_per_step"] > 0
+        assert d["n_gpus"] == 1 and d["value"] > 1e6 and "all_gather_into_tensor per step" in d["config"]["collective"] and "208-B records" in d["config"]["collective"]
+        assert d["config"]["groups"] == (1 if extra else 2) and "hand-back" in d["metric"]
         assert d["config"]["flagged_markets"] == 0 and d["roofline"]["kernel_ms"] > 0
 
 
@@ -84,8 +110,8 @@ def test_bench_fused_mode_reports_the_same_contract():
 
 def test_bench_two_ranks_on_one_gpu():
     """Two processes under torch.distributed.run, both pinned to GPU 0, gloo instead of RCCL: the multi-rank logic of bench.py
-    (global-index seeds per rank, slab all-gather sized by the world, schedule calibration with its all-reduce, max-over-ranks
-    timing) runs for real; only the transport differs from the driver's 2-GPU launch."""
+    (global-index seeds per rank, one communicator and one records all-gather per group chain sized by the world, the rebuild of the
+    global arrays, max-over-ranks timing) runs for real; only the transport differs from the driver's 2-GPU launch."""
     env = dict(os.environ, CDA_BENCH_DEVICE="0", CDA_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -96,7 +122,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 48 and "all_gather" in d["config"]["collective"] and d["config"]["flagged_markets"] == 0
-    assert "calibrated" in (d["config"]["gather_schedule"] or "") and "global 512 markets" in d["config"]["workload"]
+    assert "global 512 markets" in d["config"]["workload"] and d["timed_repeats"]["n"] == 5
     assert abs(d["value"] - 2 * 256 * 4 * 48 / (d["ms_per_step"] * 1e-3 * 48)) / d["value"] < 1e-6
 
 

@@ -1,7 +1,9 @@
-"""CPU, world_size 2, gloo: the N>1 path - contiguous market sharding, global-index seeding and the
-packed all-gather of obs/reward/flags (gym_continuousdoubleauction_amd/parallel.py).  The local stepper is
-injected (the CPU oracle stands in for the HIP env, which needs a GPU); the check is that the gathered
-global outputs are identical to one process stepping all markets - i.e. independent of the shard count."""
+"""CPU, world_size 2, gloo: the N>1 path - contiguous market sharding, global-index seeding, the packed all-gather of
+obs/reward/flags and the hand-back of compact per-market records with the receiving side's rebuild of the stacked
+observation (gym_continuousdoubleauction_amd/parallel.py).  The local stepper is injected (the CPU oracle stands in for the
+HIP env, which needs a GPU) and so is the receiving side (a numpy restatement of cda_handback_unpack; the kernel itself is
+checked against the same restatement on the GPU, tests/test_hip_facade.py); the check is that the global outputs every rank
+ends up with are identical to one process stepping all markets - i.e. independent of the shard count."""
 import os
 import sys
 
@@ -17,18 +19,33 @@ CFG = {"num_of_agents": A, "init_cash": 1000000, "max_step": 64, "is_render": Fa
 
 
 class _OracleStepper:
-    """CDAVecEnv-shaped stand-in over the CPU oracle (torch CPU tensors)."""
+    """CDAVecEnv-shaped stand-in over the CPU oracle (torch CPU tensors).  With `groups` it also keeps the hand-back records the
+    product's kernels write (include/cda.h cda_set_handback: f32 frame[42] | f64 reward[A] | terminated, truncated, restarted)."""
 
-    def __init__(self, config, n, device):
+    def __init__(self, config, n, device, groups=0):
         import oracle_lib as O
+        from gym_continuousdoubleauction_amd.parallel import handback_stride
         self.o = O.OracleEnv(config, n_markets=n)
         self.obs_dim, self.num_agents = self.o.obs_dim, self.o.A
+        self.handback = torch.zeros((n, handback_stride(self.num_agents)), dtype=torch.uint8)
+        g = max(1, groups)
+        self.group_ranges = [(n * k // g, n * (k + 1) // g - n * k // g) for k in range(g)]
+
+    def _record(self, obs, rew, term, trunc, restarted):
+        hb, a = self.handback.numpy(), self.num_agents
+        hb[:, :168] = np.ascontiguousarray(obs[:, -42:]).view(np.uint8)
+        hb[:, 168:168 + 8 * a] = np.ascontiguousarray(rew).view(np.uint8)
+        hb[:, 168 + 8 * a] = term; hb[:, 169 + 8 * a] = trunc; hb[:, 170 + 8 * a] = restarted
 
     def reset(self, seed):
-        return torch.from_numpy(self.o.reset(seeds=seed.numpy().astype(np.uint64)).copy())
+        obs = self.o.reset(seeds=seed.numpy().astype(np.uint64)).copy()
+        n = obs.shape[0]
+        self._record(obs, np.zeros((n, self.num_agents)), np.zeros(n, np.uint8), np.zeros(n, np.uint8), 1)
+        return torch.from_numpy(obs)
 
-    def step(self, cat, mean, sigma, price, off, present=None):
+    def step(self, cat, mean, sigma, price, off, present=None, pipelined=False):
         obs, rew, term, trunc, _ = self.o.step(cat.numpy(), mean.numpy(), sigma.numpy(), price.numpy(), off.numpy())
+        self._record(obs, rew, term, trunc, 0)
         return (torch.from_numpy(obs.copy()), torch.from_numpy(rew.copy()), torch.from_numpy(term.astype(bool)),
                 torch.from_numpy(trunc.astype(bool)), {})
 
@@ -45,6 +62,24 @@ def _actions(t):
             torch.from_numpy(rng.integers(0, 3, (N_TOTAL, A)).astype(np.int32)))
 
 
+def unpack_restated(records, n_segments, seg_records, seg_row_stride, row0, num_agents, n_hist, obs, reward, term, trunc):
+    """cda_handback_unpack restated in numpy (the receiving side of the hand-back): shift the row by one frame, append the new one
+    (restarted: every frame = the new one), overwrite reward and flags."""
+    rec = records.numpy().reshape(n_segments * seg_records, -1)
+    o, r, te, tr = obs.numpy(), reward.numpy(), term.numpy(), trunc.numpy()
+    a = num_agents
+    for j in range(rec.shape[0]):
+        row = row0 + (j // seg_records) * seg_row_stride + j % seg_records
+        frame = rec[j, :168].view(np.float32)
+        if rec[j, 170 + 8 * a]:
+            o[row] = np.tile(frame, n_hist)
+        else:
+            o[row, :-42] = o[row, 42:].copy()
+            o[row, -42:] = frame
+        r[row] = rec[j, 168:168 + 8 * a].view(np.float64)
+        te[row], tr[row] = rec[j, 168 + 8 * a], rec[j, 169 + 8 * a]
+
+
 def _worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -52,29 +87,28 @@ def _worker(rank, world, port, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv
-    env = ShardedVecEnv(CFG, N_TOTAL, device=None, env_factory=lambda c, n, d: _OracleStepper(c, n, d))
-    assert (env.first, env.n_local) == (rank * N_TOTAL // world, N_TOTAL // world)
-    env.reset(seed_base=1000)
-    rec, rec_async, prev = [], [], None
-
-    def _drain(h):
-        o, r, te, tr = h.wait()            # per-rank views [world, n_local, ...]
-        rec_async.append([o.reshape(N_TOTAL, -1).clone().numpy(), r.reshape(N_TOTAL, -1).clone().numpy(),
-                          te.reshape(-1).clone().numpy(), tr.reshape(-1).clone().numpy()])
-
+    # three group chains per rank, each with its own communicator and its own collective per step
+    env = ShardedVecEnv(CFG, N_TOTAL, device=None, env_factory=lambda c, n, d, g: _OracleStepper(c, n, d, g), groups=3, handback=True,
+                        unpack=unpack_restated)
+    assert (env.first, env.n_local) == (rank * N_TOTAL // world, N_TOTAL // world) and len(env.group_ranges) == 3
+    obs0 = env.reset(seed_base=1000)
+    assert np.array_equal(env.full[0][env.first:env.first + env.n_local].numpy().view(np.uint32), obs0.numpy().view(np.uint32))
+    rec = []
     for t in range(T):
         acts = [x[env.first:env.first + env.n_local] for x in _actions(t)]
-        obs, rew, term, trunc, _ = env.step(*acts)
-        g = env.gather(obs, rew, term, trunc)
+        obs, rew, term, trunc, _ = env.step(*acts)                # ... the hand-back records travel, `full` is rebuilt on every rank
+        g = env.gather(obs, rew, term, trunc)                     # the packed gather of whole observations says the same
         rec.append([x.clone().numpy() for x in g])
-        h = env.gather_async(outputs=(obs, rew, term, trunc))     # the pipelined loop of bench.py: <= 2 in flight
-        if prev is not None:
-            _drain(prev)
-        prev = h
-    _drain(prev)
-    for a, b in zip(rec, rec_async):
-        for x, y in zip(a, b):
-            assert x.dtype == y.dtype and np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        fo, fr, ft, fu = env.full
+        assert np.array_equal(fo.numpy().view(np.uint32), g[0].numpy().view(np.uint32)), (rank, t)
+        assert np.array_equal(fr.numpy().view(np.uint64), g[1].contiguous().numpy().view(np.uint64)), (rank, t)
+        assert np.array_equal(ft.numpy() != 0, g[2].numpy()) and np.array_equal(fu.numpy() != 0, g[3].numpy())
+    # a reset after the run: its records carry `restarted`, and every rank's full observation restarts from them
+    o = env.reset(seed_base=2000)
+    z = torch.zeros(env.n_local, dtype=torch.bool)
+    g = env.gather(o, torch.zeros(env.n_local, A, dtype=torch.float64), z, z)
+    assert np.array_equal(env.full[0].numpy().view(np.uint32), g[0].numpy().view(np.uint32))
+    assert not env.full[2].any() and not env.full[3].any() and not env.full[1].any()
     if rank == 0:
         np.savez(os.path.join(outdir, "gathered.npz"), obs=np.stack([r[0] for r in rec]), rew=np.stack([r[1] for r in rec]),
                  term=np.stack([r[2] for r in rec]), trunc=np.stack([r[3] for r in rec]))
@@ -90,7 +124,7 @@ def _worker_uneven(rank, world, port, outdir, n_total):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv, shard_range
-    env = ShardedVecEnv(CFG, n_total, device=None, env_factory=lambda c, n, d: _OracleStepper(c, n, d))
+    env = ShardedVecEnv(CFG, n_total, device=None, env_factory=lambda c, n, d, g: _OracleStepper(c, n, d))
     assert (env.first, env.n_local) == shard_range(rank, world, n_total) == (rank * (n_total // world), n_total // world + (n_total % world if rank == world - 1 else 0))
     env.reset(seed_base=1000)
     rec = []
@@ -103,8 +137,8 @@ def _worker_uneven(rank, world, port, outdir, n_total):
         g = env.gather(*env.step(*acts)[:4])
         assert g[0].shape[0] == n_total
         rec.append([x.clone().numpy() for x in g])
-    with pytest.raises(ValueError):
-        env.gather_async(outputs=env.step(*acts)[:4])
+    with pytest.raises(ValueError):                                # the hand-back path wants equal shards
+        ShardedVecEnv(CFG, n_total, device=None, env_factory=lambda c, n, d, g: _OracleStepper(c, n, d, g), handback=True, unpack=unpack_restated)
     if rank == 0:
         np.savez(os.path.join(outdir, "uneven.npz"), obs=np.stack([r[0] for r in rec]), rew=np.stack([r[1] for r in rec]))
     dist.barrier()

@@ -193,40 +193,44 @@ def test_random_agent_driver_runs_to_the_horizon():                  # CDA_rand.
     assert run_random(num_agents=4, max_step=200, seed=123) == 200
 
 
-def test_double_buffered_output_slabs_and_async_gather():
-    """out_buffers=2: step t+1 must not touch step t's slab; ShardedVecEnv.gather_async hands back the slab contents."""
+def test_handback_records_rebuild_the_full_outputs_on_the_receiving_side():
+    """The multi-GPU hand-back with one rank on the real kernels: k_step / k_reset write one compact record per market (newest frame |
+    reward | flags), every group chain moves its own range and cda_handback_unpack rebuilds the learner-side arrays - which
+    must equal the outputs of a plain env step for step, through a mid-run reset and with auto_reset (records flagged
+    `restarted`).  The unpack kernel is also compared with the numpy restatement the gloo tests use."""
     import numpy as np
     import torch
     from gym_continuousdoubleauction_amd import CDAVecEnv
     from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv
-    cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 64, "is_render": False}
-    n, a = 96, 4
-    ref = CDAVecEnv(cfg, n_markets=n, with_info=False)
-    sh = ShardedVecEnv(cfg, n, device="cuda:0")                 # world 1, HIP env with two slabs
-    seeds = np.arange(300, 300 + n, dtype=np.uint64)
-    o0 = ref.reset(seed=seeds).clone()
-    assert torch.equal(sh.reset(seed_base=300), o0)
-    rng = np.random.default_rng(3)
-    prev = prev_ref = held = None
-    for t in range(40):
-        acts = (torch.from_numpy(rng.integers(0, 9, (n, a)).astype(np.int32)), torch.from_numpy(rng.uniform(-1, 1, (n, a)).astype(np.float32)),
-                torch.from_numpy(rng.uniform(0, 1, (n, a)).astype(np.float32)), torch.from_numpy(rng.integers(0, 10, (n, a)).astype(np.int32)),
-                torch.from_numpy(rng.integers(0, 3, (n, a)).astype(np.int32)))
-        ro, rr, rt, ru, _ = ref.step(*acts)
-        so, sr, st, su, _ = sh.step(*acts)
-        assert torch.equal(so.view(torch.int32), ro.view(torch.int32)) and torch.equal(sr.view(torch.int64), rr.view(torch.int64))
-        assert torch.equal(st, rt) and torch.equal(su, ru)
-        if held is not None:                                    # last step's tensors still hold last step's values
-            assert torch.equal(held[0].view(torch.int32), held[1].view(torch.int32))
-        held = (so, ro.clone())
-        h = sh.gather_async()
-        if prev is not None:
-            go, gr, gt, gu = prev.wait()
-            assert go.shape == (1, n, 168) and torch.equal(go[0].view(torch.int32), prev_ref[0].view(torch.int32))
-            assert torch.equal(gr[0].view(torch.int64), prev_ref[1].view(torch.int64)) and torch.equal(gt[0], prev_ref[2])
-        prev, prev_ref = h, (ro.clone(), rr.clone(), rt.clone(), ru.clone())
-    ref.close()
-    sh.close()
+    from test_distributed_gloo import unpack_restated
+    n, a = 200, 4
+    for auto in (False, True):
+        cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 12, "is_render": False, "auto_reset": auto}
+        ref = CDAVecEnv(cfg, n_markets=n, with_info=False)
+        sh = ShardedVecEnv(cfg, n, device="cuda:0", groups=4, handback=True)           # world 1: the collective is a copy
+        assert len(sh.group_ranges) == 4 and sh.env.handback.shape == (n, 208)
+        o0 = ref.reset(seed=np.arange(300, 300 + n, dtype=np.uint64)).clone()
+        assert torch.equal(sh.reset(seed_base=300), o0) and torch.equal(sh.full[0], o0)
+        rng = np.random.default_rng(3)
+        shadow = [x.cpu().clone() for x in sh.full]                                    # the restated receiving side, fed the same records
+        for t in range(40):
+            acts = (torch.from_numpy(rng.integers(0, 9, (n, a)).astype(np.int32)), torch.from_numpy(rng.uniform(-1, 1, (n, a)).astype(np.float32)),
+                    torch.from_numpy(rng.uniform(0, 1, (n, a)).astype(np.float32)), torch.from_numpy(rng.integers(0, 10, (n, a)).astype(np.int32)),
+                    torch.from_numpy(rng.integers(0, 3, (n, a)).astype(np.int32)))
+            ro, rr, rt, ru, _ = ref.step(*acts)
+            so, sr, st, su, _ = sh.step(*acts)
+            assert torch.equal(so.view(torch.int32), ro.view(torch.int32)) and torch.equal(sr.view(torch.int64), rr.view(torch.int64))
+            fo, fr, ft, fu = sh.full
+            assert torch.equal(fo.view(torch.int32), ro.view(torch.int32)), (auto, t)
+            assert torch.equal(fr.view(torch.int64), rr.view(torch.int64)) and torch.equal(ft != 0, rt) and torch.equal(fu != 0, ru)
+            unpack_restated(sh.env.handback.cpu(), 1, n, n, 0, a, 4, *shadow)
+            assert all(torch.equal(x.cpu().view(torch.uint8), y.view(torch.uint8)) for x, y in zip(sh.full, shadow)), (auto, t)
+            if not auto and t in (11, 23):                                             # episodes end at max_step = 12: reset everybody
+                o = ref.reset().clone()
+                assert torch.equal(sh.reset(seed_base=None), o) and torch.equal(sh.full[0], o)
+                unpack_restated(sh.env.handback.cpu(), 1, n, n, 0, a, 4, *shadow)
+        ref.close()
+        sh.close()
 
 
 def test_ppo_loop_on_the_hip_env_with_graph_captured_policy_step():

@@ -246,17 +246,24 @@ def test_hip_equals_oracle_on_random_configurations():
     generator drives tests/golden/crosscheck_oracle.py, which pins the oracle to the reference on such episodes."""
     from hip_env import HipEnv
     import oracle_lib as O
-    from fuzz_cases import batch_actions, random_config
+    from fuzz_cases import batch_actions, prefill_book, random_config, random_order
     import os
     rng = np.random.default_rng(int(os.environ.get("CDA_FUZZ_SEED", "31337")))
-    for case in range(int(os.environ.get("CDA_FUZZ_CASES", "14"))):       # a longer soak: CDA_FUZZ_CASES=150 CDA_FUZZ_SEED=...
+    for case in range(int(os.environ.get("CDA_FUZZ_CASES", "18"))):       # a longer soak: CDA_FUZZ_CASES=150 CDA_FUZZ_SEED=...
         cfg, law, present_p = random_config(rng)
+        order = random_order(rng)
         n, a, steps = 40, cfg["num_of_agents"], 56
         env, ora = HipEnv(cfg, n), O.OracleEnv(cfg, n)
         seeds = rng.integers(0, 2 ** 63, n).astype(np.uint64)
         assert np.array_equal(env.reset(seeds).view(np.uint32), ora.reset(seeds).view(np.uint32)), (case, cfg)
+        if rng.random() < 0.4:            # deep books from the first step on (far beyond the LDS tile: the HBM tier is in play at once)
+            pseed = int(rng.integers(0, 2 ** 31))
+            for i in range(0, n, 3):
+                nb, na = (int(x) for x in np.random.default_rng(pseed + i).integers(0, 513, 2))
+                for e in (env, ora):
+                    prefill_book(e, i, np.random.default_rng(pseed + i + 1), a, nb, na)
         for t in range(steps):
-            acts, present = batch_actions(rng, n, a, law, present_p)
+            acts, present = batch_actions(rng, n, a, law, present_p, order)
             obs, rew, term, trunc, info = env.step(*acts, present)
             oo, orw, ot, otr, oi = ora.step(*acts, present)
             ctx = f"case {case} {cfg} law={law} step {t}"
@@ -265,9 +272,12 @@ def test_hip_equals_oracle_on_random_configurations():
             assert np.array_equal(term, ot) and np.array_equal(trunc, otr), ctx
             for k in oi:
                 assert np.array_equal(np.ascontiguousarray(info[k]).view(np.uint8), np.ascontiguousarray(oi[k]).view(np.uint8)), f"{ctx} info.{k}"
-        for i in range(0, n, 9):
+        for i in range(0, n, 3):
             assert bytes(env.get_state(i)) == bytes(ora.get_state(i)), f"case {case} market {i}"
+            for side in (0, 1):
+                assert np.array_equal(env.get_book(i, side), ora.get_book(i, side)), f"case {case} market {i} side {side}"
         assert np.array_equal(env.flags(), ora.flags()), case
+        assert (env.env.check_invariants().cpu().numpy() == 0).all(), case
         env.close(); ora.close()
 
 

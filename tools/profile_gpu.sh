@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): kernel-trace stats + PMC passes for the step kernel.
-# Usage: tools/profile_gpu.sh <tag>   -> writes gpurun_out/prof_<tag>/...
+# Usage: [BENCH_STEPS=200 BENCH_EXTRA="--groups 2"] tools/profile_gpu.sh <tag>   -> writes gpurun_out/prof_<tag>/... incl. the PMC pass
+# <markets>x<agents>_info<0|1>_g<groups>.json that is committed under profiles/pmc/ (bench.py reads it for that shape only)
 # PMC passes are separate runs with --kernel-trace only (gpurun refuses --pmc combined with sys traces).
 TAG=${1:-r1}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -10,7 +11,7 @@ export TMPDIR=/tmp
 cd /tmp
 # one timed leg, no clock primer: every k_step dispatch of the run belongs to the measured env (two concurrent group chains)
 export CDA_BENCH_PRIMER_MS=0
-BENCH="python $R/bench.py --steps 200 --warmup 16 --no-cpu-baseline --no-info-leg ${BENCH_EXTRA:-}"
+BENCH="python $R/bench.py --steps ${BENCH_STEPS:-200} --warmup 16 --repeats 1 --no-cpu-baseline --no-extra-legs ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $BENCH > /dev/null 2> $OUT/pmc_write.err

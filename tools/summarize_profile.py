@@ -101,5 +101,7 @@ if res and calib:
                     active_inst_any_over_wave_cycles=(insts.get("SQ_ACTIVE_INST_ANY", 0.0) / insts["SQ_WAVE_CYCLES"]) if insts.get("SQ_WAVE_CYCLES") else None,
                     wait_any_over_wave_cycles=(insts.get("SQ_WAIT_ANY", 0.0) / insts["SQ_WAVE_CYCLES"]) if insts.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in insts else None)
     print("k_step HBM traffic and issue picture per launch (calibrated):", json.dumps(out_json))
-    with open(os.path.join(out, "pmc_latest.json"), "w") as fh:
+    # named by the shape it was taken on: bench.py reports roofline.traffic / issue_frac only for EXACTLY that shape (profiles/pmc/)
+    name = f"{meta.get('markets')}x{meta.get('agents')}_info{int(bool(meta.get('info')))}_g{meta.get('groups')}.json"
+    with open(os.path.join(out, name), "w") as fh:
         json.dump(out_json, fh, indent=1)
