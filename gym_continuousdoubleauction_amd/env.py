@@ -126,6 +126,61 @@ def _nan_none(x):
     return None if x != x else float(x)
 
 
+def _info_dict(info, i, k, reward, model_action):
+    """info[agent k of market i] as the reference builds it (exchg/info_helper.py:30-116) from the host copy of the SoA info tensors"""
+    nav = info["nav"][i].view(DEC_DTYPE).reshape(-1)[k]
+    d = {
+        "reward": reward, "NAV": str(K.dec_to_decimal(nav)), "num_trades": int(info["num_trades"][i, k]),
+        "net_position": int(info["net_position"][i, k]), "VWAP": float(info["vwap"][i, k]), "cash": float(info["cash"][i, k]),
+        "cash_on_hold": float(info["cash_on_hold"][i, k]), "position_val": float(info["position_val"][i, k]),
+        "drawdown": float(info["drawdown"][i, k]), "max_nav": float(info["max_nav"][i, k]),
+        "num_trades_step": int(info["num_trades_step"][i, k]),
+        "num_passive_fills_step": int(info["num_passive_fills_step"][i, k]),
+        "order_step_placed": int(info["order_step_placed"][i, k]), "num_rejected_step": int(info["num_rejected_step"][i, k]),
+        "is_pass_action": bool(info["is_pass_action"][i, k]),
+        "reward_terms": {n: float(info["reward_terms"][i, k, j]) for j, n in enumerate(_TERM_NAMES)},
+        "last_price": float(info["last_price"][i]), "best_bid": _nan_none(info["best_bid"][i]), "best_ask": _nan_none(info["best_ask"][i]),
+        "spread": _nan_none(info["spread"][i]),
+    }
+    if model_action is not None:
+        d["model_action"] = _jsonable(model_action)
+    return d
+
+
+class _LazyInfo(dict):
+    """One agent's info dict of one market, built on first use.  The vector protocol hands out N x A of these per step; a consumer
+    that reads none of them (or one field of a few) does not pay for the ~25 conversions each costs.  A real dict once touched:
+    every reading method fills it first (json.dumps, ==, iteration, .get(), len() all see the full content).  It reads the
+    step's OWN host snapshot (kept alive here), so it stays valid after later steps."""
+    __slots__ = ("_src",)
+
+    def __init__(self, info, i, k, reward, model_action):
+        # "reward" is stored at once: CPython's C JSON encoder prints "{}" for a dict whose STORAGE is empty without asking it
+        # anything; with one real entry it goes through .items(), which fills the rest
+        super().__init__(reward=reward)
+        self._src = (info, i, k, reward, model_action)
+
+    def _fill(self):
+        src = getattr(self, "_src", None)                  # (unset while a pickle is being loaded into a fresh object)
+        if src is not None:
+            self._src = None
+            dict.update(self, _info_dict(*src))
+
+    def _wrap(name):                                      # noqa: N805 - class-body helper
+        base = getattr(dict, name)
+
+        def method(self, *a, **kw):
+            self._fill()
+            return base(self, *a, **kw)
+        method.__name__ = name
+        return method
+    for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__eq__", "__ne__", "__repr__", "__reduce_ex__", "__or__", "__ror__",
+               "get", "items", "keys", "values", "copy", "pop", "setdefault", "update", "__setitem__", "__delitem__", "popitem", "__reversed__"):
+        locals()[_n] = _wrap(_n)
+    del _n, _wrap
+    __hash__ = None
+
+
 class _DictSurface(_Base):
     """What both facades share: config pickup, agent ids and spaces (continuousDoubleAuction_env.py:27-137)."""
     metadata = {"render.modes": ["human"]}
@@ -200,28 +255,12 @@ class _DictSurface(_Base):
              "size": int(row[2]), "price": float(row[3])}
             for a, row in ((a, lob[index[a]]) for a in listed) if row[0] >= 0]
         infos, pass_agents, bankrupt = {}, set(), set()
-        last_price, bb, ba, sp = float(info["last_price"][i]), _nan_none(info["best_bid"][i]), _nan_none(info["best_ask"][i]), _nan_none(info["spread"][i])
         for k, a in enumerate(agents):
-            nav_dec = K.dec_to_decimal(nav[k])
-            if nav_dec <= 0:
+            if K.dec_to_decimal(nav[k]) <= 0:
                 bankrupt.add(a)
             if info["is_pass_action"][i, k]:
                 pass_agents.add(a)
-            d = {
-                "reward": rewards[a], "NAV": str(nav_dec), "num_trades": int(info["num_trades"][i, k]),
-                "net_position": int(info["net_position"][i, k]), "VWAP": float(info["vwap"][i, k]), "cash": float(info["cash"][i, k]),
-                "cash_on_hold": float(info["cash_on_hold"][i, k]), "position_val": float(info["position_val"][i, k]),
-                "drawdown": float(info["drawdown"][i, k]), "max_nav": float(info["max_nav"][i, k]),
-                "num_trades_step": int(info["num_trades_step"][i, k]),
-                "num_passive_fills_step": int(info["num_passive_fills_step"][i, k]),
-                "order_step_placed": int(info["order_step_placed"][i, k]), "num_rejected_step": int(info["num_rejected_step"][i, k]),
-                "is_pass_action": bool(info["is_pass_action"][i, k]),
-                "reward_terms": {n: float(info["reward_terms"][i, k, j]) for j, n in enumerate(_TERM_NAMES)},
-                "last_price": last_price, "best_bid": bb, "best_ask": ba, "spread": sp,
-            }
-            if actions is not None and a in actions:
-                d["model_action"] = _jsonable(actions[a])
-            infos[a] = d
+            infos[a] = _info_dict(info, i, k, rewards[a], actions.get(a) if actions is not None else None)
         return (observations, rewards, terminateds, truncateds, infos), lob_actions, pass_agents, bankrupt
 
 
@@ -419,14 +458,22 @@ class CDAVecMultiAgentEnv(_DictSurface):
         t = st.upload()                                            # ONE host-to-device copy of the batch's actions
         vec.step(t["category"], t["size_mean"], t["size_sigma"], t["price"], t["price_offset"], t["present"])
         self._host.copy_(vec.packed)                               # ONE device-to-host copy for the whole batch
-        obs, rew, term, trunc, info = vec.unpack_host(self._host)
-        obs = obs.copy()                                           # the caller keeps these rows; the staging buffer is reused
-        outs = ([], [], [], [], [])
+        # this step's own snapshot: the observations rows and the lazily built info dicts keep reading it after the staging buffer
+        # has moved on (one 1.2-KB-per-market memcpy instead of N x A x 25 eager conversions)
+        obs, rew, term, trunc, info = vec.unpack_host(self._host.numpy().copy())
+        agents = self.agents
+        rew_l, term_l, trunc_l = rew.tolist(), term.tolist(), trunc.tolist()
+        false_t = dict.fromkeys(agents, False)
+        obs_out, rew_out, term_out, trunc_out, info_out = [], [], [], [], []
         for i, actions in enumerate(action_dicts):
-            five, _, _, _ = self._decode(i, actions, obs, rew, term, trunc, info)
-            for lst, x in zip(outs, five):
-                lst.append(x)
-        return outs
+            ob, r = obs[i], rew_l[i]
+            obs_out.append(dict.fromkeys(agents, ob))              # the SAME array object for every agent
+            rew_out.append(dict(zip(agents, r)))
+            te = false_t.copy(); te["__all__"] = bool(term_l[i])
+            tr = false_t.copy(); tr["__all__"] = bool(trunc_l[i])
+            term_out.append(te); trunc_out.append(tr)
+            info_out.append({a: _LazyInfo(info, i, k, r[k], actions.get(a)) for k, a in enumerate(agents)})
+        return obs_out, rew_out, term_out, trunc_out, info_out
 
     def close(self):
         self._vec.close()

@@ -20,21 +20,85 @@ import torch.nn as nn
 CAT_N, PRICE_N, OFF_N = 9, 10, 3
 
 
+class _SplitKLinear(torch.autograd.Function):
+    """y = x W^T + b whose WEIGHT gradient is computed as a split-K batched product.  dW = g^T x has a tiny output (256 x 168 ...) and
+    a huge reduction (the minibatch, 262 144): as ONE GEMM it is a dozen workgroups on a 256-CU chip (hipBLASLt picked MT64x64x256
+    without split-K: 229 us per call, a third of the round-2 update, profiles/r02/kernel_stats_ppo.csv).  Cut into SPLIT
+    slices of the batch it is SPLIT x a dozen workgroups (torch.bmm), summed in float32 afterwards."""
+    SPLIT = 64
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w.to(x.dtype), b.to(x.dtype))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ w.to(g.dtype) if ctx.needs_input_grad[0] else None
+        n, s = g.shape[0], _SplitKLinear.SPLIT
+        acc = torch.float32 if g.dtype in (torch.bfloat16, torch.float16) else g.dtype       # the slices are summed in float32
+        if n % s == 0 and n >= 64 * s:
+            gw = torch.bmm(g.view(s, n // s, -1).transpose(1, 2), x.reshape(s, n // s, -1)).sum(0, dtype=acc)
+        else:
+            gw = (g.t() @ x).to(acc)
+        return gx, gw.to(w.dtype), g.sum(0, dtype=acc).to(w.dtype)
+
+
+class _Linear(nn.Linear):
+    def forward(self, x):
+        return _SplitKLinear.apply(x, self.weight, self.bias)
+
+
 class ActorCritic(nn.Module):
-    """Separate policy and value MLPs (256x256 tanh), as in config/train_config.json:49."""
+    """Separate policy and value MLPs (256x256 tanh), as in config/train_config.json:49 - stored and multiplied as ONE set of block
+    matrices: both read the same observation, so the first layers are one 168 -> 512 product; the second layers are the two
+    diagonal blocks of a 512 x 512 matrix; the heads are rows 0..23 (policy, reading the first 256 units) and row 24 (value, reading
+    the last 256) of a 32 x 512 matrix.  The off-block entries are held at zero by a mask, so the two halves never mix -
+    mathematically two independent networks.  Why: three well-shaped GEMMs per direction instead of five, two of them with 24 and
+    ONE output column - shapes for which the bfloat16 GEMM libraries take a slow path (the 1-column value head alone made a
+    backward pass take 12 ms of host time, tools/ppo_probe.py)."""
+    N_OUT, N_PAD = CAT_N + PRICE_N + OFF_N + 2, 32
 
     def __init__(self, obs_dim, hidden=256):
         super().__init__()
-        def mlp(out):
-            return nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, out))
-        self.pi = mlp(CAT_N + PRICE_N + OFF_N + 2)
-        self.v = mlp(1)
+        self.hidden = hidden
+        H = hidden
+        self.l1 = _Linear(obs_dim, 2 * H)                         # [policy | value] first layers
+        self.l2 = _Linear(2 * H, 2 * H)
+        self.out = _Linear(2 * H, self.N_PAD)
+        m2 = torch.zeros(2 * H, 2 * H)
+        m2[:H, :H] = 1; m2[H:, H:] = 1
+        mo = torch.zeros(self.N_PAD, 2 * H)
+        mo[:self.N_OUT, :H] = 1; mo[self.N_OUT, H:] = 1
+        self.register_buffer("mask2", m2)
+        self.register_buffer("mask_out", mo)
+        with torch.no_grad():                                      # every block initialised as the nn.Linear(256, .) it stands for
+            for w, b, rows in ((self.l2.weight, self.l2.bias, 2 * H), (self.out.weight, self.out.bias, self.N_PAD)):
+                bound = 1.0 / math.sqrt(H)
+                w.uniform_(-bound, bound); b.uniform_(-bound, bound)
+            self.l2.weight.mul_(m2); self.out.weight.mul_(mo)
+            self.out.bias[self.N_OUT + 1:] = 0
         self.log_std = nn.Parameter(torch.full((2,), -0.5))
 
-    def dists(self, obs):
-        o = self.pi(obs)
+    def trunk(self, obs):
+        """-> (policy outputs [B, 24], value [B])"""
+        h = torch.tanh(self.l1(obs))
+        h = torch.tanh(_SplitKLinear.apply(h, self.l2.weight * self.mask2, self.l2.bias))
+        o = _SplitKLinear.apply(h, self.out.weight * self.mask_out, self.out.bias)
+        return o[:, :self.N_OUT], o[:, self.N_OUT]
+
+    def pi(self, obs):
+        return self.trunk(obs)[0]
+
+    def v(self, obs):
+        return self.trunk(obs)[1].unsqueeze(-1)
+
+    def _dists(self, o):
         # validate_args=False: the argument checks read a flag back to the host, which neither a captured HIP graph
         # nor an asynchronous rollout can afford
+        o = o.float()
         cat = torch.distributions.Categorical(logits=o[:, :CAT_N], validate_args=False)
         price = torch.distributions.Categorical(logits=o[:, CAT_N:CAT_N + PRICE_N], validate_args=False)
         off = torch.distributions.Categorical(logits=o[:, CAT_N + PRICE_N:CAT_N + PRICE_N + OFF_N], validate_args=False)
@@ -42,20 +106,79 @@ class ActorCritic(nn.Module):
         cont = torch.distributions.Normal(mu, self.log_std.exp().expand_as(mu), validate_args=False)
         return cat, price, off, cont
 
+    def dists(self, obs):
+        return self._dists(self.trunk(obs)[0])
+
     def act(self, obs):
-        cat, price, off, cont = self.dists(obs)
+        o, val = self.trunk(obs)
+        cat, price, off, cont = self._dists(o)
         # Normal.sample() checks std >= 0 on the host (a sync, illegal inside a captured graph): draw the noise directly
         a_cat, a_price, a_off = cat.sample(), price.sample(), off.sample()
         a_cont = (cont.loc + cont.scale * torch.randn_like(cont.loc)).detach()
         logp = cat.log_prob(a_cat) + price.log_prob(a_price) + off.log_prob(a_off) + cont.log_prob(a_cont).sum(-1)
-        return (a_cat, a_price, a_off, a_cont), logp, self.v(obs).squeeze(-1)
+        return (a_cat, a_price, a_off, a_cont), logp, val.float()
+
+    def act_fused(self, obs, n, a, state):
+        """act() + to_env_actions() for HIP tensors with ONE sampling launch (cda_policy_sample) behind the network: returns
+        (actions, logp, value, env_actions).  `state` = (seed, counter tensor i64[1]) from new_sampler_state()."""
+        from ._lib import check, lib
+        o, val = self.trunk(obs)
+        o = o.float().contiguous()
+        B, dev = o.shape[0], o.device
+        a_cat, a_price, a_off = (torch.empty(B, dtype=torch.int64, device=dev) for _ in range(3))
+        a_cont, logp = torch.empty((B, 2), dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
+        e_cat, e_price, e_off = (torch.empty((n, a), dtype=torch.int32, device=dev) for _ in range(3))
+        e_mean, e_sigma = (torch.empty((n, a), dtype=torch.float32, device=dev) for _ in range(2))
+        seed, counter = state
+        check(lib().cda_policy_sample(o.data_ptr(), self.log_std.detach().float().contiguous().data_ptr(), B, int(seed) & (2 ** 64 - 1), counter.data_ptr(),
+                                      a_cat.data_ptr(), a_price.data_ptr(), a_off.data_ptr(), a_cont.data_ptr(), logp.data_ptr(),
+                                      e_cat.data_ptr(), e_mean.data_ptr(), e_sigma.data_ptr(), e_price.data_ptr(), e_off.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream), "cda_policy_sample")
+        return (a_cat, a_price, a_off, a_cont), logp, val.float(), (e_cat, e_mean, e_sigma, e_price, e_off)
 
     def evaluate(self, obs, actions):
+        """log-probability of `actions`, entropy and value for a batch - the three discrete heads through ONE log-softmax pass each
+        on the float32 logits, the Gaussian heads in closed form (no distribution objects: a quarter of the elementwise launches)."""
         a_cat, a_price, a_off, a_cont = actions
-        cat, price, off, cont = self.dists(obs)
-        logp = cat.log_prob(a_cat) + price.log_prob(a_price) + off.log_prob(a_off) + cont.log_prob(a_cont).sum(-1)
-        ent = cat.entropy() + price.entropy() + off.entropy() + cont.entropy().sum(-1)
-        return logp, ent, self.v(obs).squeeze(-1)
+        o, val = self.trunk(obs)
+        o = o.float()
+        logp = ent = 0.0
+        for lo, hi, a in ((0, CAT_N, a_cat), (CAT_N, CAT_N + PRICE_N, a_price), (CAT_N + PRICE_N, CAT_N + PRICE_N + OFF_N, a_off)):
+            ls = torch.log_softmax(o[:, lo:hi], dim=-1)
+            logp = logp + ls.gather(1, a.view(-1, 1)).squeeze(1)
+            ent = ent - (ls.exp() * ls).sum(-1)
+        mu, log_std = o[:, -2:], self.log_std
+        z = (a_cont - mu) * torch.exp(-log_std)
+        logp = logp + (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+        ent = ent + (0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum()
+        return logp, ent, val.float()
+
+
+class _FusedPPOLoss(torch.autograd.Function):
+    """loss(minibatch) and its gradient with respect to the network outputs in ONE launch of the HIP kernel behind cda_ppo_loss
+    (csrc/cda_ppo.hip) instead of ~100 elementwise / reduction launches; `ActorCritic.evaluate` + the formulas of ppo_update
+    are the plain PyTorch statement of the same op (the numerics reference, and the path of non-HIP tensors)."""
+
+    @staticmethod
+    def forward(ctx, logits, value, log_std, a_cat, a_price, a_off, a_cont, logp_old, adv, ret, clip, vf_coef, ent_coef):
+        from ._lib import check, lib
+        B = logits.shape[0]
+        logits, value = logits.contiguous(), value.contiguous()
+        d_logits, d_value = torch.empty_like(logits), torch.empty_like(value)
+        sums = torch.empty(5, dtype=torch.float64, device=logits.device)
+        out = torch.empty(6, dtype=torch.float32, device=logits.device)
+        check(lib().cda_ppo_loss(logits.data_ptr(), value.data_ptr(), log_std.detach().float().contiguous().data_ptr(), a_cat.data_ptr(), a_price.data_ptr(),
+                                 a_off.data_ptr(), a_cont.contiguous().data_ptr(), logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), B,
+                                 float(clip), float(vf_coef), float(ent_coef), d_logits.data_ptr(), d_value.data_ptr(), sums.data_ptr(), out.data_ptr(),
+                                 torch.cuda.current_stream(logits.device).cuda_stream), "cda_ppo_loss")
+        ctx.save_for_backward(d_logits, d_value, out)
+        ctx.mark_non_differentiable(out)
+        return out[3], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        d_logits, d_value, out = ctx.saved_tensors
+        return (d_logits * g_loss, d_value * g_loss, out[4:6] * g_loss) + (None,) * 10
 
 
 def to_env_actions(actions, n, a):
@@ -81,28 +204,43 @@ def gae(rew, val, last_val, done, gamma=0.99, lam=0.95):
     return adv, adv + val
 
 
-def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch=65536, clip=0.2, vf_coef=0.5, ent_coef=0.01, amp=False):
-    """amp: run the two MLPs' matrix products of the update in bfloat16 on the MFMA units (torch.autocast; softmax / log-prob /
-    losses stay float32, parameters and Adam state stay float32) - the update is the learner-bound 80 % of an iteration."""
+def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch=262144, clip=0.2, vf_coef=0.5, ent_coef=0.01, amp=False, fused=None):
+    """amp: the MLPs' matrix products of the update run in bfloat16 on the MFMA units (the observation batch is cast ONCE per
+    update, activations are kept in bfloat16; log-softmax / log-prob / losses, parameters and Adam state stay float32) - the
+    update is the learner-bound part of an iteration.  Per epoch the whole batch is shuffled with ONE gather per tensor and the
+    minibatches are contiguous slices of the shuffled copy (no per-minibatch index kernels); nothing is read back to the host
+    until the update is over."""
     B = obs.shape[0]
-    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+    fused = obs.is_cuda if fused is None else bool(fused)         # the HIP loss kernel (cda_ppo_loss); the PyTorch statement elsewhere
+    adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).float().contiguous()
+    logp_old, ret = logp_old.float().contiguous(), ret.float().contiguous()
+    actions = (actions[0].contiguous(), actions[1].contiguous(), actions[2].contiguous(), actions[3].float().contiguous())
+    x_all = obs.to(torch.bfloat16) if amp else obs
     stats = {}
     for _ in range(epochs):
         perm = torch.randperm(B, device=obs.device)
+        xs, acts = x_all[perm], tuple(a[perm] for a in actions)
+        lp_old, adv_s, ret_s = logp_old[perm], adv[perm], ret[perm]
         for s in range(0, B, minibatch):
-            idx = perm[s:s + minibatch]
-            with torch.autocast(obs.device.type, dtype=torch.bfloat16, enabled=amp):
-                logp, ent, v = model.evaluate(obs[idx], tuple(x[idx] for x in actions))
-            logp, ent, v = logp.float(), ent.float(), v.float()
-            ratio = (logp - logp_old[idx]).exp()
-            pg = -torch.min(ratio * adv[idx], ratio.clamp(1 - clip, 1 + clip) * adv[idx]).mean()
-            vl = (v - ret[idx]).pow(2).mean()
-            loss = pg + vf_coef * vl - ent_coef * ent.mean()
+            e = min(B, s + minibatch)
+            if fused:
+                o, v = model.trunk(xs[s:e])
+                loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, acts[0][s:e], acts[1][s:e], acts[2][s:e], acts[3][s:e],
+                                                lp_old[s:e], adv_s[s:e], ret_s[s:e], clip, vf_coef, ent_coef)
+                pg, vl, ent_m = out[0], out[1], out[2]
+            else:
+                logp, ent, v = model.evaluate(xs[s:e], tuple(a[s:e] for a in acts))
+                ratio = (logp - lp_old[s:e]).exp()
+                a_mb = adv_s[s:e]
+                pg = -torch.min(ratio * a_mb, ratio.clamp(1 - clip, 1 + clip) * a_mb).mean()
+                vl = (v - ret_s[s:e]).pow(2).mean()
+                ent_m = ent.mean()
+                loss = pg + vf_coef * vl - ent_coef * ent_m
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+            nn.utils.clip_grad_norm_(model.parameters(), 0.5, foreach=True)
             opt.step()
-            stats = {"pg_loss": pg.detach(), "v_loss": vl.detach(), "entropy": ent.mean().detach()}
+            stats = {"pg_loss": pg.detach(), "v_loss": vl.detach(), "entropy": ent_m.detach()}
     return {k: float(v) for k, v in stats.items()}          # one host sync per update, not one per minibatch
 
 
@@ -112,21 +250,25 @@ def _join(env):
         env.join()
 
 
-def _capture_policy_step(model, env, N, A):
-    """HIP graph of: observation broadcast -> policy/value forward -> sampling -> env action tensors."""
+def new_sampler_state(seed, device):
+    return int(seed), torch.zeros(1, dtype=torch.int64, device=device)
+
+
+def _capture_policy_step(model, env, N, A, seed=0):
+    """HIP graph of: observation broadcast -> policy/value forward -> ONE sampling launch (cda_policy_sample: the three categorical and
+    two Gaussian heads, log-probability, the env's action tensors).  The sampler's draw counter lives on the device and is bumped
+    inside the graph, so every replay draws fresh numbers."""
+    state = new_sampler_state(seed, env.obs.device)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side), torch.no_grad():
         for _ in range(3):                                           # warm-up outside capture (allocator, lazy init)
-            pobs = env.obs.repeat_interleave(A, dim=0)
-            actions, logp, val = model.act(pobs)
-            to_env_actions(actions, N, A)
+            model.act_fused(env.obs.repeat_interleave(A, dim=0), N, A, state)
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g), torch.no_grad():
         pobs = env.obs.repeat_interleave(A, dim=0)
-        actions, logp, val = model.act(pobs)
-        env_acts = tuple(x.contiguous() for x in to_env_actions(actions, N, A))
+        actions, logp, val, env_acts = model.act_fused(pobs, N, A, state)
     return g, (pobs, actions, logp, val, env_acts)
 
 
@@ -149,7 +291,7 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
     policy_step = None
     if dev.type == "cuda" and use_graph:
         try:
-            policy_step = _capture_policy_step(model, env, N, A)
+            policy_step = _capture_policy_step(model, env, N, A, seed=seed)
         except Exception as e:  # noqa: BLE001 - eager rollouts are always available
             log(json.dumps({"hip_graph": f"capture failed, eager rollout: {e}"}))
     for it in range(iters):
@@ -180,7 +322,7 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
                 env.reset(mask=done)                               # seed=None semantics: streams continue
         obs = env.obs
         with torch.no_grad():
-            last_val = model.v(obs.repeat_interleave(A, dim=0)).squeeze(-1)
+            last_val = model.v(obs.repeat_interleave(A, dim=0)).squeeze(-1).float()
         rew, val, dn = torch.stack(buf_rew), torch.stack(buf_val), torch.stack(buf_done)
         adv, ret = gae(rew, val, last_val, dn)
         flat = lambda xs: torch.cat(xs, 0)                         # noqa: E731
@@ -215,7 +357,7 @@ def main(argv=None):
     _, bad = env.nav_conservation()
     summary = {"metric": "agent-steps/sec end to end (rollout + PPO update), BASELINE configs[4]",
                "config": {"workload": f"{args.markets} markets x {args.agents} agents, PyTorch-ROCm PPO policy in the loop (256x256 tanh actor and critic, "
-                                      f"4 epochs, 65536-sample minibatches), horizon {args.horizon}, {args.iters} iterations, auto_reset on",
+                                      f"4 epochs, 262144-sample minibatches), horizon {args.horizon}, {args.iters} iterations, auto_reset on",
                           "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters, "update_dtype": "float32" if args.fp32_update else "bfloat16 autocast (float32 parameters, Adam state, softmax and losses)"},
                "iterations": hist,
                "value": sum(h["agent_steps"] for h in hist[1:] or hist) / sum(h["rollout_s"] + h["update_s"] for h in hist[1:] or hist),

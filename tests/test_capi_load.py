@@ -88,3 +88,15 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in txt and "libcda_oracle" not in txt and "cda_oracle" not in txt, f
+
+
+def test_product_library_has_no_measuring_probes():
+    """The decimal micro-benchmark, the clock probe and the PMC calibration kernels live in tools/libcda_tools.so:
+    the product library exports none of their entry points and holds none of their kernels."""
+    import subprocess
+    from gym_continuousdoubleauction_amd import _lib
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "cda_debug" not in syms, [ln for ln in syms.splitlines() if "cda_debug" in ln]
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"k_opbench", b"k_clock_probe", b"k_calib_read", b"k_calib_write"):
+        assert name not in blob, name

@@ -385,3 +385,89 @@ def test_league_self_play_loop_on_the_hip_env():
     assert all(math.isfinite(h["v_loss"]) and math.isfinite(h["episode_return"]) for h in hist)
     assert int(env.flags().abs().sum()) == 0
     env.close()
+
+
+def test_fused_ppo_loss_kernel_equals_the_pytorch_statement():
+    """cda_ppo_loss (csrc/cda_ppo.hip): loss, its three means and the gradients with respect to logits, value and log_std of one
+    minibatch in one launch - against the plain PyTorch fp32 formulation of the same op (ActorCritic.evaluate + the loss formulas
+    of ppo_update) on the same inputs.  float32 tolerance: 2e-5 relative on the scalars, 1e-6 absolute on the gradients (they carry
+    the 1 / B of the means; B = 20 000 here)."""
+    import torch
+    from gym_continuousdoubleauction_amd import ppo
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    B = 20000
+    m = ppo.ActorCritic(168).to(dev)
+    with torch.no_grad():
+        m.log_std.copy_(torch.tensor([-0.3, 0.2]))
+    obs = torch.randn(B, 168, device=dev)
+    with torch.no_grad():
+        acts, logp_old, _ = m.act(obs)
+        logp_old = logp_old + 0.3 * torch.randn_like(logp_old)          # ratios on both sides of the clip range
+    adv, ret = torch.randn(B, device=dev), torch.randn(B, device=dev)
+    clip, vf, ec = 0.2, 0.5, 0.01
+    # the reference: autograd through the PyTorch formulation, gradients taken at the network OUTPUTS
+    o, v = m.trunk(obs)
+    o, v = o.detach().float().requires_grad_(True), v.detach().float().requires_grad_(True)
+    ls = m.log_std.detach().clone().requires_grad_(True)
+    logp = ent = 0.0
+    for lo, hi, a in ((0, 9, acts[0]), (9, 19, acts[1]), (19, 22, acts[2])):
+        l = torch.log_softmax(o[:, lo:hi], dim=-1)
+        logp = logp + l.gather(1, a.view(-1, 1)).squeeze(1)
+        ent = ent - (l.exp() * l).sum(-1)
+    z = (acts[3] - o[:, -2:]) * torch.exp(-ls)
+    logp = logp + (-0.5 * z * z - ls - 0.9189385332046727).sum(-1)
+    ent = ent + (1.4189385332046727 + ls).sum()
+    ratio = (logp - logp_old).exp()
+    pg = -torch.min(ratio * adv, ratio.clamp(1 - clip, 1 + clip) * adv).mean()
+    vl = (v - ret).pow(2).mean()
+    loss = pg + vf * vl - ec * ent.mean()
+    loss.backward()
+    o2, v2 = o.detach().clone().requires_grad_(True), v.detach().clone().requires_grad_(True)
+    ls2 = ls.detach().clone().requires_grad_(True)
+    loss2, out = ppo._FusedPPOLoss.apply(o2, v2, ls2, acts[0], acts[1], acts[2], acts[3].float(), logp_old.float(), adv, ret, clip, vf, ec)
+    loss2.backward()
+    rel = lambda a, b: float((a - b).abs() / b.abs().clamp_min(1e-6))   # noqa: E731
+    assert rel(loss2, loss) < 2e-5 and rel(out[0], pg) < 2e-5 and rel(out[1], vl) < 2e-5 and rel(out[2], ent.mean()) < 2e-5
+    assert float((o2.grad - o.grad).abs().max()) < 1e-6 and float((v2.grad - v.grad).abs().max()) < 1e-6
+    assert float((ls2.grad - ls.grad).abs().max()) < 2e-5 * max(1.0, float(ls.grad.abs().max()))
+    assert float((o.grad != 0).float().mean()) > 0.5                      # (the comparison is not between zeros)
+
+
+def test_fused_policy_sampling_kernel_follows_the_network_outputs():
+    """cda_policy_sample: (i) the log-probability it returns for the action it drew equals ActorCritic.evaluate's for that action
+    (the plain PyTorch fp32 formulation; 1e-4 absolute); (ii) the env tensors are the squashed / cast samples; (iii) the draws
+    follow the distribution: category frequencies over 400 k rows within 4 sigma of the softmax probabilities, Gaussian samples
+    with the right mean / std; (iv) consecutive calls (and graph replays) draw different numbers, equal seeds equal numbers."""
+    import torch
+    from gym_continuousdoubleauction_amd import ppo
+    torch.manual_seed(2)
+    dev = torch.device("cuda:0")
+    n, a = 100000, 4
+    m = ppo.ActorCritic(168).to(dev)
+    with torch.no_grad():
+        m.out.bias[:9] = torch.linspace(-1.5, 1.5, 9, device=dev)             # a visibly non-uniform category head
+    obs = (0.05 * torch.randn(1, 168, device=dev)).expand(n * a, 168).contiguous()  # the same observation in every row
+    st = ppo.new_sampler_state(11, dev)
+    with torch.no_grad():
+        acts, logp, val, env_acts = m.act_fused(obs, n, a, st)
+        lp_ref, _, v_ref = m.evaluate(obs, acts)
+    assert float((logp - lp_ref).abs().max()) < 1e-4 and float((val - v_ref).abs().max()) < 1e-5
+    assert torch.equal(env_acts[0].view(-1), acts[0].to(torch.int32)) and torch.equal(env_acts[3].view(-1), acts[1].to(torch.int32))
+    assert torch.equal(env_acts[4].view(-1), acts[2].to(torch.int32))
+    assert float((env_acts[1].view(-1) - torch.tanh(acts[3][:, 0])).abs().max()) < 1e-6
+    assert float((env_acts[2].view(-1) - torch.sigmoid(acts[3][:, 1])).abs().max()) < 1e-6
+    assert int(acts[0].min()) >= 0 and int(acts[0].max()) <= 8 and int(acts[1].max()) <= 9 and int(acts[2].max()) <= 2
+    with torch.no_grad():
+        o, _ = m.trunk(obs[:1])
+    for lo, hi, x in ((0, 9, acts[0]), (9, 19, acts[1]), (19, 22, acts[2])):
+        p = torch.softmax(o[0, lo:hi].float(), -1)
+        f = torch.bincount(x, minlength=hi - lo).float() / (n * a)
+        assert float(((f - p).abs() / (p * (1 - p) / (n * a)).sqrt()).max()) < 4.5, (lo, f, p)
+    mu, sd = o[0, -2:].float(), m.log_std.detach().exp()
+    assert float(((acts[3].mean(0) - mu).abs() / (sd / (n * a) ** 0.5)).max()) < 4.5 and float((acts[3].std(0) / sd - 1).abs().max()) < 0.01
+    with torch.no_grad():
+        acts2, *_ = m.act_fused(obs, n, a, st)                                  # the device-side counter moved on
+        acts3, *_ = m.act_fused(obs, n, a, ppo.new_sampler_state(11, dev))     # same seed, fresh counter: the first draw again
+    assert not torch.equal(acts2[0], acts[0]) and torch.equal(acts3[0], acts[0]) and torch.equal(acts3[3], acts[3])
+    assert int(st[1].item()) == 2

@@ -99,3 +99,42 @@ def test_random_agent_sampler_matches_its_specification():
             assert off[i, k] == ((w1 & 0xffffffff) * 3) >> 32
             assert mean[i, k] == np.float32(((w1 >> 32) & 0xffffff) / 8388608.0 - 1.0) and sigma[i, k] == np.float32((w1 >> 40) / 16777216.0)
     assert L.cda_random_actions_host(seed, base, -1, n, a, cat.ctypes.data, mean.ctypes.data, sigma.ctypes.data, price.ctypes.data, off.ctypes.data) != 0
+
+
+def test_lazy_info_dicts_are_real_dicts_once_touched():
+    """CDAVecMultiAgentEnv.step hands out N x A info dicts per step that are BUILT ON FIRST USE (env._LazyInfo).  Whatever touches
+    them first - json.dumps (C encoder), ==, iteration, .get, len, dict(), {**d}, pickle, deepcopy - must see exactly what the eager
+    builder (env._info_dict, the one CDAEnv uses) produces."""
+    import copy
+    import ctypes
+    import json
+    import pickle
+
+    import numpy as np
+    from gym_continuousdoubleauction_amd import _capi as K
+    from gym_continuousdoubleauction_amd.env import _LazyInfo, _info_dict
+    n, a = 3, 4
+    rng = np.random.default_rng(0)
+    info = {}
+    for name, ct, per_agent, dims in K.INFO_FIELDS:
+        shape = ((n, a) if per_agent else (n,)) + tuple(dims)
+        if ct is K.Dec:
+            info[name] = np.zeros(shape + (16,), np.uint8)
+            info[name][..., 0] = rng.integers(1, 200, shape)
+        else:
+            info[name] = (rng.random(shape) * 5).astype({4: np.int32, 8: np.float64, 1: np.uint8}[ctypes.sizeof(ct)])
+    info["best_bid"][1] = np.nan                                   # None in the dict
+    act = {"category": np.int64(3), "size_mean": np.array([0.5], np.float32)}
+    for (i, k, ma) in ((1, 2, act), (0, 0, None), (2, 3, act)):
+        want = _info_dict(info, i, k, 0.25, ma)
+        mk = lambda: _LazyInfo(info, i, k, 0.25, ma)   # noqa: E731
+        assert dict.__len__(mk()) == 1                              # nothing but the reward has been built
+        assert json.dumps(mk(), sort_keys=True) == json.dumps(want, sort_keys=True)
+        assert json.dumps({"agent_0": mk()}) == json.dumps({"agent_0": want})
+        assert mk() == want and want == mk() and not (mk() != want)
+        assert list(mk()) == list(want) and list(mk().items()) == list(want.items()) and len(mk()) == len(want)
+        assert mk()["NAV"] == want["NAV"] and mk().get("best_bid") == want["best_bid"] and "spread" in mk() and mk().get("nope", 7) == 7
+        assert dict(mk()) == want and {**mk()} == want and copy.deepcopy(mk()) == want and pickle.loads(pickle.dumps(mk())) == want
+        d = mk()
+        d["extra"] = 1                                              # a consumer may add to it
+        assert {k2: v for k2, v in d.items() if k2 != "extra"} == want

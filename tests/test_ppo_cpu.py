@@ -67,3 +67,28 @@ def test_league_self_play_loop_grows_a_champion_pool():
     assert hist[0]["promoted"] == "champion_1" and mapper.available_modules[:4] == ["policy_0", "policy_1", "policy_2", "policy_3"]
     assert [n for n in mapper.available_modules if n.startswith("champion_")] == ["champion_1", "champion_2", "champion_3"]
     assert hist[-1]["pool"][-1] == "champion_3"
+
+
+def test_split_k_weight_gradient_and_closed_form_evaluate_equal_the_plain_formulation():
+    """The update's two restructurings are numerically the plain ones: (i) a Linear whose weight gradient is a split-K batched
+    product (ppo._SplitKLinear) gives the gradients of nn.Linear; (ii) evaluate()'s closed-form log-probability / entropy equal
+    the torch.distributions objects act() samples from."""
+    torch.manual_seed(0)
+    n = 64 * ppo._SplitKLinear.SPLIT
+    x = torch.randn(n, 24, dtype=torch.float64, requires_grad=True)
+    lin = ppo._Linear(24, 10).double()
+    ref = torch.nn.Linear(24, 10).double()
+    ref.load_state_dict(lin.state_dict())
+    g = torch.randn(n, 10, dtype=torch.float64)
+    (lin(x) * g).sum().backward()
+    gx, gw, gb = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    x.grad = None
+    (ref(x) * g).sum().backward()
+    assert torch.allclose(gx, x.grad) and torch.allclose(gw, ref.weight.grad, rtol=1e-10, atol=1e-10) and torch.allclose(gb, ref.bias.grad)
+    m = ppo.ActorCritic(168).double()
+    obs = torch.randn(300, 168, dtype=torch.float64)
+    acts, logp_a, val_a = m.act(obs)
+    logp_e, ent_e, val_e = m.evaluate(obs, acts)
+    cat, price, off, cont = m.dists(obs)
+    ent = cat.entropy() + price.entropy() + off.entropy() + cont.entropy().sum(-1)
+    assert torch.allclose(logp_e.double(), logp_a.double(), atol=1e-5) and torch.allclose(ent_e.double(), ent.double(), atol=1e-5) and torch.allclose(val_e.double(), val_a.double(), atol=1e-6)

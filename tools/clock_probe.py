@@ -10,7 +10,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gym_continuousdoubleauction_amd import CDAVecEnv, _lib  # noqa: E402
 
-L = _lib.lib()
+def _tools_lib():
+    """tools/libcda_tools.so: the probes are a library of their own, outside the product (built by __graft_entry__.build())"""
+    import ctypes
+    import os
+    import torch  # noqa: F401  (its HIP runtime must be in the process first, see _lib.py)
+    return ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcda_tools.so"))
+
+
+L = _tools_lib()
 L.cda_debug_clock_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
 out = torch.zeros(3, dtype=torch.int64, device="cuda:0")
 

@@ -9,7 +9,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gym_continuousdoubleauction_amd import _capi as K, _lib
 
-L = _lib.lib()
+def _tools_lib():
+    """tools/libcda_tools.so: the probes are a library of their own, outside the product (built by __graft_entry__.build())"""
+    import ctypes
+    import os
+    import torch  # noqa: F401  (its HIP runtime must be in the process first, see _lib.py)
+    return ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcda_tools.so"))
+
+
+L = _tools_lib()
 L.cda_debug_opbench.argtypes = [C.c_int, C.c_int, C.POINTER(K.Dec), C.POINTER(K.Dec), C.c_void_p]
 L.cda_debug_opbench.restype = C.c_longlong
 ITERS = 2000
