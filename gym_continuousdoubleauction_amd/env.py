@@ -199,6 +199,7 @@ class _DictSurface(_Base):
         self.snapshot_dim = 42
         agent_ids = [f"agent_{i}" for i in range(self.num_of_agents)]
         self._agent_ids = set(agent_ids)
+        self._agent_index = {a: i for i, a in enumerate(agent_ids)}
         self.agents = list(agent_ids)
         self.possible_agents = list(agent_ids)
         obs_space = _spaces.observation_space(self.n_hist)
@@ -219,21 +220,27 @@ class _DictSurface(_Base):
     def _encode(self, actions, cat, mean, sigma, price, off, present):
         """One market's action dict -> row views of the [*, A] host arrays (action_helper.py:145-172, :241-283)."""
         A = self.num_of_agents
+        index = self._agent_index
+        nd = np.ndarray
         for pos, (key, act) in enumerate(actions.items()):
-            a = int(str(key).split("_")[1])
-            if not 0 <= a < A:
-                raise KeyError(key)
-            c = int(act["category"])
+            a = index.get(key)
+            if a is None:
+                a = int(str(key).split("_")[1])
+                if not 0 <= a < A:
+                    raise KeyError(key)
+            c = act["category"]
             if not 0 <= c <= 8:
                 raise KeyError(c)                               # _CATEGORY_MAP lookup (action_helper.py:266)
             present[a] = 1 + pos                                # the dict's iteration order decides who draws which normal (:164-170)
             cat[a] = c
-            mean[a] = np.float32(np.asarray(act["size_mean"], dtype=np.float32).reshape(-1)[0])
-            sigma[a] = np.float32(np.asarray(act["size_sigma"], dtype=np.float32).reshape(-1)[0])
-            if sigma[a] < 0:
+            sm, ss = act["size_mean"], act["size_sigma"]        # Box(shape=(1,)) samples; anything array-like or scalar is accepted
+            mean[a] = sm[0] if type(sm) is nd and sm.ndim == 1 else np.asarray(sm, dtype=np.float32).reshape(-1)[0]
+            sg = ss[0] if type(ss) is nd and ss.ndim == 1 else np.asarray(ss, dtype=np.float32).reshape(-1)[0]
+            if sg < 0:
                 raise ValueError("scale < 0")                   # numpy's Generator.normal
-            price[a] = int(act.get("price", 0))
-            off[a] = int(act.get("price_offset", 1))            # neutral 'join' (action_helper.py:256-258)
+            sigma[a] = sg
+            price[a] = act.get("price", 0)
+            off[a] = act.get("price_offset", 1)                 # neutral 'join' (action_helper.py:256-258)
 
     def _decode(self, i, actions, obs, rew, term, trunc, info):
         """Market i's rows of the host copy -> the reference's five dicts (info_helper.py:30-116)."""
