@@ -245,7 +245,7 @@ def main():
         def __init__(self, with_info, n_groups, handback=False, ordered=False):
             self.with_info, self.ordered, self.handback = with_info, ordered, handback
             if handback:
-                self.sh = ShardedVecEnv(cfg, world * N, device=str(device), groups=n_groups, handback=True,
+                self.sh = ShardedVecEnv(cfg, world * N, device=str(device), groups=n_groups, handback=True, force_collective=args.force_gather,
                                         env_factory=lambda c, n, d, g: CDAVecEnv(c, n_markets=n, device=d, with_info=with_info, groups=g, handback=True))
                 self.env = self.sh.env
                 self.sh.reset(seed_base=SEED_BASE)
@@ -359,6 +359,7 @@ def main():
     peak_orders = int(env.book_peak().max().item())
     tile, spill = env.book_capacity, env.book_spill
     head_groups, head_ranges = env.groups, list(env.group_ranges)
+    head_transport = None if head.sh is None else ("ncclAllGather issued by cda_step_groups_handback" if head.sh.transport == "rccl" else "torch.distributed")
     head.close()
 
     extras = {}
@@ -418,7 +419,7 @@ def main():
                        "markets_per_gpu": N, "agents": A, "info_outputs": bool(headline_info), "groups": head_groups,
                        "actions": f"cda_random_actions(seed {ACTION_SEED}, step, global market, agent), resident in HBM",
                        "clock_primer": f"{primer_steps} untimed steps on a scratch env before the measured envs' resets",
-                       "collective": (f"{head_groups} all_gather_into_tensor per step (one per chain, own stream + communicator) of {handback_stride(A)}-B records "
+                       "collective": (f"{head_groups} all-gathers per step (one per chain, own stream + communicator; transport: {head_transport}) of {handback_stride(A)}-B records "
                                       f"(newest frame | reward | flags), rebuilt into [global markets, ...] arrays by cda_handback_unpack") if gather else "none",
                        "flagged_markets": n_flagged, "peak_resting_orders": peak_orders},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <dlfcn.h>
 
 #include "../../include/cda.h"
 #include "../../include/cda_random_agents.h"
@@ -469,6 +470,13 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
         size_t free_b = 0, total_b = 0;
         if (cfg->book_spill == 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             while (capv > 1024 && spill_region_bytes((int32_t)capv) * (size_t)n_markets > free_b / 4) capv >>= 1;
+        // a price level's size is summed in int32 (the observation's raw snapshot): the largest decodable order size times the
+        // orders one side can hold must stay below 2^31 - the same rule cfg_ok applies to the tile alone
+        const int64_t scale = (int64_t)cfg->mkt_max_size * (int64_t)cfg->limit_size_multiple + (int64_t)cfg->min_size;
+        while (capv > CDA_SPILL_MIN && scale * ((int64_t)e->cap + capv) > 0x7fffffffLL) {
+            if (cfg->book_spill > 0) { free(e); return CDA_ERR_INVALID; }
+            capv >>= 1;
+        }
         P.lay.spill_cap = (int32_t)capv;
     }
     const size_t records = (size_t)P.lay.stride * (size_t)n_markets;
@@ -586,6 +594,70 @@ int cda_step_groups(cda_env* e, int32_t n_groups,
         int32_t first, n;
         cda_group_range(e->P.n_markets, n_groups, g, &first, &n);
         rc = launch_step(e, first, n, S, (hipStream_t)streams[g]);
+        if (rc) return rc;
+    }
+    return CDA_OK;
+}
+
+// ---- the hand-back of every chain, natively: RCCL is called directly (resolved from the copy already loaded in the process) ----
+typedef int (*nccl_allgather_fn)(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, hipStream_t stream);
+static nccl_allgather_fn resolve_allgather() {
+    static nccl_allgather_fn fn = NULL;
+    static int tried = 0;
+    if (!tried) { tried = 1; fn = (nccl_allgather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather"); }
+    return fn;
+}
+static int handback_chain(cda_env* e, int32_t first, int32_t count, hipStream_t stream, void* comm, int32_t world, void* gathered,
+                          float* obs_full, double* reward_full, uint8_t* term_full, uint8_t* trunc_full) {
+    const int32_t A = e->P.cfg.num_agents, H = e->P.cfg.n_hist, stride = handback_stride_of(A);
+    const uint8_t* mine = e->handback + (size_t)first * (size_t)stride;
+    const uint8_t* src = mine;
+    if (world > 1 || comm) {                                  // (a caller may hand a one-rank communicator over to exercise the collective)
+        nccl_allgather_fn ag = resolve_allgather();
+        if (!ag || !comm || !gathered) { snprintf(g_err, sizeof g_err, "ncclAllGather is not available in this process (RCCL not loaded) or no communicator was given"); return CDA_ERR_UNSUPPORTED; }
+        const int rc = ag(mine, gathered, (size_t)count * (size_t)stride, /* ncclUint8 */ 1, comm, stream);
+        if (rc != 0) { snprintf(g_err, sizeof g_err, "ncclAllGather failed with ncclResult %d", rc); return CDA_ERR_HIP; }
+        src = (const uint8_t*)gathered;
+    }
+    hipLaunchKernelGGL(k_handback_unpack, dim3((unsigned)(((size_t)world * count + 3) / 4)), dim3(256), 0, stream, src, (int)world, (int)count,
+                       (long long)e->P.n_markets, (long long)first, (int)A, (int)H, (int)stride, obs_full, reward_full, term_full, trunc_full);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+int cda_handback_groups(cda_env* e, int32_t n_groups, void* const* streams, void* const* comms, int32_t world, void* const* gathered,
+                        float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full) {
+    if (!e || !e->handback || !streams || n_groups < 1 || n_groups > e->P.n_markets || n_groups > CDA_MAX_GROUPS || world < 1) return CDA_ERR_INVALID;
+    if (!obs_full || !reward_full || !terminated_full || !truncated_full || (world > 1 && (!comms || !gathered))) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    for (int32_t g = 0; g < n_groups; g++) {
+        int32_t first, n;
+        cda_group_range(e->P.n_markets, n_groups, g, &first, &n);
+        int rc = handback_chain(e, first, n, (hipStream_t)streams[g], comms ? comms[g] : NULL, world, gathered ? gathered[g] : NULL,
+                                obs_full, reward_full, terminated_full, truncated_full);
+        if (rc) return rc;
+    }
+    return CDA_OK;
+}
+int cda_step_groups_handback(cda_env* e, int32_t n_groups,
+                             const int32_t* category, const float* size_mean, const float* size_sigma,
+                             const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                             float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                             const cda_info_ptrs* info_out, void* const* streams,
+                             void* const* comms, int32_t world, void* const* gathered,
+                             float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full) {
+    StepArgs S;
+    int rc = fill_step_args(e, S, category, size_mean, size_sigma, price, price_offset, present, obs_out, reward_out, terminated_out, truncated_out, info_out);
+    if (rc) return rc;
+    if (!e->handback || !streams || n_groups < 1 || n_groups > e->P.n_markets || n_groups > CDA_MAX_GROUPS || world < 1) return CDA_ERR_INVALID;
+    if (!obs_full || !reward_full || !terminated_full || !truncated_full || (world > 1 && (!comms || !gathered))) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    for (int32_t g = 0; g < n_groups; g++) {                 // every chain: its step, then ITS collective and rebuild, all on its own stream
+        int32_t first, n;
+        cda_group_range(e->P.n_markets, n_groups, g, &first, &n);
+        rc = launch_step(e, first, n, S, (hipStream_t)streams[g]);
+        if (rc) return rc;
+        rc = handback_chain(e, first, n, (hipStream_t)streams[g], comms ? comms[g] : NULL, world, gathered ? gathered[g] : NULL,
+                            obs_full, reward_full, terminated_full, truncated_full);
         if (rc) return rc;
     }
     return CDA_OK;

@@ -98,6 +98,57 @@ def _hip_unpack(records, n_segments, seg_records, seg_row_stride, row0, num_agen
                                     torch.cuda.current_stream(obs.device).cuda_stream), "cda_handback_unpack")
 
 
+class _Rccl:
+    """RCCL through ctypes: only what the native hand-back needs - communicators the C side can call ncclAllGather on
+    (cda_step_groups_handback issues the collectives itself, on the chains' own HIP streams).  The library is the copy PyTorch
+    already loaded; it is re-opened RTLD_GLOBAL so that libcda_hip.so finds `ncclAllGather` in the process."""
+    _inst = None
+
+    class UniqueId(__import__("ctypes").Structure):
+        _fields_ = [("internal", __import__("ctypes").c_char * 128)]
+
+    def __init__(self):
+        import ctypes as C
+        import os
+        cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "librccl.so.1"]
+        err = None
+        for c in cands:
+            try:
+                self.lib = C.CDLL(c, mode=C.RTLD_GLOBAL)
+                break
+            except OSError as e:  # noqa: PERF203
+                err = e
+        else:
+            raise RuntimeError(f"RCCL not found: {err}")
+        self.lib.ncclGetUniqueId.argtypes = [C.POINTER(self.UniqueId)]
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, self.UniqueId, C.c_int]
+        self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+    def new_comm(self, dist, rank, world):
+        """one communicator over all ranks: rank 0 draws the id, torch.distributed carries it to the others"""
+        import ctypes as C
+        uid = self.UniqueId()
+        if rank == 0:
+            rc = self.lib.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError(f"ncclGetUniqueId: {rc}")
+        box = [C.string_at(C.byref(uid), 128) if rank == 0 else None]        # (all 128 bytes: `.internal` would stop at the first NUL)
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        rc = self.lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank: {rc}")
+        return comm
+
+
 class ShardedVecEnv:
     """This rank's shard of a global batch of `n_markets_total` markets, and - with `handback=True` - the learner-side arrays
     of the WHOLE batch on this rank's device, refreshed every step from the all-gathered hand-back records:
@@ -108,7 +159,8 @@ class ShardedVecEnv:
     `groups` chains and hand-back records; the CPU tests inject a stand-in with the same interface) and `unpack` the receiving
     side (default: the HIP kernel behind cda_handback_unpack; the CPU tests inject a restatement)."""
 
-    def __init__(self, config, n_markets_total, device=None, env_factory=None, dist=None, groups=1, handback=False, unpack=None):
+    def __init__(self, config, n_markets_total, device=None, env_factory=None, dist=None, groups=1, handback=False, unpack=None, transport="auto",
+                 force_collective=False):
         import torch.distributed as tdist
         self.dist = dist or tdist
         self.rank = self.dist.get_rank() if self.dist.is_initialized() else 0
@@ -137,9 +189,30 @@ class ShardedVecEnv:
             self.group_ranges = list(getattr(self.env, "group_ranges", None) or [(0, self.n_local)])
             self.group_streams = list(getattr(self.env, "group_streams", None) or [])
             stride = rec.shape[1]
-            # one communicator per chain: collectives of different chains may then be in flight at the same time, each on its own stream
-            self._pgs = [self.dist.new_group(ranks=list(range(self.world))) if self.world > 1 else None for _ in self.group_ranges]
             self._gbuf = [torch.zeros((self.world, cnt, stride), dtype=torch.uint8, device=dev) for _, cnt in self.group_ranges]
+            # Transport.  "rccl" (the default on HIP devices when the process group runs on RCCL, or with one rank): the whole step -
+            # every chain's k_step, ncclAllGather and rebuild - is ONE native call (cda_step_groups_handback); the library calls RCCL
+            # itself on the chains' streams.  "torch": torch.distributed collectives issued from Python, chain by chain (~25 us of host
+            # time per chain and step, tools/handback_host_probe.py) - the path of the gloo tests and of anything that is not RCCL.
+            # Either way one communicator per chain, so that the chains' collectives may be in flight together.
+            if transport == "auto":
+                on_rccl = self.world == 1 or self.dist.get_backend() == "nccl"
+                transport = "rccl" if (dev.type == "cuda" and unpack is None and hasattr(self.env, "_h") and on_rccl) else "torch"
+            self.transport = transport
+            self._pgs, self._comms = [], None
+            if transport == "rccl":
+                import ctypes as C
+                G = len(self.group_ranges)
+                if self.world > 1 or force_collective:       # (force_collective: a one-rank communicator, so that one GPU runs the real RCCL call)
+                    rccl = _Rccl.get()
+                    comms = [rccl.new_comm(self.dist, self.rank, self.world) for _ in range(G)]
+                    self._comm_handles = comms
+                    self._comms = (C.c_void_p * G)(*[c.value for c in comms])
+                else:
+                    _Rccl_optional_load()
+                self._gptrs = (C.c_void_p * G)(*[b.data_ptr() for b in self._gbuf])
+            else:
+                self._pgs = [self.dist.new_group(ranks=list(range(self.world))) if self.world > 1 else None for _ in self.group_ranges]
             self.full = (torch.zeros((self.n_total, self.obs_dim), dtype=torch.float32, device=dev),
                          torch.zeros((self.n_total, self.num_agents), dtype=torch.float64, device=dev),
                          torch.zeros(self.n_total, dtype=torch.uint8, device=dev), torch.zeros(self.n_total, dtype=torch.uint8, device=dev))
@@ -162,9 +235,21 @@ class ShardedVecEnv:
             buf[0].copy_(mine)
         self._unpack(buf, self.world, cnt, self.n_local, first, self.num_agents, self.n_hist, *self.full)
 
+    def _stream_array(self):
+        import ctypes as C
+        G = len(self.group_ranges)
+        if self.group_streams:
+            return (C.c_void_p * G)(*[s.cuda_stream for s in self.group_streams])
+        return (C.c_void_p * G)(torch.cuda.current_stream(self.full[0].device).cuda_stream)
+
     def handback(self):
         """Enqueue the hand-back of the step (or reset) just enqueued: per chain, on the chain's own stream.  `full` is complete
         for chain g's rows when its stream gets there; join() orders the caller's stream after all of them."""
+        if self.transport == "rccl":
+            from ._lib import check, lib
+            check(lib().cda_handback_groups(self.env._h, len(self.group_ranges), self._stream_array(), self._comms, self.world, self._gptrs,
+                                            *[t.data_ptr() for t in self.full]), "cda_handback_groups")
+            return
         for g in range(len(self.group_ranges)):
             with self._stream_ctx(g):
                 self._handback_group(g)
@@ -188,6 +273,8 @@ class ShardedVecEnv:
         chains' streams; pipelined=True leaves the fork / join with the caller's stream out (see CDAVecEnv.step)."""
         if not self.use_handback:
             return self.env.step(category, size_mean, size_sigma, price, price_offset, present)
+        if self.transport == "rccl":
+            return self._step_native(category, size_mean, size_sigma, price, price_offset, present, pipelined)
         if self.group_streams:
             if not pipelined:
                 self.env.fork()             # the chains start after whatever the caller's stream holds (the actions a policy just wrote)
@@ -198,6 +285,29 @@ class ShardedVecEnv:
         if not pipelined:
             self.join()
         return out
+
+    def _step_native(self, category, size_mean, size_sigma, price, price_offset, present, pipelined):
+        """every chain's step, collective and rebuild in ONE host call (cda_step_groups_handback)"""
+        import torch as _t
+        from ._lib import check, lib
+        env = self.env
+        cat, sm, ss = env._prep(category, _t.int32), env._prep(size_mean, _t.float32), env._prep(size_sigma, _t.float32)
+        pr, po = env._prep(price, _t.int32), env._prep(price_offset, _t.int32)
+        ps = None if present is None else env._prep(present, _t.uint8)
+        if self.group_streams and (not pipelined or env._need_fork):
+            env.fork()
+        if not hasattr(self, "_full_ptrs"):
+            self._full_ptrs = [t.data_ptr() for t in self.full]
+            self._streams_c = self._stream_array() if self.group_streams else None
+        streams = self._streams_c if self._streams_c is not None else self._stream_array()
+        with _t.cuda.device(env.device):
+            check(lib().cda_step_groups_handback(env._h, len(self.group_ranges), cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
+                                                 ps.data_ptr() if ps is not None else None, *env._out_ptrs[env._cur], env._info_ref, streams,
+                                                 self._comms, self.world, self._gptrs, *self._full_ptrs), "cda_step_groups_handback")
+        env._keep_prev, env._keep = getattr(env, "_keep", None), (cat, sm, ss, pr, po, ps)
+        if not pipelined:
+            self.join()
+        return env.obs, env.reward, env._term.view(_t.bool), env._trunc.view(_t.bool), env.info
 
     def gather(self, obs, reward, terminated, truncated):
         """All-gather the per-market outputs of every rank -> global (obs, reward, terminated, truncated)."""
@@ -220,4 +330,18 @@ class ShardedVecEnv:
         return unpack_outputs(g, self.obs_dim, self.num_agents)
 
     def close(self):
+        if getattr(self, "_comm_handles", None):
+            if self.full is not None and self.full[0].is_cuda:
+                torch.cuda.synchronize(self.full[0].device)
+            for c in self._comm_handles:
+                _Rccl.get().lib.ncclCommDestroy(c)
+            self._comm_handles = None
         self.env.close()
+
+
+def _Rccl_optional_load():
+    """one rank needs no collective; loading RCCL is then optional"""
+    try:
+        _Rccl.get()
+    except Exception:  # noqa: BLE001
+        pass

@@ -239,6 +239,24 @@ int cda_handback_unpack(const void* records_dev, int32_t n_segments, int32_t seg
                         int32_t num_agents, int32_t n_hist,
                         float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full, void* stream);
 
+/* cda_step_groups AND the hand-back of every chain in ONE host call (a Python loop over chains - stream context, collective, unpack -
+ * costs ~25 us of host time per chain and step, more than the step itself): on streams[g], for the markets of group g,
+ *     k_step  ->  ncclAllGather(this rank's records of group g -> gathered[g], world x count x stride bytes)  ->  cda_handback_unpack
+ * into the learner-side arrays (row of global market = rank * shard_rows + local market).  comms[g] is an RCCL communicator
+ * (ncclComm_t) the caller created for chain g - one per chain, so that the chains' collectives may be in flight together; the library
+ * resolves ncclAllGather from the RCCL already loaded in the process (no link-time dependency).  world == 1: comms may be NULL, the
+ * records are unpacked where the kernel left them.  Needs cda_set_handback. */
+int cda_step_groups_handback(cda_env* env, int32_t n_groups,
+                             const int32_t* category, const float* size_mean, const float* size_sigma,
+                             const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                             float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                             const cda_info_ptrs* info_out, void* const* streams,
+                             void* const* comms, int32_t world, void* const* gathered,
+                             float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full);
+/* the hand-back alone (after a reset: its records carry `restarted`), same arguments */
+int cda_handback_groups(cda_env* env, int32_t n_groups, void* const* streams, void* const* comms, int32_t world, void* const* gathered,
+                        float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full);
+
 /* Replaces CDA_rand.run_random (CDA_rand.py:40-85): every market plays uniform random agents (the law and the
  * counter-based sampler of include/cda_random_agents.h, keyed by action_seed, market_index_base + market, the
  * market's own step counter and the agent) for up to n_steps steps, stopping early at its episode's end

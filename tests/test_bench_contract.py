@@ -90,7 +90,7 @@ def test_bench_multi_gpu_code_path_on_one_rank():
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, out[-2000:]
         d = json.loads(lines[0])
-        assert d["n_gpus"] == 1 and d["value"] > 1e6 and "all_gather_into_tensor per step" in d["config"]["collective"] and "208-B records" in d["config"]["collective"]
+        assert d["n_gpus"] == 1 and d["value"] > 1e6 and "all-gathers per step" in d["config"]["collective"] and "208-B records" in d["config"]["collective"] and "ncclAllGather" in d["config"]["collective"]
         assert d["config"]["groups"] == (1 if extra else 2) and "hand-back" in d["metric"]
         assert d["config"]["flagged_markets"] == 0 and d["roofline"]["kernel_ms"] > 0
 
@@ -121,7 +121,7 @@ def test_bench_two_ranks_on_one_gpu():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 48 and "all_gather" in d["config"]["collective"] and d["config"]["flagged_markets"] == 0
+    assert d["n_gpus"] == 2 and d["steps"] == 48 and "all-gathers per step" in d["config"]["collective"] and "torch.distributed" in d["config"]["collective"] and d["config"]["flagged_markets"] == 0
     assert "global 512 markets" in d["config"]["workload"] and d["timed_repeats"]["n"] == 5
     assert abs(d["value"] - 2 * 256 * 4 * 48 / (d["ms_per_step"] * 1e-3 * 48)) / d["value"] < 1e-6
 

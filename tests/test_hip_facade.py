@@ -204,11 +204,13 @@ def test_handback_records_rebuild_the_full_outputs_on_the_receiving_side():
     from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv
     from test_distributed_gloo import unpack_restated
     n, a = 200, 4
-    for auto in (False, True):
+    for auto, force in ((False, False), (True, False), (False, True)):
         cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 12, "is_render": False, "auto_reset": auto}
         ref = CDAVecEnv(cfg, n_markets=n, with_info=False)
-        sh = ShardedVecEnv(cfg, n, device="cuda:0", groups=4, handback=True)           # world 1: the collective is a copy
-        assert len(sh.group_ranges) == 4 and sh.env.handback.shape == (n, 208)
+        # world 1.  force: every chain gets a one-rank RCCL communicator and the native step really calls ncclAllGather on the chain's
+        # stream (RCCL loaded and resolved from the process, unique id, ncclCommInitRank, the gathered buffer as the unpack's source)
+        sh = ShardedVecEnv(cfg, n, device="cuda:0", groups=4, handback=True, force_collective=force)
+        assert len(sh.group_ranges) == 4 and sh.env.handback.shape == (n, 208) and sh.transport == "rccl" and (sh._comms is not None) == force
         o0 = ref.reset(seed=np.arange(300, 300 + n, dtype=np.uint64)).clone()
         assert torch.equal(sh.reset(seed_base=300), o0) and torch.equal(sh.full[0], o0)
         rng = np.random.default_rng(3)
