@@ -695,6 +695,10 @@ int cda_random_actions(uint64_t action_seed, uint64_t market_index_base, int32_t
     if (step0 < 0 || n_steps < 0 || n_markets < 0 || num_agents < 1 || !category || !size_mean || !size_sigma || !price || !price_offset) return CDA_ERR_INVALID;
     const size_t total = (size_t)n_steps * (size_t)n_markets * (size_t)num_agents;
     if (total == 0) return CDA_OK;
+    {   // the launch goes to the device that owns the output arrays (this entry point has no env to ask)
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, category) == hipSuccess) HIPCHK(hipSetDevice(at.device));
+    }
     const size_t blocks = (total + 255) / 256;
     hipLaunchKernelGGL(k_random_actions, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream, action_seed, market_index_base,
                        (int)step0, (int)n_steps, (int)n_markets, (int)num_agents, category, size_mean, size_sigma, price, price_offset);

@@ -204,14 +204,28 @@ class ShardedVecEnv:
                 import ctypes as C
                 G = len(self.group_ranges)
                 if self.world > 1 or force_collective:       # (force_collective: a one-rank communicator, so that one GPU runs the real RCCL call)
-                    rccl = _Rccl.get()
-                    comms = [rccl.new_comm(self.dist, self.rank, self.world) for _ in range(G)]
-                    self._comm_handles = comms
-                    self._comms = (C.c_void_p * G)(*[c.value for c in comms])
+                    comms, err = [], None
+                    try:
+                        rccl = _Rccl.get()
+                        comms = [rccl.new_comm(self.dist, self.rank, self.world) for _ in range(G)]
+                    except Exception as e:  # noqa: BLE001 - every rank must take the same branch below
+                        err = e
+                    ok = torch.tensor([0.0 if err else 1.0], device=dev)
+                    if self.world > 1:
+                        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+                    if float(ok.item()) < 1.0:               # some rank could not build its communicators: all ranks use torch.distributed
+                        import sys
+                        print(f"[ShardedVecEnv] rank {self.rank}: native RCCL communicators unavailable ({err}); falling back to torch.distributed", file=sys.stderr)
+                        for c in comms:
+                            _Rccl.get().lib.ncclCommDestroy(c)
+                        transport = self.transport = "torch"
+                    else:
+                        self._comm_handles = comms
+                        self._comms = (C.c_void_p * G)(*[c.value for c in comms])
                 else:
                     _Rccl_optional_load()
                 self._gptrs = (C.c_void_p * G)(*[b.data_ptr() for b in self._gbuf])
-            else:
+            if transport != "rccl":
                 self._pgs = [self.dist.new_group(ranks=list(range(self.world))) if self.world > 1 else None for _ in self.group_ranges]
             self.full = (torch.zeros((self.n_total, self.obs_dim), dtype=torch.float32, device=dev),
                          torch.zeros((self.n_total, self.num_agents), dtype=torch.float64, device=dev),

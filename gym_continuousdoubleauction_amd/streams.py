@@ -5,8 +5,12 @@ queue at its first use and two streams that share a queue execute their kernels 
 (tools/stream_probe.py): of the pairs drawn from PyTorch's stream pool roughly one in four shares a queue, and a groups=2
 env on such a pair runs at HALF speed (74 us per step instead of 37).  `concurrent_streams` therefore tests candidates
 with two spin kernels and keeps a set whose members overlap pairwise; the result is cached per device, so every env of
-the process steps its market groups on the same, known-good streams.
+the process steps its market groups on the same, known-good streams (two groups > 1 envs of one process therefore share
+streams and serialise each other: give the second one its own via `CDAVecEnv(..., group_streams=[...])`).  When the pool
+does not hold enough streams that verifiably overlap - more chains than hardware queues, or another process keeping the
+GPU busy during the 5-ms test - the set is padded with unverified ones and a warning says so (expect up to half speed).
 """
+import warnings
 import time
 
 import torch
@@ -49,6 +53,10 @@ def concurrent_streams(device, n, candidates=12):
                 continue
             if all(min(_spin_pair_seconds(c, s, cycles) for _ in range(2)) < 1.5 * one for c in chosen):
                 chosen.append(s)
+        if len(chosen) < n:
+            warnings.warn(f"only {len(chosen)} of the {n} requested streams were verified to run concurrently on {device} (GPU_MAX_HW_QUEUES defaults to 4; "
+                          "a busy GPU also defeats the test): padding with unverified streams - market groups that share a hardware queue run one "
+                          "after the other", RuntimeWarning, stacklevel=2)
         for s in pool:                                       # not enough verified streams: pad
             if len(chosen) >= n:
                 break

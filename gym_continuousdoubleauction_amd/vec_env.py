@@ -23,7 +23,7 @@ class CDAVecEnv:
     """Batched env.  Tensors: actions [N,A]; obs f32[N, n_hist*42]; reward f64[N,A];
     terminated/truncated bool[N] (the reference's "__all__" flags); info = dict of SoA tensors."""
 
-    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True, out_buffers=1, groups=1, handback=False):
+    def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True, out_buffers=1, groups=1, handback=False, group_streams=None):
         self.cfg_struct, self.config = K.make_config(config)
         self.n_markets = int(n_markets)
         self.num_agents = self.cfg_struct.num_agents
@@ -97,7 +97,12 @@ class CDAVecEnv:
         self.group_streams = []
         if self.groups > 1:
             from .streams import concurrent_streams
-            self.group_streams = list(concurrent_streams(dev, self.groups))     # streams on DISTINCT hardware queues (measured once per process)
+            if group_streams is not None:                   # the caller's own streams (e.g. a second groups > 1 env of the process)
+                if len(group_streams) != self.groups:
+                    raise ValueError(f"need {self.groups} group streams")
+                self.group_streams = list(group_streams)
+            else:
+                self.group_streams = list(concurrent_streams(dev, self.groups))     # streams on DISTINCT hardware queues (measured once per process)
             self._stream_arr = (C.c_void_p * self.groups)(*[s.cuda_stream for s in self.group_streams])
             self._groups_call = lib().cda_step_groups
             self._fork_ev = torch.cuda.Event()
