@@ -16,7 +16,7 @@ include/cda_random_agents.h keyed (2024, step, GLOBAL market index, agent) - the
 reference (train/model/model_handler.py:38-53).  The whole stream is generated on the device before the timed region
 (cda_random_actions), so every input is resident in HBM; the cpu_baseline leg replays the SAME stream.
 
-The batch is stepped as `--groups` (default 4; 2 for runs shorter than 200 steps) contiguous market groups, each a chain of
+The batch is stepped as `--groups` (default 4; 2 for runs shorter than 200 steps and with the N > 1 hand-back) contiguous market groups, each a chain of
 k_step launches on its own stream (cda_step_groups): markets never interact, so the batch-wide barrier of a single launch is
 not part of the reference's semantics, and a group's slowest market then overlaps the other groups' work.
 
@@ -233,7 +233,9 @@ def main():
     # default number of group chains: 4 pays once the chains are long, 2 when the whole timed region is a few dozen steps and the
     # staggered start / drain of four chains is a visible share of it (profiles/r02)
     event_lanes = args.event_lanes or ("all" if K >= 200 else "one")
-    groups = args.groups if args.groups is not None else (1 if args.fused else (4 if K >= 200 else 2))
+    # with the hand-back two chains: every chain adds a collective and a rebuild launch per step to the host's work, and at four chains
+    # the host, not the GPU, bounds the step (tools/handback_rccl_probe.py: 47 us per step at four chains, 41.6 us at two)
+    groups = args.groups if args.groups is not None else (1 if args.fused else (2 if gather else (4 if K >= 200 else 2)))
     groups = max(1, min(groups, N))
     first_market = rank * N                           # global market index -> seed and action key, independent of the GPU count
     seeds = (SEED_BASE + first_market + torch.arange(N, dtype=torch.int64)).numpy().astype("uint64")

@@ -1,0 +1,30 @@
+"""Host / wall cost per step of the native hand-back with REAL (one-rank) RCCL communicators, by number of group chains (GPU box)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv  # noqa: E402
+
+cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 100000, "is_render": False}
+for groups in (4, 2, 1):
+    for force in (False, True):
+        sh = ShardedVecEnv(cfg, 4096, device="cuda:0", groups=groups, handback=True, force_collective=force)
+        sh.reset(seed_base=1000)
+        acts = sh.env.random_actions_device(0, 64, action_seed=1)
+        torch.cuda.synchronize()
+        f = lambda i: sh.step(acts[0][i % 64], acts[1][i % 64], acts[2][i % 64], acts[3][i % 64], acts[4][i % 64], pipelined=True)  # noqa: E731
+        for i in range(50):
+            f(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(600):
+            f(i)
+        th = (time.perf_counter() - t0) / 600
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / 600
+        print(f"groups {groups}  {'ncclAllGather on a one-rank communicator per chain' if force else 'no collective (records unpacked in place)':52s} host {th * 1e6:6.1f} us/step  wall {t * 1e6:6.1f} us/step")
+        sh.close()
