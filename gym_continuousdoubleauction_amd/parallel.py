@@ -17,6 +17,9 @@ chain's transfer runs underneath the other chains' kernels.  On the fully connec
 records (1024 markets x 208 B = 213 KB at 4096 x 4, G = 4) directly to its 7 peers, one link each.
 `gather()` is the simple synchronous packed variant (whole observations) for any env and uneven shards.
 """
+import ctypes as C
+import os
+
 import torch
 
 
@@ -104,12 +107,10 @@ class _Rccl:
     already loaded; it is re-opened RTLD_GLOBAL so that libcda_hip.so finds `ncclAllGather` in the process."""
     _inst = None
 
-    class UniqueId(__import__("ctypes").Structure):
-        _fields_ = [("internal", __import__("ctypes").c_char * 128)]
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
 
     def __init__(self):
-        import ctypes as C
-        import os
         cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "librccl.so.1"]
         err = None
         for c in cands:
@@ -132,7 +133,6 @@ class _Rccl:
 
     def new_comm(self, dist, rank, world):
         """one communicator over all ranks: rank 0 draws the id, torch.distributed carries it to the others"""
-        import ctypes as C
         uid = self.UniqueId()
         if rank == 0:
             rc = self.lib.ncclGetUniqueId(C.byref(uid))
@@ -201,7 +201,6 @@ class ShardedVecEnv:
             self.transport = transport
             self._pgs, self._comms = [], None
             if transport == "rccl":
-                import ctypes as C
                 G = len(self.group_ranges)
                 if self.world > 1 or force_collective:       # (force_collective: a one-rank communicator, so that one GPU runs the real RCCL call)
                     comms, err = [], None
@@ -250,7 +249,6 @@ class ShardedVecEnv:
         self._unpack(buf, self.world, cnt, self.n_local, first, self.num_agents, self.n_hist, *self.full)
 
     def _stream_array(self):
-        import ctypes as C
         G = len(self.group_ranges)
         if self.group_streams:
             return (C.c_void_p * G)(*[s.cuda_stream for s in self.group_streams])
