@@ -804,9 +804,9 @@ int cda_get_book(cda_env* e, int32_t market, int32_t side, cda_order* orders_out
     if (!e || market < 0 || market >= e->P.n_markets || side < 0 || side > 1 || max_orders < 0 || (max_orders > 0 && !orders_out_host) || !n_out_host) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     const Params& P = e->P;
+    HIPCHK(hipDeviceSynchronize());
     uint8_t* rec = (uint8_t*)malloc((size_t)P.lay.stride);
     if (!rec) return CDA_ERR_NOMEM;
-    HIPCHK(hipDeviceSynchronize());
     hipError_t he = hipMemcpy(rec, e->arena + (size_t)market * (size_t)P.lay.stride, (size_t)P.lay.stride, hipMemcpyDeviceToHost);
     if (he != hipSuccess) { free(rec); return hip_fail(he, "hipMemcpy D2H"); }
     int rc = read_book_side(e, market, rec, side, orders_out_host, max_orders, n_out_host);
@@ -818,9 +818,9 @@ int cda_get_state(cda_env* e, int32_t market, cda_market_state* s) {
     if (!e || !s || market < 0 || market >= e->P.n_markets) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     const Params& P = e->P;
+    HIPCHK(hipDeviceSynchronize());
     uint8_t* rec = (uint8_t*)malloc((size_t)P.lay.stride);
     if (!rec) return CDA_ERR_NOMEM;
-    HIPCHK(hipDeviceSynchronize());
     hipError_t he = hipMemcpy(rec, e->arena + (size_t)market * (size_t)P.lay.stride, (size_t)P.lay.stride, hipMemcpyDeviceToHost);
     if (he != hipSuccess) { free(rec); return hip_fail(he, "hipMemcpy D2H"); }
     memset(s, 0, sizeof *s);

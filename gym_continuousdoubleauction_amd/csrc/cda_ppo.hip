@@ -17,76 +17,98 @@
 namespace {
 constexpr int N_CAT = 9, N_PRICE = 10, N_OFF = 3, N_LOGITS = N_CAT + N_PRICE + N_OFF + 2;     // 24
 
+// softmax of one categorical head, kept per row: p_j, log p_j and the entropy
 template <int N>
-__device__ __forceinline__ void head(const float* l, int a, float g_logp, float ent_scale, float* d, float& logp, float& ent) {
+__device__ __forceinline__ void head_probs(const float* l, float* p, float* lp, float& ent) {
     float mx = l[0];
     #pragma unroll
     for (int j = 1; j < N; j++) mx = fmaxf(mx, l[j]);
-    float e[N], s = 0.0f;
+    float s = 0.0f;
     #pragma unroll
-    for (int j = 0; j < N; j++) { e[j] = __expf(l[j] - mx); s += e[j]; }
+    for (int j = 0; j < N; j++) { p[j] = __expf(l[j] - mx); s += p[j]; }
     const float ls = __logf(s), inv = 1.0f / s;
     float h = 0.0f;
     #pragma unroll
-    for (int j = 0; j < N; j++) { const float p = e[j] * inv, lp = l[j] - mx - ls; h -= p * lp; }
+    for (int j = 0; j < N; j++) { p[j] *= inv; lp[j] = l[j] - mx - ls; h -= p[j] * lp[j]; }
+    ent = h;
+}
+template <int N>
+__device__ __forceinline__ float pick(const float* v, int a) {           // v[clamp(a)] without dynamic register indexing
+    float r = v[0];
     #pragma unroll
-    for (int j = 0; j < N; j++) {
-        const float p = e[j] * inv, lp = l[j] - mx - ls;
-        // d logp / d l_j = [j == a] - p_j ;  d ent / d l_j = -p_j (log p_j + ent)
-        d[j] = g_logp * ((j == a ? 1.0f : 0.0f) - p) + ent_scale * p * (lp + h);
-    }
-    a = a < 0 ? 0 : (a >= N ? N - 1 : a);
-    logp += l[a] - mx - ls;
-    ent += h;
+    for (int j = 1; j < N; j++) r = (a == j || (j == N - 1 && a > j)) ? v[j] : r;
+    return r;
 }
 
+// One thread per ROW of network outputs.  A row serves `agents` consecutive samples (the agents of one market see the same
+// observation - state_helper.py:76,109 - so the shared policy's logits and value are the same for all of them and the network
+// runs once per market-step, not once per agent; agents == 1 is the plain per-sample op).  The softmaxes are formed once per
+// row; per sample only the gathers, the ratio and the clipping remain; the row's gradient is the sum over its samples.
 __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ logits, const float* __restrict__ value, const float* __restrict__ log_std,
                                                   const long long* __restrict__ a_cat, const long long* __restrict__ a_price, const long long* __restrict__ a_off,
                                                   const float* __restrict__ a_cont, const float* __restrict__ logp_old, const float* __restrict__ adv,
-                                                  const float* __restrict__ ret, long long B, float clip, float vf_coef, float ent_coef,
+                                                  const float* __restrict__ ret, long long R, int agents, float clip, float vf_coef, float ent_coef,
                                                   float* __restrict__ d_logits, float* __restrict__ d_value, double* __restrict__ sums) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const float invB = 1.0f / (float)B;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float invB = 1.0f / ((float)R * (float)agents);
     float pg = 0.0f, vl = 0.0f, en = 0.0f, dls0 = 0.0f, dls1 = 0.0f;
-    if (i < B) {
-        float l[N_LOGITS], d[N_LOGITS];
-        const float4* lp4 = reinterpret_cast<const float4*>(logits + i * N_LOGITS);          // 96 B per sample, 16-byte aligned
+    if (r < R) {
+        float l[N_LOGITS], d[N_LOGITS], p[N_CAT + N_PRICE + N_OFF], lp[N_CAT + N_PRICE + N_OFF];
+        const float4* lp4 = reinterpret_cast<const float4*>(logits + r * N_LOGITS);          // 96 B per row, 16-byte aligned
         #pragma unroll
         for (int q = 0; q < N_LOGITS / 4; q++) { const float4 v = lp4[q]; l[4 * q] = v.x; l[4 * q + 1] = v.y; l[4 * q + 2] = v.z; l[4 * q + 3] = v.w; }
         const float ls0 = log_std[0], ls1 = log_std[1];
         const float is0 = __expf(-ls0), is1 = __expf(-ls1);
-        const float z0 = (a_cont[2 * i] - l[22]) * is0, z1 = (a_cont[2 * i + 1] - l[23]) * is1;
         const float HALF_LOG_2PI = 0.918938533204672742f;
-        // first pass for logp (the surrogate's gradient factor needs the ratio): heads without gradients ...
-        float logp = -0.5f * z0 * z0 - ls0 - HALF_LOG_2PI - 0.5f * z1 * z1 - ls1 - HALF_LOG_2PI, ent = 0.0f;
-        {
-            float dummy[N_CAT + N_PRICE + N_OFF];
-            head<N_CAT>(l, (int)a_cat[i], 0.0f, 0.0f, dummy, logp, ent);
-            head<N_PRICE>(l + N_CAT, (int)a_price[i], 0.0f, 0.0f, dummy + N_CAT, logp, ent);
-            head<N_OFF>(l + N_CAT + N_PRICE, (int)a_off[i], 0.0f, 0.0f, dummy + N_CAT + N_PRICE, logp, ent);
+        float h0, h1, h2;
+        head_probs<N_CAT>(l, p, lp, h0);
+        head_probs<N_PRICE>(l + N_CAT, p + N_CAT, lp + N_CAT, h1);
+        head_probs<N_OFF>(l + N_CAT + N_PRICE, p + N_CAT + N_PRICE, lp + N_CAT + N_PRICE, h2);
+        const float ent = h0 + h1 + h2 + 1.0f + 2.0f * HALF_LOG_2PI + ls0 + ls1;             // two Gaussian heads: 1/2 + log(2 pi)/2 + log_std each
+        const float es = ent_coef * invB;                                                     // loss has -ent_coef * mean(ent)
+        #pragma unroll
+        for (int j = 0; j < N_LOGITS; j++) d[j] = 0.0f;
+        const float val = value[r];
+        float G = 0.0f, dval = 0.0f;                                                          // sum of d loss / d logp over the row's samples
+        for (int a = 0; a < agents; a++) {
+            const long long i = r * agents + a;
+            const int ac = (int)a_cat[i], ap = (int)a_price[i], ao = (int)a_off[i];
+            const float z0 = (a_cont[2 * i] - l[22]) * is0, z1 = (a_cont[2 * i + 1] - l[23]) * is1;
+            const float logp = -0.5f * z0 * z0 - ls0 - HALF_LOG_2PI - 0.5f * z1 * z1 - ls1 - HALF_LOG_2PI +
+                               pick<N_CAT>(lp, ac) + pick<N_PRICE>(lp + N_CAT, ap) + pick<N_OFF>(lp + N_CAT + N_PRICE, ao);
+            const float A = adv[i], ratio = __expf(logp - logp_old[i]);
+            const float un = ratio * A, cl = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip) * A;
+            pg -= fminf(un, cl);
+            const float g_logp = (un <= cl) ? -un * invB : 0.0f;             // d(-min) / d logp: the unclipped branch carries the gradient
+            const float dv = val - ret[i];
+            vl += dv * dv;
+            dval += 2.0f * vf_coef * dv * invB;
+            en += ent;
+            G += g_logp;
+            // d logp / d l_j = [j == a] - p_j : the one-hot part here, the -p_j part once per row below
+            #pragma unroll
+            for (int j = 0; j < N_CAT; j++) d[j] += (j == ac) ? g_logp : 0.0f;
+            #pragma unroll
+            for (int j = 0; j < N_PRICE; j++) d[N_CAT + j] += (j == ap) ? g_logp : 0.0f;
+            #pragma unroll
+            for (int j = 0; j < N_OFF; j++) d[N_CAT + N_PRICE + j] += (j == ao) ? g_logp : 0.0f;
+            d[22] += g_logp * z0 * is0;                                      // d logp / d mu = z exp(-log_std)
+            d[23] += g_logp * z1 * is1;
+            dls0 += g_logp * (z0 * z0 - 1.0f) - es;                          // d logp / d log_std = z^2 - 1 ; d ent / d log_std = 1
+            dls1 += g_logp * (z1 * z1 - 1.0f) - es;
         }
-        ent += 1.0f + 2.0f * HALF_LOG_2PI + ls0 + ls1;                       // two Gaussian heads: 1/2 + log(2 pi)/2 + log_std each
-        const float A = adv[i], ratio = __expf(logp - logp_old[i]);
-        const float un = ratio * A, cl = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip) * A;
-        pg = -fminf(un, cl);
-        const float g_logp = (un <= cl) ? -un * invB : 0.0f;                // d(-min) / d logp: the unclipped branch carries the gradient
-        const float dv = value[i] - ret[i];
-        vl = dv * dv;
-        en = ent;
-        // ... second pass with the gradient factors known
-        float lp2 = 0.0f, e2 = 0.0f;
-        const float es = ent_coef * invB;                                    // loss has -ent_coef * mean(ent)
-        head<N_CAT>(l, (int)a_cat[i], g_logp, es, d, lp2, e2);
-        head<N_PRICE>(l + N_CAT, (int)a_price[i], g_logp, es, d + N_CAT, lp2, e2);
-        head<N_OFF>(l + N_CAT + N_PRICE, (int)a_off[i], g_logp, es, d + N_CAT + N_PRICE, lp2, e2);
-        d[22] = g_logp * z0 * is0;                                           // d logp / d mu = z exp(-log_std)
-        d[23] = g_logp * z1 * is1;
-        dls0 = g_logp * (z0 * z0 - 1.0f) - es;                               // d logp / d log_std = z^2 - 1 ; d ent / d log_std = 1
-        dls1 = g_logp * (z1 * z1 - 1.0f) - es;
-        float4* dp4 = reinterpret_cast<float4*>(d_logits + i * N_LOGITS);
+        // d ent / d l_j = -p_j (log p_j + ent_head), once per sample of the row
+        const float esA = es * (float)agents;
+        #pragma unroll
+        for (int j = 0; j < N_CAT; j++) d[j] += -G * p[j] + esA * p[j] * (lp[j] + h0);
+        #pragma unroll
+        for (int j = 0; j < N_PRICE; j++) d[N_CAT + j] += -G * p[N_CAT + j] + esA * p[N_CAT + j] * (lp[N_CAT + j] + h1);
+        #pragma unroll
+        for (int j = 0; j < N_OFF; j++) d[N_CAT + N_PRICE + j] += -G * p[N_CAT + N_PRICE + j] + esA * p[N_CAT + N_PRICE + j] * (lp[N_CAT + N_PRICE + j] + h2);
+        float4* dp4 = reinterpret_cast<float4*>(d_logits + r * N_LOGITS);
         #pragma unroll
         for (int q = 0; q < N_LOGITS / 4; q++) dp4[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-        d_value[i] = 2.0f * vf_coef * dv * invB;
+        d_value[r] = dval;
     }
     // block reduction (wave shuffles, then one LDS round), one double atomic per block and quantity
     float v5[5] = {pg, vl, en, dls0, dls1};
@@ -148,7 +170,7 @@ __device__ __forceinline__ int sample_head(const float* l, float u, float& logp)
     logp += l[a] - mx - __logf(s);
     return a;
 }
-__global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__ logits, const float* __restrict__ log_std, long long B,
+__global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__ logits, const float* __restrict__ log_std, long long B, int agents,
                                                        unsigned long long seed, const long long* __restrict__ counter,
                                                        long long* __restrict__ a_cat, long long* __restrict__ a_price, long long* __restrict__ a_off,
                                                        float* __restrict__ a_cont, float* __restrict__ logp_out,
@@ -157,7 +179,7 @@ __global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     float l[N_LOGITS];
-    const float4* lp4 = reinterpret_cast<const float4*>(logits + i * N_LOGITS);
+    const float4* lp4 = reinterpret_cast<const float4*>(logits + (i / agents) * N_LOGITS);      // the row's samples share its logits
     #pragma unroll
     for (int q = 0; q < N_LOGITS / 4; q++) { const float4 v = lp4[q]; l[4 * q] = v.x; l[4 * q + 1] = v.y; l[4 * q + 2] = v.z; l[4 * q + 3] = v.w; }
     const unsigned long long key = mix64(seed + (unsigned long long)counter[0] * 0xd1342543de82ef95ull);
@@ -180,15 +202,33 @@ __global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__
     env_mean[i] = tanhf(x0);
     env_sigma[i] = 1.0f / (1.0f + __expf(-x1));
 }
+// Generalised advantage estimation (the recursion of ppo.gae): one thread per sample column walks its T steps backwards.
+// rew / val / done f32[T, B] (done = 1 where the episode ended WITH that step), last_val f32[B] -> adv, ret f32[T, B].
+__global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const float* __restrict__ last_val,
+                                             const float* __restrict__ done, int T, long long B, float gamma, float lam,
+                                             float* __restrict__ adv, float* __restrict__ ret) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float nxt = last_val[i], run = 0.0f;
+    for (int t = T - 1; t >= 0; t--) {
+        const long long k = (long long)t * B + i;
+        const float nd = 1.0f - done[k], v = val[k];
+        const float delta = rew[k] + gamma * nxt * nd - v;
+        run = delta + gamma * lam * nd * run;
+        adv[k] = run; ret[k] = run + v;
+        nxt = v;
+    }
+}
 __global__ void k_bump(long long* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += 1; }
 }  // namespace
 
-extern "C" int cda_policy_sample(const float* logits, const float* log_std, int64_t rows, uint64_t seed, int64_t* counter_dev,
+extern "C" int cda_policy_sample(const float* logits, const float* log_std, int64_t rows, int32_t agents_per_row, uint64_t seed, int64_t* counter_dev,
                                  int64_t* a_cat, int64_t* a_price, int64_t* a_off, float* a_cont, float* logp,
                                  int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset, void* stream) {
     if (!logits || !log_std || !counter_dev || !a_cat || !a_price || !a_off || !a_cont || !logp || !env_category || !env_size_mean || !env_size_sigma ||
-        !env_price || !env_price_offset || rows < 1) return CDA_ERR_INVALID;
-    hipLaunchKernelGGL(k_policy_sample, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, log_std, (long long)rows,
+        !env_price || !env_price_offset || rows < 1 || agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+    const long long samples = (long long)rows * agents_per_row;
+    hipLaunchKernelGGL(k_policy_sample, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, log_std, samples, (int)agents_per_row,
                        (unsigned long long)seed, (const long long*)counter_dev, (long long*)a_cat, (long long*)a_price, (long long*)a_off, a_cont, logp,
                        env_category, env_size_mean, env_size_sigma, env_price, env_price_offset);
     hipLaunchKernelGGL(k_bump, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)counter_dev);       // the next call draws fresh numbers (graph replays too)
@@ -196,13 +236,22 @@ extern "C" int cda_policy_sample(const float* logits, const float* log_std, int6
 }
 
 extern "C" int cda_ppo_loss(const float* logits, const float* value, const float* log_std, const int64_t* a_cat, const int64_t* a_price,
-                            const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret, int64_t batch,
+                            const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret, int64_t rows, int32_t agents_per_row,
                             float clip, float vf_coef, float ent_coef, float* d_logits, float* d_value, double* sums5, float* out6, void* stream) {
-    if (!logits || !value || !log_std || !a_cat || !a_price || !a_off || !a_cont || !logp_old || !adv || !ret || !d_logits || !d_value || !sums5 || !out6 || batch < 1)
-        return CDA_ERR_INVALID;
+    if (!logits || !value || !log_std || !a_cat || !a_price || !a_off || !a_cont || !logp_old || !adv || !ret || !d_logits || !d_value || !sums5 || !out6 || rows < 1 ||
+        agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
     if (hipMemsetAsync(sums5, 0, 5 * sizeof(double), (hipStream_t)stream) != hipSuccess) return CDA_ERR_HIP;
-    hipLaunchKernelGGL(k_ppo_loss, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, value, log_std, (const long long*)a_cat,
-                       (const long long*)a_price, (const long long*)a_off, a_cont, logp_old, adv, ret, (long long)batch, clip, vf_coef, ent_coef, d_logits, d_value, sums5);
-    hipLaunchKernelGGL(k_ppo_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)sums5, (long long)batch, vf_coef, ent_coef, out6);
+    hipLaunchKernelGGL(k_ppo_loss, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, value, log_std, (const long long*)a_cat,
+                       (const long long*)a_price, (const long long*)a_off, a_cont, logp_old, adv, ret, (long long)rows, (int)agents_per_row, clip, vf_coef, ent_coef,
+                       d_logits, d_value, sums5);
+    hipLaunchKernelGGL(k_ppo_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)sums5, (long long)rows * agents_per_row, vf_coef, ent_coef, out6);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_gae(const float* rew, const float* val, const float* last_val, const float* done, int32_t n_steps, int64_t batch,
+                       float gamma, float lam, float* adv, float* ret, void* stream) {
+    if (!rew || !val || !last_val || !done || !adv || !ret || n_steps < 1 || batch < 1) return CDA_ERR_INVALID;
+    hipLaunchKernelGGL(k_gae, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rew, val, last_val, done, (int)n_steps, (long long)batch,
+                       gamma, lam, adv, ret);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }

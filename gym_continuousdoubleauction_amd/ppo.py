@@ -7,6 +7,14 @@ straight from `CDAVecEnv.step`), one shared policy plays every agent slot (self-
 is produced by three categorical heads (category 9, price 10, price_offset 3) and two bounded Gaussian heads
 (size_mean in [-1,1], size_sigma in [0,1]).
 
+Shared observations: every agent of a market is handed the SAME observation vector (exchg/state_helper.py:76,109), and with one
+shared policy the network outputs (logits, value) are therefore the same for all A agents of a (step, market) pair.  By default
+(`shared_obs=True`) the network runs once per market-step - on N rows in the rollout, on the T x N unique observations in the
+update - and the A samples of a row differ only in their drawn action, advantage and return: the loss of a minibatch is the same
+sum over the same samples, its gradient with respect to a row's outputs the sum over the row's samples (csrc/cda_ppo.hip), and a
+minibatch holds whole market-steps (rows are shuffled, not single samples).  A quarter of the matrix work at 4 agents, an eighth
+at 8, for the same numbers; `shared_obs=False` is the plain one-forward-per-sample loop (the rows are then replicated A times).
+
     python -m gym_continuousdoubleauction_amd.ppo --markets 4096 --agents 4 --horizon 64 --iters 4
 """
 import argparse
@@ -118,30 +126,38 @@ class ActorCritic(nn.Module):
         logp = cat.log_prob(a_cat) + price.log_prob(a_price) + off.log_prob(a_off) + cont.log_prob(a_cont).sum(-1)
         return (a_cat, a_price, a_off, a_cont), logp, val.float()
 
-    def act_fused(self, obs, n, a, state):
+    def act_fused(self, obs, n, a, state, shared=False):
         """act() + to_env_actions() for HIP tensors with ONE sampling launch (cda_policy_sample) behind the network: returns
-        (actions, logp, value, env_actions).  `state` = (seed, counter tensor i64[1]) from new_sampler_state()."""
+        (actions, logp, value, env_actions).  `state` = (seed, counter tensor i64[1]) from new_sampler_state().
+        shared=False: `obs` holds one row per (market, agent) pair, [n * a, obs_dim].  shared=True: one row per market, [n, obs_dim] -
+        the network runs once per market and its outputs serve the market's `a` agents; `value` is then per market, [n]."""
         from ._lib import check, lib
         o, val = self.trunk(obs)
         o = o.float().contiguous()
-        B, dev = o.shape[0], o.device
+        rows, dev = o.shape[0], o.device
+        per_row = a if shared else 1
+        B = rows * per_row
         a_cat, a_price, a_off = (torch.empty(B, dtype=torch.int64, device=dev) for _ in range(3))
         a_cont, logp = torch.empty((B, 2), dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
         e_cat, e_price, e_off = (torch.empty((n, a), dtype=torch.int32, device=dev) for _ in range(3))
         e_mean, e_sigma = (torch.empty((n, a), dtype=torch.float32, device=dev) for _ in range(2))
         seed, counter = state
-        check(lib().cda_policy_sample(o.data_ptr(), self.log_std.detach().float().contiguous().data_ptr(), B, int(seed) & (2 ** 64 - 1), counter.data_ptr(),
+        check(lib().cda_policy_sample(o.data_ptr(), self.log_std.detach().float().contiguous().data_ptr(), rows, per_row, int(seed) & (2 ** 64 - 1), counter.data_ptr(),
                                       a_cat.data_ptr(), a_price.data_ptr(), a_off.data_ptr(), a_cont.data_ptr(), logp.data_ptr(),
                                       e_cat.data_ptr(), e_mean.data_ptr(), e_sigma.data_ptr(), e_price.data_ptr(), e_off.data_ptr(),
                                       torch.cuda.current_stream(dev).cuda_stream), "cda_policy_sample")
         return (a_cat, a_price, a_off, a_cont), logp, val.float(), (e_cat, e_mean, e_sigma, e_price, e_off)
 
-    def evaluate(self, obs, actions):
+    def evaluate(self, obs, actions, agents_per_row=1):
         """log-probability of `actions`, entropy and value for a batch - the three discrete heads through ONE log-softmax pass each
-        on the float32 logits, the Gaussian heads in closed form (no distribution objects: a quarter of the elementwise launches)."""
+        on the float32 logits, the Gaussian heads in closed form (no distribution objects: a quarter of the elementwise launches).
+        agents_per_row > 1: `obs` holds one row per market-step and serves that many consecutive samples of `actions`; the outputs
+        are per sample (the row's outputs repeated)."""
         a_cat, a_price, a_off, a_cont = actions
         o, val = self.trunk(obs)
         o = o.float()
+        if agents_per_row > 1:
+            o, val = o.repeat_interleave(agents_per_row, dim=0), val.repeat_interleave(agents_per_row, dim=0)
         logp = ent = 0.0
         for lo, hi, a in ((0, CAT_N, a_cat), (CAT_N, CAT_N + PRICE_N, a_price), (CAT_N + PRICE_N, CAT_N + PRICE_N + OFF_N, a_off)):
             ls = torch.log_softmax(o[:, lo:hi], dim=-1)
@@ -160,15 +176,16 @@ class _FusedPPOLoss(torch.autograd.Function):
     are the plain PyTorch statement of the same op (the numerics reference, and the path of non-HIP tensors)."""
 
     @staticmethod
-    def forward(ctx, logits, value, log_std, a_cat, a_price, a_off, a_cont, logp_old, adv, ret, clip, vf_coef, ent_coef):
+    def forward(ctx, logits, value, log_std, a_cat, a_price, a_off, a_cont, logp_old, adv, ret, clip, vf_coef, ent_coef, agents_per_row=1):
         from ._lib import check, lib
-        B = logits.shape[0]
+        rows = logits.shape[0]                                     # a row serves agents_per_row consecutive samples (cda.h cda_ppo_loss)
+        assert a_cat.numel() == rows * agents_per_row and adv.numel() == rows * agents_per_row
         logits, value = logits.contiguous(), value.contiguous()
         d_logits, d_value = torch.empty_like(logits), torch.empty_like(value)
         sums = torch.empty(5, dtype=torch.float64, device=logits.device)
         out = torch.empty(6, dtype=torch.float32, device=logits.device)
         check(lib().cda_ppo_loss(logits.data_ptr(), value.data_ptr(), log_std.detach().float().contiguous().data_ptr(), a_cat.data_ptr(), a_price.data_ptr(),
-                                 a_off.data_ptr(), a_cont.contiguous().data_ptr(), logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), B,
+                                 a_off.data_ptr(), a_cont.contiguous().data_ptr(), logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), rows, int(agents_per_row),
                                  float(clip), float(vf_coef), float(ent_coef), d_logits.data_ptr(), d_value.data_ptr(), sums.data_ptr(), out.data_ptr(),
                                  torch.cuda.current_stream(logits.device).cuda_stream), "cda_ppo_loss")
         ctx.save_for_backward(d_logits, d_value, out)
@@ -178,7 +195,7 @@ class _FusedPPOLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_out):
         d_logits, d_value, out = ctx.saved_tensors
-        return (d_logits * g_loss, d_value * g_loss, out[4:6] * g_loss) + (None,) * 10
+        return (d_logits * g_loss, d_value * g_loss, out[4:6] * g_loss) + (None,) * 11
 
 
 def to_env_actions(actions, n, a):
@@ -190,8 +207,18 @@ def to_env_actions(actions, n, a):
             a_price.view(n, a).to(torch.int32), a_off.view(n, a).to(torch.int32))
 
 
-def gae(rew, val, last_val, done, gamma=0.99, lam=0.95):
-    """rew/val/done: [T, B]; returns advantages and returns [T, B]."""
+def gae(rew, val, last_val, done, gamma=0.99, lam=0.95, fused=None):
+    """rew/val/done: [T, B]; returns advantages and returns [T, B].  HIP tensors take ONE launch (cda_gae, csrc/cda_ppo.hip: a thread
+    per column walks its T steps backwards); the loop below is the plain statement of the same recursion (and the path elsewhere)."""
+    fused = (rew.is_cuda and rew.dtype == torch.float32) if fused is None else bool(fused)
+    if fused:
+        from ._lib import check, lib
+        T, B = rew.shape
+        rew, val, done, last_val = rew.contiguous(), val.float().contiguous(), done.float().contiguous(), last_val.float().contiguous()
+        adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+        check(lib().cda_gae(rew.data_ptr(), val.data_ptr(), last_val.data_ptr(), done.data_ptr(), T, B, float(gamma), float(lam), adv.data_ptr(), ret.data_ptr(),
+                            torch.cuda.current_stream(rew.device).cuda_stream), "cda_gae")
+        return adv, ret
     T = rew.shape[0]
     adv = torch.zeros_like(rew)
     nxt, run = last_val, torch.zeros_like(last_val)
@@ -204,36 +231,101 @@ def gae(rew, val, last_val, done, gamma=0.99, lam=0.95):
     return adv, adv + val
 
 
-def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch=262144, clip=0.2, vf_coef=0.5, ent_coef=0.01, amp=False, fused=None):
+class _GraphedUpdate:
+    """The minibatch steps of ppo_update as captured HIP graphs: one graph per minibatch slot (forward, fused loss, backward, gradient
+    clipping, Adam step - ~70 launches that cost more host time than device time once the network runs once per market-step), reading
+    STATIC shuffled buffers that every epoch refills with one gather per tensor.  Needs a capturable optimizer (Adam(capturable=True))
+    and parameters that were stepped eagerly at least once (allocator, GEMM workspaces, Adam state)."""
+
+    def __init__(self, model, opt, R, A, obs_dim, x_dtype, rows_mb, clip, vf_coef, ent_coef, device):
+        self.R, self.A, self.rows_mb = R, A, rows_mb
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)          # noqa: E731
+        self.xs = e((R, obs_dim), x_dtype)
+        self.acts = (e((R, A), torch.int64), e((R, A), torch.int64), e((R, A), torch.int64), e((R, A, 2), torch.float32))
+        self.lp_old, self.adv, self.ret = e((R, A), torch.float32), e((R, A), torch.float32), e((R, A), torch.float32)
+        self.graphs, self.out = [], None
+        pool = None
+        for s in range(0, R, rows_mb):
+            t = min(R, s + rows_mb)
+            g = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)                            # the graph's backward allocates (and from then on overwrites) the gradients
+            with torch.cuda.graph(g, pool=pool):
+                o, v = model.trunk(self.xs[s:t])
+                loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, self.acts[0][s:t], self.acts[1][s:t], self.acts[2][s:t], self.acts[3][s:t],
+                                                self.lp_old[s:t], self.adv[s:t], self.ret[s:t], clip, vf_coef, ent_coef, A)
+                loss.backward()
+                nn.utils.clip_grad_norm_(model.parameters(), 0.5, foreach=True)
+                opt.step()
+            pool = pool or g.pool()                                     # replayed one after the other, in capture order: one pool serves all
+            self.graphs.append(g)
+            self.out = out
+
+    def run(self, x_all, actions, logp_old, adv, ret, epochs):
+        R, A = self.R, self.A
+        by_row = lambda t: t.view(R, A, *t.shape[1:])                 # noqa: E731
+        for _ in range(epochs):
+            perm = torch.randperm(R, device=x_all.device)
+            torch.index_select(x_all, 0, perm, out=self.xs)
+            for src, dst in zip(actions, self.acts):
+                torch.index_select(by_row(src), 0, perm, out=dst)
+            torch.index_select(by_row(logp_old), 0, perm, out=self.lp_old)
+            torch.index_select(by_row(adv), 0, perm, out=self.adv)
+            torch.index_select(by_row(ret), 0, perm, out=self.ret)
+            for g in self.graphs:
+                g.replay()
+        return {"pg_loss": self.out[0], "v_loss": self.out[1], "entropy": self.out[2]}
+
+
+def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch=262144, clip=0.2, vf_coef=0.5, ent_coef=0.01, amp=False, fused=None,
+               agents_per_row=1, graphs=None):
     """amp: the MLPs' matrix products of the update run in bfloat16 on the MFMA units (the observation batch is cast ONCE per
     update, activations are kept in bfloat16; log-softmax / log-prob / losses, parameters and Adam state stay float32) - the
     update is the learner-bound part of an iteration.  Per epoch the whole batch is shuffled with ONE gather per tensor and the
     minibatches are contiguous slices of the shuffled copy (no per-minibatch index kernels); nothing is read back to the host
-    until the update is over."""
-    B = obs.shape[0]
+    until the update is over.
+    agents_per_row = A > 1: `obs` holds the R unique observations (one row per market-step) and the per-sample tensors hold R * A
+    entries, sample r * A + a belonging to row r (module docstring, "Shared observations").  Rows are shuffled - a minibatch of
+    `minibatch` samples is minibatch / A whole rows - and the network sees every row once per epoch.
+    graphs: a dict the caller keeps between calls; when given (HIP tensors, fused loss, a capturable optimizer that has stepped
+    before) the minibatch steps are captured once as HIP graphs (_GraphedUpdate) and replayed from then on."""
+    A = int(agents_per_row)
+    R = obs.shape[0]
+    B = R * A
+    assert adv.numel() == B and logp_old.numel() == B and actions[0].numel() == B, "per-sample tensors must hold rows * agents_per_row entries"
     fused = obs.is_cuda if fused is None else bool(fused)         # the HIP loss kernel (cda_ppo_loss); the PyTorch statement elsewhere
     adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).float().contiguous()
     logp_old, ret = logp_old.float().contiguous(), ret.float().contiguous()
     actions = (actions[0].contiguous(), actions[1].contiguous(), actions[2].contiguous(), actions[3].float().contiguous())
+    by_row = lambda t: t.view(R, A, *t.shape[1:])                 # noqa: E731 - [R * A, ...] -> [R, A, ...]
+    flat = lambda t: t.reshape(-1, *t.shape[2:])                  # noqa: E731 - back to one entry per sample
     x_all = obs.to(torch.bfloat16) if amp else obs
+    rows_mb = max(1, minibatch // A)
     stats = {}
+    if graphs is not None and fused and obs.is_cuda:
+        key = (R, A, obs.shape[1], x_all.dtype, rows_mb, clip, vf_coef, ent_coef)
+        if graphs.get("key") != key:
+            graphs.clear()
+            graphs["key"] = key
+            graphs["update"] = _GraphedUpdate(model, opt, R, A, obs.shape[1], x_all.dtype, rows_mb, clip, vf_coef, ent_coef, obs.device)
+        stats = graphs["update"].run(x_all, actions, logp_old, adv, ret, epochs)
+        return {k: float(v) for k, v in stats.items()}
     for _ in range(epochs):
-        perm = torch.randperm(B, device=obs.device)
-        xs, acts = x_all[perm], tuple(a[perm] for a in actions)
-        lp_old, adv_s, ret_s = logp_old[perm], adv[perm], ret[perm]
-        for s in range(0, B, minibatch):
-            e = min(B, s + minibatch)
+        perm = torch.randperm(R, device=obs.device)
+        xs, acts = x_all[perm], tuple(by_row(a)[perm] for a in actions)
+        lp_old, adv_s, ret_s = by_row(logp_old)[perm], by_row(adv)[perm], by_row(ret)[perm]
+        for s in range(0, R, rows_mb):
+            e = min(R, s + rows_mb)
             if fused:
                 o, v = model.trunk(xs[s:e])
                 loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, acts[0][s:e], acts[1][s:e], acts[2][s:e], acts[3][s:e],
-                                                lp_old[s:e], adv_s[s:e], ret_s[s:e], clip, vf_coef, ent_coef)
+                                                lp_old[s:e], adv_s[s:e], ret_s[s:e], clip, vf_coef, ent_coef, A)
                 pg, vl, ent_m = out[0], out[1], out[2]
             else:
-                logp, ent, v = model.evaluate(xs[s:e], tuple(a[s:e] for a in acts))
-                ratio = (logp - lp_old[s:e]).exp()
-                a_mb = adv_s[s:e]
+                logp, ent, v = model.evaluate(xs[s:e], tuple(flat(a[s:e]) for a in acts), agents_per_row=A)
+                ratio = (logp - flat(lp_old[s:e])).exp()
+                a_mb = flat(adv_s[s:e])
                 pg = -torch.min(ratio * a_mb, ratio.clamp(1 - clip, 1 + clip) * a_mb).mean()
-                vl = (v - ret_s[s:e]).pow(2).mean()
+                vl = (v - flat(ret_s[s:e])).pow(2).mean()
                 ent_m = ent.mean()
                 loss = pg + vf_coef * vl - ent_coef * ent_m
             opt.zero_grad(set_to_none=True)
@@ -254,82 +346,161 @@ def new_sampler_state(seed, device):
     return int(seed), torch.zeros(1, dtype=torch.int64, device=device)
 
 
-def _capture_policy_step(model, env, N, A, seed=0):
-    """HIP graph of: observation broadcast -> policy/value forward -> ONE sampling launch (cda_policy_sample: the three categorical and
+def _capture_policy_step(model, env, N, A, seed=0, shared=True):
+    """HIP graph of: (observation broadcast ->) policy/value forward -> ONE sampling launch (cda_policy_sample: the three categorical and
     two Gaussian heads, log-probability, the env's action tensors).  The sampler's draw counter lives on the device and is bumped
-    inside the graph, so every replay draws fresh numbers."""
+    inside the graph, so every replay draws fresh numbers.  shared: the network reads the env's [N, obs_dim] buffer as it is."""
     state = new_sampler_state(seed, env.obs.device)
+    rows = (lambda: env.obs) if shared else (lambda: env.obs.repeat_interleave(A, dim=0))
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side), torch.no_grad():
         for _ in range(3):                                           # warm-up outside capture (allocator, lazy init)
-            model.act_fused(env.obs.repeat_interleave(A, dim=0), N, A, state)
+            model.act_fused(rows(), N, A, state, shared=shared)
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g), torch.no_grad():
-        pobs = env.obs.repeat_interleave(A, dim=0)
-        actions, logp, val, env_acts = model.act_fused(pobs, N, A, state)
-    return g, (pobs, actions, logp, val, env_acts)
+        pobs = rows()
+        actions, logp, val, env_acts = model.act_fused(pobs, N, A, state, shared=shared)
+    # `state` is returned because the graph holds the RAW address of its draw counter (and bumps it on every replay): the tensor
+    # must live as long as the graph does
+    return g, (pobs, actions, logp, val, env_acts), state
 
 
-def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, rollout_hook=None, amp=None):
+def _capture_rollout_step(model, env, N, A, T, seed=0, shared=True):
+    """HIP graph of ONE WHOLE rollout step - policy step (as _capture_policy_step), the env step itself (cda_step / cda_step_groups are
+    plain kernel launches on the capturing stream, or forked from it; the device-side auto reset included) and the writes of everything
+    the update needs into [T, ...] rollout buffers at a step index that lives on the device and is bumped inside the graph.  A rollout
+    is then T replays and nothing else: no per-step host work beyond one graph launch.  Needs an auto_reset env (episode ends are
+    handled on the device) and no per-step host callback."""
+    dev = env.obs.device
+    state = new_sampler_state(seed, dev)
+    rows, B = (N if shared else N * A), N * A
+    e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)    # noqa: E731
+    buf = {"obs": e((T, rows, env.obs_dim), torch.float32), "val": e((T, rows), torch.float32), "logp": e((T, B), torch.float32),
+           "a_cat": e((T, B), torch.int64), "a_price": e((T, B), torch.int64), "a_off": e((T, B), torch.int64), "a_cont": e((T, B, 2), torch.float32),
+           "rew": e((T, N, A), torch.float64), "term": e((T, N), torch.bool), "trunc": e((T, N), torch.bool)}
+    t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    put = lambda name, x: buf[name].index_copy_(0, t_dev, x.unsqueeze(0))      # noqa: E731 - slot t of a buffer, t read on the device
+
+    def policy_part():
+        pobs = env.obs if shared else env.obs.repeat_interleave(A, dim=0)
+        actions, logp, val, env_acts = model.act_fused(pobs, N, A, state, shared=shared)
+        put("obs", pobs); put("val", val); put("logp", logp)
+        for name, x in zip(("a_cat", "a_price", "a_off", "a_cont"), actions):
+            put(name, x)
+        return env_acts
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(3):                                           # warm-up outside capture (allocator, lazy init); the env is not stepped
+            policy_part()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        env_acts = policy_part()
+        _, r, term, trunc, _ = env.step(*env_acts)                    # groups > 1: forks from / joins into the capturing stream
+        put("rew", r); put("term", term); put("trunc", trunc)
+        t_dev.add_(1)
+    buf["_sampler_state"] = state            # the graph holds the RAW address of the draw counter: it must live as long as the graph
+    return g, buf, t_dev
+
+
+def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, rollout_hook=None, amp=None,
+          shared_obs=True):
     """On-device PPO over a CDAVecEnv-shaped env. Returns per-iteration stats (incl. agent-steps/s).
     rollout_hook(iteration, step, env_actions, obs, reward, terminated, truncated): called after every env step with the
-    five [N,A] action tensors the policy produced and the step's output tensors (device tensors; clone what you keep)."""
+    five [N,A] action tensors the policy produced and the step's output tensors (device tensors; clone what you keep).
+    shared_obs: run the network once per market-step instead of once per agent (module docstring); False = one row per sample.
+    use_graph (HIP devices): the rollout step is replayed from a captured HIP graph - the whole step (policy, env step, buffer writes:
+    _capture_rollout_step) on an auto_reset env without a rollout_hook, else the policy step alone (_capture_policy_step) - and from
+    the second iteration on the update's minibatch steps are too (_GraphedUpdate)."""
     torch.manual_seed(seed)
     dev = env.obs.device
     amp = (dev.type == "cuda") if amp is None else bool(amp)
     N, A = env.n_markets, env.num_agents
+    per_row = A if shared_obs else 1
     model = ActorCritic(env.obs_dim).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=lr, fused=dev.type == "cuda")     # one kernel per step instead of one per tensor
+    hip = dev.type == "cuda"
+    opt = torch.optim.Adam(model.parameters(), lr=lr, fused=hip, capturable=hip and bool(use_graph))     # one kernel per step instead of one per tensor
     env.reset(seed=seed)
     auto_reset = bool(getattr(env, "config", {}).get("auto_reset", False))
     history = []
     # The policy step of the rollout (MLP forward, five samplers, log-probabilities: ~60 small kernels) is launch bound
-    # next to a 55-us env step, so it is captured ONCE in a HIP graph that reads the env's own observation buffer and
-    # replayed every step; the env step itself is enqueued between replays on the same stream.
-    policy_step = None
-    if dev.type == "cuda" and use_graph:
+    # next to a 40-us env step, so it is captured ONCE in a HIP graph that reads the env's own observation buffer and
+    # replayed every step; with a device-side auto reset and no host callback the env step and the buffer writes are in it too.
+    policy_step = rollout_step = None
+    if hip and use_graph:
         try:
-            policy_step = _capture_policy_step(model, env, N, A, seed=seed)
+            if auto_reset and rollout_hook is None:
+                rollout_step = _capture_rollout_step(model, env, N, A, horizon, seed=seed, shared=shared_obs)
+            else:
+                policy_step = _capture_policy_step(model, env, N, A, seed=seed, shared=shared_obs)
         except Exception as e:  # noqa: BLE001 - eager rollouts are always available
             log(json.dumps({"hip_graph": f"capture failed, eager rollout: {e}"}))
+            policy_step = rollout_step = None
+    update_graphs = {} if (hip and use_graph) else None
     for it in range(iters):
         t0 = time.perf_counter()
-        buf_obs, buf_act, buf_logp, buf_val, buf_rew, buf_done = [], [], [], [], [], []
-        for _ in range(horizon):
-            if policy_step is not None:
-                g, (pobs_s, actions_s, logp_s, val_s, env_acts_s) = policy_step
-                g.replay()                                           # reads env.obs (this step's observation)
-                pobs, actions, logp, val = pobs_s.clone(), tuple(x.clone() for x in actions_s), logp_s.clone(), val_s.clone()
-                o, r, term, trunc, _ = env.step(*env_acts_s)
-                _join(env)
-                if rollout_hook is not None:
-                    rollout_hook(it, len(buf_obs), env_acts_s, o, r, term, trunc)
-            else:
-                pobs = env.obs.repeat_interleave(A, dim=0)           # every agent of a market sees the same vector
-                with torch.no_grad():
-                    actions, logp, val = model.act(pobs)
-                env_acts = to_env_actions(actions, N, A)
-                o, r, term, trunc, _ = env.step(*env_acts)
-                _join(env)
-                if rollout_hook is not None:
-                    rollout_hook(it, len(buf_obs), env_acts, o, r, term, trunc)
-            done = (term | trunc)
-            buf_obs.append(pobs); buf_act.append(actions); buf_logp.append(logp); buf_val.append(val)
-            buf_rew.append((r.float() * reward_scale).reshape(-1)); buf_done.append(done.repeat_interleave(A).float())
-            if not auto_reset and bool(done.any()):                # (a host sync per step; auto_reset envs reset on the device)
-                env.reset(mask=done)                               # seed=None semantics: streams continue
-        obs = env.obs
+        if rollout_step is not None:
+            g, buf, t_dev = rollout_step
+            t_dev.zero_()
+            for _ in range(horizon):
+                g.replay()
+            obs_rows = buf["obs"].view(-1, env.obs_dim)
+            acts = tuple(buf[k].view(horizon * N * A, *buf[k].shape[2:]) for k in ("a_cat", "a_price", "a_off", "a_cont"))
+            logp_all = buf["logp"].view(-1)
+            val = buf["val"].repeat_interleave(A, dim=1) if shared_obs else buf["val"]
+            rew = (buf["rew"].float() * reward_scale).view(horizon, N * A)
+            dn = (buf["term"] | buf["trunc"]).repeat_interleave(A, dim=1).float()
+        else:
+            buf_obs, buf_act, buf_logp, buf_val, buf_rew, buf_done = [], [], [], [], [], []
+            for _ in range(horizon):
+                if policy_step is not None:
+                    g, (pobs_s, actions_s, logp_s, val_s, env_acts_s), _state = policy_step
+                    g.replay()                                           # reads env.obs (this step's observation)
+                    pobs, actions, logp, val = pobs_s.clone(), tuple(x.clone() for x in actions_s), logp_s.clone(), val_s.clone()
+                    o, r, term, trunc, _ = env.step(*env_acts_s)
+                    _join(env)
+                    if rollout_hook is not None:
+                        rollout_hook(it, len(buf_obs), env_acts_s, o, r, term, trunc)
+                else:
+                    pobs = env.obs.clone() if shared_obs else env.obs.repeat_interleave(A, dim=0)   # every agent of a market sees the same vector
+                    with torch.no_grad():
+                        if shared_obs:                                   # one forward per market; its outputs serve the market's A draws
+                            o_rows, val = model.trunk(pobs)
+                            o_rep = o_rows.float().repeat_interleave(A, dim=0)
+                            cat, price, off, cont = model._dists(o_rep)
+                            a_cat, a_price, a_off = cat.sample(), price.sample(), off.sample()
+                            a_cont = (cont.loc + cont.scale * torch.randn_like(cont.loc)).detach()
+                            logp = cat.log_prob(a_cat) + price.log_prob(a_price) + off.log_prob(a_off) + cont.log_prob(a_cont).sum(-1)
+                            actions, val = (a_cat, a_price, a_off, a_cont), val.float()
+                        else:
+                            actions, logp, val = model.act(pobs)
+                    env_acts = to_env_actions(actions, N, A)
+                    o, r, term, trunc, _ = env.step(*env_acts)
+                    _join(env)
+                    if rollout_hook is not None:
+                        rollout_hook(it, len(buf_obs), env_acts, o, r, term, trunc)
+                done = (term | trunc)
+                if shared_obs:
+                    val = val.repeat_interleave(A)                       # the market's value, once per agent (returns differ per agent)
+                buf_obs.append(pobs); buf_act.append(actions); buf_logp.append(logp); buf_val.append(val)
+                buf_rew.append((r.float() * reward_scale).reshape(-1)); buf_done.append(done.repeat_interleave(A).float())
+                if not auto_reset and bool(done.any()):                # (a host sync per step; auto_reset envs reset on the device)
+                    env.reset(mask=done)                               # seed=None semantics: streams continue
+            flat = lambda xs: torch.cat(xs, 0)                         # noqa: E731
+            obs_rows, logp_all = flat(buf_obs), flat(buf_logp)
+            acts = tuple(flat([b[i] for b in buf_act]) for i in range(4))
+            rew, val, dn = torch.stack(buf_rew), torch.stack(buf_val), torch.stack(buf_done)
         with torch.no_grad():
-            last_val = model.v(obs.repeat_interleave(A, dim=0)).squeeze(-1).float()
-        rew, val, dn = torch.stack(buf_rew), torch.stack(buf_val), torch.stack(buf_done)
+            last_val = model.v(env.obs).squeeze(-1).float().repeat_interleave(A)
         adv, ret = gae(rew, val, last_val, dn)
-        flat = lambda xs: torch.cat(xs, 0)                         # noqa: E731
-        acts = tuple(flat([b[i] for b in buf_act]) for i in range(4))
         t_roll = time.perf_counter()
-        stats = ppo_update(model, opt, flat(buf_obs), acts, flat(buf_logp), adv.reshape(-1), ret.reshape(-1), epochs=epochs, amp=amp)
-        if dev.type == "cuda":
+        stats = ppo_update(model, opt, obs_rows, acts, logp_all, adv.reshape(-1), ret.reshape(-1), epochs=epochs, amp=amp,
+                           agents_per_row=per_row, graphs=update_graphs if it > 0 else None)       # (the first update runs eagerly: see _GraphedUpdate)
+        if hip:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
         stats.update(iter=it, mean_reward=float(rew.mean()) / reward_scale, agent_steps=N * A * horizon,
@@ -347,18 +518,27 @@ def main(argv=None):
     p.add_argument("--iters", type=int, default=4)
     p.add_argument("--max-step", type=int, default=4096)
     p.add_argument("--fp32-update", action="store_true", help="PPO update in float32 instead of bfloat16 autocast")
+    p.add_argument("--groups", type=int, default=1, help="market groups of the env step (independent launch chains, vec_env.CDAVecEnv)")
+    p.add_argument("--no-graphs", action="store_true", help="eager rollout and update (no HIP graphs)")
+    p.add_argument("--per-sample-forward", action="store_true", help="run the network once per (market, agent) sample instead of once per market-step (shared_obs=False)")
     p.add_argument("--out", default=None, help="write a JSON summary (config, per-iteration stats, end-of-run env checks) to this file")
     args = p.parse_args(argv)
     from .vec_env import CDAVecEnv
+    p_groups = max(1, min(args.groups, args.markets))
     env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False, "auto_reset": True},
-                    n_markets=args.markets, device="cuda:0", with_info=False)
-    _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update)
+                    n_markets=args.markets, device="cuda:0", with_info=False, groups=p_groups)
+    _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update, shared_obs=not args.per_sample_forward, use_graph=not args.no_graphs)
     flags = env.flags()
     _, bad = env.nav_conservation()
     summary = {"metric": "agent-steps/sec end to end (rollout + PPO update), BASELINE configs[4]",
                "config": {"workload": f"{args.markets} markets x {args.agents} agents, PyTorch-ROCm PPO policy in the loop (256x256 tanh actor and critic, "
                                       f"4 epochs, 262144-sample minibatches), horizon {args.horizon}, {args.iters} iterations, auto_reset on",
-                          "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters, "update_dtype": "float32" if args.fp32_update else "bfloat16 autocast (float32 parameters, Adam state, softmax and losses)"},
+                          "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters, "env_groups": p_groups,
+                          "hip_graphs": "none" if args.no_graphs else "one graph per rollout step (policy + env step + buffer writes), one per minibatch step of the update",
+                          "update_dtype": "float32" if args.fp32_update else "bfloat16 autocast (float32 parameters, Adam state, softmax and losses)",
+                          "network_forward": "once per (market, agent) sample" if args.per_sample_forward else
+                                             "once per market-step: the market's agents share the observation, the policy is shared, so their logits and value are one row "
+                                             "(same samples, same loss, same gradients; ppo.py module docstring)"},
                "iterations": hist,
                "value": sum(h["agent_steps"] for h in hist[1:] or hist) / sum(h["rollout_s"] + h["update_s"] for h in hist[1:] or hist),
                "rollout_agent_steps_per_s": sum(h["agent_steps"] for h in hist[1:] or hist) / sum(h["rollout_s"] for h in hist[1:] or hist),

@@ -351,22 +351,32 @@ int cda_selftest_libm_host(int32_t op, int32_t n, const double* x_host, double* 
 
 /* Learner side of the PPO loop on the batched env (the reference trains through RLlib's PPO, train/train.py:453-541,
  * config/train_config.json `ppo`): clipped-surrogate + value + entropy loss of one minibatch and its gradient with respect to the
- * network outputs in ONE launch (csrc/cda_ppo.hip).  logits f32[B,24] = category 9 | price 10 | price_offset 3 | two Gaussian means,
- * value f32[B], log_std f32[2], actions a_cat / a_price / a_off i64[B] and a_cont f32[B,2], logp_old / adv / ret f32[B].
- * Out: d_logits f32[B,24], d_value f32[B] (gradients of the loss), sums5 f64[5] (scratch), out6 f32[6] = mean policy loss, mean value
- * loss, mean entropy, loss, d loss / d log_std[0..1].  All device pointers. */
+ * network outputs in ONE launch (csrc/cda_ppo.hip).  A ROW of network outputs serves `agents_per_row` consecutive samples: every agent
+ * of a market is handed the same observation (state_helper.py:76,109), so a shared policy's outputs are the same for all of them and
+ * the network runs once per market-step; agents_per_row = 1 is the plain one-row-per-sample op.  With B = rows * agents_per_row:
+ * logits f32[rows,24] = category 9 | price 10 | price_offset 3 | two Gaussian means, value f32[rows], log_std f32[2], actions
+ * a_cat / a_price / a_off i64[B] and a_cont f32[B,2], logp_old / adv / ret f32[B] (sample r * agents_per_row + a belongs to row r).
+ * Out: d_logits f32[rows,24], d_value f32[rows] (gradients of the loss, summed over the row's samples), sums5 f64[5] (scratch), out6
+ * f32[6] = mean policy loss, mean value loss, mean entropy, loss, d loss / d log_std[0..1] (means over the B samples).  Device pointers. */
 int cda_ppo_loss(const float* logits, const float* value, const float* log_std, const int64_t* a_cat, const int64_t* a_price,
-                 const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret, int64_t batch,
-                 float clip, float vf_coef, float ent_coef, float* d_logits, float* d_value, double* sums5, float* out6, void* stream);
+                 const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret, int64_t rows,
+                 int32_t agents_per_row, float clip, float vf_coef, float ent_coef, float* d_logits, float* d_value, double* sums5,
+                 float* out6, void* stream);
 
-/* The rollout's policy step (csrc/cda_ppo.hip): sample the Dict action of `rows` = N x A (market, agent) rows from the network outputs
- * (layout as in cda_ppo_loss) in ONE launch: a_cat / a_price / a_off i64[rows], a_cont f32[rows,2] (the raw Gaussian samples), logp
- * f32[rows], and the env's five action arrays i32 / f32 [rows] (size_mean = tanh, size_sigma = sigmoid of the Gaussian samples:
- * the Box bounds of action_helper.py:126-138).  Randomness is counter based, keyed (seed, *counter_dev, row); counter_dev (i64[1],
- * device) is incremented on the stream after every call, so a captured HIP graph draws fresh numbers on every replay. */
-int cda_policy_sample(const float* logits, const float* log_std, int64_t rows, uint64_t seed, int64_t* counter_dev,
+/* The rollout's policy step (csrc/cda_ppo.hip): sample the Dict action of B = rows * agents_per_row (market, agent) pairs from the
+ * network outputs (logits f32[rows,24], layout and row sharing as in cda_ppo_loss) in ONE launch: a_cat / a_price / a_off i64[B],
+ * a_cont f32[B,2] (the raw Gaussian samples), logp f32[B], and the env's five action arrays i32 / f32 [B] (size_mean = tanh,
+ * size_sigma = sigmoid of the Gaussian samples: the Box bounds of action_helper.py:126-138).  Randomness is counter based, keyed
+ * (seed, *counter_dev, sample); counter_dev (i64[1], device) is incremented on the stream after every call, so a captured HIP graph
+ * draws fresh numbers on every replay. */
+int cda_policy_sample(const float* logits, const float* log_std, int64_t rows, int32_t agents_per_row, uint64_t seed, int64_t* counter_dev,
                       int64_t* a_cat, int64_t* a_price, int64_t* a_off, float* a_cont, float* logp,
                       int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset, void* stream);
+
+/* Generalised advantage estimation over a rollout (ppo.gae's recursion, one launch): rew / val / done f32[n_steps, batch] (done = 1 where
+ * the episode ended with that step), last_val f32[batch] -> adv, ret f32[n_steps, batch].  Device pointers. */
+int cda_gae(const float* rew, const float* val, const float* last_val, const float* done, int32_t n_steps, int64_t batch,
+            float gamma, float lam, float* adv, float* ret, void* stream);
 
 const char* cda_strerror(int status);
 int32_t cda_num_markets(const cda_env* env);

@@ -254,6 +254,62 @@ def test_ppo_loop_on_the_hip_env_with_graph_captured_policy_step():
     torch.cuda.synchronize()
 
 
+def test_whole_rollout_step_graph_with_market_groups_and_graphed_update():
+    """The rollout step captured as ONE HIP graph (policy, env step on TWO group streams forked from / joined into the capturing
+    stream, device-side auto reset, buffer writes at a device-side step index) and the update's minibatch steps replayed from graphs
+    from the second iteration on: the loop learns on what the env produced - the buffers hold T distinct steps (the step index moved),
+    the recorded actions are the ones the env consumed (its own trade counters move), nothing is flagged - and the per-sample variant
+    runs through the same machinery."""
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecEnv, ppo
+    cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 12, "is_render": False, "auto_reset": True}
+    env = CDAVecEnv(cfg, n_markets=256, with_info=False, groups=2)
+    logs = []
+    model, hist = ppo.train(env, iters=3, horizon=16, log=logs.append)
+    assert not any("capture failed" in x for x in logs), logs
+    assert len(hist) == 3 and all(math.isfinite(h["pg_loss"]) and math.isfinite(h["v_loss"]) and math.isfinite(h["entropy"]) for h in hist)
+    assert hist[1]["v_loss"] != hist[2]["v_loss"]                       # (the graphed updates see fresh rollouts)
+    assert int(env.flags().abs().sum()) == 0 and int((env.check_invariants() != 0).sum()) == 0
+    model2, hist2 = ppo.train(env, iters=2, horizon=8, log=logs.append, shared_obs=False)
+    assert all(math.isfinite(h["v_loss"]) for h in hist2) and not any("capture failed" in x for x in logs), logs
+    # the graph's buffers against an eager replay of the same policy draws: rebuild the step by hand for one fresh env
+    env2 = CDAVecEnv(cfg, n_markets=64, with_info=False)
+    env2.reset(seed=5)
+    m = ppo.ActorCritic(env2.obs_dim).to(env2.device)
+    g, buf, t_dev = ppo._capture_rollout_step(m, env2, 64, 4, 6, seed=9, shared=True)
+    env2.reset(seed=5)
+    for _ in range(6):
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(t_dev.item()) == 6
+    ref = CDAVecEnv(cfg, n_markets=64, with_info=False)
+    ref.reset(seed=5)
+    st = ppo.new_sampler_state(9, ref.device)
+    st[1].fill_(3)                                                       # the capture's three warm-up draws moved the counter
+    for t in range(6):
+        assert torch.equal(buf["obs"][t], ref.obs)
+        with torch.no_grad():
+            acts, logp, val, env_acts = m.act_fused(ref.obs, 64, 4, st, shared=True)
+        assert torch.equal(buf["a_cat"][t], acts[0]) and torch.equal(buf["a_cont"][t], acts[3]) and torch.equal(buf["logp"][t], logp)
+        _, r, term, trunc, _ = ref.step(*env_acts)
+        assert torch.equal(buf["rew"][t], r) and torch.equal(buf["term"][t], term) and torch.equal(buf["trunc"][t], trunc)
+    assert torch.equal(env2.obs, ref.obs)
+    env.close(); env2.close(); ref.close()
+
+
+def test_fused_gae_kernel_equals_the_recursion():
+    import torch
+    from gym_continuousdoubleauction_amd import ppo
+    torch.manual_seed(1)
+    dev = torch.device("cuda:0")
+    T, B = 37, 5000
+    rew, val, last = torch.randn(T, B, device=dev), torch.randn(T, B, device=dev), torch.randn(B, device=dev)
+    done = (torch.rand(T, B, device=dev) < 0.1).float()
+    adv, ret = ppo.gae(rew, val, last, done)
+    adv_ref, ret_ref = ppo.gae(rew.double(), val.double(), last.double(), done.double(), fused=False)
+    assert float((adv.double() - adv_ref).abs().max()) < 1e-4 and float((ret.double() - ret_ref).abs().max()) < 1e-4
+
+
 def test_league_rollout_routes_modules_per_market():
     """League slot mapping on the batched env: a trainable policy in slot 0, fixed random opponents and a champion elsewhere."""
     import numpy as np
@@ -389,47 +445,52 @@ def test_league_self_play_loop_on_the_hip_env():
     env.close()
 
 
-def test_fused_ppo_loss_kernel_equals_the_pytorch_statement():
+@pytest.mark.parametrize("per_row", [1, 4, 16])
+def test_fused_ppo_loss_kernel_equals_the_pytorch_statement(per_row):
     """cda_ppo_loss (csrc/cda_ppo.hip): loss, its three means and the gradients with respect to logits, value and log_std of one
     minibatch in one launch - against the plain PyTorch fp32 formulation of the same op (ActorCritic.evaluate + the loss formulas
     of ppo_update) on the same inputs.  float32 tolerance: 2e-5 relative on the scalars, 1e-6 absolute on the gradients (they carry
-    the 1 / B of the means; B = 20 000 here)."""
+    the 1 / B of the means; B = 20 000 samples here).
+    per_row > 1: a row of network outputs serves that many consecutive samples (the agents of a market share the observation); the
+    PyTorch statement is the plain per-sample one on the REPLICATED rows, whose gradient with respect to a row autograd sums."""
     import torch
     from gym_continuousdoubleauction_amd import ppo
     torch.manual_seed(5)
     dev = torch.device("cuda:0")
     B = 20000
+    R = B // per_row
     m = ppo.ActorCritic(168).to(dev)
     with torch.no_grad():
         m.log_std.copy_(torch.tensor([-0.3, 0.2]))
-    obs = torch.randn(B, 168, device=dev)
+    obs = torch.randn(R, 168, device=dev)
     with torch.no_grad():
-        acts, logp_old, _ = m.act(obs)
+        acts, logp_old, _ = m.act(obs.repeat_interleave(per_row, dim=0))
         logp_old = logp_old + 0.3 * torch.randn_like(logp_old)          # ratios on both sides of the clip range
     adv, ret = torch.randn(B, device=dev), torch.randn(B, device=dev)
     clip, vf, ec = 0.2, 0.5, 0.01
-    # the reference: autograd through the PyTorch formulation, gradients taken at the network OUTPUTS
+    # the reference: autograd through the PyTorch formulation, gradients taken at the network OUTPUTS (one row per market-step)
     o, v = m.trunk(obs)
     o, v = o.detach().float().requires_grad_(True), v.detach().float().requires_grad_(True)
     ls = m.log_std.detach().clone().requires_grad_(True)
+    os_, vs_ = o.repeat_interleave(per_row, dim=0), v.repeat_interleave(per_row, dim=0)
     logp = ent = 0.0
     for lo, hi, a in ((0, 9, acts[0]), (9, 19, acts[1]), (19, 22, acts[2])):
-        l = torch.log_softmax(o[:, lo:hi], dim=-1)
+        l = torch.log_softmax(os_[:, lo:hi], dim=-1)
         logp = logp + l.gather(1, a.view(-1, 1)).squeeze(1)
         ent = ent - (l.exp() * l).sum(-1)
-    z = (acts[3] - o[:, -2:]) * torch.exp(-ls)
+    z = (acts[3] - os_[:, -2:]) * torch.exp(-ls)
     logp = logp + (-0.5 * z * z - ls - 0.9189385332046727).sum(-1)
     ent = ent + (1.4189385332046727 + ls).sum()
     ratio = (logp - logp_old).exp()
     pg = -torch.min(ratio * adv, ratio.clamp(1 - clip, 1 + clip) * adv).mean()
-    vl = (v - ret).pow(2).mean()
+    vl = (vs_ - ret).pow(2).mean()
     loss = pg + vf * vl - ec * ent.mean()
     loss.backward()
     o2, v2 = o.detach().clone().requires_grad_(True), v.detach().clone().requires_grad_(True)
     ls2 = ls.detach().clone().requires_grad_(True)
-    loss2, out = ppo._FusedPPOLoss.apply(o2, v2, ls2, acts[0], acts[1], acts[2], acts[3].float(), logp_old.float(), adv, ret, clip, vf, ec)
+    loss2, out = ppo._FusedPPOLoss.apply(o2, v2, ls2, acts[0], acts[1], acts[2], acts[3].float(), logp_old.float(), adv, ret, clip, vf, ec, per_row)
     loss2.backward()
-    rel = lambda a, b: float((a - b).abs() / b.abs().clamp_min(1e-6))   # noqa: E731
+    rel = lambda a, b: float((a.detach() - b.detach()).abs() / b.detach().abs().clamp_min(1e-6))   # noqa: E731
     assert rel(loss2, loss) < 2e-5 and rel(out[0], pg) < 2e-5 and rel(out[1], vl) < 2e-5 and rel(out[2], ent.mean()) < 2e-5
     assert float((o2.grad - o.grad).abs().max()) < 1e-6 and float((v2.grad - v.grad).abs().max()) < 1e-6
     assert float((ls2.grad - ls.grad).abs().max()) < 2e-5 * max(1.0, float(ls.grad.abs().max()))
@@ -473,3 +534,12 @@ def test_fused_policy_sampling_kernel_follows_the_network_outputs():
         acts3, *_ = m.act_fused(obs, n, a, ppo.new_sampler_state(11, dev))     # same seed, fresh counter: the first draw again
     assert not torch.equal(acts2[0], acts[0]) and torch.equal(acts3[0], acts[0]) and torch.equal(acts3[3], acts[3])
     assert int(st[1].item()) == 2
+    # shared rows: the network runs on ONE row per market and the market's `a` agents draw from it - same numbers as the replicated
+    # rows above (the draw is keyed by the sample, the logits are equal), value per market
+    with torch.no_grad():
+        acts4, logp4, val4, env4 = m.act_fused(obs[:n].contiguous(), n, a, ppo.new_sampler_state(11, dev), shared=True)
+    # (the n-row and the n*a-row products may round their logits differently in the last bit: a draw that sits on a CDF boundary can flip)
+    same = (acts4[0] == acts[0]) & (acts4[1] == acts[1]) & (acts4[2] == acts[2])
+    assert float(same.float().mean()) > 0.9995 and float((acts4[3] - acts[3]).abs().max()) < 1e-5 and val4.shape == (n,)
+    assert float((logp4 - logp)[same].abs().max()) < 1e-4 and float((val4 - val[::a]).abs().max()) < 1e-5
+    assert torch.equal(env4[0].view(-1), acts4[0].to(torch.int32)) and float((env4[1].view(-1) - torch.tanh(acts4[3][:, 0])).abs().max()) < 1e-6

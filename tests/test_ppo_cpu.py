@@ -92,3 +92,42 @@ def test_split_k_weight_gradient_and_closed_form_evaluate_equal_the_plain_formul
     cat, price, off, cont = m.dists(obs)
     ent = cat.entropy() + price.entropy() + off.entropy() + cont.entropy().sum(-1)
     assert torch.allclose(logp_e.double(), logp_a.double(), atol=1e-5) and torch.allclose(ent_e.double(), ent.double(), atol=1e-5) and torch.allclose(val_e.double(), val_a.double(), atol=1e-6)
+
+
+def test_shared_observation_update_equals_the_per_sample_update():
+    """`agents_per_row = A`: the network sees each market-step's observation ONCE and the row's outputs serve its A samples.  One
+    full-batch epoch of that update must move the parameters exactly as the plain update on the A-times replicated rows does (same
+    samples, same loss, gradients summed per row instead of per replica).  float64 network; the loss side runs in float32 in both
+    (evaluate() casts the logits), so the two parameter steps agree to float32 rounding of the gradient sums: 1e-5 of the step."""
+    import copy
+    torch.manual_seed(3)
+    R, A = 96, 4
+    base = ppo.ActorCritic(168).double()
+    obs = torch.randn(R, 168, dtype=torch.float64)
+    with torch.no_grad():
+        acts, logp_old, _ = base.act(obs.repeat_interleave(A, dim=0))
+        logp_old = logp_old + 0.2 * torch.randn_like(logp_old)
+    adv, ret = torch.randn(R * A, dtype=torch.float64), torch.randn(R * A, dtype=torch.float64)
+    results = []
+    for per_row in (A, 1):
+        m = copy.deepcopy(base)
+        opt = torch.optim.SGD(m.parameters(), lr=0.1)
+        x = obs if per_row == A else obs.repeat_interleave(A, dim=0)
+        st = ppo.ppo_update(m, opt, x, acts, logp_old, adv, ret, epochs=1, minibatch=R * A, fused=False, agents_per_row=per_row)
+        results.append((m, st))
+    (m_shared, s_shared), (m_plain, s_plain) = results
+    for k in s_plain:
+        assert abs(s_shared[k] - s_plain[k]) < 1e-6 * max(1.0, abs(s_plain[k])), (k, s_shared, s_plain)     # (the statistics pass through float32)
+    moved = 0.0
+    with torch.no_grad():
+        for (n1, p1), (_, p2), (_, p0) in zip(m_shared.named_parameters(), m_plain.named_parameters(), base.named_parameters()):
+            step = float((p2 - p0).abs().max())
+            assert float((p1 - p2).abs().max()) <= 1e-5 * step + 1e-12, (n1, float((p1 - p2).abs().max()), step)
+            moved += float((p1 - p0).abs().sum())
+    assert moved > 1e-3                                                  # (the step was not a no-op)
+
+
+def test_ppo_loop_per_sample_forward_still_runs():
+    env = _CpuEnv(4, 3, max_step=5)
+    model, hist = ppo.train(env, iters=1, horizon=8, log=lambda s: None, shared_obs=False)
+    assert len(hist) == 1 and np.isfinite(hist[0]["pg_loss"]) and hist[0]["agent_steps"] == 4 * 3 * 8

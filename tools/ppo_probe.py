@@ -36,6 +36,7 @@ def timed(name, fn, n=3):
 for amp in (True, False):
     print("amp", amp)
     timed("whole update (4 epochs x 4 minibatches)", lambda: ppo.ppo_update(m, opt, obs, acts, logp_old, adv, ret, amp=amp))
+    timed("the same samples, one network row per 4 (shared obs)", lambda: ppo.ppo_update(m, opt, obs[:B // 4], acts, logp_old, adv, ret, amp=amp, agents_per_row=4))
 x = obs.to(torch.bfloat16)[:MB]
 a = tuple(t[:MB].contiguous() for t in acts)
 lo, ad, re = logp_old[:MB].contiguous(), adv[:MB].contiguous(), ret[:MB].contiguous()
