@@ -19,7 +19,7 @@ SYMBOLS = [
     "cda_selftest_dec", "cda_selftest_rng", "cda_strerror", "cda_num_markets", "cda_obs_dim",
     "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host", "cda_nav_conservation",
     "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants", "cda_selftest_libm", "cda_selftest_libm_host", "cda_book_capacity",
-    "cda_get_book", "cda_book_spill", "cda_handback_stride", "cda_set_handback", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_step_groups_handback", "cda_handback_groups",
+    "cda_get_book", "cda_book_spill", "cda_handback_stride", "cda_set_handback", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
 ]
 
 
@@ -74,7 +74,8 @@ def lib():
     L.cda_book_spill.argtypes = [vp]
     L.cda_policy_sample.argtypes = [vp, vp, i64, i32, u64, vp] + [vp] * 10 + [vp]
     L.cda_gae.argtypes = [vp, vp, vp, vp, i32, i64, C.c_float, C.c_float, vp, vp, vp]
-    L.cda_ppo_loss.argtypes = [vp] * 10 + [i64, i32, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp]
+    L.cda_ppo_loss.argtypes = [vp] * 11 + [i64, i32, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp]
+    L.cda_store_slots.argtypes = [i32, vp, vp, vp, vp, i32, vp]
     L.cda_step_groups_handback.argtypes = [vp, i32] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp)] + [vp] * 4
     L.cda_handback_groups.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp)] + [vp] * 4
     L.cda_handback_stride.argtypes = [i32]

@@ -47,7 +47,8 @@ __device__ __forceinline__ float pick(const float* v, int a) {           // v[cl
 __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ logits, const float* __restrict__ value, const float* __restrict__ log_std,
                                                   const long long* __restrict__ a_cat, const long long* __restrict__ a_price, const long long* __restrict__ a_off,
                                                   const float* __restrict__ a_cont, const float* __restrict__ logp_old, const float* __restrict__ adv,
-                                                  const float* __restrict__ ret, long long R, int agents, float clip, float vf_coef, float ent_coef,
+                                                  const float* __restrict__ ret, const long long* __restrict__ row_index, long long R, int agents,
+                                                  float clip, float vf_coef, float ent_coef,
                                                   float* __restrict__ d_logits, float* __restrict__ d_value, double* __restrict__ sums) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const float invB = 1.0f / ((float)R * (float)agents);
@@ -70,8 +71,11 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ logi
         for (int j = 0; j < N_LOGITS; j++) d[j] = 0.0f;
         const float val = value[r];
         float G = 0.0f, dval = 0.0f;                                                          // sum of d loss / d logp over the row's samples
+        // the row's samples: rows r of the network outputs are a shuffled minibatch, row_index[r] is where its samples live in the
+        // (unshuffled) per-sample arrays - the epoch's shuffle then moves the observations only
+        const long long src_row = row_index ? row_index[r] : r;
         for (int a = 0; a < agents; a++) {
-            const long long i = r * agents + a;
+            const long long i = src_row * agents + a;
             const int ac = (int)a_cat[i], ap = (int)a_price[i], ao = (int)a_off[i];
             const float z0 = (a_cont[2 * i] - l[22]) * is0, z1 = (a_cont[2 * i + 1] - l[23]) * is1;
             const float logp = -0.5f * z0 * z0 - ls0 - HALF_LOG_2PI - 0.5f * z1 * z1 - ls1 - HALF_LOG_2PI +
@@ -219,6 +223,24 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, cons
         nxt = v;
     }
 }
+// Rollout buffers: item k's `bytes` bytes go to slot *slot of its [T, bytes] buffer - every per-step tensor of a rollout in ONE launch,
+// the step index read on the device (a captured HIP graph replays it unchanged).  blockIdx.y = item.
+struct SlotItems { const unsigned char* src[CDA_SLOT_ITEMS_MAX]; unsigned char* dst[CDA_SLOT_ITEMS_MAX]; long long bytes[CDA_SLOT_ITEMS_MAX]; int n; };
+__global__ __launch_bounds__(256) void k_store_slots(SlotItems it, const long long* __restrict__ slot) {
+    const int k = (int)blockIdx.y;
+    if (k >= it.n) return;
+    const long long nb = it.bytes[k], t = slot[0];
+    const unsigned char* s = it.src[k];
+    unsigned char* d = it.dst[k] + t * nb;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    if ((((unsigned long long)s | (unsigned long long)d | (unsigned long long)nb) & 15ull) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(s);
+        uint4* d4 = reinterpret_cast<uint4*>(d);
+        for (long long i = tid; i < (nb >> 4); i += nth) d4[i] = s4[i];
+    } else {
+        for (long long i = tid; i < nb; i += nth) d[i] = s[i];
+    }
+}
 __global__ void k_bump(long long* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += 1; }
 }  // namespace
 
@@ -236,14 +258,14 @@ extern "C" int cda_policy_sample(const float* logits, const float* log_std, int6
 }
 
 extern "C" int cda_ppo_loss(const float* logits, const float* value, const float* log_std, const int64_t* a_cat, const int64_t* a_price,
-                            const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret, int64_t rows, int32_t agents_per_row,
-                            float clip, float vf_coef, float ent_coef, float* d_logits, float* d_value, double* sums5, float* out6, void* stream) {
+                            const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret, const int64_t* row_index,
+                            int64_t rows, int32_t agents_per_row, float clip, float vf_coef, float ent_coef, float* d_logits, float* d_value, double* sums5, float* out6, void* stream) {
     if (!logits || !value || !log_std || !a_cat || !a_price || !a_off || !a_cont || !logp_old || !adv || !ret || !d_logits || !d_value || !sums5 || !out6 || rows < 1 ||
         agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
     if (hipMemsetAsync(sums5, 0, 5 * sizeof(double), (hipStream_t)stream) != hipSuccess) return CDA_ERR_HIP;
     hipLaunchKernelGGL(k_ppo_loss, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, value, log_std, (const long long*)a_cat,
-                       (const long long*)a_price, (const long long*)a_off, a_cont, logp_old, adv, ret, (long long)rows, (int)agents_per_row, clip, vf_coef, ent_coef,
-                       d_logits, d_value, sums5);
+                       (const long long*)a_price, (const long long*)a_off, a_cont, logp_old, adv, ret, (const long long*)row_index, (long long)rows, (int)agents_per_row,
+                       clip, vf_coef, ent_coef, d_logits, d_value, sums5);
     hipLaunchKernelGGL(k_ppo_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)sums5, (long long)rows * agents_per_row, vf_coef, ent_coef, out6);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
@@ -253,5 +275,22 @@ extern "C" int cda_gae(const float* rew, const float* val, const float* last_val
     if (!rew || !val || !last_val || !done || !adv || !ret || n_steps < 1 || batch < 1) return CDA_ERR_INVALID;
     hipLaunchKernelGGL(k_gae, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rew, val, last_val, done, (int)n_steps, (long long)batch,
                        gamma, lam, adv, ret);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_store_slots(int32_t n_items, const void* const* src, void* const* dst_base, const int64_t* bytes, int64_t* slot_dev, int32_t bump, void* stream) {
+    if (n_items < 1 || n_items > CDA_SLOT_ITEMS_MAX || !src || !dst_base || !bytes || !slot_dev) return CDA_ERR_INVALID;
+    SlotItems it;
+    long long largest = 0;
+    for (int k = 0; k < n_items; k++) {
+        if (!src[k] || !dst_base[k] || bytes[k] < 1) return CDA_ERR_INVALID;
+        it.src[k] = (const unsigned char*)src[k]; it.dst[k] = (unsigned char*)dst_base[k]; it.bytes[k] = (long long)bytes[k];
+        largest = bytes[k] > largest ? bytes[k] : largest;
+    }
+    it.n = n_items;
+    long long blocks = (largest / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    hipLaunchKernelGGL(k_store_slots, dim3((unsigned)blocks, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, it, (const long long*)slot_dev);
+    if (bump) hipLaunchKernelGGL(k_bump, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)slot_dev);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }

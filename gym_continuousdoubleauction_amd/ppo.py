@@ -176,16 +176,20 @@ class _FusedPPOLoss(torch.autograd.Function):
     are the plain PyTorch statement of the same op (the numerics reference, and the path of non-HIP tensors)."""
 
     @staticmethod
-    def forward(ctx, logits, value, log_std, a_cat, a_price, a_off, a_cont, logp_old, adv, ret, clip, vf_coef, ent_coef, agents_per_row=1):
+    def forward(ctx, logits, value, log_std, a_cat, a_price, a_off, a_cont, logp_old, adv, ret, clip, vf_coef, ent_coef, agents_per_row=1, row_index=None):
         from ._lib import check, lib
         rows = logits.shape[0]                                     # a row serves agents_per_row consecutive samples (cda.h cda_ppo_loss)
-        assert a_cat.numel() == rows * agents_per_row and adv.numel() == rows * agents_per_row
+        if row_index is None:
+            assert a_cat.numel() == rows * agents_per_row and adv.numel() == rows * agents_per_row
+        else:                                                      # the rows are a shuffled minibatch; the per-sample arrays hold the whole batch
+            assert row_index.numel() == rows and row_index.dtype == torch.int64 and row_index.is_contiguous()
         logits, value = logits.contiguous(), value.contiguous()
         d_logits, d_value = torch.empty_like(logits), torch.empty_like(value)
         sums = torch.empty(5, dtype=torch.float64, device=logits.device)
         out = torch.empty(6, dtype=torch.float32, device=logits.device)
         check(lib().cda_ppo_loss(logits.data_ptr(), value.data_ptr(), log_std.detach().float().contiguous().data_ptr(), a_cat.data_ptr(), a_price.data_ptr(),
-                                 a_off.data_ptr(), a_cont.contiguous().data_ptr(), logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), rows, int(agents_per_row),
+                                 a_off.data_ptr(), a_cont.contiguous().data_ptr(), logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(),
+                                 row_index.data_ptr() if row_index is not None else None, rows, int(agents_per_row),
                                  float(clip), float(vf_coef), float(ent_coef), d_logits.data_ptr(), d_value.data_ptr(), sums.data_ptr(), out.data_ptr(),
                                  torch.cuda.current_stream(logits.device).cuda_stream), "cda_ppo_loss")
         ctx.save_for_backward(d_logits, d_value, out)
@@ -195,7 +199,7 @@ class _FusedPPOLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_out):
         d_logits, d_value, out = ctx.saved_tensors
-        return (d_logits * g_loss, d_value * g_loss, out[4:6] * g_loss) + (None,) * 11
+        return (d_logits * g_loss, d_value * g_loss, out[4:6] * g_loss) + (None,) * 12
 
 
 def to_env_actions(actions, n, a):
@@ -234,15 +238,16 @@ def gae(rew, val, last_val, done, gamma=0.99, lam=0.95, fused=None):
 class _GraphedUpdate:
     """The minibatch steps of ppo_update as captured HIP graphs: one graph per minibatch slot (forward, fused loss, backward, gradient
     clipping, Adam step - ~70 launches that cost more host time than device time once the network runs once per market-step), reading
-    STATIC shuffled buffers that every epoch refills with one gather per tensor.  Needs a capturable optimizer (Adam(capturable=True))
-    and parameters that were stepped eagerly at least once (allocator, GEMM workspaces, Adam state)."""
+    STATIC buffers: the epoch's shuffled observations and its permutation (the loss kernel finds a row's samples through it, so the
+    per-sample tensors are copied in once per update and never shuffled).  Needs a capturable optimizer (Adam(capturable=True)) and
+    parameters that were stepped eagerly at least once (allocator, GEMM workspaces, Adam state)."""
 
     def __init__(self, model, opt, R, A, obs_dim, x_dtype, rows_mb, clip, vf_coef, ent_coef, device):
         self.R, self.A, self.rows_mb = R, A, rows_mb
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)          # noqa: E731
-        self.xs = e((R, obs_dim), x_dtype)
-        self.acts = (e((R, A), torch.int64), e((R, A), torch.int64), e((R, A), torch.int64), e((R, A, 2), torch.float32))
-        self.lp_old, self.adv, self.ret = e((R, A), torch.float32), e((R, A), torch.float32), e((R, A), torch.float32)
+        self.xs, self.perm = e((R, obs_dim), x_dtype), e((R,), torch.int64)
+        self.acts = (e((R * A,), torch.int64), e((R * A,), torch.int64), e((R * A,), torch.int64), e((R * A, 2), torch.float32))
+        self.lp_old, self.adv, self.ret = e((R * A,), torch.float32), e((R * A,), torch.float32), e((R * A,), torch.float32)
         self.graphs, self.out = [], None
         pool = None
         for s in range(0, R, rows_mb):
@@ -251,8 +256,8 @@ class _GraphedUpdate:
             opt.zero_grad(set_to_none=True)                            # the graph's backward allocates (and from then on overwrites) the gradients
             with torch.cuda.graph(g, pool=pool):
                 o, v = model.trunk(self.xs[s:t])
-                loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, self.acts[0][s:t], self.acts[1][s:t], self.acts[2][s:t], self.acts[3][s:t],
-                                                self.lp_old[s:t], self.adv[s:t], self.ret[s:t], clip, vf_coef, ent_coef, A)
+                loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, self.acts[0], self.acts[1], self.acts[2], self.acts[3],
+                                                self.lp_old, self.adv, self.ret, clip, vf_coef, ent_coef, A, self.perm[s:t])
                 loss.backward()
                 nn.utils.clip_grad_norm_(model.parameters(), 0.5, foreach=True)
                 opt.step()
@@ -261,16 +266,11 @@ class _GraphedUpdate:
             self.out = out
 
     def run(self, x_all, actions, logp_old, adv, ret, epochs):
-        R, A = self.R, self.A
-        by_row = lambda t: t.view(R, A, *t.shape[1:])                 # noqa: E731
+        for src, dst in zip(actions + (logp_old, adv, ret), self.acts + (self.lp_old, self.adv, self.ret)):
+            dst.copy_(src.view(dst.shape))
         for _ in range(epochs):
-            perm = torch.randperm(R, device=x_all.device)
-            torch.index_select(x_all, 0, perm, out=self.xs)
-            for src, dst in zip(actions, self.acts):
-                torch.index_select(by_row(src), 0, perm, out=dst)
-            torch.index_select(by_row(logp_old), 0, perm, out=self.lp_old)
-            torch.index_select(by_row(adv), 0, perm, out=self.adv)
-            torch.index_select(by_row(ret), 0, perm, out=self.ret)
+            torch.randperm(self.R, device=x_all.device, out=self.perm)
+            torch.index_select(x_all, 0, self.perm, out=self.xs)
             for g in self.graphs:
                 g.replay()
         return {"pg_loss": self.out[0], "v_loss": self.out[1], "entropy": self.out[2]}
@@ -311,21 +311,22 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
         return {k: float(v) for k, v in stats.items()}
     for _ in range(epochs):
         perm = torch.randperm(R, device=obs.device)
-        xs, acts = x_all[perm], tuple(by_row(a)[perm] for a in actions)
-        lp_old, adv_s, ret_s = by_row(logp_old)[perm], by_row(adv)[perm], by_row(ret)[perm]
+        xs = x_all[perm]                                          # the shuffle moves the observations; a row's samples are found through `perm`
         for s in range(0, R, rows_mb):
             e = min(R, s + rows_mb)
             if fused:
                 o, v = model.trunk(xs[s:e])
-                loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, acts[0][s:e], acts[1][s:e], acts[2][s:e], acts[3][s:e],
-                                                lp_old[s:e], adv_s[s:e], ret_s[s:e], clip, vf_coef, ent_coef, A)
+                loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, actions[0], actions[1], actions[2], actions[3],
+                                                logp_old, adv, ret, clip, vf_coef, ent_coef, A, perm[s:e])
                 pg, vl, ent_m = out[0], out[1], out[2]
             else:
-                logp, ent, v = model.evaluate(xs[s:e], tuple(flat(a[s:e]) for a in acts), agents_per_row=A)
-                ratio = (logp - flat(lp_old[s:e])).exp()
-                a_mb = flat(adv_s[s:e])
+                rows = perm[s:e]
+                pick = lambda t: flat(by_row(t)[rows])           # noqa: E731 - the minibatch's samples, row by row
+                logp, ent, v = model.evaluate(xs[s:e], tuple(pick(a) for a in actions), agents_per_row=A)
+                ratio = (logp - pick(logp_old)).exp()
+                a_mb = pick(adv)
                 pg = -torch.min(ratio * a_mb, ratio.clamp(1 - clip, 1 + clip) * a_mb).mean()
-                vl = (v - flat(ret_s[s:e])).pow(2).mean()
+                vl = (v - pick(ret)).pow(2).mean()
                 ent_m = ent.mean()
                 loss = pg + vf_coef * vl - ent_coef * ent_m
             opt.zero_grad(set_to_none=True)
@@ -381,14 +382,24 @@ def _capture_rollout_step(model, env, N, A, T, seed=0, shared=True):
            "a_cat": e((T, B), torch.int64), "a_price": e((T, B), torch.int64), "a_off": e((T, B), torch.int64), "a_cont": e((T, B, 2), torch.float32),
            "rew": e((T, N, A), torch.float64), "term": e((T, N), torch.bool), "trunc": e((T, N), torch.bool)}
     t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-    put = lambda name, x: buf[name].index_copy_(0, t_dev, x.unsqueeze(0))      # noqa: E731 - slot t of a buffer, t read on the device
+
+    def put(pairs, bump):
+        """slot *t_dev of every named buffer <- its tensor, ONE launch (cda_store_slots; t read on the device)"""
+        import ctypes as C
+        from ._lib import check, lib
+        n = len(pairs)
+        xs = [x.contiguous() for _, x in pairs]
+        src = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        dst = (C.c_void_p * n)(*[buf[name].data_ptr() for name, _ in pairs])
+        nb = (C.c_int64 * n)(*[x.numel() * x.element_size() for x in xs])
+        for (name, _), x in zip(pairs, xs):
+            assert buf[name][0].numel() * buf[name].element_size() == x.numel() * x.element_size(), name
+        check(lib().cda_store_slots(n, src, dst, nb, t_dev.data_ptr(), int(bump), torch.cuda.current_stream(dev).cuda_stream), "cda_store_slots")
 
     def policy_part():
         pobs = env.obs if shared else env.obs.repeat_interleave(A, dim=0)
         actions, logp, val, env_acts = model.act_fused(pobs, N, A, state, shared=shared)
-        put("obs", pobs); put("val", val); put("logp", logp)
-        for name, x in zip(("a_cat", "a_price", "a_off", "a_cont"), actions):
-            put(name, x)
+        put([("obs", pobs), ("val", val), ("logp", logp)] + list(zip(("a_cat", "a_price", "a_off", "a_cont"), actions)), bump=False)
         return env_acts
 
     side = torch.cuda.Stream()
@@ -401,8 +412,7 @@ def _capture_rollout_step(model, env, N, A, T, seed=0, shared=True):
     with torch.cuda.graph(g), torch.no_grad():
         env_acts = policy_part()
         _, r, term, trunc, _ = env.step(*env_acts)                    # groups > 1: forks from / joins into the capturing stream
-        put("rew", r); put("term", term); put("trunc", trunc)
-        t_dev.add_(1)
+        put([("rew", r), ("term", term), ("trunc", trunc)], bump=True)
     buf["_sampler_state"] = state            # the graph holds the RAW address of the draw counter: it must live as long as the graph
     return g, buf, t_dev
 

@@ -357,11 +357,14 @@ int cda_selftest_libm_host(int32_t op, int32_t n, const double* x_host, double* 
  * logits f32[rows,24] = category 9 | price 10 | price_offset 3 | two Gaussian means, value f32[rows], log_std f32[2], actions
  * a_cat / a_price / a_off i64[B] and a_cont f32[B,2], logp_old / adv / ret f32[B] (sample r * agents_per_row + a belongs to row r).
  * Out: d_logits f32[rows,24], d_value f32[rows] (gradients of the loss, summed over the row's samples), sums5 f64[5] (scratch), out6
- * f32[6] = mean policy loss, mean value loss, mean entropy, loss, d loss / d log_std[0..1] (means over the B samples).  Device pointers. */
+ * f32[6] = mean policy loss, mean value loss, mean entropy, loss, d loss / d log_std[0..1] (means over the B samples).  Device pointers.
+ * row_index i64[rows] (optional, NULL = identity): the rows are a shuffled minibatch and the samples of row r live at
+ * row_index[r] * agents_per_row + a in the per-sample arrays (which then hold the WHOLE batch, unshuffled) - an epoch's shuffle moves
+ * the observations only. */
 int cda_ppo_loss(const float* logits, const float* value, const float* log_std, const int64_t* a_cat, const int64_t* a_price,
-                 const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret, int64_t rows,
-                 int32_t agents_per_row, float clip, float vf_coef, float ent_coef, float* d_logits, float* d_value, double* sums5,
-                 float* out6, void* stream);
+                 const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret,
+                 const int64_t* row_index, int64_t rows, int32_t agents_per_row, float clip, float vf_coef, float ent_coef,
+                 float* d_logits, float* d_value, double* sums5, float* out6, void* stream);
 
 /* The rollout's policy step (csrc/cda_ppo.hip): sample the Dict action of B = rows * agents_per_row (market, agent) pairs from the
  * network outputs (logits f32[rows,24], layout and row sharing as in cda_ppo_loss) in ONE launch: a_cat / a_price / a_off i64[B],
@@ -377,6 +380,13 @@ int cda_policy_sample(const float* logits, const float* log_std, int64_t rows, i
  * the episode ended with that step), last_val f32[batch] -> adv, ret f32[n_steps, batch].  Device pointers. */
 int cda_gae(const float* rew, const float* val, const float* last_val, const float* done, int32_t n_steps, int64_t batch,
             float gamma, float lam, float* adv, float* ret, void* stream);
+
+/* Rollout buffers in one launch: for k < n_items copy bytes[k] bytes from src[k] to dst_base[k] + *slot_dev * bytes[k] (slot t of a
+ * [T, bytes[k]] buffer; the caller keeps *slot_dev below T), then, if bump, *slot_dev += 1 on the stream.  The slot index is read on
+ * the device, so a captured HIP graph replays the call unchanged for every step of a rollout.  src / dst_base / bytes are HOST arrays
+ * of device pointers / sizes (read at call time); n_items <= CDA_SLOT_ITEMS_MAX. */
+#define CDA_SLOT_ITEMS_MAX 12
+int cda_store_slots(int32_t n_items, const void* const* src, void* const* dst_base, const int64_t* bytes, int64_t* slot_dev, int32_t bump, void* stream);
 
 const char* cda_strerror(int status);
 int32_t cda_num_markets(const cda_env* env);

@@ -495,6 +495,20 @@ def test_fused_ppo_loss_kernel_equals_the_pytorch_statement(per_row):
     assert float((o2.grad - o.grad).abs().max()) < 1e-6 and float((v2.grad - v.grad).abs().max()) < 1e-6
     assert float((ls2.grad - ls.grad).abs().max()) < 2e-5 * max(1.0, float(ls.grad.abs().max()))
     assert float((o.grad != 0).float().mean()) > 0.5                      # (the comparison is not between zeros)
+    # row_index: the rows are handed over SHUFFLED and the kernel finds each row's samples through the permutation - same loss, the
+    # same gradients in the shuffled order
+    perm = torch.randperm(R, device=dev)
+    o3, v3 = o.detach()[perm].clone().requires_grad_(True), v.detach()[perm].clone().requires_grad_(True)
+    loss3, out3 = ppo._FusedPPOLoss.apply(o3, v3, ls.detach(), acts[0], acts[1], acts[2], acts[3].float(), logp_old.float(), adv, ret, clip, vf, ec, per_row, perm)
+    loss3.backward()
+    assert rel(loss3, loss2) < 1e-6 and torch.equal(o3.grad, o2.grad[perm]) and torch.equal(v3.grad, v2.grad[perm])
+    half = perm[: R // 2].contiguous()                                    # a minibatch: half of the rows, means over ITS samples
+    loss4, out4 = ppo._FusedPPOLoss.apply(o.detach()[half], v.detach()[half], ls.detach(), acts[0], acts[1], acts[2], acts[3].float(), logp_old.float(), adv, ret,
+                                          clip, vf, ec, per_row, half)
+    sel = (half.view(-1, 1) * per_row + torch.arange(per_row, device=dev)).view(-1)
+    r4 = ratio.detach()[sel]
+    pg4 = -torch.min(r4 * adv[sel], r4.clamp(1 - clip, 1 + clip) * adv[sel]).mean()
+    assert rel(out4[0], pg4) < 2e-5 and rel(out4[1], (vs_.detach()[sel] - ret[sel]).pow(2).mean()) < 2e-5
 
 
 def test_fused_policy_sampling_kernel_follows_the_network_outputs():
