@@ -72,9 +72,9 @@ def lib():
     L.cda_num_markets.argtypes = [vp]
     L.cda_book_capacity.argtypes = [vp]
     L.cda_book_spill.argtypes = [vp]
-    L.cda_policy_sample.argtypes = [vp, vp, i64, i32, u64, vp] + [vp] * 10 + [vp]
+    L.cda_policy_sample.argtypes = [vp, i32, vp, vp, i64, i32, u64, vp] + [vp] * 10 + [vp]
     L.cda_gae.argtypes = [vp, vp, vp, vp, i32, i64, C.c_float, C.c_float, vp, vp, vp]
-    L.cda_ppo_loss.argtypes = [vp] * 11 + [i64, i32, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp]
+    L.cda_ppo_loss.argtypes = [vp] * 11 + [i64, i32, i32, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp]
     L.cda_store_slots.argtypes = [i32, vp, vp, vp, vp, i32, vp]
     L.cda_step_groups_handback.argtypes = [vp, i32] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp)] + [vp] * 4
     L.cda_handback_groups.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp)] + [vp] * 4

@@ -48,14 +48,14 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ logi
                                                   const long long* __restrict__ a_cat, const long long* __restrict__ a_price, const long long* __restrict__ a_off,
                                                   const float* __restrict__ a_cont, const float* __restrict__ logp_old, const float* __restrict__ adv,
                                                   const float* __restrict__ ret, const long long* __restrict__ row_index, long long R, int agents,
-                                                  float clip, float vf_coef, float ent_coef,
+                                                  int stride, int packed, float clip, float vf_coef, float ent_coef,
                                                   float* __restrict__ d_logits, float* __restrict__ d_value, double* __restrict__ sums) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const float invB = 1.0f / ((float)R * (float)agents);
     float pg = 0.0f, vl = 0.0f, en = 0.0f, dls0 = 0.0f, dls1 = 0.0f;
     if (r < R) {
         float l[N_LOGITS], d[N_LOGITS], p[N_CAT + N_PRICE + N_OFF], lp[N_CAT + N_PRICE + N_OFF];
-        const float4* lp4 = reinterpret_cast<const float4*>(logits + r * N_LOGITS);          // 96 B per row, 16-byte aligned
+        const float4* lp4 = reinterpret_cast<const float4*>(logits + r * stride);            // 96 B per row, 16-byte aligned (stride % 4 == 0)
         #pragma unroll
         for (int q = 0; q < N_LOGITS / 4; q++) { const float4 v = lp4[q]; l[4 * q] = v.x; l[4 * q + 1] = v.y; l[4 * q + 2] = v.z; l[4 * q + 3] = v.w; }
         const float ls0 = log_std[0], ls1 = log_std[1];
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ logi
         const float es = ent_coef * invB;                                                     // loss has -ent_coef * mean(ent)
         #pragma unroll
         for (int j = 0; j < N_LOGITS; j++) d[j] = 0.0f;
-        const float val = value[r];
+        const float val = packed ? logits[r * stride + N_LOGITS] : value[r];                 // packed: the value is column 24 of the same row
         float G = 0.0f, dval = 0.0f;                                                          // sum of d loss / d logp over the row's samples
         // the row's samples: rows r of the network outputs are a shuffled minibatch, row_index[r] is where its samples live in the
         // (unshuffled) per-sample arrays - the epoch's shuffle then moves the observations only
@@ -109,10 +109,13 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ logi
         for (int j = 0; j < N_PRICE; j++) d[N_CAT + j] += -G * p[N_CAT + j] + esA * p[N_CAT + j] * (lp[N_CAT + j] + h1);
         #pragma unroll
         for (int j = 0; j < N_OFF; j++) d[N_CAT + N_PRICE + j] += -G * p[N_CAT + N_PRICE + j] + esA * p[N_CAT + N_PRICE + j] * (lp[N_CAT + N_PRICE + j] + h2);
-        float4* dp4 = reinterpret_cast<float4*>(d_logits + r * N_LOGITS);
+        float4* dp4 = reinterpret_cast<float4*>(d_logits + r * stride);
         #pragma unroll
         for (int q = 0; q < N_LOGITS / 4; q++) dp4[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-        d_value[r] = dval;
+        if (packed) {                                                                        // the gradient of the whole padded row: value in column 24, zeros behind it
+            dp4[N_LOGITS / 4] = make_float4(dval, 0.0f, 0.0f, 0.0f);
+            for (int q = N_LOGITS / 4 + 1; q < stride / 4; q++) dp4[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else d_value[r] = dval;
     }
     // block reduction (wave shuffles, then one LDS round), one double atomic per block and quantity
     float v5[5] = {pg, vl, en, dls0, dls1};
@@ -174,8 +177,8 @@ __device__ __forceinline__ int sample_head(const float* l, float u, float& logp)
     logp += l[a] - mx - __logf(s);
     return a;
 }
-__global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__ logits, const float* __restrict__ log_std, long long B, int agents,
-                                                       unsigned long long seed, const long long* __restrict__ counter,
+__global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__ logits, const float* __restrict__ log_std, long long B, int agents, int stride,
+                                                       float* __restrict__ value_out, unsigned long long seed, const long long* __restrict__ counter,
                                                        long long* __restrict__ a_cat, long long* __restrict__ a_price, long long* __restrict__ a_off,
                                                        float* __restrict__ a_cont, float* __restrict__ logp_out,
                                                        int* __restrict__ env_cat, float* __restrict__ env_mean, float* __restrict__ env_sigma,
@@ -183,7 +186,9 @@ __global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     float l[N_LOGITS];
-    const float4* lp4 = reinterpret_cast<const float4*>(logits + (i / agents) * N_LOGITS);      // the row's samples share its logits
+    const long long row = i / agents;
+    const float4* lp4 = reinterpret_cast<const float4*>(logits + row * stride);                 // the row's samples share its logits
+    if (value_out && i == row * agents) value_out[row] = logits[row * stride + N_LOGITS];       // packed rows: the value, made contiguous on the way
     #pragma unroll
     for (int q = 0; q < N_LOGITS / 4; q++) { const float4 v = lp4[q]; l[4 * q] = v.x; l[4 * q + 1] = v.y; l[4 * q + 2] = v.z; l[4 * q + 3] = v.w; }
     const unsigned long long key = mix64(seed + (unsigned long long)counter[0] * 0xd1342543de82ef95ull);
@@ -244,14 +249,16 @@ __global__ __launch_bounds__(256) void k_store_slots(SlotItems it, const long lo
 __global__ void k_bump(long long* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += 1; }
 }  // namespace
 
-extern "C" int cda_policy_sample(const float* logits, const float* log_std, int64_t rows, int32_t agents_per_row, uint64_t seed, int64_t* counter_dev,
+extern "C" int cda_policy_sample(const float* logits, int32_t logits_stride, float* value_out, const float* log_std, int64_t rows, int32_t agents_per_row,
+                                 uint64_t seed, int64_t* counter_dev,
                                  int64_t* a_cat, int64_t* a_price, int64_t* a_off, float* a_cont, float* logp,
                                  int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset, void* stream) {
     if (!logits || !log_std || !counter_dev || !a_cat || !a_price || !a_off || !a_cont || !logp || !env_category || !env_size_mean || !env_size_sigma ||
         !env_price || !env_price_offset || rows < 1 || agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+    if (logits_stride < N_LOGITS || (logits_stride & 3) || (value_out && logits_stride <= N_LOGITS)) return CDA_ERR_INVALID;
     const long long samples = (long long)rows * agents_per_row;
-    hipLaunchKernelGGL(k_policy_sample, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, log_std, samples, (int)agents_per_row,
-                       (unsigned long long)seed, (const long long*)counter_dev, (long long*)a_cat, (long long*)a_price, (long long*)a_off, a_cont, logp,
+    hipLaunchKernelGGL(k_policy_sample, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, log_std, samples, (int)agents_per_row, (int)logits_stride,
+                       value_out, (unsigned long long)seed, (const long long*)counter_dev, (long long*)a_cat, (long long*)a_price, (long long*)a_off, a_cont, logp,
                        env_category, env_size_mean, env_size_sigma, env_price, env_price_offset);
     hipLaunchKernelGGL(k_bump, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)counter_dev);       // the next call draws fresh numbers (graph replays too)
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
@@ -259,13 +266,15 @@ extern "C" int cda_policy_sample(const float* logits, const float* log_std, int6
 
 extern "C" int cda_ppo_loss(const float* logits, const float* value, const float* log_std, const int64_t* a_cat, const int64_t* a_price,
                             const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret, const int64_t* row_index,
-                            int64_t rows, int32_t agents_per_row, float clip, float vf_coef, float ent_coef, float* d_logits, float* d_value, double* sums5, float* out6, void* stream) {
-    if (!logits || !value || !log_std || !a_cat || !a_price || !a_off || !a_cont || !logp_old || !adv || !ret || !d_logits || !d_value || !sums5 || !out6 || rows < 1 ||
+                            int64_t rows, int32_t agents_per_row, int32_t out_stride, float clip, float vf_coef, float ent_coef, float* d_logits, float* d_value, double* sums5, float* out6, void* stream) {
+    if (!logits || !log_std || !a_cat || !a_price || !a_off || !a_cont || !logp_old || !adv || !ret || !d_logits || !sums5 || !out6 || rows < 1 ||
         agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+    const int packed = out_stride != 0;                       // one padded [rows, out_stride] matrix holds logits | value | zeros, and so does its gradient
+    if (packed ? (out_stride <= N_LOGITS || (out_stride & 3)) : (!value || !d_value)) return CDA_ERR_INVALID;
     if (hipMemsetAsync(sums5, 0, 5 * sizeof(double), (hipStream_t)stream) != hipSuccess) return CDA_ERR_HIP;
     hipLaunchKernelGGL(k_ppo_loss, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, value, log_std, (const long long*)a_cat,
                        (const long long*)a_price, (const long long*)a_off, a_cont, logp_old, adv, ret, (const long long*)row_index, (long long)rows, (int)agents_per_row,
-                       clip, vf_coef, ent_coef, d_logits, d_value, sums5);
+                       packed ? (int)out_stride : N_LOGITS, packed, clip, vf_coef, ent_coef, d_logits, d_value, sums5);
     hipLaunchKernelGGL(k_ppo_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)sums5, (long long)rows * agents_per_row, vf_coef, ent_coef, out6);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }

@@ -36,13 +36,17 @@ class _SplitKLinear(torch.autograd.Function):
     SPLIT = 64
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, b, mask=None):
+        """mask (optional, same shape as w): a block structure of w - entries where mask == 0 ARE zero in w and must stay so; their
+        gradient is dropped here (what multiplying w by the mask in the forward pass would do in its backward, without the two
+        elementwise passes over w per call)."""
+        ctx.save_for_backward(x, w, mask) if mask is not None else ctx.save_for_backward(x, w)
+        ctx.has_mask = mask is not None
         return torch.nn.functional.linear(x, w.to(x.dtype), b.to(x.dtype))
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors[:2]
         g = g.contiguous()
         gx = g @ w.to(g.dtype) if ctx.needs_input_grad[0] else None
         n, s = g.shape[0], _SplitKLinear.SPLIT
@@ -51,7 +55,9 @@ class _SplitKLinear(torch.autograd.Function):
             gw = torch.bmm(g.view(s, n // s, -1).transpose(1, 2), x.reshape(s, n // s, -1)).sum(0, dtype=acc)
         else:
             gw = (g.t() @ x).to(acc)
-        return gx, gw.to(w.dtype), g.sum(0, dtype=acc).to(w.dtype)
+        if ctx.has_mask:
+            gw = gw * ctx.saved_tensors[2]
+        return gx, gw.to(w.dtype), g.sum(0, dtype=acc).to(w.dtype), None
 
 
 class _Linear(nn.Linear):
@@ -63,8 +69,8 @@ class ActorCritic(nn.Module):
     """Separate policy and value MLPs (256x256 tanh), as in config/train_config.json:49 - stored and multiplied as ONE set of block
     matrices: both read the same observation, so the first layers are one 168 -> 512 product; the second layers are the two
     diagonal blocks of a 512 x 512 matrix; the heads are rows 0..23 (policy, reading the first 256 units) and row 24 (value, reading
-    the last 256) of a 32 x 512 matrix.  The off-block entries are held at zero by a mask, so the two halves never mix -
-    mathematically two independent networks.  Why: three well-shaped GEMMs per direction instead of five, two of them with 24 and
+    the last 256) of a 32 x 512 matrix.  The off-block entries start at zero and their gradient is masked out (_SplitKLinear), so they stay
+    zero and the two halves never mix - mathematically two independent networks.  Why: three well-shaped GEMMs per direction instead of five, two of them with 24 and
     ONE output column - shapes for which the bfloat16 GEMM libraries take a slow path (the 1-column value head alone made a
     backward pass take 12 ms of host time, tools/ppo_probe.py)."""
     N_OUT, N_PAD = CAT_N + PRICE_N + OFF_N + 2, 32
@@ -92,10 +98,15 @@ class ActorCritic(nn.Module):
 
     def trunk(self, obs):
         """-> (policy outputs [B, 24], value [B])"""
-        h = torch.tanh(self.l1(obs))
-        h = torch.tanh(_SplitKLinear.apply(h, self.l2.weight * self.mask2, self.l2.bias))
-        o = _SplitKLinear.apply(h, self.out.weight * self.mask_out, self.out.bias)
+        o = self.trunk_packed(obs)
         return o[:, :self.N_OUT], o[:, self.N_OUT]
+
+    def trunk_packed(self, obs):
+        """-> the padded output matrix [B, 32] as the last product leaves it: policy outputs in columns 0..23, the value in column 24
+        (what cda_ppo_loss / cda_policy_sample read in place, `out_stride` / `logits_stride` = 32)"""
+        h = torch.tanh(self.l1(obs))
+        h = torch.tanh(_SplitKLinear.apply(h, self.l2.weight, self.l2.bias, self.mask2))     # (off-block entries: zero at init, zero gradient)
+        return _SplitKLinear.apply(h, self.out.weight, self.out.bias, self.mask_out)
 
     def pi(self, obs):
         return self.trunk(obs)[0]
@@ -132,9 +143,9 @@ class ActorCritic(nn.Module):
         shared=False: `obs` holds one row per (market, agent) pair, [n * a, obs_dim].  shared=True: one row per market, [n, obs_dim] -
         the network runs once per market and its outputs serve the market's `a` agents; `value` is then per market, [n]."""
         from ._lib import check, lib
-        o, val = self.trunk(obs)
-        o = o.float().contiguous()
+        o = self.trunk_packed(obs).float().contiguous()           # [rows, 32]: read in place, the value made contiguous by the sampler
         rows, dev = o.shape[0], o.device
+        val = torch.empty(rows, dtype=torch.float32, device=dev)
         per_row = a if shared else 1
         B = rows * per_row
         a_cat, a_price, a_off = (torch.empty(B, dtype=torch.int64, device=dev) for _ in range(3))
@@ -142,11 +153,12 @@ class ActorCritic(nn.Module):
         e_cat, e_price, e_off = (torch.empty((n, a), dtype=torch.int32, device=dev) for _ in range(3))
         e_mean, e_sigma = (torch.empty((n, a), dtype=torch.float32, device=dev) for _ in range(2))
         seed, counter = state
-        check(lib().cda_policy_sample(o.data_ptr(), self.log_std.detach().float().contiguous().data_ptr(), rows, per_row, int(seed) & (2 ** 64 - 1), counter.data_ptr(),
+        check(lib().cda_policy_sample(o.data_ptr(), self.N_PAD, val.data_ptr(), self.log_std.detach().float().contiguous().data_ptr(), rows, per_row,
+                                      int(seed) & (2 ** 64 - 1), counter.data_ptr(),
                                       a_cat.data_ptr(), a_price.data_ptr(), a_off.data_ptr(), a_cont.data_ptr(), logp.data_ptr(),
                                       e_cat.data_ptr(), e_mean.data_ptr(), e_sigma.data_ptr(), e_price.data_ptr(), e_off.data_ptr(),
                                       torch.cuda.current_stream(dev).cuda_stream), "cda_policy_sample")
-        return (a_cat, a_price, a_off, a_cont), logp, val.float(), (e_cat, e_mean, e_sigma, e_price, e_off)
+        return (a_cat, a_price, a_off, a_cont), logp, val, (e_cat, e_mean, e_sigma, e_price, e_off)
 
     def evaluate(self, obs, actions, agents_per_row=1):
         """log-probability of `actions`, entropy and value for a batch - the three discrete heads through ONE log-softmax pass each
@@ -189,7 +201,7 @@ class _FusedPPOLoss(torch.autograd.Function):
         out = torch.empty(6, dtype=torch.float32, device=logits.device)
         check(lib().cda_ppo_loss(logits.data_ptr(), value.data_ptr(), log_std.detach().float().contiguous().data_ptr(), a_cat.data_ptr(), a_price.data_ptr(),
                                  a_off.data_ptr(), a_cont.contiguous().data_ptr(), logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(),
-                                 row_index.data_ptr() if row_index is not None else None, rows, int(agents_per_row),
+                                 row_index.data_ptr() if row_index is not None else None, rows, int(agents_per_row), 0,
                                  float(clip), float(vf_coef), float(ent_coef), d_logits.data_ptr(), d_value.data_ptr(), sums.data_ptr(), out.data_ptr(),
                                  torch.cuda.current_stream(logits.device).cuda_stream), "cda_ppo_loss")
         ctx.save_for_backward(d_logits, d_value, out)
@@ -200,6 +212,37 @@ class _FusedPPOLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g_out):
         d_logits, d_value, out = ctx.saved_tensors
         return (d_logits * g_loss, d_value * g_loss, out[4:6] * g_loss) + (None,) * 12
+
+
+class _FusedPPOLossPacked(torch.autograd.Function):
+    """_FusedPPOLoss on the network's padded output matrix [rows, 32] as it stands (ActorCritic.trunk_packed): no slicing of logits
+    and value before the kernel, no zero-filled reassembly of their gradients behind it - one tensor in, its gradient out."""
+
+    @staticmethod
+    def forward(ctx, outputs, log_std, a_cat, a_price, a_off, a_cont, logp_old, adv, ret, clip, vf_coef, ent_coef, agents_per_row=1, row_index=None):
+        from ._lib import check, lib
+        outputs = outputs.contiguous()
+        rows, stride = outputs.shape
+        if row_index is None:
+            assert a_cat.numel() == rows * agents_per_row and adv.numel() == rows * agents_per_row
+        else:
+            assert row_index.numel() == rows and row_index.dtype == torch.int64 and row_index.is_contiguous()
+        d_out = torch.empty_like(outputs)
+        sums = torch.empty(5, dtype=torch.float64, device=outputs.device)
+        out = torch.empty(6, dtype=torch.float32, device=outputs.device)
+        check(lib().cda_ppo_loss(outputs.data_ptr(), None, log_std.detach().float().contiguous().data_ptr(), a_cat.data_ptr(), a_price.data_ptr(),
+                                 a_off.data_ptr(), a_cont.contiguous().data_ptr(), logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(),
+                                 row_index.data_ptr() if row_index is not None else None, rows, int(agents_per_row), int(stride),
+                                 float(clip), float(vf_coef), float(ent_coef), d_out.data_ptr(), None, sums.data_ptr(), out.data_ptr(),
+                                 torch.cuda.current_stream(outputs.device).cuda_stream), "cda_ppo_loss")
+        ctx.save_for_backward(d_out, out)
+        ctx.mark_non_differentiable(out)
+        return out[3], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        d_out, out = ctx.saved_tensors
+        return (d_out * g_loss, out[4:6] * g_loss) + (None,) * 12
 
 
 def to_env_actions(actions, n, a):
@@ -255,9 +298,8 @@ class _GraphedUpdate:
             g = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)                            # the graph's backward allocates (and from then on overwrites) the gradients
             with torch.cuda.graph(g, pool=pool):
-                o, v = model.trunk(self.xs[s:t])
-                loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, self.acts[0], self.acts[1], self.acts[2], self.acts[3],
-                                                self.lp_old, self.adv, self.ret, clip, vf_coef, ent_coef, A, self.perm[s:t])
+                loss, out = _FusedPPOLossPacked.apply(model.trunk_packed(self.xs[s:t]).float(), model.log_std, self.acts[0], self.acts[1], self.acts[2],
+                                                      self.acts[3], self.lp_old, self.adv, self.ret, clip, vf_coef, ent_coef, A, self.perm[s:t])
                 loss.backward()
                 nn.utils.clip_grad_norm_(model.parameters(), 0.5, foreach=True)
                 opt.step()
@@ -315,9 +357,8 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
         for s in range(0, R, rows_mb):
             e = min(R, s + rows_mb)
             if fused:
-                o, v = model.trunk(xs[s:e])
-                loss, out = _FusedPPOLoss.apply(o.float(), v.float(), model.log_std, actions[0], actions[1], actions[2], actions[3],
-                                                logp_old, adv, ret, clip, vf_coef, ent_coef, A, perm[s:e])
+                loss, out = _FusedPPOLossPacked.apply(model.trunk_packed(xs[s:e]).float(), model.log_std, actions[0], actions[1], actions[2], actions[3],
+                                                      logp_old, adv, ret, clip, vf_coef, ent_coef, A, perm[s:e])
                 pg, vl, ent_m = out[0], out[1], out[2]
             else:
                 rows = perm[s:e]

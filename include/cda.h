@@ -360,19 +360,24 @@ int cda_selftest_libm_host(int32_t op, int32_t n, const double* x_host, double* 
  * f32[6] = mean policy loss, mean value loss, mean entropy, loss, d loss / d log_std[0..1] (means over the B samples).  Device pointers.
  * row_index i64[rows] (optional, NULL = identity): the rows are a shuffled minibatch and the samples of row r live at
  * row_index[r] * agents_per_row + a in the per-sample arrays (which then hold the WHOLE batch, unshuffled) - an epoch's shuffle moves
- * the observations only. */
+ * the observations only.
+ * out_stride != 0 (a multiple of 4 above 24): `logits` is the network's padded output matrix f32[rows, out_stride] as it stands - logits
+ * in columns 0..23, the value in column 24 - and `d_logits` its gradient in the same shape (d value in column 24, zeros behind);
+ * `value` / `d_value` are not used (may be NULL).  out_stride == 0: the separate arrays described above. */
 int cda_ppo_loss(const float* logits, const float* value, const float* log_std, const int64_t* a_cat, const int64_t* a_price,
                  const int64_t* a_off, const float* a_cont, const float* logp_old, const float* adv, const float* ret,
-                 const int64_t* row_index, int64_t rows, int32_t agents_per_row, float clip, float vf_coef, float ent_coef,
+                 const int64_t* row_index, int64_t rows, int32_t agents_per_row, int32_t out_stride, float clip, float vf_coef, float ent_coef,
                  float* d_logits, float* d_value, double* sums5, float* out6, void* stream);
 
 /* The rollout's policy step (csrc/cda_ppo.hip): sample the Dict action of B = rows * agents_per_row (market, agent) pairs from the
- * network outputs (logits f32[rows,24], layout and row sharing as in cda_ppo_loss) in ONE launch: a_cat / a_price / a_off i64[B],
+ * network outputs (logits f32[rows, logits_stride]: 24 for the bare logits, or the padded output matrix of cda_ppo_loss's out_stride,
+ * whose column 24 is then copied to value_out f32[rows] if that is not NULL; row sharing as in cda_ppo_loss) in ONE launch: a_cat / a_price / a_off i64[B],
  * a_cont f32[B,2] (the raw Gaussian samples), logp f32[B], and the env's five action arrays i32 / f32 [B] (size_mean = tanh,
  * size_sigma = sigmoid of the Gaussian samples: the Box bounds of action_helper.py:126-138).  Randomness is counter based, keyed
  * (seed, *counter_dev, sample); counter_dev (i64[1], device) is incremented on the stream after every call, so a captured HIP graph
  * draws fresh numbers on every replay. */
-int cda_policy_sample(const float* logits, const float* log_std, int64_t rows, int32_t agents_per_row, uint64_t seed, int64_t* counter_dev,
+int cda_policy_sample(const float* logits, int32_t logits_stride, float* value_out, const float* log_std, int64_t rows, int32_t agents_per_row,
+                      uint64_t seed, int64_t* counter_dev,
                       int64_t* a_cat, int64_t* a_price, int64_t* a_off, float* a_cont, float* logp,
                       int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset, void* stream);
 

@@ -502,6 +502,12 @@ def test_fused_ppo_loss_kernel_equals_the_pytorch_statement(per_row):
     loss3, out3 = ppo._FusedPPOLoss.apply(o3, v3, ls.detach(), acts[0], acts[1], acts[2], acts[3].float(), logp_old.float(), adv, ret, clip, vf, ec, per_row, perm)
     loss3.backward()
     assert rel(loss3, loss2) < 1e-6 and torch.equal(o3.grad, o2.grad[perm]) and torch.equal(v3.grad, v2.grad[perm])
+    # packed: the network's padded output matrix [R, 32] (logits | value | zeros) in, its gradient out
+    pad = torch.cat([o.detach(), v.detach().unsqueeze(1), torch.zeros(R, 7, device=dev)], dim=1).requires_grad_(True)
+    loss5, out5 = ppo._FusedPPOLossPacked.apply(pad, ls.detach(), acts[0], acts[1], acts[2], acts[3].float(), logp_old.float(), adv, ret, clip, vf, ec, per_row)
+    loss5.backward()
+    assert torch.equal(loss5.detach(), loss2.detach()) and torch.equal(pad.grad[:, :24], o2.grad) and torch.equal(pad.grad[:, 24], v2.grad)
+    assert float(pad.grad[:, 25:].abs().max()) == 0.0
     half = perm[: R // 2].contiguous()                                    # a minibatch: half of the rows, means over ITS samples
     loss4, out4 = ppo._FusedPPOLoss.apply(o.detach()[half], v.detach()[half], ls.detach(), acts[0], acts[1], acts[2], acts[3].float(), logp_old.float(), adv, ret,
                                           clip, vf, ec, per_row, half)

@@ -131,3 +131,32 @@ def test_ppo_loop_per_sample_forward_still_runs():
     env = _CpuEnv(4, 3, max_step=5)
     model, hist = ppo.train(env, iters=1, horizon=8, log=lambda s: None, shared_obs=False)
     assert len(hist) == 1 and np.isfinite(hist[0]["pg_loss"]) and hist[0]["agent_steps"] == 4 * 3 * 8
+
+
+def test_block_structure_of_the_actor_critic_survives_updates():
+    """Policy and value networks are stored as block matrices whose off-block entries start at zero and get no gradient: after real
+    optimizer steps they are still exactly zero (the value head never reads policy units and vice versa), and the block network
+    equals two separate 256x256 MLPs built from its blocks."""
+    torch.manual_seed(4)
+    m = ppo.ActorCritic(168).double()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    R, A = 64, 2
+    obs = torch.randn(R, 168, dtype=torch.float64)
+    with torch.no_grad():
+        acts, logp_old, _ = m.act(obs.repeat_interleave(A, dim=0))
+    adv, ret = torch.randn(R * A, dtype=torch.float64), torch.randn(R * A, dtype=torch.float64)
+    w2_before = m.l2.weight.detach().clone()
+    ppo.ppo_update(m, opt, obs, acts, logp_old, adv, ret, epochs=3, minibatch=64, fused=False, agents_per_row=A)
+    H = m.hidden
+    w2, wo = m.l2.weight.detach(), m.out.weight.detach()
+    assert float((w2 - w2_before).abs().max()) > 1e-4                                    # (the steps were real)
+    assert float(w2[:H, H:].abs().max()) == 0.0 and float(w2[H:, :H].abs().max()) == 0.0
+    assert float(wo[:m.N_OUT, H:].abs().max()) == 0.0 and float(wo[m.N_OUT, :H].abs().max()) == 0.0 and float(wo[m.N_OUT + 1:].abs().max()) == 0.0
+    with torch.no_grad():
+        o, v = m.trunk(obs)
+        h1 = torch.tanh(obs @ m.l1.weight.t() + m.l1.bias)
+        hp = torch.tanh(h1[:, :H] @ w2[:H, :H].t() + m.l2.bias[:H])
+        hv = torch.tanh(h1[:, H:] @ w2[H:, H:].t() + m.l2.bias[H:])
+        o_sep = hp @ wo[:m.N_OUT, :H].t() + m.out.bias[:m.N_OUT]
+        v_sep = hv @ wo[m.N_OUT, H:] + m.out.bias[m.N_OUT]
+    assert torch.allclose(o, o_sep, atol=1e-12) and torch.allclose(v, v_sep, atol=1e-12)
