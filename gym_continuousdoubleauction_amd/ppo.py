@@ -328,8 +328,8 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
     agents_per_row = A > 1: `obs` holds the R unique observations (one row per market-step) and the per-sample tensors hold R * A
     entries, sample r * A + a belonging to row r (module docstring, "Shared observations").  Rows are shuffled - a minibatch of
     `minibatch` samples is minibatch / A whole rows - and the network sees every row once per epoch.
-    graphs: a dict the caller keeps between calls; when given (HIP tensors, fused loss, a capturable optimizer that has stepped
-    before) the minibatch steps are captured once as HIP graphs (_GraphedUpdate) and replayed from then on."""
+    graphs: a dict the caller keeps between calls; when given (HIP tensors, fused loss, a capturable optimizer) the first call runs
+    eagerly and then captures the minibatch steps as HIP graphs (_GraphedUpdate); later calls of the same shape replay them."""
     A = int(agents_per_row)
     R = obs.shape[0]
     B = R * A
@@ -343,38 +343,44 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
     x_all = obs.to(torch.bfloat16) if amp else obs
     rows_mb = max(1, minibatch // A)
     stats = {}
-    if graphs is not None and fused and obs.is_cuda:
-        key = (R, A, obs.shape[1], x_all.dtype, rows_mb, clip, vf_coef, ent_coef)
-        if graphs.get("key") != key:
-            graphs.clear()
-            graphs["key"] = key
-            graphs["update"] = _GraphedUpdate(model, opt, R, A, obs.shape[1], x_all.dtype, rows_mb, clip, vf_coef, ent_coef, obs.device)
+    graph_key = (R, A, obs.shape[1], x_all.dtype, rows_mb, clip, vf_coef, ent_coef)
+    use_graphs = graphs is not None and fused and obs.is_cuda
+    if use_graphs and graphs.get("key") == graph_key:
         stats = graphs["update"].run(x_all, actions, logp_old, adv, ret, epochs)
         return {k: float(v) for k, v in stats.items()}
-    for _ in range(epochs):
-        perm = torch.randperm(R, device=obs.device)
-        xs = x_all[perm]                                          # the shuffle moves the observations; a row's samples are found through `perm`
-        for s in range(0, R, rows_mb):
-            e = min(R, s + rows_mb)
-            if fused:
-                loss, out = _FusedPPOLossPacked.apply(model.trunk_packed(xs[s:e]).float(), model.log_std, actions[0], actions[1], actions[2], actions[3],
-                                                      logp_old, adv, ret, clip, vf_coef, ent_coef, A, perm[s:e])
-                pg, vl, ent_m = out[0], out[1], out[2]
-            else:
-                rows = perm[s:e]
-                pick = lambda t: flat(by_row(t)[rows])           # noqa: E731 - the minibatch's samples, row by row
-                logp, ent, v = model.evaluate(xs[s:e], tuple(pick(a) for a in actions), agents_per_row=A)
-                ratio = (logp - pick(logp_old)).exp()
-                a_mb = pick(adv)
-                pg = -torch.min(ratio * a_mb, ratio.clamp(1 - clip, 1 + clip) * a_mb).mean()
-                vl = (v - pick(ret)).pow(2).mean()
-                ent_m = ent.mean()
-                loss = pg + vf_coef * vl - ent_coef * ent_m
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            nn.utils.clip_grad_norm_(model.parameters(), 0.5, foreach=True)
-            opt.step()
-            stats = {"pg_loss": pg.detach(), "v_loss": vl.detach(), "entropy": ent_m.detach()}
+    def eager_epochs():
+        stats = {}
+        for _ in range(epochs):
+            perm = torch.randperm(R, device=obs.device)
+            xs = x_all[perm]                                          # the shuffle moves the observations; a row's samples are found through `perm`
+            for s in range(0, R, rows_mb):
+                e = min(R, s + rows_mb)
+                if fused:
+                    loss, out = _FusedPPOLossPacked.apply(model.trunk_packed(xs[s:e]).float(), model.log_std, actions[0], actions[1], actions[2], actions[3],
+                                                          logp_old, adv, ret, clip, vf_coef, ent_coef, A, perm[s:e])
+                    pg, vl, ent_m = out[0], out[1], out[2]
+                else:
+                    rows = perm[s:e]
+                    pick = lambda t: flat(by_row(t)[rows])           # noqa: E731 - the minibatch's samples, row by row
+                    logp, ent, v = model.evaluate(xs[s:e], tuple(pick(a) for a in actions), agents_per_row=A)
+                    ratio = (logp - pick(logp_old)).exp()
+                    a_mb = pick(adv)
+                    pg = -torch.min(ratio * a_mb, ratio.clamp(1 - clip, 1 + clip) * a_mb).mean()
+                    vl = (v - pick(ret)).pow(2).mean()
+                    ent_m = ent.mean()
+                    loss = pg + vf_coef * vl - ent_coef * ent_m
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                nn.utils.clip_grad_norm_(model.parameters(), 0.5, foreach=True)
+                opt.step()
+                stats = {"pg_loss": pg.detach(), "v_loss": vl.detach(), "entropy": ent_m.detach()}
+        return stats
+
+    stats = eager_epochs()                                   # (its locals - the last autograd graph among them - are gone before any capture)
+    if use_graphs:                                            # this call ran eagerly (it warmed everything up): capture for the next ones
+        graphs.clear()
+        graphs["update"] = _GraphedUpdate(model, opt, R, A, obs.shape[1], x_all.dtype, rows_mb, clip, vf_coef, ent_coef, obs.device)
+        graphs["key"] = graph_key
     return {k: float(v) for k, v in stats.items()}          # one host sync per update, not one per minibatch
 
 
@@ -548,9 +554,11 @@ def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0
         with torch.no_grad():
             last_val = model.v(env.obs).squeeze(-1).float().repeat_interleave(A)
         adv, ret = gae(rew, val, last_val, dn)
+        if hip:
+            torch.cuda.synchronize()                                   # (so that rollout_s / update_s are device times, not enqueue times)
         t_roll = time.perf_counter()
         stats = ppo_update(model, opt, obs_rows, acts, logp_all, adv.reshape(-1), ret.reshape(-1), epochs=epochs, amp=amp,
-                           agents_per_row=per_row, graphs=update_graphs if it > 0 else None)       # (the first update runs eagerly: see _GraphedUpdate)
+                           agents_per_row=per_row, graphs=update_graphs)       # (the first update runs eagerly and captures: see _GraphedUpdate)
         if hip:
             torch.cuda.synchronize()
         t1 = time.perf_counter()

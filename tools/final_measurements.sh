@@ -20,7 +20,9 @@ python tools/book_census.py > $O/book_census.json 2>/dev/null
 echo "markets agents  M agent-steps/s with info / without info   us per step (with info)" > $O/batch_scaling.txt
 for n in 1024 2048 8192 16384 65536; do python bench.py --markets $n --no-cpu-baseline --steps 400 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print($n, d['config']['agents'], round(d['value']/1e6,1), round(d['value_without_info']/1e6,1), round(d['ms_per_step']*1000,1))"; done >> $O/batch_scaling.txt
 for a in 8 16; do python bench.py --agents $a --no-cpu-baseline --steps 400 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(4096, $a, round(d['value']/1e6,1), round(d['value_without_info']/1e6,1), round(d['ms_per_step']*1000,1))"; done >> $O/batch_scaling.txt
-python -m gym_continuousdoubleauction_amd.ppo --iters 5 --out $O/bench_ppo.json > $O/ppo.log 2>&1
+python -m gym_continuousdoubleauction_amd.ppo --iters 8 --out $O/bench_ppo.json > $O/ppo.log 2>&1
+python -m gym_continuousdoubleauction_amd.ppo --iters 6 --per-sample-forward --out $O/bench_ppo_per_sample_forward.json > $O/ppo_per_sample.log 2>&1
+
 tools/profile_gpu.sh ${TAG}_g4 > $O/profile_g4.log 2>&1
 BENCH_EXTRA="--groups 2" tools/profile_gpu.sh ${TAG}_g2 > $O/profile_g2.log 2>&1
 mkdir -p $O/pmc; cp $R/gpurun_out/prof_${TAG}_g4/*x*_info*_g*.json $R/gpurun_out/prof_${TAG}_g2/*x*_info*_g*.json $O/pmc/ 2>/dev/null
@@ -28,7 +30,7 @@ cp $R/gpurun_out/prof_${TAG}_g4/summary.txt $O/rocprof_summary.txt; cp $R/gpurun
 cp $R/gpurun_out/prof_${TAG}_g4/trace_bench.json $O/bench_under_rocprof.json 2>/dev/null
 cp $R/gpurun_out/prof_${TAG}_g4/trace/t_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 export PYTHONPATH=$R TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ppo_trace -o t -- python -m gym_continuousdoubleauction_amd.ppo --iters 3 > $O/ppo_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ppo_trace -o t -- python -m gym_continuousdoubleauction_amd.ppo --iters 6 > $O/ppo_under_rocprof.log 2>&1
 cp $O/ppo_trace/t_kernel_stats.csv $O/kernel_stats_ppo.csv 2>/dev/null; rm -rf $O/ppo_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fused_trace -o t -- python $R/bench.py --fused 64 --steps 1024 --warmup 64 --no-cpu-baseline > /dev/null 2>&1
 cp $O/fused_trace/t_kernel_stats.csv $O/kernel_stats_fused.csv 2>/dev/null; rm -rf $O/fused_trace
