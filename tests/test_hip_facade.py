@@ -297,6 +297,41 @@ def test_whole_rollout_step_graph_with_market_groups_and_graphed_update():
     env.close(); env2.close(); ref.close()
 
 
+def test_graph_replayed_update_equals_the_eager_update():
+    """ppo_update(graphs=...): the first call runs eagerly and captures one HIP graph per minibatch step; later calls replay them.  Two
+    copies of one model, one always eager, one through the graphs, fed the same data under the same torch seed (= the same epoch
+    permutations): the parameters must stay together - through the capturing call exactly as eager as the other, and through two
+    replayed updates to float32 / bfloat16 rounding of differently ordered atomic sums (log_std's gradient comes from atomics)."""
+    import copy
+    import torch
+    from gym_continuousdoubleauction_amd import ppo
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    R, A = 8192, 4
+    m1 = ppo.ActorCritic(168).to(dev)
+    m2 = copy.deepcopy(m1)
+    o1 = torch.optim.Adam(m1.parameters(), lr=1e-3, fused=True, capturable=True)
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, fused=True, capturable=True)
+    graphs = {}
+    for call in range(3):
+        obs = torch.randn(R, 168, device=dev)
+        with torch.no_grad():
+            acts, logp_old, _ = m1.act(obs.repeat_interleave(A, dim=0))
+        adv, ret = torch.randn(R * A, device=dev), torch.randn(R * A, device=dev)
+        stats = []
+        for m, o, g in ((m1, o1, None), (m2, o2, graphs)):
+            torch.manual_seed(100 + call)
+            stats.append(ppo.ppo_update(m, o, obs, acts, logp_old, adv, ret, epochs=2, minibatch=4096 * A // 2, amp=True, agents_per_row=A, graphs=g))
+        assert ("update" in graphs) and len(graphs["update"].graphs) == 4          # 8192 rows in minibatches of 2048 rows
+        worst = 0.0
+        with torch.no_grad():
+            for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+                worst = max(worst, float((p1 - p2).abs().max()))
+                assert torch.allclose(p1, p2, rtol=0, atol=2e-4), (call, n1, float((p1 - p2).abs().max()))
+        assert abs(stats[0]["v_loss"] - stats[1]["v_loss"]) < 1e-3 * max(1.0, abs(stats[0]["v_loss"])), (call, stats)
+    assert worst < 2e-4
+
+
 def test_fused_gae_kernel_equals_the_recursion():
     import torch
     from gym_continuousdoubleauction_amd import ppo
