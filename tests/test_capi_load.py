@@ -100,3 +100,23 @@ def test_product_library_has_no_measuring_probes():
     blob = open(_lib.LIB_PATH, "rb").read()
     for name in (b"k_opbench", b"k_clock_probe", b"k_calib_read", b"k_calib_write"):
         assert name not in blob, name
+
+
+def test_learner_side_entry_points_refuse_bad_arguments_before_touching_the_device(hip_lib):
+    """cda_ppo_loss / cda_policy_sample / cda_gae / cda_store_slots validate their arguments first: NULL pointers, empty batches, more
+    samples per row than agents exist, a packed stride that cannot hold logits | value - CDA_ERR_INVALID, no launch (no GPU needed)."""
+    L, _ = hip_lib
+    INVALID = -1
+    one = C.c_void_p(16)                                          # a non-NULL pointer that is never dereferenced: validation fails first
+    args_loss = lambda rows, per_row, stride, logits=one, value=one: L.cda_ppo_loss(   # noqa: E731
+        logits, value, one, one, one, one, one, one, one, one, None, rows, per_row, stride, 0.2, 0.5, 0.01, one, one, one, one, None)
+    assert args_loss(0, 1, 0) == INVALID and args_loss(8, 0, 0) == INVALID and args_loss(8, 17, 0) == INVALID
+    assert args_loss(8, 4, 24) == INVALID and args_loss(8, 4, 30) == INVALID            # packed rows need more than 24 columns, a multiple of 4
+    assert args_loss(8, 4, 0, value=None) == INVALID and args_loss(8, 4, 0, logits=None) == INVALID
+    samp = lambda stride, value_out, rows=8, per_row=4: L.cda_policy_sample(one, stride, value_out, one, rows, per_row, 1, one, *([one] * 10), None)   # noqa: E731
+    assert samp(20, None) == INVALID and samp(26, None) == INVALID and samp(24, one) == INVALID and samp(32, None, rows=0) == INVALID
+    assert samp(32, None, per_row=17) == INVALID
+    assert L.cda_gae(one, one, one, one, 0, 8, 0.99, 0.95, one, one, None) == INVALID and L.cda_gae(None, one, one, one, 4, 8, 0.99, 0.95, one, one, None) == INVALID
+    src, dst, nb = (C.c_void_p * 1)(16), (C.c_void_p * 1)(16), (C.c_int64 * 1)(64)
+    assert L.cda_store_slots(0, src, dst, nb, one, 0, None) == INVALID and L.cda_store_slots(13, src, dst, nb, one, 0, None) == INVALID
+    assert L.cda_store_slots(1, src, dst, (C.c_int64 * 1)(0), one, 0, None) == INVALID and L.cda_store_slots(1, src, dst, nb, None, 0, None) == INVALID
