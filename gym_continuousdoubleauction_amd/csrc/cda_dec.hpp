@@ -310,53 +310,47 @@ __device__ __forceinline__ u128 mul_pow10_128(u128 x, int k) {   // caller guara
 // does c * 10^k stay below 2^126 ?  (3402/1024 > log2(10))
 __device__ __forceinline__ bool scale_fits128(u128 c, int k) { return bits128(c) + ((k * 3402) >> 10) + 1 <= 126; }
 
-// Decimal._fix for a 128-bit coefficient r >= 10^28 (the caller has checked), r < 2^127: ONE division by 10^D where
-// D = (upper estimate of the digit count) - 28 comes from the bit length alone.  The quotient shows whether the
-// estimate was one too high (27 digits instead of 28); then the dropped digit is restored from the remainder with
-// 32-bit arithmetic.  No table, no digit count, no second long division; the remainder decides half-even exactly.
+// Decimal._fix for a 128-bit coefficient r >= 10^28 (the caller has checked), r < 2^127: the digit count comes from the bit length
+// and ONE table compare (len(str(r)) = t or t + 1 with t = floor(bits * log10 2)), so the number of digits to drop is exact and the
+// quotient of the one long division by 10^drop has exactly 28 digits.  Everything the division needs for BOTH candidate counts is
+// requested from the LDS table up front (one round trip, next to the compare's operand) and selected afterwards; the rounding is
+// straight-line (selects, no branches): the lanes of a call - an owner and its helper lanes, each with its own operands - would
+// take different arms anyway.
 __device__ __noinline__ D d_round_mid(int sign, u128 r, int exp) {      // a LEAF: no calls, so no return-address spill
     DEC_COUNT(2);
-    const int nd_hi = ((bits128(r) * 1233) >> 12) + 1;          // len(str(r)) is nd_hi or nd_hi - 1
-    int drop = nd_hi - 28;                                      // 1 .. 11 (r < 2^127 < 10^39)
+    const int t = (bits128(r) * 1233) >> 12;                    // 28 .. 38
+    const int d0 = t - 28, d0c = d0 > 9 ? 9 : d0, d1c = d0 + 1 > 9 ? 9 : d0 + 1;    // drop is d0 or d0 + 1 (clamped: valid table indices whatever happens)
+    const lds_u32p pt = lds_pow10(t);
+    const uint32_t t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3];
+    const uint32_t pw_a = lds_pow10(d0c)[0], pw_b = lds_pow10(d1c)[0];
+    const double rd_a = lds_rcp10(d0c), rd_b = lds_rcp10(d1c);
+    const u128 pw_t = ((u128)t3 << 96) | ((u128)t2 << 64) | ((u128)t1 << 32) | (u128)t0;
+    const bool more = r >= pw_t;                                // t + 1 digits
+    int drop = d0 + (more ? 1 : 0);                             // 1 .. 11, exact
+    exp += drop;
     W4 x = w4_from128(r);
     bool sticky = false;
-    if (drop > 9) {                                             // rare: peel the excess over nine digits first
+    uint32_t pw = more ? pw_b : pw_a;
+    double rd = more ? rd_b : rd_a;
+    if (drop > 9) {                                             // rare (r >= 10^37): peel the excess over nine digits first
         const int pre = drop - 9;
         sticky = w_div_small(x, lds_pow10(pre)[0], lds_rcp10(pre)) != 0;
-        drop = 9;
+        drop = 9; pw = 1000000000u; rd = lds_rcp10(9);
     }
-    uint32_t pw = lds_pow10(drop)[0];
     // r < 10^(28 + drop), so the quotient is below 10^28 < 2^94: its top limb is zero and the top limb of r (< 10^drop, or the
     // division could not come out below 2^96) is simply the first partial remainder - three limb steps instead of four
-    uint32_t rem;
-    {
-        const double rd = lds_rcp10(drop);
-        WN<3> lo; lo.w[0] = x.w[0]; lo.w[1] = x.w[1]; lo.w[2] = x.w[2];
-        rem = w_div_small_seeded(lo, pw, rd, x.w[3]);
-        x.w[0] = lo.w[0]; x.w[1] = lo.w[1]; x.w[2] = lo.w[2]; x.w[3] = 0;
-    }
-    // 10^27 = 0x033b2e3c_9fd0803c_e8000000
-    const bool full = x.w[2] > 0x033b2e3cu || (x.w[2] == 0x033b2e3cu && (x.w[1] > 0x9fd0803cu || (x.w[1] == 0x9fd0803cu && x.w[0] >= 0xe8000000u)));
-    if (!full) {                                                // r has nd_hi - 1 digits: one digit fewer to drop
-        drop -= 1;
-        const uint32_t pw1 = lds_pow10(drop)[0];
-        uint32_t dg = (uint32_t)((double)rem * lds_rcp10(drop));            // 0..9, off by at most one
-        int32_t rr = (int32_t)(rem - dg * pw1);
-        if (rr < 0) { dg -= 1; rr += (int32_t)pw1; }
-        if (rr >= (int32_t)pw1) { dg += 1; rr -= (int32_t)pw1; }
-        rem = (uint32_t)rr; pw = pw1;
-        w_mul_small(x, 10u);
-        x.w[0] += dg;                                           // x * 10 ends in 0: no carry
-    }
-    exp += (nd_hi - 28) - (full ? 0 : 1);
-    const uint32_t half = pw >> 1;                              // 5 * 10^(drop-1); drop == 0 cannot round (rem == 0, half == 0)
-    if (rem > half || (rem == half && drop > 0 && (sticky || (x.w[0] & 1u)))) {
-        w_inc(x);
-        if (x.w[0] == 0x10000000u && x.w[1] == 0x3e250261u && x.w[2] == 0x204fce5eu) {    // reached 10^28
-            x.w[0] = 0xe8000000u; x.w[1] = 0x9fd0803cu; x.w[2] = 0x033b2e3cu; exp += 1;   // 10^27
-        }
-    }
-    return d_make(x.w[0], x.w[1], x.w[2], exp, sign);
+    WN<3> q; q.w[0] = x.w[0]; q.w[1] = x.w[1]; q.w[2] = x.w[2];
+    const uint32_t rem = w_div_small_seeded(q, pw, rd, x.w[3]);
+    const uint32_t half = pw >> 1;                              // 5 * 10^(drop-1)
+    const bool up = rem > half || (rem == half && (sticky || (q.w[0] & 1u) != 0));
+    // q + up, and 10^28 (= 0x204fce5e_3e250261_10000000) becomes 10^27 (= 0x033b2e3c_9fd0803c_e8000000) one exponent up
+    const uint64_t s0 = (uint64_t)q.w[0] + (up ? 1u : 0u);
+    const uint64_t s1 = (uint64_t)q.w[1] + (s0 >> 32);
+    uint32_t w0 = (uint32_t)s0, w1 = (uint32_t)s1, w2 = q.w[2] + (uint32_t)(s1 >> 32);
+    const bool ten28 = w0 == 0x10000000u && w1 == 0x3e250261u && w2 == 0x204fce5eu;
+    w0 = ten28 ? 0xe8000000u : w0; w1 = ten28 ? 0x9fd0803cu : w1; w2 = ten28 ? 0x033b2e3cu : w2;
+    exp += ten28 ? 1 : 0;
+    return d_make(w0, w1, w2, exp, sign);
 }
 
 // ---- addition: Decimal.__add__ (_pydecimal.py:1157) with _normalize (:5640) and _rescale (:2612) ----
