@@ -621,15 +621,19 @@ __device__ __forceinline__ int d_cmp(D a, D b) {
     if (bz) return a.sign ? -1 : 1;
     if (a.sign != b.sign) return a.sign ? -1 : 1;
     const int s = a.sign ? -1 : 1;
-    const int diff = a.exp - b.exp;
-    u128 ca, cb;
-    if (diff == 0) { ca = d_c128(a); cb = d_c128(b); }
-    else if (diff > 0 && (a.w1 | a.w2) == 0 && diff <= 28) { ca = mul_u32_pow10_lds(a.w0, diff); cb = d_c128(b); }
-    else if (diff < 0 && (b.w1 | b.w2) == 0 && diff >= -28) { ca = d_c128(a); cb = mul_u32_pow10_lds(b.w0, -diff); }
-    else if (diff > 0 && diff <= 9) { ca = d_c128(a) * (u128)lds_pow10(diff)[0]; cb = d_c128(b); }  // nav vs max_nav: two long
-    else if (diff < 0 && diff >= -9) { ca = d_c128(a); cb = d_c128(b) * (u128)lds_pow10(-diff)[0]; } // coefficients, a few digits apart
-    else return d_cmp_mid(a, b);
-    return ca == cb ? 0 : (ca > cb ? s : -s);
+    // the operand with the larger exponent is scaled: the same one multiply as in d_add (short coefficient x table entry, or a long
+    // coefficient x a power of ten below 2^32 - nav against max_nav: two long coefficients a few digits apart)
+    const bool swp = a.exp < b.exp;
+    const D t = swp ? b : a, o = swp ? a : b;
+    const int diff = t.exp - o.exp;
+    const bool short_t = (t.w1 | t.w2) == 0;
+    if (!(short_t ? diff <= 28 : diff <= 9)) return d_cmp_mid(a, b);
+    const lds_u32p p = lds_pow10(diff);
+    const uint32_t p0 = p[0], p1 = p[1], p2 = p[2];
+    const u128 big = short_t ? (((u128)p2 << 64) | ((u128)p1 << 32) | (u128)p0) : d_c128(t);
+    const u128 ct = big * (u128)(short_t ? t.w0 : p0), co = d_c128(o);
+    const int c = ct == co ? 0 : (ct > co ? s : -s);        // t against o
+    return swp ? -c : c;
 }
 
 // ---- Decimal.__float__ (_pydecimal.py:1610) = correctly rounded nearest double of coeff * 10^exp ----
