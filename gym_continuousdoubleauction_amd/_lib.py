@@ -19,8 +19,21 @@ SYMBOLS = [
     "cda_selftest_dec", "cda_selftest_rng", "cda_strerror", "cda_num_markets", "cda_obs_dim",
     "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host", "cda_nav_conservation",
     "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants", "cda_selftest_libm", "cda_selftest_libm_host", "cda_book_capacity",
-    "cda_get_book", "cda_book_spill", "cda_handback_stride", "cda_set_handback", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
+    "cda_get_book", "cda_book_spill", "cda_num_agents", "cda_handback_stride", "cda_set_handback", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
 ]
+
+
+# every symbol include/cda_mlp.h declares
+MLP_SYMBOLS = [
+    "cda_mlp_tile_rows", "cda_mlp_pack", "cda_mlp_policy_step", "cda_mlp_forward", "cda_mlp_prep_rows", "cda_mlp_forward_train", "cda_mlp_backward",
+    "cda_mlp_wgrad", "cda_mlp_adam", "cda_ppo_loss32", "cda_mlp_rollout_chain", "cda_mlp_selftest_mfma",
+]
+
+
+class RolloutBufs(C.Structure):
+    """cda_rollout_bufs (include/cda_mlp.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "category", "size_mean", "size_sigma", "price", "price_offset", "a_cont", "logp", "value", "reward",
+                                          "terminated", "truncated")]
 
 
 class CDAError(RuntimeError):
@@ -70,6 +83,7 @@ def lib():
     L.cda_strerror.argtypes = [C.c_int]
     L.cda_strerror.restype = C.c_char_p
     L.cda_num_markets.argtypes = [vp]
+    L.cda_num_agents.argtypes = [vp]
     L.cda_book_capacity.argtypes = [vp]
     L.cda_book_spill.argtypes = [vp]
     L.cda_policy_sample.argtypes = [vp, i32, vp, vp, i64, i32, u64, vp] + [vp] * 10 + [vp]
@@ -85,6 +99,20 @@ def lib():
     L.cda_obs_dim.argtypes = [vp]
     L.cda_state_bytes_per_market.argtypes = [vp]
     L.cda_state_bytes_per_market.restype = i64
+    f32 = C.c_float
+    L.cda_mlp_tile_rows.argtypes = []
+    L.cda_mlp_tile_rows.restype = i32
+    L.cda_mlp_pack.argtypes = [vp, vp, vp]
+    L.cda_mlp_policy_step.argtypes = [vp, vp, vp, i32, i32, i32, u64, vp, i64] + [vp] * 8 + [vp]
+    L.cda_mlp_forward.argtypes = [vp, vp, vp, i64, i64, vp, vp]
+    L.cda_mlp_prep_rows.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.cda_mlp_forward_train.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
+    L.cda_mlp_backward.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.cda_mlp_wgrad.argtypes = [vp] * 6 + [i64, i32, vp, vp]
+    L.cda_mlp_adam.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, f32, f32, f32, f32, f32, vp, vp, vp]
+    L.cda_ppo_loss32.argtypes = [vp] * 10 + [i64, i32, i32, f32, f32, f32, vp, vp, vp, i64, i32, i32, vp]
+    L.cda_mlp_rollout_chain.argtypes = [vp, vp, vp, i32, i32, i32, u64, vp, C.POINTER(RolloutBufs), i32, vp]
+    L.cda_mlp_selftest_mfma.argtypes = [i32, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("cda_strerror", "cda_group_range"):

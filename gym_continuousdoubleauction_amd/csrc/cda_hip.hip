@@ -1055,6 +1055,7 @@ int cda_debug_dec_calls(unsigned long long* host8, int reset) {
 int32_t cda_book_capacity(const cda_env* e) { return e ? e->cap : 0; }
 int32_t cda_book_spill(const cda_env* e) { return e ? e->P.lay.spill_cap : 0; }
 int32_t cda_num_markets(const cda_env* e) { return e ? e->P.n_markets : 0; }
+int32_t cda_num_agents(const cda_env* e) { return e ? e->P.cfg.num_agents : 0; }
 int32_t cda_obs_dim(const cda_env* e) { return e ? e->P.cfg.n_hist * CDA_SNAPSHOT_DIM : 0; }
 int64_t cda_state_bytes_per_market(const cda_env* e) { return e ? (int64_t)e->P.lay.stride : 0; }
 

@@ -1,0 +1,879 @@
+// cda_mlp.hip - the policy / value network of the PPO loop on the batched env (include/cda_mlp.h; the reference's
+// network: config/train_config.json:45-53, trained through RLlib at train/train.py:453-541) as hand-written bf16 MFMA kernels for
+// gfx950.  This is the one dense contraction next to the env path, so it is the one place where the matrix cores are used.
+//
+// Conventions (checked on the device by cda_mlp_selftest_mfma):
+//   v_mfma_f32_32x32x16_bf16  D[i][j] += sum_k A[i][k] B[k][j]
+//     A operand, lane l: row i = l & 31, the 8 values k = 8 (l >> 5) .. + 7            (8 bf16 = 4 VGPRs)
+//     B operand, lane l: column j = l & 31, the same 8 k
+//     D, lane l, register r (16 f32): column j = l & 31, row i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+//   Every product here is "activations x weights^T": i = batch row, j = output feature, so A comes from a row-major bf16 image of the
+//   activations in LDS ([row][k], 16-B reads, rows padded by 16 B: conflict free) and B straight from global memory, because
+//   nn.Linear's [out][in] layout IS k-contiguous per output feature.  The accumulator then holds, per lane, ONE feature and 16 rows -
+//   which is exactly an operand of the weight-gradient product (dW[i][j] = sum over ROWS of dz[row][i] h[row][j]: lane = feature,
+//   the 8 slots = 8 rows; the pairing of slots between A and B is all that matters, not which rows they are).  So activations and
+//   pre-activation gradients are written to HBM as the accumulators stand ("packed": 16 B per lane, 1 KB per wave store) and the
+//   weight-gradient kernel loads them as MFMA operands with no transposition at all.
+//
+// Workgroup = 4 waves = M rows (M = 32 MT) x the 256 features of one network half at a time: wave w owns features 64 w .. 64 w + 63
+// (2 feature tiles) for all MT row tiles; the two halves (policy, value) run one after the other through the same LDS buffers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "../../include/cda_mlp.h"
+
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int OBS = CDA_MLP_OBS, KX = CDA_MLP_KX, XT = CDA_MLP_XTILES, HID = CDA_MLP_HID, NOUT = CDA_MLP_NOUT;
+constexpr int XS_LD = KX + 8;        // LDS row of the observation tile: 184 bf16 = 368 B = 16 x 23 (odd: ds_read_b128 conflict free)
+constexpr int ACT_LD = HID + 8;      // LDS row of an activation tile: 264 bf16 = 528 B = 16 x 33
+constexpr int DO_LD = NOUT + 8;      // LDS row of the d_out tile: 40 bf16 = 80 B = 16 x 5
+constexpr int OUTS_LD = NOUT + 1;    // f32 row of the output tile kept in LDS for the sampling epilogue
+constexpr int N_CAT = 9, N_PRICE = 10, N_OFF = 3, N_LOGITS = 24;
+
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); exp overflows to +inf for large x (-> 1), underflows to 0 (-> -1): no clamp needed
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int r = 0; r < 16; r++) z[r] = 0.0f; return z; }
+
+// ---- the observation tile: M rows -> LDS image [row][XS_LD] bf16, columns 168 .. 175 zero --------------------------------------
+template <int M>
+__device__ __forceinline__ void load_x_bf16(const __bf16* __restrict__ x_rm, long long row0, long long rows_end, __bf16* xs) {
+    constexpr int CH = KX / 8;                                            // 22 chunks of 16 B per row
+    for (int c = (int)threadIdx.x; c < M * CH; c += 256) {
+        const int r = c / CH, q = c - r * CH;
+        long long gr = row0 + r; if (gr >= rows_end) gr = rows_end - 1;   // clamp: rows past the end repeat the last one (never stored)
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x_rm + gr * KX + q * 8);
+        *reinterpret_cast<bf16x8*>(xs + r * XS_LD + q * 8) = v;
+    }
+}
+template <int M>
+__device__ __forceinline__ void load_x_f32(const float* __restrict__ obs, long long row0, long long rows_end, __bf16* xs) {
+    constexpr int CH = KX / 4;                                            // 44 chunks of 4 values per row (42 real + 2 of zeros)
+    for (int c = (int)threadIdx.x; c < M * CH; c += 256) {
+        const int r = c / CH, q = c - r * CH;
+        long long gr = row0 + r; if (gr >= rows_end) gr = rows_end - 1;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (q < OBS / 4) v = *reinterpret_cast<const float4*>(obs + gr * OBS + q * 4);
+        bf16x4 b; b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(xs + r * XS_LD + q * 4) = b;
+    }
+}
+
+// ---- one layer for one wave: acc[it][jt] += A(LDS, rows 32 it .., K) x B(global, features f0 + 32 jt .., K) --------------------
+// The B operand (weights) of a layer goes through a register ring of RING k-steps, statically indexed (the loops are unrolled): a layer is
+// PRIMED - its first RING steps requested - before the previous layer's epilogue and barrier, and while step ks multiplies, step ks + RING
+// is requested.  hipcc on its own looks ONE step ahead and sinks every other request to just before its use, which leaves a wave with
+// 2 .. 8 MFMAs per step waiting ~600 cycles for L2 each time: hence the sched_barriers.
+template <int JT, int KSTEPS, int PF>
+struct WRing {
+    static constexpr int RING = PF < KSTEPS ? PF : KSTEPS;
+    bf16x8 b[RING][JT];
+    const __bf16* base;                                                          // this lane's first 16 bytes: row (j), half-step (h)
+    int ld;
+    __device__ __forceinline__ void prime(const __bf16* __restrict__ b_glob, int b_ld, int lane) {
+        base = b_glob + (size_t)(lane & 31) * b_ld + 8 * (lane >> 5); ld = b_ld;
+        #pragma unroll
+        for (int ks = 0; ks < RING; ks++)
+            #pragma unroll
+            for (int jt = 0; jt < JT; jt++) b[ks][jt] = *reinterpret_cast<const bf16x8*>(base + (size_t)(32 * jt) * ld + 16 * ks);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+template <int MT, int JT, int KSTEPS, int PF>
+__device__ __forceinline__ void layer_mma(const __bf16* a_lds, int a_ld, WRing<JT, KSTEPS, PF>& W, int lane, f32x16 (&acc)[MT][JT]) {
+    constexpr int RING = WRing<JT, KSTEPS, PF>::RING;
+    const int j = lane & 31, h = lane >> 5;
+    #pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) {
+        bf16x8 a[MT];
+        #pragma unroll
+        for (int it = 0; it < MT; it++) a[it] = *reinterpret_cast<const bf16x8*>(a_lds + (32 * it + j) * a_ld + 16 * ks + 8 * h);
+        #pragma unroll
+        for (int it = 0; it < MT; it++)
+            #pragma unroll
+            for (int jt = 0; jt < JT; jt++) acc[it][jt] = mfma(a[it], W.b[ks % RING][jt], acc[it][jt]);
+        if (ks + RING < KSTEPS) {
+            #pragma unroll
+            for (int jt = 0; jt < JT; jt++) W.b[ks % RING][jt] = *reinterpret_cast<const bf16x8*>(W.base + (size_t)(32 * jt) * W.ld + 16 * (ks + RING));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// One accumulator tile -> its packed HBM image (two 16-B stores per lane) and / or its row-major LDS image.
+__device__ __forceinline__ void store_packed(__bf16* __restrict__ base, long long rt, int nft, int ft, int lane, const __bf16 (&v)[16]) {
+    bf16x8 p0, p1;
+    #pragma unroll
+    for (int r = 0; r < 8; r++) { p0[r] = v[r]; p1[r] = v[8 + r]; }
+    bf16x8* dst = reinterpret_cast<bf16x8*>(base) + ((rt * nft + ft) * 2) * 64 + lane;
+    dst[0] = p0; dst[64] = p1;
+}
+__device__ __forceinline__ void load_packed(const __bf16* __restrict__ base, long long rt, int nft, int ft, int lane, float (&v)[16]) {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(base) + ((rt * nft + ft) * 2) * 64 + lane;
+    const bf16x8 p0 = src[0], p1 = src[64];
+    #pragma unroll
+    for (int r = 0; r < 8; r++) { v[r] = (float)p0[r]; v[8 + r] = (float)p1[r]; }
+}
+// row-major LDS image: lane (feature j, half h) holds rows rowmap(r, h) of ONE column, so neighbouring lanes are paired first (a DPP
+// swap inside lane pairs): the even lane writes {f, f+1} of row r, the odd lane {f-1, f} of row r+1 - 8 ds_write_b32 per tile instead
+// of 16 two-byte writes
+__device__ __forceinline__ void store_lds_tile(__bf16* act, int ld, int row_base, int col_base, int lane, const __bf16 (&v)[16]) {
+    const int j = lane & 31, h = lane >> 5, odd = lane & 1;
+    #pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const unsigned short mine_keep = __builtin_bit_cast(unsigned short, odd ? v[r + 1] : v[r]);
+        const unsigned short mine_send = __builtin_bit_cast(unsigned short, odd ? v[r] : v[r + 1]);
+        const unsigned int got = (unsigned int)__builtin_amdgcn_mov_dpp((int)mine_send, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true) & 0xffffu;
+        const unsigned int word = odd ? (got | ((unsigned int)mine_keep << 16)) : ((unsigned int)mine_keep | (got << 16));
+        const int row = row_base + rowmap(r + odd, h);
+        *reinterpret_cast<unsigned int*>(act + row * ld + col_base + (j & ~1)) = word;
+    }
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+enum { MODE_TRAIN = 0, MODE_OUT = 1, MODE_SAMPLE = 2, MODE_VALUE = 3 };
+struct FwdArgs {
+    const __bf16* x_rm;          // MODE_TRAIN: [n_rows][176] bf16
+    const float* obs;            // otherwise: f32 [*][168]
+    long long first_row, n_rows; // rows [first_row, first_row + n_rows) of obs / out (MODE_TRAIN: first_row = 0)
+    const __bf16* wb; const float* theta;
+    __bf16* h1p; __bf16* h2p;    // MODE_TRAIN
+    float* out;                  // MODE_TRAIN / MODE_OUT: f32 [*][32] (same row indexing as the input); MODE_SAMPLE / MODE_VALUE: unused
+    // MODE_SAMPLE
+    int agents; unsigned long long seed; const long long* counter; long long draw;
+    int* env_cat; float* env_mean; float* env_sigma; int* env_price; int* env_off; float* a_cont; float* logp; float* value;
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(unsigned long long w, int half) {               // (0, 1): 24 bits of one 32-bit half
+    const unsigned int x = half ? (unsigned int)(w >> 32) : (unsigned int)w;
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+template <int N>
+__device__ __forceinline__ int sample_head(const float* l, float u, float& logp) {
+    float mx = l[0];
+    #pragma unroll
+    for (int j = 1; j < N; j++) mx = fmaxf(mx, l[j]);
+    float e[N], s = 0.0f;
+    #pragma unroll
+    for (int j = 0; j < N; j++) { e[j] = __expf(l[j] - mx); s += e[j]; }
+    const float t = u * s;
+    float c = 0.0f, la = l[N - 1];
+    int a = N - 1;
+    bool found = false;
+    #pragma unroll
+    for (int j = 0; j < N; j++) { c += e[j]; if (!found && t < c) { a = j; la = l[j]; found = true; } }
+    logp += la - mx - __logf(s);
+    return a;
+}
+
+template <int MT, int MODE>
+__global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
+    constexpr int M = 32 * MT, PF = MT == 1 ? 16 : (MT == 2 ? 3 : 4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* xs = reinterpret_cast<__bf16*>(smem);                               // [M][XS_LD]
+    __bf16* act = xs + M * XS_LD;                                               // [M][ACT_LD]
+    float* outs = reinterpret_cast<float*>(act + M * ACT_LD);                   // MODE_SAMPLE: [M][OUTS_LD]
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const long long row0 = A.first_row + (long long)blockIdx.x * M, rows_end = A.first_row + A.n_rows;
+    if (MODE == MODE_TRAIN) load_x_bf16<M>(A.x_rm, row0, rows_end, xs); else load_x_f32<M>(A.obs, row0, rows_end, xs);
+    __syncthreads();
+    const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
+    f32x16 acc3[1][1]; acc3[0][0] = zero16();                                   // heads: wave w owns row tile w (waves >= MT idle there)
+    WRing<2, KX / 16, PF> R1; WRing<2, HID / 16, PF> R2; WRing<1, HID / 16, PF> RO;
+    R1.prime(W1b + (size_t)(64 * w) * KX, KX, lane);
+    #pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        const int f0 = 256 * half + 64 * w;                                     // this wave's first feature (of 512)
+        {   // layer 1: [M, 176] x W1[f0 .. f0 + 63]^T
+            f32x16 acc[MT][2];
+            #pragma unroll
+            for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+            layer_mma<MT, 2, KX / 16, PF>(xs, XS_LD, R1, lane, acc);
+            R2.prime(W2b + ((size_t)half * HID + 64 * w) * HID, HID, lane);     // (in flight across the epilogue and its barrier)
+            if (half == 1) __syncthreads();                                     // the heads of half 0 still read `act`
+            #pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                const float bias = A.theta[CDA_MLP_OFF_B1 + f0 + 32 * jt + j];
+                #pragma unroll
+                for (int it = 0; it < MT; it++) {
+                    __bf16 v[16];
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = (__bf16)fast_tanh(acc[it][jt][r] + bias);
+                    if (MODE == MODE_TRAIN && row0 + 32 * it < rows_end) store_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, v);
+                    store_lds_tile(act, ACT_LD, 32 * it, 64 * w + 32 * jt, lane, v);
+                }
+            }
+        }
+        __syncthreads();
+        {   // layer 2: [M, 256] x W2[half][64 w .. + 63]^T
+            f32x16 acc[MT][2];
+            #pragma unroll
+            for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+            layer_mma<MT, 2, HID / 16, PF>(act, ACT_LD, R2, lane, acc);
+            RO.prime(Wob + (size_t)half * NOUT * HID, HID, lane);
+            __syncthreads();                                                    // every wave has read h1: h2 takes its place
+            #pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                const float bias = A.theta[CDA_MLP_OFF_B2 + f0 + 32 * jt + j];
+                #pragma unroll
+                for (int it = 0; it < MT; it++) {
+                    __bf16 v[16];
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = (__bf16)fast_tanh(acc[it][jt][r] + bias);
+                    if (MODE == MODE_TRAIN && row0 + 32 * it < rows_end) store_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, v);
+                    store_lds_tile(act, ACT_LD, 32 * it, 64 * w + 32 * jt, lane, v);
+                }
+            }
+        }
+        if (half == 0) R1.prime(W1b + (size_t)(256 + 64 * w) * KX, KX, lane);   // the value half's first layer, requested across the heads
+        __syncthreads();
+        // heads: [32 rows of tile w, 256] x Wob[half]^T (the other half's rows of Wob are zero); waves >= MT multiply a tile nobody reads
+        layer_mma<1, 1, HID / 16, PF>(act + (w < MT ? 32 * w : 0) * ACT_LD, ACT_LD, RO, lane, acc3);
+    }
+    // outputs: column j of rows rowmap(r, h) of row tile w
+    if (w < MT) {
+        const float bo = A.theta[CDA_MLP_OFF_BO + j];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = 32 * w + rowmap(r, h);
+            const float o = acc3[0][0][r] + bo;
+            if (MODE == MODE_SAMPLE) outs[row * OUTS_LD + j] = o;
+            else if (MODE == MODE_VALUE) { if (j == N_LOGITS && row0 + row < rows_end) A.value[row0 + row] = o; }
+            else if (row0 + row < rows_end) A.out[(row0 + row) * NOUT + j] = o;
+        }
+    }
+    if (MODE == MODE_SAMPLE) {
+        __syncthreads();
+        // one thread per (row, agent) sample: three categorical heads by inverse CDF, two Gaussian heads by Box-Muller, the action's
+        // log-probability, and the env's five action words (size_mean = tanh, size_sigma = sigmoid: the Box bounds of
+        // action_helper.py:126-138)
+        const int ag = A.agents;
+        const unsigned long long key = mix64(A.seed + (unsigned long long)A.counter[0] * 0xd1342543de82ef95ull + (unsigned long long)A.draw * 0x2545f4914f6cdd1dull);
+        const float ls0 = A.theta[CDA_MLP_OFF_LS], ls1 = A.theta[CDA_MLP_OFF_LS + 1];
+        const float HALF_LOG_2PI = 0.918938533204672742f;
+        for (int s = (int)threadIdx.x; s < M * ag; s += 256) {
+            const int row = s / ag, a = s - row * ag;
+            const long long grow = row0 + row;
+            if (grow >= rows_end) continue;
+            const long long i = grow * ag + a;
+            float l[N_LOGITS];
+            #pragma unroll
+            for (int q = 0; q < N_LOGITS; q++) l[q] = outs[row * OUTS_LD + q];
+            if (a == 0) A.value[grow] = outs[row * OUTS_LD + N_LOGITS];
+            const unsigned long long w0 = mix64(key + (unsigned long long)i), w1 = mix64(w0), w2 = mix64(w1);
+            float lp = 0.0f;
+            const int c = sample_head<N_CAT>(l, u01(w0, 0), lp);
+            const int p = sample_head<N_PRICE>(l + N_CAT, u01(w0, 1), lp);
+            const int o = sample_head<N_OFF>(l + N_CAT + N_PRICE, u01(w1, 0), lp);
+            const float rr = sqrtf(-2.0f * __logf(u01(w1, 1))), th = 6.283185307179586f * u01(w2, 0);
+            const float n0 = rr * __cosf(th), n1 = rr * __sinf(th);
+            const float x0 = l[22] + __expf(ls0) * n0, x1 = l[23] + __expf(ls1) * n1;
+            lp += -0.5f * n0 * n0 - ls0 - HALF_LOG_2PI - 0.5f * n1 * n1 - ls1 - HALF_LOG_2PI;
+            A.env_cat[i] = c; A.env_price[i] = p; A.env_off[i] = o;
+            A.env_mean[i] = tanhf(x0);
+            A.env_sigma[i] = 1.0f / (1.0f + __expf(-x1));
+            A.a_cont[2 * i] = x0; A.a_cont[2 * i + 1] = x1;
+            A.logp[i] = lp;
+        }
+    }
+}
+
+// ---- update, step 0: gather + convert + both images of the observation rows ---------------------------------------------------
+// one workgroup per 32-row tile: the tile goes through LDS as f32 [32][193]; row-major bf16 rows out of it, and the packed image
+// (lane = (feature, row half), slots = rows)
+__global__ __launch_bounds__(256) void k_prep_rows(const float* __restrict__ obs, const long long* __restrict__ perm, long long n_rows,
+                                                   __bf16* __restrict__ x_rm, __bf16* __restrict__ x_pk) {
+    __shared__ float t[32][193];
+    const long long rt = blockIdx.x;
+    for (int c = (int)threadIdx.x; c < 32 * 48; c += 256) {                     // 48 chunks of 4 floats per row: 42 real, 6 of zeros
+        const int r = c / 48, q = c - r * 48;
+        const long long src = perm ? perm[rt * 32 + r] : rt * 32 + r;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (q < OBS / 4) v = *reinterpret_cast<const float4*>(obs + src * OBS + q * 4);
+        t[r][4 * q] = v.x; t[r][4 * q + 1] = v.y; t[r][4 * q + 2] = v.z; t[r][4 * q + 3] = v.w;
+    }
+    __syncthreads();
+    for (int c = (int)threadIdx.x; c < 32 * (KX / 8); c += 256) {               // row-major: 22 chunks of 8 per row
+        const int r = c / (KX / 8), q = c - r * (KX / 8);
+        bf16x8 v;
+        #pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (__bf16)t[r][8 * q + e];
+        *reinterpret_cast<bf16x8*>(x_rm + (rt * 32 + r) * KX + 8 * q) = v;
+    }
+    for (int c = (int)threadIdx.x; c < XT * 2 * 64; c += 256) {                 // packed: [ft][ks][lane] 16-B pieces
+        const int lane = c & 63, ks = (c >> 6) & 1, ft = c >> 7;
+        const int j = lane & 31, h = lane >> 5;
+        bf16x8 v;
+        #pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (__bf16)t[rowmap(8 * ks + e, h)][32 * ft + j];
+        reinterpret_cast<bf16x8*>(x_pk)[((rt * XT + ft) * 2 + ks) * 64 + lane] = v;
+    }
+}
+
+// ---- update, step 2: back-propagation to the pre-activations -------------------------------------------------------------------
+struct BwdArgs {
+    const __bf16* wb; const float* d_out; const __bf16* h1p; const __bf16* h2p; long long n_rows;
+    __bf16* dz1p; __bf16* dz2p; __bf16* doutp; float* bias_slab;
+};
+template <int MT>
+__global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
+    constexpr int M = 32 * MT, PF = MT == 1 ? 16 : (MT == 2 ? 3 : 4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* dos = reinterpret_cast<__bf16*>(smem);                              // [M][DO_LD]   d_out, bf16 (the A operand)
+    __bf16* dact = dos + M * DO_LD;                                             // [M][ACT_LD]  dz2 of the current half
+    float* dof = reinterpret_cast<float*>(dact + M * ACT_LD);                   // [M][OUTS_LD] d_out, f32 (bias sums)
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const long long row0 = (long long)blockIdx.x * M;
+    float* bs = A.bias_slab + (size_t)blockIdx.x * CDA_MLP_BSLAB;
+    for (int c = (int)threadIdx.x; c < M * (NOUT / 4); c += 256) {
+        const int r = c / (NOUT / 4), q = c - r * (NOUT / 4);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row0 + r < A.n_rows) v = *reinterpret_cast<const float4*>(A.d_out + (row0 + r) * NOUT + 4 * q);
+        bf16x4 b; b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(dos + r * DO_LD + 4 * q) = b;
+        dof[r * OUTS_LD + 4 * q] = v.x; dof[r * OUTS_LD + 4 * q + 1] = v.y; dof[r * OUTS_LD + 4 * q + 2] = v.z; dof[r * OUTS_LD + 4 * q + 3] = v.w;
+    }
+    __syncthreads();
+    // d_out in the packed layout (lane = output column, slots = rows) for the heads' weight gradient, and its column sums
+    if (w < MT && row0 + 32 * w < A.n_rows) {
+        __bf16 v[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = dos[(32 * w + rowmap(r, h)) * DO_LD + j];
+        store_packed(A.doutp, row0 / 32 + w, 1, 0, lane, v);
+    }
+    if (threadIdx.x < NOUT) {
+        float s = 0.0f;
+        for (int r = 0; r < M; r++) s += dof[r * OUTS_LD + threadIdx.x];
+        bs[2 * CDA_MLP_FEAT + threadIdx.x] = s;
+    }
+    const __bf16* W2T = A.wb + CDA_MLP_WB_W2T; const __bf16* WoT = A.wb + CDA_MLP_WB_WOT;
+    WRing<2, NOUT / 16, PF> RO; WRing<2, HID / 16, PF> R2;
+    RO.prime(WoT + (size_t)(64 * w) * NOUT, NOUT, lane);
+    #pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        const int f0 = 256 * half + 64 * w;
+        {   // dH2 = d_out x Wo (K = 32), times tanh'
+            f32x16 acc[MT][2];
+            #pragma unroll
+            for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+            layer_mma<MT, 2, NOUT / 16, PF>(dos, DO_LD, RO, lane, acc);
+            R2.prime(W2T + ((size_t)half * HID + 64 * w) * HID, HID, lane);
+            if (half == 1) __syncthreads();                                     // dH1 of half 0 still reads `dact`
+            #pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                float colsum = 0.0f;
+                #pragma unroll
+                for (int it = 0; it < MT; it++) {
+                    const bool live = row0 + 32 * it < A.n_rows;
+                    float hv[16]; __bf16 v[16];
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) hv[r] = 1.0f;
+                    if (live) load_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, hv);
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        v[r] = (__bf16)(acc[it][jt][r] * (1.0f - hv[r] * hv[r]));   // (rows past the end: d_out = 0 there, so acc = 0)
+                        colsum += (float)v[r];
+                    }
+                    if (live) store_packed(A.dz2p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, v);
+                    store_lds_tile(dact, ACT_LD, 32 * it, 64 * w + 32 * jt, lane, v);
+                }
+                colsum += __shfl_xor(colsum, 32, 64);
+                if (h == 0) bs[CDA_MLP_FEAT + f0 + 32 * jt + j] = colsum;
+            }
+        }
+        __syncthreads();
+        {   // dH1 = dz2 x W2[half] (K = 256), times tanh'
+            f32x16 acc[MT][2];
+            #pragma unroll
+            for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+            layer_mma<MT, 2, HID / 16, PF>(dact, ACT_LD, R2, lane, acc);
+            if (half == 0) RO.prime(WoT + (size_t)(256 + 64 * w) * NOUT, NOUT, lane);
+            #pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                float colsum = 0.0f;
+                #pragma unroll
+                for (int it = 0; it < MT; it++) {
+                    if (row0 + 32 * it >= A.n_rows) continue;
+                    float hv[16]; __bf16 v[16];
+                    load_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, hv);
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) { v[r] = (__bf16)(acc[it][jt][r] * (1.0f - hv[r] * hv[r])); colsum += (float)v[r]; }
+                    store_packed(A.dz1p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, v);
+                }
+                colsum += __shfl_xor(colsum, 32, 64);
+                if (h == 0) bs[f0 + 32 * jt + j] = colsum;
+            }
+        }
+    }
+}
+
+// ---- update, step 3: weight gradients ------------------------------------------------------------------------------------------
+// dW[i][j] = sum over rows of dz[row][i] h[row][j]: both operands come out of HBM in the packed layout, 16 B per lane, straight into
+// the MFMA (no LDS).  One workgroup = one JOB (an output panel) x one row chunk; the chunk's partial sum goes to the slab.
+//   job 0, 1: dW2[b]   256 x 256  = dz2[:, b] ^T h1[:, b]     wave (wi, wj): 128 x 128
+//   job 2, 3: dW1[256 b ..]  256 x 192 = dz1[:, b]^T x        wave (wi, wj): 128 x 96
+//   job 4:    dWo      32 x 512   = d_out^T h2                 wave w: 32 x 128
+template <int TI, int TJ>
+__device__ __forceinline__ void wgrad_wave(const bf16x8* __restrict__ Ap, int a_nft, int a_ft0, const bf16x8* __restrict__ Bp, int b_nft, int b_ft0,
+                                           long long rt0, long long rt1, int lane, f32x16 (&acc)[TI][TJ]) {
+    // a step s = (row tile, k-step of 16 rows); operands of step s + D - 1 are requested before step s multiplies (ring of D register
+    // sets, statically indexed; requests past the end repeat the last step and are never multiplied)
+    constexpr int D = 4;
+    bf16x8 a[D][TI], b[D][TJ];
+    const long long s0 = rt0 * 2, s1 = rt1 * 2;
+    auto request = [&](auto slot_c, long long s) {
+        constexpr int slot = decltype(slot_c)::value;
+        const long long sc = s < s1 ? s : s1 - 1, rt = sc >> 1; const int ks = (int)(sc & 1);
+        #pragma unroll
+        for (int ti = 0; ti < TI; ti++) a[slot][ti] = Ap[((rt * a_nft + a_ft0 + ti) * 2 + ks) * 64 + lane];
+        #pragma unroll
+        for (int tj = 0; tj < TJ; tj++) b[slot][tj] = Bp[((rt * b_nft + b_ft0 + tj) * 2 + ks) * 64 + lane];
+    };
+    request(std::integral_constant<int, 0>{}, s0); request(std::integral_constant<int, 1>{}, s0 + 1); request(std::integral_constant<int, 2>{}, s0 + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    #define CDA_WG_STEP(d, nxt) \
+        request(std::integral_constant<int, nxt>{}, s + d + D - 1); \
+        __builtin_amdgcn_sched_barrier(0); \
+        if (s + d < s1) { \
+            _Pragma("unroll") for (int ti = 0; ti < TI; ti++) \
+                _Pragma("unroll") for (int tj = 0; tj < TJ; tj++) acc[ti][tj] = mfma(a[d][ti], b[d][tj], acc[ti][tj]); \
+        }
+    #pragma unroll 1
+    for (long long s = s0; s < s1; s += D) {
+        CDA_WG_STEP(0, 3) CDA_WG_STEP(1, 0) CDA_WG_STEP(2, 1) CDA_WG_STEP(3, 2)
+    }
+    #undef CDA_WG_STEP
+}
+template <int TI, int TJ>
+__device__ __forceinline__ void wgrad_store(float* __restrict__ dst, int ld, int i0, int j0, int lane, const f32x16 (&acc)[TI][TJ]) {
+    const int j = lane & 31, h = lane >> 5;
+    #pragma unroll
+    for (int ti = 0; ti < TI; ti++)
+        #pragma unroll
+        for (int tj = 0; tj < TJ; tj++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) dst[(size_t)(i0 + 32 * ti + rowmap(r, h)) * ld + j0 + 32 * tj + j] = acc[ti][tj][r];
+}
+struct WgradArgs { const bf16x8* x_pk; const bf16x8* h1p; const bf16x8* h2p; const bf16x8* dz1p; const bf16x8* dz2p; const bf16x8* doutp;
+                   long long n_rt; int n_chunks; float* slab; };
+__global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, wi = w >> 1, wj = w & 1;
+    const int job = (int)blockIdx.y, chunk = (int)blockIdx.x;
+    const long long rt0 = A.n_rt * chunk / A.n_chunks, rt1 = A.n_rt * (chunk + 1) / A.n_chunks;
+    float* slab = A.slab + (size_t)chunk * CDA_MLP_SLAB;
+    if (job < 2) {
+        f32x16 acc[4][4];
+        #pragma unroll
+        for (int a = 0; a < 4; a++)
+            #pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] = zero16();
+        wgrad_wave<4, 4>(A.dz2p, 16, 8 * job + 4 * wi, A.h1p, 16, 8 * job + 4 * wj, rt0, rt1, lane, acc);
+        wgrad_store<4, 4>(slab + CDA_MLP_SLAB_W2 + (size_t)job * HID * HID, HID, 128 * wi, 128 * wj, lane, acc);
+    } else if (job < 4) {
+        const int b = job - 2;
+        f32x16 acc[4][3];
+        #pragma unroll
+        for (int a = 0; a < 4; a++)
+            #pragma unroll
+            for (int c = 0; c < 3; c++) acc[a][c] = zero16();
+        wgrad_wave<4, 3>(A.dz1p, 16, 8 * b + 4 * wi, A.x_pk, XT, 3 * wj, rt0, rt1, lane, acc);
+        wgrad_store<4, 3>(slab + CDA_MLP_SLAB_W1, 32 * XT, 256 * b + 128 * wi, 96 * wj, lane, acc);
+    } else {
+        f32x16 acc[1][4];
+        #pragma unroll
+        for (int c = 0; c < 4; c++) acc[0][c] = zero16();
+        wgrad_wave<1, 4>(A.doutp, 1, 0, A.h2p, 16, 4 * w, rt0, rt1, lane, acc);
+        wgrad_store<1, 4>(slab + CDA_MLP_SLAB_WO, CDA_MLP_FEAT, 0, 128 * w, lane, acc);
+    }
+}
+
+// ---- update, step 4: reduce, clip, Adam, repack --------------------------------------------------------------------------------
+__device__ __forceinline__ float grad_of(int p, const float* __restrict__ slab, int n_chunks, const float* __restrict__ bslab, int n_tiles, const float* __restrict__ loss6) {
+    const float* src; int n, stride;
+    if (p < CDA_MLP_OFF_B1) { const int o = p / OBS, i = p - o * OBS; src = slab + CDA_MLP_SLAB_W1 + o * (32 * XT) + i; n = n_chunks; stride = CDA_MLP_SLAB; }
+    else if (p < CDA_MLP_OFF_W2) { src = bslab + (p - CDA_MLP_OFF_B1); n = n_tiles; stride = CDA_MLP_BSLAB; }
+    else if (p < CDA_MLP_OFF_B2) { src = slab + CDA_MLP_SLAB_W2 + (p - CDA_MLP_OFF_W2); n = n_chunks; stride = CDA_MLP_SLAB; }
+    else if (p < CDA_MLP_OFF_WO) { src = bslab + CDA_MLP_FEAT + (p - CDA_MLP_OFF_B2); n = n_tiles; stride = CDA_MLP_BSLAB; }
+    else if (p < CDA_MLP_OFF_BO) {
+        const int q = p - CDA_MLP_OFF_WO, o = q / HID, i = q - o * HID;
+        if (o > N_LOGITS) return 0.0f;                                          // rows 25 .. 31 do not exist
+        src = slab + CDA_MLP_SLAB_WO + o * CDA_MLP_FEAT + (o == N_LOGITS ? HID : 0) + i; n = n_chunks; stride = CDA_MLP_SLAB;
+    } else if (p < CDA_MLP_OFF_LS) {
+        const int o = p - CDA_MLP_OFF_BO;
+        if (o > N_LOGITS) return 0.0f;
+        src = bslab + 2 * CDA_MLP_FEAT + o; n = n_tiles; stride = CDA_MLP_BSLAB;
+    } else return loss6[4 + (p - CDA_MLP_OFF_LS)];
+    float s = 0.0f;
+    for (int c = 0; c < n; c++) s += src[(size_t)c * stride];
+    return s;
+}
+__global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slab, int n_chunks, const float* __restrict__ bslab, int n_tiles,
+                                                     const float* __restrict__ loss6, float* __restrict__ grad, double* __restrict__ norm2) {
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    float g = 0.0f;
+    if (p < CDA_MLP_PARAMS) { g = grad_of(p, slab, n_chunks, bslab, n_tiles, loss6); grad[p] = g; }
+    float x = g * g;
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(norm2, (double)part[0] + (double)part[1] + (double)part[2] + (double)part[3]);
+}
+__device__ __forceinline__ void pack_one(int p, float v, __bf16* __restrict__ wb) {
+    const __bf16 b = (__bf16)v;
+    if (p < CDA_MLP_OFF_B1) { const int o = p / OBS, i = p - o * OBS; wb[CDA_MLP_WB_W1 + o * KX + i] = b; }
+    else if (p >= CDA_MLP_OFF_W2 && p < CDA_MLP_OFF_B2) {
+        const int q = p - CDA_MLP_OFF_W2, blk = q / (HID * HID), o = (q / HID) % HID, i = q % HID;
+        wb[CDA_MLP_WB_W2 + q] = b;
+        wb[CDA_MLP_WB_W2T + ((size_t)blk * HID + i) * HID + o] = b;
+    } else if (p >= CDA_MLP_OFF_WO && p < CDA_MLP_OFF_BO) {
+        const int q = p - CDA_MLP_OFF_WO, o = q / HID, i = q - o * HID;
+        if (o <= N_LOGITS) {
+            const int hf = o == N_LOGITS ? 1 : 0;
+            wb[CDA_MLP_WB_WO + ((size_t)hf * NOUT + o) * HID + i] = b;
+            wb[CDA_MLP_WB_WOT + ((size_t)hf * HID + i) * NOUT + o] = b;
+        }
+    }
+}
+__global__ void k_pack(const float* __restrict__ theta, __bf16* __restrict__ wb) {
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p < CDA_MLP_PARAMS) pack_one(p, theta[p], wb);
+}
+__global__ void k_adam(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step, __bf16* __restrict__ wb,
+                       const float* __restrict__ grad, const double* __restrict__ norm2, float lr, float b1, float b2, float eps, float max_norm) {
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p >= CDA_MLP_PARAMS) return;
+    const float t = step[0] + 1.0f;                                             // (k_bump_step raises it after this launch)
+    const float total = (float)sqrt(norm2[0]);
+    const float coef = fminf(1.0f, max_norm / (total + 1e-6f));
+    const float g = grad[p] * coef;
+    const float mm = b1 * m[p] + (1.0f - b1) * g, vv = b2 * v[p] + (1.0f - b2) * g * g;
+    m[p] = mm; v[p] = vv;
+    const float c1 = 1.0f - __powf(b1, t), c2 = 1.0f - __powf(b2, t);
+    const float th = theta[p] - (lr / c1) * mm / (sqrtf(vv) / sqrtf(c2) + eps);
+    theta[p] = th;
+    pack_one(p, th, wb);
+}
+__global__ void k_bump_step(float* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1.0f; }
+
+// ---- the loss for int32 actions (cda_ppo.hip's k_ppo_loss, same arithmetic; the env's own action tensors) ----------------------
+template <int N>
+__device__ __forceinline__ void head_probs(const float* l, float* p, float* lp, float& ent) {
+    float mx = l[0];
+    #pragma unroll
+    for (int q = 1; q < N; q++) mx = fmaxf(mx, l[q]);
+    float s = 0.0f;
+    #pragma unroll
+    for (int q = 0; q < N; q++) { p[q] = __expf(l[q] - mx); s += p[q]; }
+    const float ls = __logf(s), inv = 1.0f / s;
+    float hh = 0.0f;
+    #pragma unroll
+    for (int q = 0; q < N; q++) { p[q] *= inv; lp[q] = l[q] - mx - ls; hh -= p[q] * lp[q]; }
+    ent = hh;
+}
+template <int N>
+__device__ __forceinline__ float pick(const float* v, int a) {
+    float r = v[0];
+    #pragma unroll
+    for (int q = 1; q < N; q++) r = (a == q || (q == N - 1 && a > q)) ? v[q] : r;
+    return r;
+}
+__global__ __launch_bounds__(256) void k_ppo_loss32(const float* __restrict__ outputs, const float* __restrict__ log_std,
+                                                    const int* __restrict__ a_cat, const int* __restrict__ a_price, const int* __restrict__ a_off,
+                                                    const float* __restrict__ a_cont, const float* __restrict__ logp_old, const float* __restrict__ adv,
+                                                    const float* __restrict__ ret, const long long* __restrict__ row_index, long long R, long long Rnorm, int agents,
+                                                    int stride, float clip, float vf_coef, float ent_coef, float* __restrict__ d_out, double* __restrict__ sums) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float invB = 1.0f / ((float)Rnorm * (float)agents);
+    float pg = 0.0f, vl = 0.0f, en = 0.0f, dls0 = 0.0f, dls1 = 0.0f;
+    if (r < R) {
+        float l[N_LOGITS], d[N_LOGITS], p[N_CAT + N_PRICE + N_OFF], lp[N_CAT + N_PRICE + N_OFF];
+        const float4* lp4 = reinterpret_cast<const float4*>(outputs + r * stride);
+        #pragma unroll
+        for (int q = 0; q < N_LOGITS / 4; q++) { const float4 v = lp4[q]; l[4 * q] = v.x; l[4 * q + 1] = v.y; l[4 * q + 2] = v.z; l[4 * q + 3] = v.w; }
+        const float ls0 = log_std[0], ls1 = log_std[1];
+        const float is0 = __expf(-ls0), is1 = __expf(-ls1);
+        const float HALF_LOG_2PI = 0.918938533204672742f;
+        float h0, h1, h2;
+        head_probs<N_CAT>(l, p, lp, h0);
+        head_probs<N_PRICE>(l + N_CAT, p + N_CAT, lp + N_CAT, h1);
+        head_probs<N_OFF>(l + N_CAT + N_PRICE, p + N_CAT + N_PRICE, lp + N_CAT + N_PRICE, h2);
+        const float ent = h0 + h1 + h2 + 1.0f + 2.0f * HALF_LOG_2PI + ls0 + ls1;
+        const float es = ent_coef * invB;
+        #pragma unroll
+        for (int q = 0; q < N_LOGITS; q++) d[q] = 0.0f;
+        const float val = outputs[r * stride + N_LOGITS];
+        float G = 0.0f, dval = 0.0f;
+        const long long src_row = row_index ? row_index[r] : r;
+        for (int a = 0; a < agents; a++) {
+            const long long i = src_row * agents + a;
+            const int ac = a_cat[i], ap = a_price[i], ao = a_off[i];
+            const float z0 = (a_cont[2 * i] - l[22]) * is0, z1 = (a_cont[2 * i + 1] - l[23]) * is1;
+            const float logp = -0.5f * z0 * z0 - ls0 - HALF_LOG_2PI - 0.5f * z1 * z1 - ls1 - HALF_LOG_2PI +
+                               pick<N_CAT>(lp, ac) + pick<N_PRICE>(lp + N_CAT, ap) + pick<N_OFF>(lp + N_CAT + N_PRICE, ao);
+            const float Av = adv[i], ratio = __expf(logp - logp_old[i]);
+            const float un = ratio * Av, cl = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip) * Av;
+            pg -= fminf(un, cl);
+            const float g_logp = (un <= cl) ? -un * invB : 0.0f;
+            const float dv = val - ret[i];
+            vl += dv * dv;
+            dval += 2.0f * vf_coef * dv * invB;
+            en += ent;
+            G += g_logp;
+            #pragma unroll
+            for (int q = 0; q < N_CAT; q++) d[q] += (q == ac) ? g_logp : 0.0f;
+            #pragma unroll
+            for (int q = 0; q < N_PRICE; q++) d[N_CAT + q] += (q == ap) ? g_logp : 0.0f;
+            #pragma unroll
+            for (int q = 0; q < N_OFF; q++) d[N_CAT + N_PRICE + q] += (q == ao) ? g_logp : 0.0f;
+            d[22] += g_logp * z0 * is0;
+            d[23] += g_logp * z1 * is1;
+            dls0 += g_logp * (z0 * z0 - 1.0f) - es;
+            dls1 += g_logp * (z1 * z1 - 1.0f) - es;
+        }
+        const float esA = es * (float)agents;
+        #pragma unroll
+        for (int q = 0; q < N_CAT; q++) d[q] += -G * p[q] + esA * p[q] * (lp[q] + h0);
+        #pragma unroll
+        for (int q = 0; q < N_PRICE; q++) d[N_CAT + q] += -G * p[N_CAT + q] + esA * p[N_CAT + q] * (lp[N_CAT + q] + h1);
+        #pragma unroll
+        for (int q = 0; q < N_OFF; q++) d[N_CAT + N_PRICE + q] += -G * p[N_CAT + N_PRICE + q] + esA * p[N_CAT + N_PRICE + q] * (lp[N_CAT + N_PRICE + q] + h2);
+        float4* dp4 = reinterpret_cast<float4*>(d_out + r * stride);
+        #pragma unroll
+        for (int q = 0; q < N_LOGITS / 4; q++) dp4[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+        dp4[N_LOGITS / 4] = make_float4(dval, 0.0f, 0.0f, 0.0f);
+        for (int q = N_LOGITS / 4 + 1; q < stride / 4; q++) dp4[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    float v5[5] = {pg, vl, en, dls0, dls1};
+    __shared__ float part[5][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    #pragma unroll
+    for (int q = 0; q < 5; q++) {
+        float x = v5[q];
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+        if (lane == 0) part[q][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const double t = (double)part[threadIdx.x][0] + (double)part[threadIdx.x][1] + (double)part[threadIdx.x][2] + (double)part[threadIdx.x][3];
+        atomicAdd(&sums[threadIdx.x], t);
+    }
+}
+__global__ void k_ppo_finish32(const double* sums, long long B, float vf_coef, float ent_coef, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double pg = sums[0] / (double)B, vl = sums[1] / (double)B, en = sums[2] / (double)B;
+        out[0] = (float)pg; out[1] = (float)vl; out[2] = (float)en; out[3] = (float)(pg + (double)vf_coef * vl - (double)ent_coef * en);
+        out[4] = (float)sums[3]; out[5] = (float)sums[4];
+    }
+}
+
+__global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+}
+
+__global__ void k_selftest_mfma(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ d) {
+    const int lane = (int)threadIdx.x, j = lane & 31, h = lane >> 5;
+    bf16x8 av, bv;
+    #pragma unroll
+    for (int e = 0; e < 8; e++) { av[e] = (__bf16)a[j * 16 + 8 * h + e]; bv[e] = (__bf16)b[(8 * h + e) * 32 + j]; }
+    f32x16 acc = zero16();
+    acc = mfma(av, bv, acc);
+    #pragma unroll
+    for (int r = 0; r < 16; r++) d[rowmap(r, h) * 32 + j] = acc[r];
+}
+
+// tile size of the forward / backward kernels of the update: 32 * MT rows per workgroup (CDA_MLP_MT = 1, 2 or 4; default 4)
+int train_mt() {
+    static int mt = 0;
+    if (!mt) { const char* e = getenv("CDA_MLP_MT"); mt = e ? atoi(e) : 4; if (mt != 1 && mt != 2 && mt != 4) mt = 4; }
+    return mt;
+}
+int rollout_mt() {
+    static int mt = 0;
+    if (!mt) { const char* e = getenv("CDA_MLP_ROLLOUT_MT"); mt = e ? atoi(e) : 1; if (mt != 1 && mt != 2 && mt != 4) mt = 1; }
+    return mt;
+}
+size_t fwd_lds(int mt, int mode) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + M * ACT_LD * 2 + (mode == MODE_SAMPLE ? M * OUTS_LD * 4 : 0); }
+size_t bwd_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * ACT_LD * 2 + M * OUTS_LD * 4; }
+
+template <typename K>
+int allow_lds(K kern, size_t bytes) {
+    if (bytes <= 64 * 1024) return CDA_OK;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+template <int MODE>
+int launch_fwd(const FwdArgs& A, int mt, hipStream_t st) {
+    const size_t lds = fwd_lds(mt, MODE);
+    const unsigned grid = (unsigned)((A.n_rows + 32 * mt - 1) / (32 * mt));
+    int rc = CDA_OK;
+    if (mt == 4) { rc = allow_lds(k_mlp_fwd<4, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<4, MODE>), dim3(grid), dim3(256), lds, st, A); }
+    else if (mt == 2) { rc = allow_lds(k_mlp_fwd<2, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<2, MODE>), dim3(grid), dim3(256), lds, st, A); }
+    else { rc = allow_lds(k_mlp_fwd<1, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<1, MODE>), dim3(grid), dim3(256), lds, st, A); }
+    if (rc) return rc;
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+}  // namespace
+
+extern "C" int32_t cda_mlp_tile_rows(void) { return 32 * train_mt(); }
+
+extern "C" int cda_mlp_pack(const float* theta, void* wb, void* stream) {
+    if (!theta || !wb) return CDA_ERR_INVALID;
+    if (hipMemsetAsync(wb, 0, (size_t)CDA_MLP_WB_ELEMS * 2, (hipStream_t)stream) != hipSuccess) return CDA_ERR_HIP;   // paddings and the masked blocks
+    hipLaunchKernelGGL(k_pack, dim3((CDA_MLP_PARAMS + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, (__bf16*)wb);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_mlp_policy_step(const void* wb, const float* theta, const float* obs, int32_t first_market, int32_t n_markets, int32_t num_agents,
+                                   uint64_t seed, const int64_t* counter_dev, int64_t draw,
+                                   int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset,
+                                   float* a_cont, float* logp, float* value, void* stream) {
+    if (!wb || !theta || !obs || !counter_dev || !env_category || !env_size_mean || !env_size_sigma || !env_price || !env_price_offset || !a_cont || !logp || !value ||
+        first_market < 0 || n_markets < 1 || num_agents < 1 || num_agents > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+    FwdArgs A; memset(&A, 0, sizeof A);
+    A.obs = obs; A.first_row = first_market; A.n_rows = n_markets; A.wb = (const __bf16*)wb; A.theta = theta;
+    A.agents = num_agents; A.seed = seed; A.counter = (const long long*)counter_dev; A.draw = draw;
+    A.env_cat = env_category; A.env_mean = env_size_mean; A.env_sigma = env_size_sigma; A.env_price = env_price; A.env_off = env_price_offset;
+    A.a_cont = a_cont; A.logp = logp; A.value = value;
+    return launch_fwd<MODE_SAMPLE>(A, rollout_mt(), (hipStream_t)stream);
+}
+
+extern "C" int cda_mlp_forward(const void* wb, const float* theta, const float* obs, int64_t first_row, int64_t n_rows, float* out, void* stream) {
+    if (!wb || !theta || !obs || !out || first_row < 0 || n_rows < 1) return CDA_ERR_INVALID;
+    FwdArgs A; memset(&A, 0, sizeof A);
+    A.obs = obs; A.first_row = first_row; A.n_rows = n_rows; A.wb = (const __bf16*)wb; A.theta = theta; A.out = out;
+    return launch_fwd<MODE_OUT>(A, n_rows >= 32768 ? train_mt() : rollout_mt(), (hipStream_t)stream);
+}
+
+extern "C" int cda_mlp_prep_rows(const float* obs, const int64_t* perm, int64_t n_rows, void* x_rm, void* x_pk, void* stream) {
+    if (!obs || !x_rm || !x_pk || n_rows < 32 || (n_rows & 31)) return CDA_ERR_INVALID;
+    hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)(n_rows / 32)), dim3(256), 0, (hipStream_t)stream, obs, (const long long*)perm, (long long)n_rows, (__bf16*)x_rm, (__bf16*)x_pk);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_mlp_forward_train(const void* wb, const float* theta, const void* x_rm, int64_t n_rows, void* h1p, void* h2p, float* out, void* stream) {
+    if (!wb || !theta || !x_rm || !h1p || !h2p || !out || n_rows < 32 || (n_rows & 31)) return CDA_ERR_INVALID;
+    FwdArgs A; memset(&A, 0, sizeof A);
+    A.x_rm = (const __bf16*)x_rm; A.first_row = 0; A.n_rows = n_rows; A.wb = (const __bf16*)wb; A.theta = theta;
+    A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.out = out;
+    return launch_fwd<MODE_TRAIN>(A, train_mt(), (hipStream_t)stream);
+}
+
+extern "C" int cda_mlp_backward(const void* wb, const float* d_out, const void* h1p, const void* h2p, int64_t n_rows,
+                                void* dz1p, void* dz2p, void* doutp, float* bias_slab, void* stream) {
+    if (!wb || !d_out || !h1p || !h2p || !dz1p || !dz2p || !doutp || !bias_slab || n_rows < 32 || (n_rows & 31)) return CDA_ERR_INVALID;
+    BwdArgs A; A.wb = (const __bf16*)wb; A.d_out = d_out; A.h1p = (const __bf16*)h1p; A.h2p = (const __bf16*)h2p; A.n_rows = n_rows;
+    A.dz1p = (__bf16*)dz1p; A.dz2p = (__bf16*)dz2p; A.doutp = (__bf16*)doutp; A.bias_slab = bias_slab;
+    const int mt = train_mt();
+    const size_t lds = bwd_lds(mt);
+    const unsigned grid = (unsigned)((n_rows + 32 * mt - 1) / (32 * mt));
+    int rc;
+    if (mt == 4) { rc = allow_lds(k_mlp_bwd<4>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_bwd<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, A); }
+    else if (mt == 2) { rc = allow_lds(k_mlp_bwd<2>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_bwd<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, A); }
+    else { rc = allow_lds(k_mlp_bwd<1>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_bwd<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, A); }
+    if (rc) return rc;
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p, const void* dz1p, const void* dz2p, const void* doutp,
+                             int64_t n_rows, int32_t n_chunks, float* slab, void* stream) {
+    if (!x_pk || !h1p || !h2p || !dz1p || !dz2p || !doutp || !slab || n_rows < 32 || (n_rows & 31) || n_chunks < 1 || n_chunks > n_rows / 32) return CDA_ERR_INVALID;
+    WgradArgs A; A.x_pk = (const bf16x8*)x_pk; A.h1p = (const bf16x8*)h1p; A.h2p = (const bf16x8*)h2p; A.dz1p = (const bf16x8*)dz1p; A.dz2p = (const bf16x8*)dz2p;
+    A.doutp = (const bf16x8*)doutp; A.n_rt = n_rows / 32; A.n_chunks = n_chunks; A.slab = slab;
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)n_chunks, 5), dim3(256), 0, (hipStream_t)stream, A);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* step_dev, void* wb,
+                            const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles, const float* loss_out6,
+                            float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* norm2, void* stream) {
+    if (!theta || !adam_m || !adam_v || !step_dev || !wb || !slab || !bias_slab || !loss_out6 || !grad || !norm2 || n_chunks < 1 || n_bias_tiles < 1) return CDA_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(norm2, 0, sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
+    const unsigned grid = (CDA_MLP_PARAMS + 255) / 256;
+    hipLaunchKernelGGL(k_grad_reduce, dim3(grid), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, loss_out6, grad, norm2);
+    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, st, theta, adam_m, adam_v, (const float*)step_dev, (__bf16*)wb, (const float*)grad, (const double*)norm2,
+                       lr, beta1, beta2, eps, max_norm);
+    hipLaunchKernelGGL(k_bump_step, dim3(1), dim3(64), 0, st, step_dev);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_ppo_loss32(const float* outputs, const float* log_std, const int32_t* a_cat, const int32_t* a_price, const int32_t* a_off,
+                              const float* a_cont, const float* logp_old, const float* adv, const float* ret, const int64_t* row_index,
+                              int64_t rows, int32_t agents_per_row, int32_t out_stride, float clip, float vf_coef, float ent_coef,
+                              float* d_outputs, double* sums5, float* out6, int64_t norm_rows, int32_t clear, int32_t finish, void* stream) {
+    if (!outputs || !log_std || !a_cat || !a_price || !a_off || !a_cont || !logp_old || !adv || !ret || !d_outputs || !sums5 || !out6 || rows < 1 ||
+        agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS || out_stride <= N_LOGITS || (out_stride & 3) || norm_rows < 0) return CDA_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rn = norm_rows > 0 ? norm_rows : rows;
+    if (clear && hipMemsetAsync(sums5, 0, 5 * sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
+    hipLaunchKernelGGL(k_ppo_loss32, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, outputs, log_std, a_cat, a_price, a_off, a_cont, logp_old, adv, ret,
+                       (const long long*)row_index, (long long)rows, rn, (int)agents_per_row, (int)out_stride, clip, vf_coef, ent_coef, d_outputs, sums5);
+    if (finish) hipLaunchKernelGGL(k_ppo_finish32, dim3(1), dim3(64), 0, st, (const double*)sums5, rn * agents_per_row, vf_coef, ent_coef, out6);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
+                                     uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* B, int32_t copy_first_obs, void* stream) {
+    if (!env || !wb || !theta || !counter_dev || !B || n_steps < 1 || first_market < 0 || n_markets < 1) return CDA_ERR_INVALID;
+    if (!B->obs || !B->category || !B->size_mean || !B->size_sigma || !B->price || !B->price_offset || !B->a_cont || !B->logp || !B->value || !B->reward ||
+        !B->terminated || !B->truncated) return CDA_ERR_INVALID;
+    const int64_t N = cda_num_markets(env);
+    if (cda_obs_dim(env) != OBS || (int64_t)first_market + n_markets > N) return CDA_ERR_INVALID;
+    const int32_t A = cda_num_agents(env);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t NA = (size_t)N * A;
+    if (copy_first_obs) {
+        const long long n4 = (long long)n_markets * OBS / 4;
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, B->obs + ((size_t)n_steps * N + first_market) * OBS,
+                           B->obs + (size_t)first_market * OBS, n4);
+    }
+    for (int32_t t = 0; t < n_steps; t++) {
+        const size_t o = (size_t)t * NA;
+        int rc = cda_mlp_policy_step(wb, theta, B->obs + (size_t)t * N * OBS, first_market, n_markets, A, seed, counter_dev, t,
+                                     B->category + o, B->size_mean + o, B->size_sigma + o, B->price + o, B->price_offset + o,
+                                     B->a_cont + 2 * o, B->logp + o, B->value + (size_t)t * N, stream);
+        if (rc) return rc;
+        rc = cda_step_range(env, first_market, n_markets, B->category + o, B->size_mean + o, B->size_sigma + o, B->price + o, B->price_offset + o, NULL,
+                            B->obs + (size_t)(t + 1) * N * OBS, B->reward + o, B->terminated + (size_t)t * N, B->truncated + (size_t)t * N, NULL, stream);
+        if (rc) return rc;
+    }
+    // the bootstrap value of the last observation
+    FwdArgs V; memset(&V, 0, sizeof V);
+    V.obs = B->obs + (size_t)n_steps * N * OBS; V.first_row = first_market; V.n_rows = n_markets; V.wb = (const __bf16*)wb; V.theta = theta;
+    V.value = B->value + (size_t)n_steps * N;
+    return launch_fwd<MODE_VALUE>(V, rollout_mt(), st);
+}
+
+extern "C" int cda_mlp_selftest_mfma(int32_t device, const float* a_host, const float* b_host, float* d_host) {
+    if (!a_host || !b_host || !d_host) return CDA_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return CDA_ERR_NO_DEVICE;
+    float *a = NULL, *b = NULL, *d = NULL;
+    if (hipMalloc((void**)&a, 32 * 16 * 4) != hipSuccess || hipMalloc((void**)&b, 16 * 32 * 4) != hipSuccess || hipMalloc((void**)&d, 32 * 32 * 4) != hipSuccess) return CDA_ERR_NOMEM;
+    int rc = CDA_OK;
+    if (hipMemcpy(a, a_host, 32 * 16 * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(b, b_host, 16 * 32 * 4, hipMemcpyHostToDevice) != hipSuccess) rc = CDA_ERR_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, 0, (const float*)a, (const float*)b, d);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(d_host, d, 32 * 32 * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = CDA_ERR_HIP;
+    }
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(d);
+    return rc;
+}

@@ -464,6 +464,51 @@ def _capture_rollout_step(model, env, N, A, T, seed=0, shared=True):
     return g, buf, t_dev
 
 
+def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, chains=4, minibatch=262144,
+                gamma=0.99, lam=0.95, clip=0.2, vf_coef=0.5, ent_coef=0.01, policy=None, keep=None):
+    """The PPO loop on the hand-written network kernels (mlp.py, include/cda_mlp.h): rollouts as `chains` independent per-chain launch
+    sequences (policy forward + sampling -> env step -> auto reset, one HIP graph per chain, no cross-stream edge inside the horizon), the
+    update as {forward, loss, back-propagation, weight gradients, clip + Adam} launches per minibatch step - no autograd, no GEMM library.
+    Needs a HIP CDAVecEnv with auto_reset and 168-float observations.  Returns (FusedPolicy, history); `keep` (a dict) receives the last
+    rollout's buffers and the RolloutChains object."""
+    from .mlp import FusedPolicy, FusedUpdate, RolloutChains
+    dev = env.obs.device
+    N, A, T = env.n_markets, env.num_agents, int(horizon)
+    if policy is None:
+        policy = FusedPolicy(dev, seed=seed)
+    env.reset(seed=seed)
+    roll = RolloutChains(env, policy, T, groups=chains, seed=seed, use_graphs=use_graph)
+    R = T * N
+    rows_mb = max(32, min(R, (max(1, minibatch // A) // 32) * 32))
+    upd = FusedUpdate(policy, R, rows_mb, A)
+    history = []
+    for it in range(iters):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        buf = roll.run()
+        val = buf["value"][:T].unsqueeze(-1).expand(T, N, A).reshape(T, N * A)
+        last_val = buf["value"][T].unsqueeze(-1).expand(N, A).reshape(N * A)
+        rew = (buf["reward"].float() * reward_scale).view(T, N * A)
+        dn = (buf["terminated"] | buf["truncated"]).unsqueeze(-1).expand(T, N, A).reshape(T, N * A).float()
+        adv, ret = gae(rew, val, last_val, dn, gamma=gamma, lam=lam)
+        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).reshape(-1).contiguous()
+        torch.cuda.synchronize(dev)
+        t_roll = time.perf_counter()
+        acts = (buf["category"].view(-1), buf["price"].view(-1), buf["price_offset"].view(-1), buf["a_cont"].view(-1, 2))
+        stats = upd.run(buf["obs"][:T].view(R, -1), acts, buf["logp"].view(-1), adv, ret.reshape(-1).contiguous(), epochs=epochs, clip=clip, vf_coef=vf_coef,
+                        ent_coef=ent_coef, lr=lr)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        stats = {k: float(v) for k, v in stats.items()}
+        stats.update(iter=it, mean_reward=float(rew.mean()) / reward_scale, agent_steps=N * A * T, agent_steps_per_s=N * A * T / (t1 - t0),
+                     rollout_s=t_roll - t0, update_s=t1 - t_roll)
+        history.append(stats)
+        log(json.dumps(stats))
+    if keep is not None:
+        keep.update(buffers=roll.buf, rollout=roll, update=upd)
+    return policy, history
+
+
 def train(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, rollout_hook=None, amp=None,
           shared_obs=True):
     """On-device PPO over a CDAVecEnv-shaped env. Returns per-iteration stats (incl. agent-steps/s).
@@ -581,20 +626,27 @@ def main(argv=None):
     p.add_argument("--no-graphs", action="store_true", help="eager rollout and update (no HIP graphs)")
     p.add_argument("--per-sample-forward", action="store_true", help="run the network once per (market, agent) sample instead of once per market-step (shared_obs=False)")
     p.add_argument("--out", default=None, help="write a JSON summary (config, per-iteration stats, end-of-run env checks) to this file")
+    p.add_argument("--legacy", action="store_true", help="the round-3 loop: PyTorch network (library GEMMs, autograd), one graph per rollout step")
+    p.add_argument("--chains", type=int, default=4, help="fused loop: independent rollout chains (market groups on their own streams)")
     args = p.parse_args(argv)
     from .vec_env import CDAVecEnv
     p_groups = max(1, min(args.groups, args.markets))
     env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False, "auto_reset": True},
                     n_markets=args.markets, device="cuda:0", with_info=False, groups=p_groups)
-    _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update, shared_obs=not args.per_sample_forward, use_graph=not args.no_graphs)
+    if args.legacy:
+        _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update, shared_obs=not args.per_sample_forward, use_graph=not args.no_graphs)
+    else:
+        _, hist = train_fused(env, iters=args.iters, horizon=args.horizon, use_graph=not args.no_graphs, chains=args.chains)
     flags = env.flags()
     _, bad = env.nav_conservation()
     summary = {"metric": "agent-steps/sec end to end (rollout + PPO update), BASELINE configs[4]",
                "config": {"workload": f"{args.markets} markets x {args.agents} agents, PyTorch-ROCm PPO policy in the loop (256x256 tanh actor and critic, "
                                       f"4 epochs, 262144-sample minibatches), horizon {args.horizon}, {args.iters} iterations, auto_reset on",
                           "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters, "env_groups": p_groups,
-                          "hip_graphs": "none" if args.no_graphs else "one graph per rollout step (policy + env step + buffer writes), one per minibatch step of the update",
-                          "update_dtype": "float32" if args.fp32_update else "bfloat16 autocast (float32 parameters, Adam state, softmax and losses)",
+                          "loop": "legacy (PyTorch network)" if args.legacy else f"fused: hand-written bf16 MFMA network (csrc/cda_mlp.hip), {args.chains} rollout chains",
+                          "hip_graphs": "none" if args.no_graphs else ("one graph per rollout step (policy + env step + buffer writes), one per minibatch step of the update"
+                                                                      if args.legacy else "one graph per rollout chain (the whole horizon); the update is plain launches"),
+                          "update_dtype": "float32" if args.fp32_update else "bfloat16 operands, float32 accumulation (float32 parameters, Adam state, softmax and losses)",
                           "network_forward": "once per (market, agent) sample" if args.per_sample_forward else
                                              "once per market-step: the market's agents share the observation, the policy is shared, so their logits and value are one row "
                                              "(same samples, same loss, same gradients; ppo.py module docstring)"},

@@ -395,6 +395,7 @@ int cda_store_slots(int32_t n_items, const void* const* src, void* const* dst_ba
 
 const char* cda_strerror(int status);
 int32_t cda_num_markets(const cda_env* env);
+int32_t cda_num_agents(const cda_env* env);
 int32_t cda_book_capacity(const cda_env* env);   /* 256 or 512: the LDS tile this env was built with */
 int32_t cda_obs_dim(const cda_env* env);
 /* Bytes the arena keeps per market in HBM. */

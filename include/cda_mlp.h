@@ -1,0 +1,148 @@
+/*
+ * cda_mlp.h - C-ABI of the policy / value network on the consumer side of the env path (BASELINE configs[4]).
+ *
+ * The reference trains through RLlib's PPO (gym_continuousDoubleAuction/train/train.py:453-541) with the network of
+ * config/train_config.json:45-53: separate policy and value MLPs, 256 x 256, tanh.  Every agent of a market is handed the same
+ * 168-float observation (envs/exchg/state_helper.py:76,109), so the network runs once per market-step.  This header is the whole
+ * network as hand-written bf16 MFMA kernels for gfx950 (csrc/cda_mlp.hip) - the one dense contraction next to the env path:
+ *
+ *     obs f32[168] -> [policy | value] first layers 168 -> 2 x 256, tanh -> two independent 256 x 256 layers, tanh
+ *                  -> heads: 24 policy outputs (category 9 | price 10 | price_offset 3 | two Gaussian means) from the policy half,
+ *                     1 value from the value half: a padded row of 32 floats (columns 0..23 | 24 | zeros)
+ *
+ * Arithmetic: bf16 operands, f32 accumulation (v_mfma_f32_32x32x16_bf16), f32 biases, tanh in f32, activations rounded to bf16
+ * between layers.  The SAME forward code serves the rollout (cda_mlp_policy_step) and the update (cda_mlp_forward_train), so the
+ * log-probabilities a rollout records are the ones the first minibatch step of its update recomputes.
+ *
+ * Parameters: ONE f32 vector `theta` of CDA_MLP_PARAMS floats (the optimiser's master copy)
+ *     W1 [512][168] | b1 [512] | W2 [2][256][256] | b2 [512] | Wo [32][256] | bo [32] | log_std [2]
+ * rows 0..255 of W1 / b1 / b2 and block 0 of W2 are the policy network, the rest the value network; Wo rows 0..23 are the policy
+ * heads (reading the policy half), row 24 the value head (reading the value half), rows 25..31 unused (zero, never updated).
+ * cda_mlp_pack derives the bf16 operand copies `wb` (CDA_MLP_WB_ELEMS bf16) the kernels multiply with:
+ *     W1b [512][176] | W2b [2][256][256] | Wob [2][32][256] | W2T [2][256][256] | WoT [2][256][32]
+ *
+ * Tensors of the update live in HBM in the MFMA's own register layout ("packed": [rows/32][feature tiles of 32][2][64 lanes][8 bf16],
+ * lane = (feature, row-half), the 8 slots = 8 rows) so that the weight-gradient kernel reads its operands with no transposition.
+ *
+ * Conventions as in cda.h: device pointers, caller-owned, plain sizes; CDA_OK or a negative cda_status; kernels are enqueued on
+ * `stream`.  No CPU fallback.
+ */
+#ifndef CDA_MLP_H
+#define CDA_MLP_H
+
+#include <stdint.h>
+#include "cda.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDA_MLP_OBS       168
+#define CDA_MLP_KX        176                    /* observation padded to 11 MFMA k-steps of 16 */
+#define CDA_MLP_XTILES    6                      /* ... and to 6 feature tiles of 32 in the packed layout */
+#define CDA_MLP_HID       256
+#define CDA_MLP_FEAT      512
+#define CDA_MLP_NOUT      32
+#define CDA_MLP_OFF_W1    0
+#define CDA_MLP_OFF_B1    86016
+#define CDA_MLP_OFF_W2    86528
+#define CDA_MLP_OFF_B2    217600
+#define CDA_MLP_OFF_WO    218112
+#define CDA_MLP_OFF_BO    226304
+#define CDA_MLP_OFF_LS    226336
+#define CDA_MLP_PARAMS    226338
+#define CDA_MLP_WB_W1     0                      /* offsets (bf16 elements) inside the operand blob */
+#define CDA_MLP_WB_W2     90112
+#define CDA_MLP_WB_WO     221184
+#define CDA_MLP_WB_W2T    237568
+#define CDA_MLP_WB_WOT    368640
+#define CDA_MLP_WB_ELEMS  385024
+/* dense gradient slab of one row chunk: dW1 [512][192] | dW2 [2][256][256] | dWo [32][512]  (f32) */
+#define CDA_MLP_SLAB_W1   0
+#define CDA_MLP_SLAB_W2   98304
+#define CDA_MLP_SLAB_WO   229376
+#define CDA_MLP_SLAB      245760
+/* bias partial sums of one row tile of the backward kernel: db1 [512] | db2 [512] | dbo [32]  (f32) */
+#define CDA_MLP_BSLAB     1056
+
+/* rows per workgroup of the update's forward / backward kernels (32, 64 or 128: CDA_MLP_MT in the environment, default 128) = rows per
+ * bias partial of cda_mlp_backward */
+int32_t cda_mlp_tile_rows(void);
+
+/* theta -> wb (one launch).  Called after every optimiser step (cda_mlp_adam does it itself). */
+int cda_mlp_pack(const float* theta, void* wb, void* stream);
+
+/* Rollout: network forward on the observations of the markets [first_market, first_market + n_markets) and, from its outputs, the
+ * Dict action of every (market, agent) pair (action_helper.py:126-138), in ONE launch:
+ *   obs f32[N,168] (full array, indexed by global market) ->
+ *   env_* [N,A]: category i32, size_mean f32 (tanh of the Gaussian sample), size_sigma f32 (sigmoid), price i32, price_offset i32 -
+ *   what cda_step consumes; a_cont f32[N,A,2] the raw Gaussian samples; logp f32[N,A]; value f32[N].
+ * Randomness: counter based (include/cda_random_agents.h's splitmix64), keyed (seed, *counter_dev, draw, global sample index); nothing
+ * is bumped - the caller varies `draw` (the step index inside a rollout) and *counter_dev (once per rollout). */
+int cda_mlp_policy_step(const void* wb, const float* theta, const float* obs, int32_t first_market, int32_t n_markets, int32_t num_agents,
+                        uint64_t seed, const int64_t* counter_dev, int64_t draw,
+                        int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset,
+                        float* a_cont, float* logp, float* value, void* stream);
+/* The network outputs alone for rows [first_row, first_row + n_rows) of obs f32[*,168] -> out f32[*,32] (same row indexing). */
+int cda_mlp_forward(const void* wb, const float* theta, const float* obs, int64_t first_row, int64_t n_rows, float* out, void* stream);
+
+/* Update, step 0: rows of obs f32[*,168] selected by perm i64[n_rows] (NULL = identity) -> x_rm bf16[n_rows][176] (row-major, zero
+ * padded) and x_pk (packed, 6 feature tiles).  n_rows % 32 == 0. */
+int cda_mlp_prep_rows(const float* obs, const int64_t* perm, int64_t n_rows, void* x_rm, void* x_pk, void* stream);
+/* step 1: forward on n_rows (% 32 == 0) prepared rows: h1p / h2p packed bf16 [n_rows/32][16][2][64][8], out f32[n_rows][32]. */
+int cda_mlp_forward_train(const void* wb, const float* theta, const void* x_rm, int64_t n_rows, void* h1p, void* h2p, float* out, void* stream);
+/* step 2 (after the loss: cda_ppo_loss with out_stride 32 gives d_out f32[n_rows][32]): back-propagation through the heads and both
+ * hidden layers: dz1p / dz2p packed bf16 (gradients at the pre-activations), doutp packed bf16 [n_rows/32][1][2][64][8], and the bias
+ * partial sums bias_slab f32[ceil(n_rows / cda_mlp_tile_rows())][CDA_MLP_BSLAB]. */
+int cda_mlp_backward(const void* wb, const float* d_out, const void* h1p, const void* h2p, int64_t n_rows,
+                     void* dz1p, void* dz2p, void* doutp, float* bias_slab, void* stream);
+/* step 3: weight gradients as n_chunks partial sums over row chunks: slab f32[n_chunks][CDA_MLP_SLAB]. */
+int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p, const void* dz1p, const void* dz2p, const void* doutp,
+                  int64_t n_rows, int32_t n_chunks, float* slab, void* stream);
+/* step 4: reduce the partials (+ d loss / d log_std from cda_ppo_loss's out6[4..5]) to the gradient of theta, clip its global norm to
+ * max_norm (torch.nn.utils.clip_grad_norm_), one Adam step (torch.optim.Adam: no weight decay, bias-corrected; *step_dev f32[1] is
+ * incremented on the device), and refresh wb.  grad f32[CDA_MLP_PARAMS] and norm2 f64[1] are scratch outputs (the gradient before
+ * clipping and its squared norm). */
+int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* step_dev, void* wb,
+                 const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles, const float* loss_out6,
+                 float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* norm2, void* stream);
+
+/* cda_ppo_loss (cda.h) for int32 action arrays - the env's own action tensors as the rollout kernel wrote them.  norm_rows > 0:
+ * the means (and the gradient's 1/B) are over norm_rows * agents_per_row samples instead of rows * agents_per_row (a minibatch
+ * processed in several sub-batches); sums5 is then NOT cleared and out6 not written unless finish != 0. */
+int cda_ppo_loss32(const float* outputs, const float* log_std, const int32_t* a_cat, const int32_t* a_price, const int32_t* a_off,
+                   const float* a_cont, const float* logp_old, const float* adv, const float* ret, const int64_t* row_index,
+                   int64_t rows, int32_t agents_per_row, int32_t out_stride, float clip, float vf_coef, float ent_coef,
+                   float* d_outputs, double* sums5, float* out6, int64_t norm_rows, int32_t clear, int32_t finish, void* stream);
+
+/* One whole rollout of one market chain on `stream` (a loop of launches, no host work in between): for t = 0 .. n_steps - 1
+ *     cda_mlp_policy_step(obs[t]) -> env actions [t] | a_cont[t] | logp[t] | value[t]
+ *     cda_step_range(env, first_market, n_markets, actions [t]) -> obs[t + 1], reward[t], terminated[t], truncated[t]  (+ auto reset)
+ * then cda_mlp_forward's value column for obs[n_steps] -> value[n_steps].  Every buffer is [n_steps (+ 1 for obs, value)][N, ...] of
+ * the env's full market count N; chains of disjoint market ranges may run concurrently on different streams.  obs[0] must hold the
+ * current observation of the range (copy_first_obs != 0: it is first copied from obs[n_steps], the previous rollout's last). */
+typedef struct cda_rollout_bufs {
+    float*   obs;            /* [T+1][N][168] */
+    int32_t* category;       /* [T][N][A] */
+    float*   size_mean;      /* [T][N][A] */
+    float*   size_sigma;     /* [T][N][A] */
+    int32_t* price;          /* [T][N][A] */
+    int32_t* price_offset;   /* [T][N][A] */
+    float*   a_cont;         /* [T][N][A][2] */
+    float*   logp;           /* [T][N][A] */
+    float*   value;          /* [T+1][N] */
+    double*  reward;         /* [T][N][A] */
+    uint8_t* terminated;     /* [T][N] */
+    uint8_t* truncated;      /* [T][N] */
+} cda_rollout_bufs;
+int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
+                          uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* bufs, int32_t copy_first_obs, void* stream);
+
+/* Device self-test of the operand / accumulator conventions this file is built on: D f32[32][32] = A bf16-rounded f32[32][16] x
+ * B f32[16][32] through one v_mfma_f32_32x32x16_bf16 (host pointers; synchronous). */
+int cda_mlp_selftest_mfma(int32_t device, const float* a_host, const float* b_host, float* d_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDA_MLP_H */
