@@ -92,21 +92,25 @@ struct WRing {
 template <int MT, int JT, int KSTEPS, int PF>
 __device__ __forceinline__ void layer_mma(const __bf16* a_lds, int a_ld, WRing<JT, KSTEPS, PF>& W, int lane, f32x16 (&acc)[MT][JT]) {
     constexpr int RING = WRing<JT, KSTEPS, PF>::RING;
-    const int j = lane & 31, h = lane >> 5;
+    const __bf16* a_base = a_lds + (lane & 31) * a_ld + 8 * (lane >> 5);
+    bf16x8 a[2][MT];                                                            // the A operand (LDS) one step ahead as well: its read
+    #pragma unroll                                                              // latency hides under this step's MFMAs
+    for (int it = 0; it < MT; it++) a[0][it] = *reinterpret_cast<const bf16x8*>(a_base + 32 * it * a_ld);
     #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) {
-        bf16x8 a[MT];
-        #pragma unroll
-        for (int it = 0; it < MT; it++) a[it] = *reinterpret_cast<const bf16x8*>(a_lds + (32 * it + j) * a_ld + 16 * ks + 8 * h);
+        if (ks + 1 < KSTEPS) {
+            #pragma unroll
+            for (int it = 0; it < MT; it++) a[(ks + 1) & 1][it] = *reinterpret_cast<const bf16x8*>(a_base + 32 * it * a_ld + 16 * (ks + 1));
+        }
         #pragma unroll
         for (int it = 0; it < MT; it++)
             #pragma unroll
-            for (int jt = 0; jt < JT; jt++) acc[it][jt] = mfma(a[it], W.b[ks % RING][jt], acc[it][jt]);
+            for (int jt = 0; jt < JT; jt++) acc[it][jt] = mfma(a[ks & 1][it], W.b[ks % RING][jt], acc[it][jt]);
         if (ks + RING < KSTEPS) {
             #pragma unroll
             for (int jt = 0; jt < JT; jt++) W.b[ks % RING][jt] = *reinterpret_cast<const bf16x8*>(W.base + (size_t)(32 * jt) * W.ld + 16 * (ks + RING));
-            __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -152,7 +156,13 @@ struct FwdArgs {
     // MODE_SAMPLE
     int agents; unsigned long long seed; const long long* counter; long long draw;
     int* env_cat; float* env_mean; float* env_sigma; int* env_price; int* env_off; float* a_cont; float* logp; float* value;
+    unsigned long long* dbg; int dbg_block;       // CDA_MLP_TIMING builds (tools/libcda_tools.so) only: cycle stamps of one workgroup, [4 waves][32]
 };
+#ifdef CDA_MLP_TIMING
+#define MLP_MARK(i) do { if (A.dbg && (int)blockIdx.x == A.dbg_block && lane == 0) A.dbg[w * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MLP_MARK(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     z += 0x9e3779b97f4a7c15ull;
@@ -191,8 +201,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     float* outs = reinterpret_cast<float*>(act + M * ACT_LD);                   // MODE_SAMPLE: [M][OUTS_LD]
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const long long row0 = A.first_row + (long long)blockIdx.x * M, rows_end = A.first_row + A.n_rows;
+    MLP_MARK(0);
     if (MODE == MODE_TRAIN) load_x_bf16<M>(A.x_rm, row0, rows_end, xs); else load_x_f32<M>(A.obs, row0, rows_end, xs);
     __syncthreads();
+    MLP_MARK(1);
     const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
     f32x16 acc3[1][1]; acc3[0][0] = zero16();                                   // heads: wave w owns row tile w (waves >= MT idle there)
     WRing<2, KX / 16, PF> R1; WRing<2, HID / 16, PF> R2; WRing<1, HID / 16, PF> RO;
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             #pragma unroll
             for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
             layer_mma<MT, 2, KX / 16, PF>(xs, XS_LD, R1, lane, acc);
+            MLP_MARK(2 + 8 * half);
             R2.prime(W2b + ((size_t)half * HID + 64 * w) * HID, HID, lane);     // (in flight across the epilogue and its barrier)
             if (half == 1) __syncthreads();                                     // the heads of half 0 still read `act`
             #pragma unroll
@@ -220,12 +233,15 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
                 }
             }
         }
+        MLP_MARK(3 + 8 * half);
         __syncthreads();
+        MLP_MARK(4 + 8 * half);
         {   // layer 2: [M, 256] x W2[half][64 w .. + 63]^T
             f32x16 acc[MT][2];
             #pragma unroll
             for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
             layer_mma<MT, 2, HID / 16, PF>(act, ACT_LD, R2, lane, acc);
+            MLP_MARK(5 + 8 * half);
             RO.prime(Wob + (size_t)half * NOUT * HID, HID, lane);
             __syncthreads();                                                    // every wave has read h1: h2 takes its place
             #pragma unroll
@@ -241,10 +257,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
                 }
             }
         }
+        MLP_MARK(6 + 8 * half);
         if (half == 0) R1.prime(W1b + (size_t)(256 + 64 * w) * KX, KX, lane);   // the value half's first layer, requested across the heads
         __syncthreads();
+        MLP_MARK(7 + 8 * half);
         // heads: [32 rows of tile w, 256] x Wob[half]^T (the other half's rows of Wob are zero); waves >= MT multiply a tile nobody reads
         layer_mma<1, 1, HID / 16, PF>(act + (w < MT ? 32 * w : 0) * ACT_LD, ACT_LD, RO, lane, acc3);
+        MLP_MARK(8 + 8 * half);
     }
     // outputs: column j of rows rowmap(r, h) of row tile w
     if (w < MT) {
@@ -258,6 +277,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             else if (row0 + row < rows_end) A.out[(row0 + row) * NOUT + j] = o;
         }
     }
+    MLP_MARK(18);
     if (MODE == MODE_SAMPLE) {
         __syncthreads();
         // one thread per (row, agent) sample: three categorical heads by inverse CDF, two Gaussian heads by Box-Muller, the action's
@@ -292,6 +312,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             A.logp[i] = lp;
         }
     }
+    MLP_MARK(19);
 }
 
 // ---- update, step 0: gather + convert + both images of the observation rows ---------------------------------------------------
@@ -504,37 +525,45 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
 }
 
 // ---- update, step 4: reduce, clip, Adam, repack --------------------------------------------------------------------------------
-__device__ __forceinline__ float grad_of(int p, const float* __restrict__ slab, int n_chunks, const float* __restrict__ bslab, int n_tiles, const float* __restrict__ loss6) {
-    const float* src; int n, stride;
-    if (p < CDA_MLP_OFF_B1) { const int o = p / OBS, i = p - o * OBS; src = slab + CDA_MLP_SLAB_W1 + o * (32 * XT) + i; n = n_chunks; stride = CDA_MLP_SLAB; }
-    else if (p < CDA_MLP_OFF_W2) { src = bslab + (p - CDA_MLP_OFF_B1); n = n_tiles; stride = CDA_MLP_BSLAB; }
-    else if (p < CDA_MLP_OFF_B2) { src = slab + CDA_MLP_SLAB_W2 + (p - CDA_MLP_OFF_W2); n = n_chunks; stride = CDA_MLP_SLAB; }
-    else if (p < CDA_MLP_OFF_WO) { src = bslab + CDA_MLP_FEAT + (p - CDA_MLP_OFF_B2); n = n_tiles; stride = CDA_MLP_BSLAB; }
-    else if (p < CDA_MLP_OFF_BO) {
-        const int q = p - CDA_MLP_OFF_WO, o = q / HID, i = q - o * HID;
-        if (o > N_LOGITS) return 0.0f;                                          // rows 25 .. 31 do not exist
-        src = slab + CDA_MLP_SLAB_WO + o * CDA_MLP_FEAT + (o == N_LOGITS ? HID : 0) + i; n = n_chunks; stride = CDA_MLP_SLAB;
-    } else if (p < CDA_MLP_OFF_LS) {
-        const int o = p - CDA_MLP_OFF_BO;
-        if (o > N_LOGITS) return 0.0f;
-        src = bslab + 2 * CDA_MLP_FEAT + o; n = n_tiles; stride = CDA_MLP_BSLAB;
-    } else return loss6[4 + (p - CDA_MLP_OFF_LS)];
-    float s = 0.0f;
-    for (int c = 0; c < n; c++) s += src[(size_t)c * stride];
-    return s;
-}
+// 64 consecutive parameters per block; the partial sums of a parameter are split over 4 threads (lane groups of 64), each of which keeps
+// several loads in flight, and combined through LDS
 __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slab, int n_chunks, const float* __restrict__ bslab, int n_tiles,
                                                      const float* __restrict__ loss6, float* __restrict__ grad, double* __restrict__ norm2) {
-    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    float g = 0.0f;
-    if (p < CDA_MLP_PARAMS) { g = grad_of(p, slab, n_chunks, bslab, n_tiles, loss6); grad[p] = g; }
-    float x = g * g;
-    #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = x;
+    const int p = (int)blockIdx.x * 64 + ((int)threadIdx.x & 63), part = (int)threadIdx.x >> 6;
+    float s = 0.0f;
+    if (p < CDA_MLP_PARAMS) {
+        const float* src = nullptr; int n = 0, stride = 0; float direct = 0.0f;
+        if (p < CDA_MLP_OFF_B1) { const int o = p / OBS, i = p - o * OBS; src = slab + CDA_MLP_SLAB_W1 + o * (32 * XT) + i; n = n_chunks; stride = CDA_MLP_SLAB; }
+        else if (p < CDA_MLP_OFF_W2) { src = bslab + (p - CDA_MLP_OFF_B1); n = n_tiles; stride = CDA_MLP_BSLAB; }
+        else if (p < CDA_MLP_OFF_B2) { src = slab + CDA_MLP_SLAB_W2 + (p - CDA_MLP_OFF_W2); n = n_chunks; stride = CDA_MLP_SLAB; }
+        else if (p < CDA_MLP_OFF_WO) { src = bslab + CDA_MLP_FEAT + (p - CDA_MLP_OFF_B2); n = n_tiles; stride = CDA_MLP_BSLAB; }
+        else if (p < CDA_MLP_OFF_BO) {
+            const int q = p - CDA_MLP_OFF_WO, o = q / HID, i = q - o * HID;
+            if (o <= N_LOGITS) { src = slab + CDA_MLP_SLAB_WO + o * CDA_MLP_FEAT + (o == N_LOGITS ? HID : 0) + i; n = n_chunks; stride = CDA_MLP_SLAB; }   // rows 25 .. 31 do not exist
+        } else if (p < CDA_MLP_OFF_LS) {
+            const int o = p - CDA_MLP_OFF_BO;
+            if (o <= N_LOGITS) { src = bslab + 2 * CDA_MLP_FEAT + o; n = n_tiles; stride = CDA_MLP_BSLAB; }
+        } else direct = part == 0 ? loss6[4 + (p - CDA_MLP_OFF_LS)] : 0.0f;
+        s = direct;
+        if (src) {
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            int c = part;
+            for (; c + 12 < n; c += 16) { s0 += src[(size_t)c * stride]; s1 += src[(size_t)(c + 4) * stride]; s2 += src[(size_t)(c + 8) * stride]; s3 += src[(size_t)(c + 12) * stride]; }
+            for (; c < n; c += 4) s0 += src[(size_t)c * stride];
+            s = (s0 + s1) + (s2 + s3);
+        }
+    }
+    __shared__ float red[4][64];
+    red[part][threadIdx.x & 63] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(norm2, (double)part[0] + (double)part[1] + (double)part[2] + (double)part[3]);
+    if (part == 0) {
+        const float g = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (p < CDA_MLP_PARAMS) grad[p] = g;
+        float x = g * g;
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+        if (threadIdx.x == 0) atomicAdd(norm2, (double)x);
+    }
 }
 __device__ __forceinline__ void pack_one(int p, float v, __bf16* __restrict__ wb) {
     const __bf16 b = (__bf16)v;
@@ -733,6 +762,24 @@ int launch_fwd(const FwdArgs& A, int mt, hipStream_t st) {
 }
 }  // namespace
 
+#ifdef CDA_MLP_TIMING
+// tools/mlp_timing.py: one launch of the training / sampling forward with cycle stamps of workgroup `block` -> dbg u64[4][32] (device)
+extern "C" int cda_tools_mlp_fwd_timing(const void* wb, const float* theta, const void* x_rm, const float* obs, int64_t n_rows, int32_t agents, void* h1p, void* h2p, float* out,
+                                        void* scratch_i32x3_f32x5, const int64_t* counter, int32_t mt, int32_t sample, void* dbg, int32_t block, void* stream) {
+    FwdArgs A; memset(&A, 0, sizeof A);
+    A.x_rm = (const __bf16*)x_rm; A.obs = obs; A.first_row = 0; A.n_rows = n_rows; A.wb = (const __bf16*)wb; A.theta = theta;
+    A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.out = out; A.dbg = (unsigned long long*)dbg; A.dbg_block = block;
+    if (sample) {
+        const size_t NA = (size_t)n_rows * agents; char* s = (char*)scratch_i32x3_f32x5;
+        A.agents = agents; A.seed = 1; A.counter = (const long long*)counter; A.draw = 0;
+        A.env_cat = (int*)s; A.env_price = (int*)(s + 4 * NA); A.env_off = (int*)(s + 8 * NA); A.env_mean = (float*)(s + 12 * NA); A.env_sigma = (float*)(s + 16 * NA);
+        A.a_cont = (float*)(s + 20 * NA); A.logp = (float*)(s + 28 * NA); A.value = (float*)(s + 32 * NA);
+        return launch_fwd<MODE_SAMPLE>(A, mt, (hipStream_t)stream);
+    }
+    return launch_fwd<MODE_TRAIN>(A, mt, (hipStream_t)stream);
+}
+#endif
+
 extern "C" int32_t cda_mlp_tile_rows(void) { return 32 * train_mt(); }
 
 extern "C" int cda_mlp_pack(const float* theta, void* wb, void* stream) {
@@ -809,7 +856,7 @@ extern "C" int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* s
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(norm2, 0, sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
     const unsigned grid = (CDA_MLP_PARAMS + 255) / 256;
-    hipLaunchKernelGGL(k_grad_reduce, dim3(grid), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, loss_out6, grad, norm2);
+    hipLaunchKernelGGL(k_grad_reduce, dim3((CDA_MLP_PARAMS + 63) / 64), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, loss_out6, grad, norm2);
     hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, st, theta, adam_m, adam_v, (const float*)step_dev, (__bf16*)wb, (const float*)grad, (const double*)norm2,
                        lr, beta1, beta2, eps, max_norm);
     hipLaunchKernelGGL(k_bump_step, dim3(1), dim3(64), 0, st, step_dev);

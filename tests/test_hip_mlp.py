@@ -183,18 +183,21 @@ def test_clip_and_adam_equal_torch():
     d_out = torch.zeros(n, 32); d_out[:, :25] = torch.randn(n, 25, generator=torch.Generator().manual_seed(8)) * 3e-3
     ws = _full_backward(p, x, d_out, chunks)
     grad = ws["grad"].clone()
+    p.adam_m.zero_(); p.adam_v.zero_(); p.adam_step.zero_()      # (the lr = 0 step above moved the moments)
     th = torch.nn.Parameter(p.theta.clone())
     opt = torch.optim.Adam([th], lr=5e-5)
     tile = int(lib().cda_mlp_tile_rows()); tiles = (n + tile - 1) // tile
     st = torch.cuda.current_stream().cuda_stream
-    for step in range(3):                                # the same gradient three times: bias correction and moments move
-        th.grad = grad.clone()
+    scale = 1.0
+    for step, f in enumerate((1.0, 40.0, 0.003)):         # the partial sums scaled between steps: clipped and unclipped steps, moments that disagree with the gradient
+        ws["slab"].mul_(f); ws["bias_slab"].mul_(f); scale *= f
+        th.grad = grad * scale
         torch.nn.utils.clip_grad_norm_([th], 0.5)
         opt.step()
         check(lib().cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), ws["slab"].data_ptr(), chunks,
                                  ws["bias_slab"].data_ptr(), tiles, ws["loss6"].data_ptr(), 5e-5, 0.9, 0.999, 1e-8, 0.5, ws["grad"].data_ptr(), ws["norm2"].data_ptr(), st), "adam")
         torch.cuda.synchronize()
-        # float32 update of magnitude ~lr: agreement to 1e-3 of a step
+        # float32 update of magnitude ~lr = 5e-5: agreement to 1e-3 of a step
         assert (p.theta - th.detach()).abs().max() <= 5e-8, (step, float((p.theta - th.detach()).abs().max()))
     assert float(p.adam_step.item()) == 3.0
     # the operand blob follows theta

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Cycle stamps of ONE workgroup of the network's forward kernel (the CDA_MLP_TIMING build inside tools/libcda_tools.so): where a tile's
+time goes - observation load, the MFMA loops, the tanh / store epilogues, the barriers.  Usage: python tools/mlp_timing.py [--mt 4] [--sample]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from gym_continuousdoubleauction_amd import mlp  # noqa: E402
+
+NAMES = {0: "start", 1: "x tile in LDS", 18: "outputs written", 19: "end"}
+for h in (0, 1):
+    NAMES.update({2 + 8 * h: f"half {h}: layer 1 MFMAs", 3 + 8 * h: f"half {h}: layer 1 epilogue", 4 + 8 * h: f"half {h}: barrier", 5 + 8 * h: f"half {h}: layer 2 MFMAs",
+                  6 + 8 * h: f"half {h}: barrier + layer 2 epilogue", 7 + 8 * h: f"half {h}: barrier", 8 + 8 * h: f"half {h}: heads"})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mt", type=int, default=4)
+    ap.add_argument("--rows", type=int, default=65536)
+    ap.add_argument("--sample", action="store_true")
+    ap.add_argument("--block", type=int, default=7)
+    a = ap.parse_args()
+    T = C.CDLL(os.path.join(ROOT, "tools", "libcda_tools.so"))
+    dev = torch.device("cuda:0")
+    p = mlp.FusedPolicy(dev, seed=1)
+    R = a.rows
+    upd = mlp.FusedUpdate(p, R, R, 4)
+    obs = torch.randn(R, 168, device=dev)
+    from gym_continuousdoubleauction_amd._lib import check, lib
+    check(lib().cda_mlp_prep_rows(obs.data_ptr(), None, R, upd.x_rm.data_ptr(), upd.x_pk.data_ptr(), torch.cuda.current_stream().cuda_stream), "prep")
+    dbg = torch.zeros(4 * 32, dtype=torch.int64, device=dev)
+    scratch = torch.zeros(R * 4 * 40, dtype=torch.uint8, device=dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    vp = C.c_void_p
+    T.cda_tools_mlp_fwd_timing.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp, C.c_int32, vp]
+    for rep in range(3):
+        rc = T.cda_tools_mlp_fwd_timing(p.wb.data_ptr(), p.theta.data_ptr(), upd.x_rm.data_ptr(), obs.data_ptr(), R, 4, upd.h1p.data_ptr(), upd.h2p.data_ptr(), upd.out.data_ptr(),
+                                        scratch.data_ptr(), counter.data_ptr(), a.mt, int(a.sample), dbg.data_ptr(), a.block, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+    d = dbg.cpu().view(4, 32)
+    print(f"forward kernel, {'sampling' if a.sample else 'training'} mode, {32 * a.mt} rows per workgroup, {R} rows; workgroup {a.block}; shader cycles per segment, waves 0..3")
+    keys = sorted(NAMES)
+    for prev, k in zip(keys, keys[1:]):
+        seg = [int(d[w, k] - d[w, prev]) for w in range(4)]
+        print(f"  {NAMES[k]:40s} " + " ".join(f"{x:8d}" for x in seg))
+    print(f"  {'total':40s} " + " ".join(f"{int(d[w, 19] - d[w, 0]):8d}" for w in range(4)))
+
+
+if __name__ == "__main__":
+    main()
