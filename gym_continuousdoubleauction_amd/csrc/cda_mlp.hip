@@ -24,6 +24,9 @@
 #include <type_traits>
 #include "../../include/cda_mlp.h"
 
+// The env kernels are built with -ffp-contract=off (their f64 sums must match CPython's); nothing here has such a constraint.
+#pragma clang fp contract(fast)
+
 namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -37,10 +40,12 @@ constexpr int OUTS_LD = NOUT + 1;    // f32 row of the output tile kept in LDS f
 constexpr int N_CAT = 9, N_PRICE = 10, N_OFF = 3, N_LOGITS = 24;
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-__device__ __forceinline__ float fast_tanh(float x) {
-    // tanh(x) = 1 - 2 / (exp(2x) + 1); exp overflows to +inf for large x (-> 1), underflows to 0 (-> -1): no clamp needed
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+constexpr float TWO_LOG2E = 2.885390081777926814f;
+__device__ __forceinline__ float tanh_biased(float a, float bias_scaled) {
+    // tanh(a + b) = 1 - 2 / (2^((a + b) 2 log2 e) + 1), b 2 log2 e folded by the caller: fma, v_exp_f32, add, v_rcp_f32, fma.  2^t overflows to
+    // +inf for large t (-> 1) and underflows to 0 (-> -1): no clamp needed
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(a, TWO_LOG2E, bias_scaled));
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int r = 0; r < 16; r++) z[r] = 0.0f; return z; }
@@ -74,24 +79,31 @@ __device__ __forceinline__ void load_x_f32(const float* __restrict__ obs, long l
 // PRIMED - its first RING steps requested - before the previous layer's epilogue and barrier, and while step ks multiplies, step ks + RING
 // is requested.  hipcc on its own looks ONE step ahead and sinks every other request to just before its use, which leaves a wave with
 // 2 .. 8 MFMAs per step waiting ~600 cycles for L2 each time: hence the sched_barriers.
-template <int JT, int KSTEPS, int PF>
+// PAIRED (two column tiles): tile jt, lane j multiplies weight row 2 j + jt - a lane then holds two NEIGHBOURING output features of the
+// same rows, which is one dword of the row-major LDS image of the activations (no cross-lane exchange) - see feature_of().
+template <int JT, int KSTEPS, int PF, bool PAIRED = false>
 struct WRing {
     static constexpr int RING = PF < KSTEPS ? PF : KSTEPS;
+    static constexpr int TILE_STEP = PAIRED ? 1 : 32;                            // weight rows between the column tiles of one lane
     bf16x8 b[RING][JT];
-    const __bf16* base;                                                          // this lane's first 16 bytes: row (j), half-step (h)
+    const __bf16* base;                                                          // this lane's first 16 bytes: row, half-step (h)
     int ld;
     __device__ __forceinline__ void prime(const __bf16* __restrict__ b_glob, int b_ld, int lane) {
-        base = b_glob + (size_t)(lane & 31) * b_ld + 8 * (lane >> 5); ld = b_ld;
+        base = b_glob + (size_t)((PAIRED ? 2 : 1) * (lane & 31)) * b_ld + 8 * (lane >> 5); ld = b_ld;
         #pragma unroll
         for (int ks = 0; ks < RING; ks++)
             #pragma unroll
-            for (int jt = 0; jt < JT; jt++) b[ks][jt] = *reinterpret_cast<const bf16x8*>(base + (size_t)(32 * jt) * ld + 16 * ks);
+            for (int jt = 0; jt < JT; jt++) b[ks][jt] = *reinterpret_cast<const bf16x8*>(base + (size_t)(TILE_STEP * jt) * ld + 16 * ks);
         __builtin_amdgcn_sched_barrier(0);
     }
 };
-template <int MT, int JT, int KSTEPS, int PF>
-__device__ __forceinline__ void layer_mma(const __bf16* a_lds, int a_ld, WRing<JT, KSTEPS, PF>& W, int lane, f32x16 (&acc)[MT][JT]) {
-    constexpr int RING = WRing<JT, KSTEPS, PF>::RING;
+// Feature tiles of the hidden activations come in pairs (one wave's 64 features): position q of tile ft is feature
+// 64 (ft / 2) + 2 q + (ft & 1) - in the packed HBM images of h1 / h2 / dz1 / dz2 and wherever they are consumed.
+__host__ __device__ __forceinline__ constexpr int feature_of(int ft, int q) { return 64 * (ft >> 1) + 2 * q + (ft & 1); }
+template <int MT, int JT, int KSTEPS, int PF, bool PAIRED>
+__device__ __forceinline__ void layer_mma(const __bf16* a_lds, int a_ld, WRing<JT, KSTEPS, PF, PAIRED>& W, int lane, f32x16 (&acc)[MT][JT]) {
+    constexpr int RING = WRing<JT, KSTEPS, PF, PAIRED>::RING;
+    constexpr int TILE_STEP = WRing<JT, KSTEPS, PF, PAIRED>::TILE_STEP;
     const __bf16* a_base = a_lds + (lane & 31) * a_ld + 8 * (lane >> 5);
     bf16x8 a[2][MT];                                                            // the A operand (LDS) one step ahead as well: its read
     #pragma unroll                                                              // latency hides under this step's MFMAs
@@ -108,39 +120,42 @@ __device__ __forceinline__ void layer_mma(const __bf16* a_lds, int a_ld, WRing<J
             for (int jt = 0; jt < JT; jt++) acc[it][jt] = mfma(a[ks & 1][it], W.b[ks % RING][jt], acc[it][jt]);
         if (ks + RING < KSTEPS) {
             #pragma unroll
-            for (int jt = 0; jt < JT; jt++) W.b[ks % RING][jt] = *reinterpret_cast<const bf16x8*>(W.base + (size_t)(32 * jt) * W.ld + 16 * (ks + RING));
+            for (int jt = 0; jt < JT; jt++) W.b[ks % RING][jt] = *reinterpret_cast<const bf16x8*>(W.base + (size_t)(TILE_STEP * jt) * W.ld + 16 * (ks + RING));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// One accumulator tile -> its packed HBM image (two 16-B stores per lane) and / or its row-major LDS image.
-__device__ __forceinline__ void store_packed(__bf16* __restrict__ base, long long rt, int nft, int ft, int lane, const __bf16 (&v)[16]) {
+// One accumulator tile -> its packed HBM image: two 16-B stores per lane, 1 KB per wave and store.
+__device__ __forceinline__ void store_packed(__bf16* __restrict__ base, long long rt, int nft, int ft, int lane, const float (&v)[16]) {
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    f32x8 f0, f1;
+    #pragma unroll
+    for (int r = 0; r < 8; r++) { f0[r] = v[r]; f1[r] = v[8 + r]; }
+    bf16x8* dst = reinterpret_cast<bf16x8*>(base) + ((rt * nft + ft) * 2) * 64 + lane;
+    dst[0] = __builtin_convertvector(f0, bf16x8); dst[64] = __builtin_convertvector(f1, bf16x8);      // 4 + 4 v_cvt_pk_bf16_f32
+}
+__device__ __forceinline__ void store_packed_bf(__bf16* __restrict__ base, long long rt, int nft, int ft, int lane, const __bf16 (&v)[16]) {
     bf16x8 p0, p1;
     #pragma unroll
     for (int r = 0; r < 8; r++) { p0[r] = v[r]; p1[r] = v[8 + r]; }
     bf16x8* dst = reinterpret_cast<bf16x8*>(base) + ((rt * nft + ft) * 2) * 64 + lane;
     dst[0] = p0; dst[64] = p1;
 }
-__device__ __forceinline__ void load_packed(const __bf16* __restrict__ base, long long rt, int nft, int ft, int lane, float (&v)[16]) {
+__device__ __forceinline__ void load_packed(const __bf16* __restrict__ base, long long rt, int nft, int ft, int lane, bf16x8 (&p)[2]) {
     const bf16x8* src = reinterpret_cast<const bf16x8*>(base) + ((rt * nft + ft) * 2) * 64 + lane;
-    const bf16x8 p0 = src[0], p1 = src[64];
-    #pragma unroll
-    for (int r = 0; r < 8; r++) { v[r] = (float)p0[r]; v[8 + r] = (float)p1[r]; }
+    p[0] = src[0]; p[1] = src[64];
 }
-// row-major LDS image: lane (feature j, half h) holds rows rowmap(r, h) of ONE column, so neighbouring lanes are paired first (a DPP
-// swap inside lane pairs): the even lane writes {f, f+1} of row r, the odd lane {f-1, f} of row r+1 - 8 ds_write_b32 per tile instead
-// of 16 two-byte writes
-__device__ __forceinline__ void store_lds_tile(__bf16* act, int ld, int row_base, int col_base, int lane, const __bf16 (&v)[16]) {
-    const int j = lane & 31, h = lane >> 5, odd = lane & 1;
+// Two paired accumulator tiles -> the row-major LDS image: lane (q, h) holds features 2 q and 2 q + 1 of rows rowmap(r, h): one dword per
+// row, 32 lanes = 128 contiguous bytes (conflict free), one v_cvt_pk_bf16_f32 + one ds_write_b32 per two values
+__device__ __forceinline__ void store_lds_pair(__bf16* act, int ld, int row_base, int col_base, int lane, const float (&v0)[16], const float (&v1)[16]) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const int q = lane & 31, h = lane >> 5;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
     #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const unsigned short mine_keep = __builtin_bit_cast(unsigned short, odd ? v[r + 1] : v[r]);
-        const unsigned short mine_send = __builtin_bit_cast(unsigned short, odd ? v[r] : v[r + 1]);
-        const unsigned int got = (unsigned int)__builtin_amdgcn_mov_dpp((int)mine_send, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true) & 0xffffu;
-        const unsigned int word = odd ? (got | ((unsigned int)mine_keep << 16)) : ((unsigned int)mine_keep | (got << 16));
-        const int row = row_base + rowmap(r + odd, h);
-        *reinterpret_cast<unsigned int*>(act + row * ld + col_base + (j & ~1)) = word;
+    for (int r = 0; r < 16; r++) {
+        f32x2 f; f[0] = v0[r]; f[1] = v1[r];
+        *reinterpret_cast<bf16x2*>(act + (row_base + rowmap(r, h)) * ld + col_base + 2 * q) = __builtin_convertvector(f, bf16x2);
     }
 }
 
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     MLP_MARK(1);
     const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
     f32x16 acc3[1][1]; acc3[0][0] = zero16();                                   // heads: wave w owns row tile w (waves >= MT idle there)
-    WRing<2, KX / 16, PF> R1; WRing<2, HID / 16, PF> R2; WRing<1, HID / 16, PF> RO;
+    WRing<2, KX / 16, PF, true> R1; WRing<2, HID / 16, PF, true> R2; WRing<1, HID / 16, PF> RO;
     R1.prime(W1b + (size_t)(64 * w) * KX, KX, lane);
     #pragma unroll 1
     for (int half = 0; half < 2; half++) {
@@ -216,21 +231,21 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             f32x16 acc[MT][2];
             #pragma unroll
             for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
-            layer_mma<MT, 2, KX / 16, PF>(xs, XS_LD, R1, lane, acc);
+            layer_mma(xs, XS_LD, R1, lane, acc);
             MLP_MARK(2 + 8 * half);
             R2.prime(W2b + ((size_t)half * HID + 64 * w) * HID, HID, lane);     // (in flight across the epilogue and its barrier)
             if (half == 1) __syncthreads();                                     // the heads of half 0 still read `act`
+            const float bias0 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j] * TWO_LOG2E, bias1 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j + 1] * TWO_LOG2E;
             #pragma unroll
-            for (int jt = 0; jt < 2; jt++) {
-                const float bias = A.theta[CDA_MLP_OFF_B1 + f0 + 32 * jt + j];
+            for (int it = 0; it < MT; it++) {
+                float v0[16], v1[16];
                 #pragma unroll
-                for (int it = 0; it < MT; it++) {
-                    __bf16 v[16];
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) v[r] = (__bf16)fast_tanh(acc[it][jt][r] + bias);
-                    if (MODE == MODE_TRAIN && row0 + 32 * it < rows_end) store_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, v);
-                    store_lds_tile(act, ACT_LD, 32 * it, 64 * w + 32 * jt, lane, v);
+                for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], bias0); v1[r] = tanh_biased(acc[it][1][r], bias1); }
+                if (MODE == MODE_TRAIN && row0 + 32 * it < rows_end) {
+                    store_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5), lane, v0);
+                    store_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5) + 1, lane, v1);
                 }
+                store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
             }
         }
         MLP_MARK(3 + 8 * half);
@@ -240,21 +255,21 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             f32x16 acc[MT][2];
             #pragma unroll
             for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
-            layer_mma<MT, 2, HID / 16, PF>(act, ACT_LD, R2, lane, acc);
+            layer_mma(act, ACT_LD, R2, lane, acc);
             MLP_MARK(5 + 8 * half);
             RO.prime(Wob + (size_t)half * NOUT * HID, HID, lane);
             __syncthreads();                                                    // every wave has read h1: h2 takes its place
+            const float bias0 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j] * TWO_LOG2E, bias1 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j + 1] * TWO_LOG2E;
             #pragma unroll
-            for (int jt = 0; jt < 2; jt++) {
-                const float bias = A.theta[CDA_MLP_OFF_B2 + f0 + 32 * jt + j];
+            for (int it = 0; it < MT; it++) {
+                float v0[16], v1[16];
                 #pragma unroll
-                for (int it = 0; it < MT; it++) {
-                    __bf16 v[16];
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) v[r] = (__bf16)fast_tanh(acc[it][jt][r] + bias);
-                    if (MODE == MODE_TRAIN && row0 + 32 * it < rows_end) store_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, v);
-                    store_lds_tile(act, ACT_LD, 32 * it, 64 * w + 32 * jt, lane, v);
+                for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], bias0); v1[r] = tanh_biased(acc[it][1][r], bias1); }
+                if (MODE == MODE_TRAIN && row0 + 32 * it < rows_end) {
+                    store_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5), lane, v0);
+                    store_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5) + 1, lane, v1);
                 }
+                store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
             }
         }
         MLP_MARK(6 + 8 * half);
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
         __syncthreads();
         MLP_MARK(7 + 8 * half);
         // heads: [32 rows of tile w, 256] x Wob[half]^T (the other half's rows of Wob are zero); waves >= MT multiply a tile nobody reads
-        layer_mma<1, 1, HID / 16, PF>(act + (w < MT ? 32 * w : 0) * ACT_LD, ACT_LD, RO, lane, acc3);
+        layer_mma(act + (w < MT ? 32 * w : 0) * ACT_LD, ACT_LD, RO, lane, acc3);
         MLP_MARK(8 + 8 * half);
     }
     // outputs: column j of rows rowmap(r, h) of row tile w
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
         __bf16 v[16];
         #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = dos[(32 * w + rowmap(r, h)) * DO_LD + j];
-        store_packed(A.doutp, row0 / 32 + w, 1, 0, lane, v);
+        store_packed_bf(A.doutp, row0 / 32 + w, 1, 0, lane, v);
     }
     if (threadIdx.x < NOUT) {
         float s = 0.0f;
@@ -384,62 +399,68 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
         bs[2 * CDA_MLP_FEAT + threadIdx.x] = s;
     }
     const __bf16* W2T = A.wb + CDA_MLP_WB_W2T; const __bf16* WoT = A.wb + CDA_MLP_WB_WOT;
-    WRing<2, NOUT / 16, PF> RO; WRing<2, HID / 16, PF> R2;
+    WRing<2, NOUT / 16, PF, true> RO; WRing<2, HID / 16, PF, true> R2;
     RO.prime(WoT + (size_t)(64 * w) * NOUT, NOUT, lane);
     #pragma unroll 1
     for (int half = 0; half < 2; half++) {
-        const int f0 = 256 * half + 64 * w;
+        const int f0 = 256 * half + 64 * w, ft0 = f0 >> 5;
         {   // dH2 = d_out x Wo (K = 32), times tanh'
+            // h2 in the accumulators' own layout (the packed image the forward wrote), requested before the product
+            bf16x8 hp[MT][2][2];
+            #pragma unroll
+            for (int it = 0; it < MT; it++) {
+                const long long rt = row0 + 32 * it < A.n_rows ? row0 / 32 + it : row0 / 32;    // (tiles past the end re-read the first one; d_out is zero there)
+                load_packed(A.h2p, rt, 16, ft0, lane, hp[it][0]); load_packed(A.h2p, rt, 16, ft0 + 1, lane, hp[it][1]);
+            }
             f32x16 acc[MT][2];
             #pragma unroll
             for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
-            layer_mma<MT, 2, NOUT / 16, PF>(dos, DO_LD, RO, lane, acc);
+            layer_mma(dos, DO_LD, RO, lane, acc);
             R2.prime(W2T + ((size_t)half * HID + 64 * w) * HID, HID, lane);
             if (half == 1) __syncthreads();                                     // dH1 of half 0 still reads `dact`
+            float colsum0 = 0.0f, colsum1 = 0.0f;
             #pragma unroll
-            for (int jt = 0; jt < 2; jt++) {
-                float colsum = 0.0f;
+            for (int it = 0; it < MT; it++) {
+                float v0[16], v1[16];
                 #pragma unroll
-                for (int it = 0; it < MT; it++) {
-                    const bool live = row0 + 32 * it < A.n_rows;
-                    float hv[16]; __bf16 v[16];
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) hv[r] = 1.0f;
-                    if (live) load_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, hv);
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        v[r] = (__bf16)(acc[it][jt][r] * (1.0f - hv[r] * hv[r]));   // (rows past the end: d_out = 0 there, so acc = 0)
-                        colsum += (float)v[r];
-                    }
-                    if (live) store_packed(A.dz2p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, v);
-                    store_lds_tile(dact, ACT_LD, 32 * it, 64 * w + 32 * jt, lane, v);
+                for (int r = 0; r < 16; r++) {
+                    const float h0 = (float)hp[it][0][r >> 3][r & 7], h1 = (float)hp[it][1][r >> 3][r & 7];
+                    v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
+                    colsum0 += v0[r]; colsum1 += v1[r];
                 }
-                colsum += __shfl_xor(colsum, 32, 64);
-                if (h == 0) bs[CDA_MLP_FEAT + f0 + 32 * jt + j] = colsum;
+                if (row0 + 32 * it < A.n_rows) { store_packed(A.dz2p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz2p, row0 / 32 + it, 16, ft0 + 1, lane, v1); }
+                store_lds_pair(dact, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
             }
+            colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
+            if (h == 0) { bs[CDA_MLP_FEAT + f0 + 2 * j] = colsum0; bs[CDA_MLP_FEAT + f0 + 2 * j + 1] = colsum1; }
         }
         __syncthreads();
         {   // dH1 = dz2 x W2[half] (K = 256), times tanh'
+            bf16x8 hp[MT][2][2];
+            #pragma unroll
+            for (int it = 0; it < MT; it++) {
+                const long long rt = row0 + 32 * it < A.n_rows ? row0 / 32 + it : row0 / 32;
+                load_packed(A.h1p, rt, 16, ft0, lane, hp[it][0]); load_packed(A.h1p, rt, 16, ft0 + 1, lane, hp[it][1]);
+            }
             f32x16 acc[MT][2];
             #pragma unroll
             for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
-            layer_mma<MT, 2, HID / 16, PF>(dact, ACT_LD, R2, lane, acc);
+            layer_mma(dact, ACT_LD, R2, lane, acc);
             if (half == 0) RO.prime(WoT + (size_t)(256 + 64 * w) * NOUT, NOUT, lane);
+            float colsum0 = 0.0f, colsum1 = 0.0f;
             #pragma unroll
-            for (int jt = 0; jt < 2; jt++) {
-                float colsum = 0.0f;
+            for (int it = 0; it < MT; it++) {
+                float v0[16], v1[16];
                 #pragma unroll
-                for (int it = 0; it < MT; it++) {
-                    if (row0 + 32 * it >= A.n_rows) continue;
-                    float hv[16]; __bf16 v[16];
-                    load_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, hv);
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) { v[r] = (__bf16)(acc[it][jt][r] * (1.0f - hv[r] * hv[r])); colsum += (float)v[r]; }
-                    store_packed(A.dz1p, row0 / 32 + it, 16, (f0 >> 5) + jt, lane, v);
+                for (int r = 0; r < 16; r++) {
+                    const float h0 = (float)hp[it][0][r >> 3][r & 7], h1 = (float)hp[it][1][r >> 3][r & 7];
+                    v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
+                    colsum0 += v0[r]; colsum1 += v1[r];
                 }
-                colsum += __shfl_xor(colsum, 32, 64);
-                if (h == 0) bs[f0 + 32 * jt + j] = colsum;
+                if (row0 + 32 * it < A.n_rows) { store_packed(A.dz1p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz1p, row0 / 32 + it, 16, ft0 + 1, lane, v1); }
             }
+            colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
+            if (h == 0) { bs[f0 + 2 * j] = colsum0; bs[f0 + 2 * j + 1] = colsum1; }
         }
     }
 }
@@ -481,15 +502,22 @@ __device__ __forceinline__ void wgrad_wave(const bf16x8* __restrict__ Ap, int a_
     }
     #undef CDA_WG_STEP
 }
-template <int TI, int TJ>
-__device__ __forceinline__ void wgrad_store(float* __restrict__ dst, int ld, int i0, int j0, int lane, const f32x16 (&acc)[TI][TJ]) {
+// A_PAIRED / B_PAIRED: the operand's feature tiles are the paired ones of the hidden activations (feature_of); a_ft0 / b_ft0: first tile of
+// this wave inside the panel (i0 / j0 of the panel itself are folded into dst)
+template <int TI, int TJ, bool A_PAIRED, bool B_PAIRED>
+__device__ __forceinline__ void wgrad_store(float* __restrict__ dst, int ld, int a_ft0, int b_ft0, int lane, const f32x16 (&acc)[TI][TJ]) {
     const int j = lane & 31, h = lane >> 5;
     #pragma unroll
     for (int ti = 0; ti < TI; ti++)
         #pragma unroll
-        for (int tj = 0; tj < TJ; tj++)
+        for (int tj = 0; tj < TJ; tj++) {
+            const int col = B_PAIRED ? feature_of(b_ft0 + tj, j) : 32 * (b_ft0 + tj) + j;
             #pragma unroll
-            for (int r = 0; r < 16; r++) dst[(size_t)(i0 + 32 * ti + rowmap(r, h)) * ld + j0 + 32 * tj + j] = acc[ti][tj][r];
+            for (int r = 0; r < 16; r++) {
+                const int row = A_PAIRED ? feature_of(a_ft0 + ti, rowmap(r, h)) : 32 * (a_ft0 + ti) + rowmap(r, h);
+                dst[(size_t)row * ld + col] = acc[ti][tj][r];
+            }
+        }
 }
 struct WgradArgs { const bf16x8* x_pk; const bf16x8* h1p; const bf16x8* h2p; const bf16x8* dz1p; const bf16x8* dz2p; const bf16x8* doutp;
                    long long n_rt; int n_chunks; float* slab; };
@@ -505,7 +533,7 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
             #pragma unroll
             for (int b = 0; b < 4; b++) acc[a][b] = zero16();
         wgrad_wave<4, 4>(A.dz2p, 16, 8 * job + 4 * wi, A.h1p, 16, 8 * job + 4 * wj, rt0, rt1, lane, acc);
-        wgrad_store<4, 4>(slab + CDA_MLP_SLAB_W2 + (size_t)job * HID * HID, HID, 128 * wi, 128 * wj, lane, acc);
+        wgrad_store<4, 4, true, true>(slab + CDA_MLP_SLAB_W2 + (size_t)job * HID * HID, HID, 4 * wi, 4 * wj, lane, acc);
     } else if (job < 4) {
         const int b = job - 2;
         f32x16 acc[4][3];
@@ -514,56 +542,82 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
             #pragma unroll
             for (int c = 0; c < 3; c++) acc[a][c] = zero16();
         wgrad_wave<4, 3>(A.dz1p, 16, 8 * b + 4 * wi, A.x_pk, XT, 3 * wj, rt0, rt1, lane, acc);
-        wgrad_store<4, 3>(slab + CDA_MLP_SLAB_W1, 32 * XT, 256 * b + 128 * wi, 96 * wj, lane, acc);
+        wgrad_store<4, 3, true, false>(slab + CDA_MLP_SLAB_W1 + (size_t)(256 * b) * (32 * XT), 32 * XT, 4 * wi, 3 * wj, lane, acc);
     } else {
         f32x16 acc[1][4];
         #pragma unroll
         for (int c = 0; c < 4; c++) acc[0][c] = zero16();
         wgrad_wave<1, 4>(A.doutp, 1, 0, A.h2p, 16, 4 * w, rt0, rt1, lane, acc);
-        wgrad_store<1, 4>(slab + CDA_MLP_SLAB_WO, CDA_MLP_FEAT, 0, 128 * w, lane, acc);
+        wgrad_store<1, 4, false, true>(slab + CDA_MLP_SLAB_WO, CDA_MLP_FEAT, 0, 4 * w, lane, acc);
     }
 }
 
 // ---- update, step 4: reduce, clip, Adam, repack --------------------------------------------------------------------------------
-// 64 consecutive parameters per block; the partial sums of a parameter are split over 4 threads (lane groups of 64), each of which keeps
-// several loads in flight, and combined through LDS
+// The partial sums -> the gradient of theta and its squared norm.  Weights: one thread per FOUR consecutive entries of the dense slab
+// (16-B loads, a wave reads 1 KB per chunk, eight chunks in flight), mapped back to the parameter index (the slab's paddings and the heads'
+// masked blocks have none).  Biases (+ log_std): 64 entries per block, the row tiles split over 16 threads each.
+constexpr int RED_DENSE_BLOCKS = CDA_MLP_SLAB / 4 / 256;                          // 240
+constexpr int RED_BIAS_BLOCKS = (CDA_MLP_BSLAB + 2 + 63) / 64;                    // 17
+__device__ __forceinline__ int param_of_dense(int d) {
+    if (d < CDA_MLP_SLAB_W2) { const int o = d / (32 * XT), i = d - o * (32 * XT); return i < OBS ? CDA_MLP_OFF_W1 + o * OBS + i : -1; }
+    if (d < CDA_MLP_SLAB_WO) return CDA_MLP_OFF_W2 + (d - CDA_MLP_SLAB_W2);
+    const int q = d - CDA_MLP_SLAB_WO, o = q / CDA_MLP_FEAT, c = q - o * CDA_MLP_FEAT;
+    if (o < N_LOGITS) return c < HID ? CDA_MLP_OFF_WO + o * HID + c : -1;
+    if (o == N_LOGITS) return c >= HID ? CDA_MLP_OFF_WO + N_LOGITS * HID + (c - HID) : -1;
+    return -1;
+}
 __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slab, int n_chunks, const float* __restrict__ bslab, int n_tiles,
                                                      const float* __restrict__ loss6, float* __restrict__ grad, double* __restrict__ norm2) {
-    const int p = (int)blockIdx.x * 64 + ((int)threadIdx.x & 63), part = (int)threadIdx.x >> 6;
-    float s = 0.0f;
-    if (p < CDA_MLP_PARAMS) {
-        const float* src = nullptr; int n = 0, stride = 0; float direct = 0.0f;
-        if (p < CDA_MLP_OFF_B1) { const int o = p / OBS, i = p - o * OBS; src = slab + CDA_MLP_SLAB_W1 + o * (32 * XT) + i; n = n_chunks; stride = CDA_MLP_SLAB; }
-        else if (p < CDA_MLP_OFF_W2) { src = bslab + (p - CDA_MLP_OFF_B1); n = n_tiles; stride = CDA_MLP_BSLAB; }
-        else if (p < CDA_MLP_OFF_B2) { src = slab + CDA_MLP_SLAB_W2 + (p - CDA_MLP_OFF_W2); n = n_chunks; stride = CDA_MLP_SLAB; }
-        else if (p < CDA_MLP_OFF_WO) { src = bslab + CDA_MLP_FEAT + (p - CDA_MLP_OFF_B2); n = n_tiles; stride = CDA_MLP_BSLAB; }
-        else if (p < CDA_MLP_OFF_BO) {
-            const int q = p - CDA_MLP_OFF_WO, o = q / HID, i = q - o * HID;
-            if (o <= N_LOGITS) { src = slab + CDA_MLP_SLAB_WO + o * CDA_MLP_FEAT + (o == N_LOGITS ? HID : 0) + i; n = n_chunks; stride = CDA_MLP_SLAB; }   // rows 25 .. 31 do not exist
-        } else if (p < CDA_MLP_OFF_LS) {
-            const int o = p - CDA_MLP_OFF_BO;
-            if (o <= N_LOGITS) { src = bslab + 2 * CDA_MLP_FEAT + o; n = n_tiles; stride = CDA_MLP_BSLAB; }
-        } else direct = part == 0 ? loss6[4 + (p - CDA_MLP_OFF_LS)] : 0.0f;
-        s = direct;
-        if (src) {
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-            int c = part;
-            for (; c + 12 < n; c += 16) { s0 += src[(size_t)c * stride]; s1 += src[(size_t)(c + 4) * stride]; s2 += src[(size_t)(c + 8) * stride]; s3 += src[(size_t)(c + 12) * stride]; }
-            for (; c < n; c += 4) s0 += src[(size_t)c * stride];
-            s = (s0 + s1) + (s2 + s3);
+    __shared__ float red[16][64];
+    float sq = 0.0f;
+    if ((int)blockIdx.x < RED_DENSE_BLOCKS) {
+        const int d = 4 * ((int)blockIdx.x * 256 + (int)threadIdx.x);
+        const float4* src = reinterpret_cast<const float4*>(slab + d);
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        int c = 0;
+        for (; c + 8 <= n_chunks; c += 8) {
+            float4 v[8];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(size_t)(c + u) * (CDA_MLP_SLAB / 4)];
+            #pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                s0.x += v[u].x; s0.y += v[u].y; s0.z += v[u].z; s0.w += v[u].w;
+                s1.x += v[u + 1].x; s1.y += v[u + 1].y; s1.z += v[u + 1].z; s1.w += v[u + 1].w;
+                s2.x += v[u + 2].x; s2.y += v[u + 2].y; s2.z += v[u + 2].z; s2.w += v[u + 2].w;
+                s3.x += v[u + 3].x; s3.y += v[u + 3].y; s3.z += v[u + 3].z; s3.w += v[u + 3].w;
+            }
+        }
+        for (; c < n_chunks; c++) { const float4 v = src[(size_t)c * (CDA_MLP_SLAB / 4)]; s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w; }
+        const float g[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+        const int p = param_of_dense(d);                                          // (groups of four never straddle a row: 168, 192, 256, 512 are multiples of 4)
+        if (p >= 0) {
+            #pragma unroll
+            for (int e = 0; e < 4; e++) { grad[p + e] = g[e]; sq += g[e] * g[e]; }
+        }
+    } else {
+        const int e = ((int)blockIdx.x - RED_DENSE_BLOCKS) * 64 + ((int)threadIdx.x & 63), part = (int)threadIdx.x >> 6;   // entry of the bias slab (+ 2 for log_std)
+        float s = 0.0f;
+        if (e < CDA_MLP_BSLAB) {
+            for (int t = part; t < n_tiles; t += 4) s += bslab[(size_t)t * CDA_MLP_BSLAB + e];
+        }
+        red[part][threadIdx.x & 63] = s;
+        __syncthreads();
+        if (part == 0) {
+            float g = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            int p = -1;
+            if (e < CDA_MLP_FEAT) p = CDA_MLP_OFF_B1 + e;
+            else if (e < 2 * CDA_MLP_FEAT) p = CDA_MLP_OFF_B2 + (e - CDA_MLP_FEAT);
+            else if (e < CDA_MLP_BSLAB) { const int o = e - 2 * CDA_MLP_FEAT; p = CDA_MLP_OFF_BO + o; if (o > N_LOGITS) g = 0.0f; }
+            else if (e < CDA_MLP_BSLAB + 2) { p = CDA_MLP_OFF_LS + (e - CDA_MLP_BSLAB); g = loss6[4 + (e - CDA_MLP_BSLAB)]; }
+            if (p >= 0) { grad[p] = g; sq = g * g; }
         }
     }
-    __shared__ float red[4][64];
-    red[part][threadIdx.x & 63] = s;
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (part == 0) {
-        const float g = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        if (p < CDA_MLP_PARAMS) grad[p] = g;
-        float x = g * g;
-        #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-        if (threadIdx.x == 0) atomicAdd(norm2, (double)x);
-    }
+    if (threadIdx.x == 0) atomicAdd(norm2, (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3]);
 }
 __device__ __forceinline__ void pack_one(int p, float v, __bf16* __restrict__ wb) {
     const __bf16 b = (__bf16)v;
@@ -855,8 +909,9 @@ extern "C" int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* s
     if (!theta || !adam_m || !adam_v || !step_dev || !wb || !slab || !bias_slab || !loss_out6 || !grad || !norm2 || n_chunks < 1 || n_bias_tiles < 1) return CDA_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(norm2, 0, sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
+    if (hipMemsetAsync(grad + CDA_MLP_OFF_WO + (N_LOGITS + 1) * HID, 0, (size_t)(NOUT - N_LOGITS - 1) * HID * sizeof(float), st) != hipSuccess) return CDA_ERR_HIP;   // Wo rows 25 .. 31 do not exist
     const unsigned grid = (CDA_MLP_PARAMS + 255) / 256;
-    hipLaunchKernelGGL(k_grad_reduce, dim3((CDA_MLP_PARAMS + 63) / 64), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, loss_out6, grad, norm2);
+    hipLaunchKernelGGL(k_grad_reduce, dim3(RED_DENSE_BLOCKS + RED_BIAS_BLOCKS), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, loss_out6, grad, norm2);
     hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, st, theta, adam_m, adam_v, (const float*)step_dev, (__bf16*)wb, (const float*)grad, (const double*)norm2,
                        lr, beta1, beta2, eps, max_norm);
     hipLaunchKernelGGL(k_bump_step, dim3(1), dim3(64), 0, st, step_dev);
@@ -878,6 +933,7 @@ extern "C" int cda_ppo_loss32(const float* outputs, const float* log_std, const 
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
+#ifndef CDA_MLP_TIMING          /* (the tools build holds the network kernels only, not the env) */
 extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
                                      uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* B, int32_t copy_first_obs, void* stream) {
     if (!env || !wb || !theta || !counter_dev || !B || n_steps < 1 || first_market < 0 || n_markets < 1) return CDA_ERR_INVALID;
@@ -909,6 +965,7 @@ extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* 
     V.value = B->value + (size_t)n_steps * N;
     return launch_fwd<MODE_VALUE>(V, rollout_mt(), st);
 }
+#endif
 
 extern "C" int cda_mlp_selftest_mfma(int32_t device, const float* a_host, const float* b_host, float* d_host) {
     if (!a_host || !b_host || !d_host) return CDA_ERR_INVALID;

@@ -129,8 +129,9 @@ def reference_gradients(theta, xb, h1, h2, d_out, dtype=torch.float64):
     return g, dz1, dz2
 
 
-def unpack_rows(packed, n_rows, n_feat):
-    """packed bf16 image [n_rows/32][n_feat/32][2][64][8] -> [n_rows, n_feat] (host; tests and diagnostics)."""
+def unpack_rows(packed, n_rows, n_feat, paired=False):
+    """packed bf16 image [n_rows/32][n_feat/32][2][64][8] -> [n_rows, n_feat] (host; tests and diagnostics).  paired: the feature tiles of
+    the hidden activations (h1 / h2 / dz1 / dz2): position q of tile ft is feature 64 (ft // 2) + 2 q + (ft & 1) (csrc/cda_mlp.hip feature_of)."""
     p = packed.detach().cpu().float().view(n_rows // 32, n_feat // 32, 2, 64, 8)
     out = torch.zeros(n_rows, n_feat)
     lane = torch.arange(64)
@@ -141,7 +142,8 @@ def unpack_rows(packed, n_rows, n_feat):
             row = (r & 3) + 8 * (r >> 2) + 4 * h                       # [64]
             for rt in range(n_rows // 32):
                 for ft in range(n_feat // 32):
-                    out[rt * 32 + row, ft * 32 + j] = p[rt, ft, ks, :, e]
+                    col = (64 * (ft // 2) + 2 * j + (ft & 1)) if paired else ft * 32 + j
+                    out[rt * 32 + row, col] = p[rt, ft, ks, :, e]
     return out
 
 
@@ -248,6 +250,7 @@ class RolloutChains:
         self.graphs = None
         self._have_obs = False
         self.use_graphs = bool(use_graphs)
+        self.join_mode = "events"
 
     def _enqueue(self, g, copy_first_obs):
         first, cnt = self.ranges[g]
@@ -293,7 +296,12 @@ class RolloutChains:
                     self._enqueue(g, True)
             if s.cuda_stream != cur.cuda_stream:
                 self._joins[g].record(s)
-                cur.wait_event(self._joins[g])
+        # the joins only after EVERY chain is enqueued: a wait placed on the caller's stream between two chains' launches delays the later
+        # chain's start when the caller's stream is the legacy default stream (tools/rollout_probe.py)
+        if self.join_mode != "none":
+            for g, s in enumerate(self.streams):
+                if s.cuda_stream != cur.cuda_stream:
+                    cur.wait_event(self._joins[g])
         return self.buf
 
 
@@ -308,7 +316,7 @@ class FusedUpdate:
         dev = policy.device
         self.tile_rows = int(_lib().cda_mlp_tile_rows())
         self.n_tiles = (self.rows_mb + self.tile_rows - 1) // self.tile_rows
-        self.chunks = int(chunks) if chunks else max(1, min(64, self.rows_mb // 512))
+        self.chunks = int(chunks) if chunks else max(1, min(51, self.rows_mb // 512))      # 5 jobs x 51 chunks = 255 workgroups: one wave of the 256 CUs
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)                      # noqa: E731
         self.x_rm, self.x_pk = e(self.R * KX, bf), e(self.R * 32 * XT, bf)

@@ -101,7 +101,7 @@ def test_training_forward_and_its_packed_images(n):
     x_pk = mlp.unpack_rows(ws["x_pk"], n, 192)
     assert torch.equal(x_pk[:, :168].double(), xb) and (x_pk[:, 168:] == 0).all()
     # activations: bfloat16 values in [-1, 1]; a float32-vs-float64 pre-activation can land on the other side of a rounding boundary: one ulp = 2^-8
-    g1, g2 = mlp.unpack_rows(ws["h1p"], n, 512).double(), mlp.unpack_rows(ws["h2p"], n, 512).double()
+    g1, g2 = mlp.unpack_rows(ws["h1p"], n, 512, paired=True).double(), mlp.unpack_rows(ws["h2p"], n, 512, paired=True).double()
     assert (g1 - h1).abs().max() <= 2 ** -8 and (g1 != h1).double().mean() < 0.02
     assert (g2 - h2).abs().max() <= 2 ** -7 and (g2 != h2).double().mean() < 0.05
     out = ws["out"].cpu().double()
@@ -148,10 +148,10 @@ def test_backward_and_weight_gradients_equal_the_rounded_reference(n, chunks):
     d_out[:, :25] = torch.randn(n, 25, generator=g) * 1e-3
     ws = _full_backward(p, x, d_out, chunks)
     # the reference is fed the kernel's own activations, so that only the backward arithmetic is compared
-    h1, h2 = mlp.unpack_rows(ws["h1p"], n, 512).double(), mlp.unpack_rows(ws["h2p"], n, 512).double()
+    h1, h2 = mlp.unpack_rows(ws["h1p"], n, 512, paired=True).double(), mlp.unpack_rows(ws["h2p"], n, 512, paired=True).double()
     xb = mlp.unpack_rows(ws["x_pk"], n, 192)[:, :168].double()
     gref, dz1, dz2 = mlp.reference_gradients(p.theta, xb, h1, h2, d_out)
-    k2, k1 = mlp.unpack_rows(ws["dz2p"], n, 512).double(), mlp.unpack_rows(ws["dz1p"], n, 512).double()
+    k2, k1 = mlp.unpack_rows(ws["dz2p"], n, 512, paired=True).double(), mlp.unpack_rows(ws["dz1p"], n, 512, paired=True).double()
     # pre-activation gradients: bfloat16 values; one ulp (2^-8 relative) where float32 and float64 round differently
     assert (k2 - dz2).abs().max() <= 2 ** -7 * dz2.abs().max() and (k1 - dz1).abs().max() <= 2 ** -6 * dz1.abs().max()
     assert torch.equal(mlp.unpack_rows(ws["doutp"], n, 32).double(), mlp._r(d_out.double()))
@@ -223,7 +223,8 @@ def test_whole_gradient_equals_float32_autograd_through_the_pytorch_network():
     check(lib().cda_mlp_prep_rows(xd.data_ptr(), None, R, upd.x_rm.data_ptr(), upd.x_pk.data_ptr(), torch.cuda.current_stream().cuda_stream), "prep")
     acts = (a_cat.int().to(DEV), a_price.int().to(DEV), a_off.int().to(DEV), a_cont.to(DEV))
     theta0 = p.theta.clone()
-    upd.minibatch_step(0, R, acts, lp_old.to(DEV), adv.to(DEV), ret.to(DEV), 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5)
+    lpd0, advd0, retd0 = lp_old.to(DEV), adv.to(DEV), ret.to(DEV)
+    upd.minibatch_step(0, R, acts, lpd0, advd0, retd0, 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5)
     torch.cuda.synchronize()
     assert torch.equal(p.theta, theta0)
     grad = upd.grad.cpu().double()
@@ -255,8 +256,9 @@ def test_whole_gradient_equals_float32_autograd_through_the_pytorch_network():
     assert abs(float(out6[3]) - float(loss)) <= 2e-2 * abs(float(loss)) + 1e-3
     # the int32 loss kernel and cda_ppo_loss (int64 actions) agree bit for bit on the same outputs
     d64 = torch.zeros_like(upd.d_out); sums = torch.zeros(5, dtype=torch.float64, device=DEV); o6 = torch.zeros(6, device=DEV)
-    check(lib().cda_ppo_loss(upd.out.data_ptr(), None, p.theta.data_ptr() + mlp.OFF_LS * 4, a_cat.to(DEV).data_ptr(), a_price.to(DEV).data_ptr(), a_off.to(DEV).data_ptr(),
-                             acts[3].data_ptr(), lp_old.to(DEV).data_ptr(), adv.to(DEV).data_ptr(), ret.to(DEV).data_ptr(), upd.perm.data_ptr(), R, A, 32, 0.2, 0.5, 0.01,
+    c64, p64, f64, lpd, advd, retd = a_cat.to(DEV), a_price.to(DEV), a_off.to(DEV), lp_old.to(DEV), adv.to(DEV), ret.to(DEV)       # (kept alive: raw pointers below)
+    check(lib().cda_ppo_loss(upd.out.data_ptr(), None, p.theta.data_ptr() + mlp.OFF_LS * 4, c64.data_ptr(), p64.data_ptr(), f64.data_ptr(),
+                             acts[3].data_ptr(), lpd.data_ptr(), advd.data_ptr(), retd.data_ptr(), upd.perm.data_ptr(), R, A, 32, 0.2, 0.5, 0.01,
                              d64.data_ptr(), None, sums.data_ptr(), o6.data_ptr(), torch.cuda.current_stream().cuda_stream), "cda_ppo_loss")
     torch.cuda.synchronize()
     assert torch.equal(d64, upd.d_out)

@@ -2,12 +2,12 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; O=$R/gpurun_out/r4c; mkdir -p $O
 export TMPDIR=/tmp PYTHONPATH=$R
-timeout 600 python -m pytest tests/test_hip_mlp.py -x -q -m gpu > $O/test_mlp.log 2>&1; tail -3 $O/test_mlp.log
+timeout 600 python -m pytest tests/test_hip_mlp.py -q -m gpu > $O/test_mlp.log 2>&1; tail -3 $O/test_mlp.log
 for mt in 4 2; do
   CDA_MLP_MT=$mt timeout 300 python tools/mlp_bench.py --json $O/bench_mt$mt.json > $O/bench_mt$mt.log 2>&1; grep -v "^ *\"rows\|agents" $O/bench_mt$mt.log | tr '\n' ' '; echo
   timeout 120 python tools/mlp_timing.py --mt $mt > $O/timing_mt$mt.txt 2>&1; cat $O/timing_mt$mt.txt
 done
-timeout 120 python tools/mlp_timing.py --mt 1 --sample --rows 1024 > $O/timing_sample.txt 2>&1; cat $O/timing_sample.txt
+timeout 120 python tools/mlp_timing.py --mt 1 --sample --rows 1024 --block 3 > $O/timing_sample.txt 2>&1; cat $O/timing_sample.txt
 cd /tmp
 PM="python $R/tools/mlp_bench.py --iters 5"
 rocprofv3 -L > $O/counters.txt 2>&1
