@@ -109,7 +109,7 @@ def lib():
     L.cda_mlp_forward_train.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
     L.cda_mlp_backward.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]
     L.cda_mlp_wgrad.argtypes = [vp] * 6 + [i64, i32, vp, vp]
-    L.cda_mlp_adam.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, f32, f32, f32, f32, f32, vp, vp, vp]
+    L.cda_mlp_adam.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i64, f32, f32, vp, f32, f32, f32, f32, f32, vp, vp, vp]
     L.cda_ppo_loss32.argtypes = [vp] * 10 + [i64, i32, i32, f32, f32, f32, vp, vp, vp, i64, i32, i32, vp]
     L.cda_mlp_rollout_chain.argtypes = [vp, vp, vp, i32, i32, i32, u64, vp, C.POINTER(RolloutBufs), i32, vp]
     L.cda_mlp_selftest_mfma.argtypes = [i32, vp, vp, vp]

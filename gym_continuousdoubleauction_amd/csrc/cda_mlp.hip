@@ -241,11 +241,12 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
                 float v0[16], v1[16];
                 #pragma unroll
                 for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], bias0); v1[r] = tanh_biased(acc[it][1][r], bias1); }
-                if (MODE == MODE_TRAIN && row0 + 32 * it < rows_end) {
+                if (MODE == MODE_TRAIN) {                                       // (buffers are padded to whole workgroup tiles: no tail predicate)
                     store_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5), lane, v0);
                     store_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5) + 1, lane, v1);
                 }
                 store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
+                __builtin_amdgcn_sched_barrier(0);                              // (one row tile's tanh chains at a time: register pressure)
             }
         }
         MLP_MARK(3 + 8 * half);
@@ -265,11 +266,12 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
                 float v0[16], v1[16];
                 #pragma unroll
                 for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], bias0); v1[r] = tanh_biased(acc[it][1][r], bias1); }
-                if (MODE == MODE_TRAIN && row0 + 32 * it < rows_end) {
+                if (MODE == MODE_TRAIN) {
                     store_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5), lane, v0);
                     store_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5) + 1, lane, v1);
                 }
                 store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
+                __builtin_amdgcn_sched_barrier(0);                              // (one row tile's tanh chains at a time: register pressure)
             }
         }
         MLP_MARK(6 + 8 * half);
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             const float o = acc3[0][0][r] + bo;
             if (MODE == MODE_SAMPLE) outs[row * OUTS_LD + j] = o;
             else if (MODE == MODE_VALUE) { if (j == N_LOGITS && row0 + row < rows_end) A.value[row0 + row] = o; }
-            else if (row0 + row < rows_end) A.out[(row0 + row) * NOUT + j] = o;
+            else if (MODE == MODE_TRAIN || row0 + row < rows_end) A.out[(row0 + row) * NOUT + j] = o;
         }
     }
     MLP_MARK(18);
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
     }
     __syncthreads();
     // d_out in the packed layout (lane = output column, slots = rows) for the heads' weight gradient, and its column sums
-    if (w < MT && row0 + 32 * w < A.n_rows) {
+    if (w < MT) {
         __bf16 v[16];
         #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = dos[(32 * w + rowmap(r, h)) * DO_LD + j];
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
             bf16x8 hp[MT][2][2];
             #pragma unroll
             for (int it = 0; it < MT; it++) {
-                const long long rt = row0 + 32 * it < A.n_rows ? row0 / 32 + it : row0 / 32;    // (tiles past the end re-read the first one; d_out is zero there)
+                const long long rt = row0 / 32 + it;                            // (buffers are padded to whole workgroup tiles; d_out is zero past the end)
                 load_packed(A.h2p, rt, 16, ft0, lane, hp[it][0]); load_packed(A.h2p, rt, 16, ft0 + 1, lane, hp[it][1]);
             }
             f32x16 acc[MT][2];
@@ -428,8 +430,9 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
                     v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
                     colsum0 += v0[r]; colsum1 += v1[r];
                 }
-                if (row0 + 32 * it < A.n_rows) { store_packed(A.dz2p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz2p, row0 / 32 + it, 16, ft0 + 1, lane, v1); }
+                store_packed(A.dz2p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz2p, row0 / 32 + it, 16, ft0 + 1, lane, v1);
                 store_lds_pair(dact, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
+                __builtin_amdgcn_sched_barrier(0);
             }
             colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
             if (h == 0) { bs[CDA_MLP_FEAT + f0 + 2 * j] = colsum0; bs[CDA_MLP_FEAT + f0 + 2 * j + 1] = colsum1; }
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
             bf16x8 hp[MT][2][2];
             #pragma unroll
             for (int it = 0; it < MT; it++) {
-                const long long rt = row0 + 32 * it < A.n_rows ? row0 / 32 + it : row0 / 32;
+                const long long rt = row0 / 32 + it;
                 load_packed(A.h1p, rt, 16, ft0, lane, hp[it][0]); load_packed(A.h1p, rt, 16, ft0 + 1, lane, hp[it][1]);
             }
             f32x16 acc[MT][2];
@@ -457,7 +460,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
                     v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
                     colsum0 += v0[r]; colsum1 += v1[r];
                 }
-                if (row0 + 32 * it < A.n_rows) { store_packed(A.dz1p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz1p, row0 / 32 + it, 16, ft0 + 1, lane, v1); }
+                store_packed(A.dz1p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz1p, row0 / 32 + it, 16, ft0 + 1, lane, v1);
+                __builtin_amdgcn_sched_barrier(0);
             }
             colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
             if (h == 0) { bs[f0 + 2 * j] = colsum0; bs[f0 + 2 * j + 1] = colsum1; }
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
 // (16-B loads, a wave reads 1 KB per chunk, eight chunks in flight), mapped back to the parameter index (the slab's paddings and the heads'
 // masked blocks have none).  Biases (+ log_std): 64 entries per block, the row tiles split over 16 threads each.
 constexpr int RED_DENSE_BLOCKS = CDA_MLP_SLAB / 4 / 256;                          // 240
-constexpr int RED_BIAS_BLOCKS = (CDA_MLP_BSLAB + 2 + 63) / 64;                    // 17
+constexpr int RED_BIAS_BLOCKS = (CDA_MLP_BSLAB + 1 + 63) / 64;                    // 17 (entry 1056 = the log_std pair)
 __device__ __forceinline__ int param_of_dense(int d) {
     if (d < CDA_MLP_SLAB_W2) { const int o = d / (32 * XT), i = d - o * (32 * XT); return i < OBS ? CDA_MLP_OFF_W1 + o * OBS + i : -1; }
     if (d < CDA_MLP_SLAB_WO) return CDA_MLP_OFF_W2 + (d - CDA_MLP_SLAB_W2);
@@ -566,8 +570,9 @@ __device__ __forceinline__ int param_of_dense(int d) {
     if (o == N_LOGITS) return c >= HID ? CDA_MLP_OFF_WO + N_LOGITS * HID + (c - HID) : -1;
     return -1;
 }
+struct LossFinish { double* sums5; long long samples; float vf_coef, ent_coef; float* out6; };
 __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slab, int n_chunks, const float* __restrict__ bslab, int n_tiles,
-                                                     const float* __restrict__ loss6, float* __restrict__ grad, double* __restrict__ norm2) {
+                                                     LossFinish LF, float* __restrict__ grad, double* __restrict__ norm2) {
     __shared__ float red[16][64];
     float sq = 0.0f;
     if ((int)blockIdx.x < RED_DENSE_BLOCKS) {
@@ -608,8 +613,21 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
             if (e < CDA_MLP_FEAT) p = CDA_MLP_OFF_B1 + e;
             else if (e < 2 * CDA_MLP_FEAT) p = CDA_MLP_OFF_B2 + (e - CDA_MLP_FEAT);
             else if (e < CDA_MLP_BSLAB) { const int o = e - 2 * CDA_MLP_FEAT; p = CDA_MLP_OFF_BO + o; if (o > N_LOGITS) g = 0.0f; }
-            else if (e < CDA_MLP_BSLAB + 2) { p = CDA_MLP_OFF_LS + (e - CDA_MLP_BSLAB); g = loss6[4 + (e - CDA_MLP_BSLAB)]; }
             if (p >= 0) { grad[p] = g; sq = g * g; }
+            if (e == CDA_MLP_BSLAB) {
+                // log_std: its gradient comes with the loss sums (cda_ppo_loss32's sums5[3..4]); this one thread also finishes the loss
+                // statistics (out6, what k_ppo_finish32 would write) and clears the sums for the next minibatch - no memset, no extra launch
+                float g0 = 0.0f, g1 = 0.0f;
+                if (LF.sums5) {
+                    const double pg = LF.sums5[0] / (double)LF.samples, vl = LF.sums5[1] / (double)LF.samples, en = LF.sums5[2] / (double)LF.samples;
+                    g0 = (float)LF.sums5[3]; g1 = (float)LF.sums5[4];
+                    if (LF.out6) { LF.out6[0] = (float)pg; LF.out6[1] = (float)vl; LF.out6[2] = (float)en; LF.out6[3] = (float)(pg + (double)LF.vf_coef * vl - (double)LF.ent_coef * en);
+                                   LF.out6[4] = g0; LF.out6[5] = g1; }
+                    #pragma unroll
+                    for (int q = 0; q < 5; q++) LF.sums5[q] = 0.0;
+                }
+                grad[CDA_MLP_OFF_LS] = g0; grad[CDA_MLP_OFF_LS + 1] = g1; sq = g0 * g0 + g1 * g1;
+            }
         }
     }
     #pragma unroll
@@ -639,22 +657,30 @@ __global__ void k_pack(const float* __restrict__ theta, __bf16* __restrict__ wb)
     const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (p < CDA_MLP_PARAMS) pack_one(p, theta[p], wb);
 }
-__global__ void k_adam(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step, __bf16* __restrict__ wb,
-                       const float* __restrict__ grad, const double* __restrict__ norm2, float lr, float b1, float b2, float eps, float max_norm) {
+// scratch f64[3]: [0] the squared-norm accumulator (zero between calls: the last block to finish clears it), [1] the finished-block counter
+// (as an integer), [2] the squared norm of this call's gradient (output)
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v, float* __restrict__ step, __bf16* __restrict__ wb,
+                                              const float* __restrict__ grad, double* __restrict__ scratch, float lr, float b1, float b2, float eps, float max_norm) {
     const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (p >= CDA_MLP_PARAMS) return;
-    const float t = step[0] + 1.0f;                                             // (k_bump_step raises it after this launch)
-    const float total = (float)sqrt(norm2[0]);
-    const float coef = fminf(1.0f, max_norm / (total + 1e-6f));
-    const float g = grad[p] * coef;
-    const float mm = b1 * m[p] + (1.0f - b1) * g, vv = b2 * v[p] + (1.0f - b2) * g * g;
-    m[p] = mm; v[p] = vv;
-    const float c1 = 1.0f - __powf(b1, t), c2 = 1.0f - __powf(b2, t);
-    const float th = theta[p] - (lr / c1) * mm / (sqrtf(vv) / sqrtf(c2) + eps);
-    theta[p] = th;
-    pack_one(p, th, wb);
+    const float t = step[0] + 1.0f;
+    const double n2 = scratch[0];
+    if (p < CDA_MLP_PARAMS) {
+        const float coef = fminf(1.0f, max_norm / ((float)sqrt(n2) + 1e-6f));    // torch.nn.utils.clip_grad_norm_
+        const float g = grad[p] * coef;
+        const float mm = b1 * m[p] + (1.0f - b1) * g, vv = b2 * v[p] + (1.0f - b2) * g * g;
+        m[p] = mm; v[p] = vv;
+        const float c1 = 1.0f - __powf(b1, t), c2 = 1.0f - __powf(b2, t);
+        const float th = theta[p] - (lr / c1) * mm / (sqrtf(vv) / sqrtf(c2) + eps);
+        theta[p] = th;
+        pack_one(p, th, wb);
+    }
+    __syncthreads();                                                            // every thread of the block has read step and the norm
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned int* done = reinterpret_cast<unsigned int*>(scratch + 1);
+        if (atomicAdd(done, 1u) == gridDim.x - 1) { scratch[2] = n2; scratch[0] = 0.0; *done = 0u; step[0] = t; }
+    }
 }
-__global__ void k_bump_step(float* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1.0f; }
 
 // ---- the loss for int32 actions (cda_ppo.hip's k_ppo_loss, same arithmetic; the env's own action tensors) ----------------------
 template <int N>
@@ -904,17 +930,15 @@ extern "C" int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p,
 }
 
 extern "C" int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* step_dev, void* wb,
-                            const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles, const float* loss_out6,
-                            float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* norm2, void* stream) {
-    if (!theta || !adam_m || !adam_v || !step_dev || !wb || !slab || !bias_slab || !loss_out6 || !grad || !norm2 || n_chunks < 1 || n_bias_tiles < 1) return CDA_ERR_INVALID;
+                            const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
+                            double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float* loss_out6,
+                            float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* scratch3, void* stream) {
+    if (!theta || !adam_m || !adam_v || !step_dev || !wb || !slab || !bias_slab || !grad || !scratch3 || n_chunks < 1 || n_bias_tiles < 1 || (loss_sums5 && loss_samples < 1)) return CDA_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(norm2, 0, sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
-    if (hipMemsetAsync(grad + CDA_MLP_OFF_WO + (N_LOGITS + 1) * HID, 0, (size_t)(NOUT - N_LOGITS - 1) * HID * sizeof(float), st) != hipSuccess) return CDA_ERR_HIP;   // Wo rows 25 .. 31 do not exist
-    const unsigned grid = (CDA_MLP_PARAMS + 255) / 256;
-    hipLaunchKernelGGL(k_grad_reduce, dim3(RED_DENSE_BLOCKS + RED_BIAS_BLOCKS), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, loss_out6, grad, norm2);
-    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, st, theta, adam_m, adam_v, (const float*)step_dev, (__bf16*)wb, (const float*)grad, (const double*)norm2,
+    LossFinish LF; LF.sums5 = loss_sums5; LF.samples = loss_samples; LF.vf_coef = vf_coef; LF.ent_coef = ent_coef; LF.out6 = loss_out6;
+    hipLaunchKernelGGL(k_grad_reduce, dim3(RED_DENSE_BLOCKS + RED_BIAS_BLOCKS), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, LF, grad, scratch3);
+    hipLaunchKernelGGL(k_adam, dim3((CDA_MLP_PARAMS + 255) / 256), dim3(256), 0, st, theta, adam_m, adam_v, step_dev, (__bf16*)wb, (const float*)grad, scratch3,
                        lr, beta1, beta2, eps, max_norm);
-    hipLaunchKernelGGL(k_bump_step, dim3(1), dim3(64), 0, st, step_dev);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 

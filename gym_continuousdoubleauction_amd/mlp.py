@@ -316,15 +316,16 @@ class FusedUpdate:
         dev = policy.device
         self.tile_rows = int(_lib().cda_mlp_tile_rows())
         self.n_tiles = (self.rows_mb + self.tile_rows - 1) // self.tile_rows
+        pad = self.n_tiles * self.tile_rows                            # the kernels write whole workgroup tiles
         self.chunks = int(chunks) if chunks else max(1, min(51, self.rows_mb // 512))      # 5 jobs x 51 chunks = 255 workgroups: one wave of the 256 CUs
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)                      # noqa: E731
         self.x_rm, self.x_pk = e(self.R * KX, bf), e(self.R * 32 * XT, bf)
-        self.h1p, self.h2p, self.dz1p, self.dz2p = (e(self.rows_mb * FEAT, bf) for _ in range(4))
-        self.doutp = e(self.rows_mb * NOUT, bf)
-        self.out, self.d_out = e(self.rows_mb * NOUT, f32).view(-1, NOUT), e(self.rows_mb * NOUT, f32).view(-1, NOUT)
+        self.h1p, self.h2p, self.dz1p, self.dz2p = (e(pad * FEAT, bf) for _ in range(4))
+        self.doutp = e(pad * NOUT, bf)
+        self.out, self.d_out = e(pad * NOUT, f32).view(-1, NOUT), e(pad * NOUT, f32).view(-1, NOUT)
         self.slab, self.bias_slab = e(self.chunks * SLAB, f32), e(self.n_tiles * BSLAB, f32)
-        self.grad, self.norm2 = e(PARAMS, f32), e(1, torch.float64)
+        self.grad, self.norm2 = e(PARAMS, f32), e(3, torch.float64)          # (norm2[2] = the squared gradient norm of the last step)
         self.sums5, self.out6 = e(5, torch.float64), e(6, f32)
         self.perm = torch.zeros(self.R, dtype=torch.int64, device=dev)
 
@@ -339,14 +340,16 @@ class FusedUpdate:
         _check(L.cda_mlp_forward_train(p.wb.data_ptr(), p.theta.data_ptr(), x_rm, rows, self.h1p.data_ptr(), self.h2p.data_ptr(), self.out.data_ptr(), st), "cda_mlp_forward_train")
         _check(L.cda_ppo_loss32(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(), acts[3].data_ptr(),
                                 logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), self.perm.data_ptr() + s * 8, rows, self.A, NOUT,
-                                float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(), self.sums5.data_ptr(), self.out6.data_ptr(), 0, 1, 1, st), "cda_ppo_loss32")
+                                float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(), self.sums5.data_ptr(), self.out6.data_ptr(), 0, 0 if apply else 1, 0 if apply else 1, st),
+               "cda_ppo_loss32")            # (apply: the sums are finished and cleared by cda_mlp_adam)
         _check(L.cda_mlp_backward(p.wb.data_ptr(), self.d_out.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), rows, self.dz1p.data_ptr(), self.dz2p.data_ptr(),
                                   self.doutp.data_ptr(), self.bias_slab.data_ptr(), st), "cda_mlp_backward")
         _check(L.cda_mlp_wgrad(x_pk, self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(), rows, chunks,
                                self.slab.data_ptr(), st), "cda_mlp_wgrad")
         if apply:
             _check(L.cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), self.slab.data_ptr(), chunks,
-                                  self.bias_slab.data_ptr(), tiles, self.out6.data_ptr(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(max_norm),
+                                  self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A, float(vf_coef), float(ent_coef), self.out6.data_ptr(),
+                                  float(lr), float(betas[0]), float(betas[1]), float(eps), float(max_norm),
                                   self.grad.data_ptr(), self.norm2.data_ptr(), st), "cda_mlp_adam")
         return chunks, tiles
 

@@ -89,23 +89,31 @@ int cda_mlp_forward(const void* wb, const float* theta, const float* obs, int64_
 /* Update, step 0: rows of obs f32[*,168] selected by perm i64[n_rows] (NULL = identity) -> x_rm bf16[n_rows][176] (row-major, zero
  * padded) and x_pk (packed, 6 feature tiles).  n_rows % 32 == 0. */
 int cda_mlp_prep_rows(const float* obs, const int64_t* perm, int64_t n_rows, void* x_rm, void* x_pk, void* stream);
-/* step 1: forward on n_rows (% 32 == 0) prepared rows: h1p / h2p packed bf16 [n_rows/32][16][2][64][8], out f32[n_rows][32]. */
+/* step 1: forward on n_rows (% 32 == 0) prepared rows: h1p / h2p packed bf16 [n_rows/32][16][2][64][8], out f32[n_rows][32] (all three padded
+ * to whole workgroup tiles, see cda_mlp_backward). */
 int cda_mlp_forward_train(const void* wb, const float* theta, const void* x_rm, int64_t n_rows, void* h1p, void* h2p, float* out, void* stream);
 /* step 2 (after the loss: cda_ppo_loss with out_stride 32 gives d_out f32[n_rows][32]): back-propagation through the heads and both
  * hidden layers: dz1p / dz2p packed bf16 (gradients at the pre-activations), doutp packed bf16 [n_rows/32][1][2][64][8], and the bias
- * partial sums bias_slab f32[ceil(n_rows / cda_mlp_tile_rows())][CDA_MLP_BSLAB]. */
+ * partial sums bias_slab f32[ceil(n_rows / cda_mlp_tile_rows())][CDA_MLP_BSLAB].
+ * h1p / h2p / dz1p / dz2p / doutp / out must hold ceil(n_rows / cda_mlp_tile_rows()) * cda_mlp_tile_rows() rows: the kernels write whole workgroup
+ * tiles (rows past n_rows are scratch); d_out holds n_rows rows. */
 int cda_mlp_backward(const void* wb, const float* d_out, const void* h1p, const void* h2p, int64_t n_rows,
                      void* dz1p, void* dz2p, void* doutp, float* bias_slab, void* stream);
 /* step 3: weight gradients as n_chunks partial sums over row chunks: slab f32[n_chunks][CDA_MLP_SLAB]. */
 int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p, const void* dz1p, const void* dz2p, const void* doutp,
                   int64_t n_rows, int32_t n_chunks, float* slab, void* stream);
-/* step 4: reduce the partials (+ d loss / d log_std from cda_ppo_loss's out6[4..5]) to the gradient of theta, clip its global norm to
- * max_norm (torch.nn.utils.clip_grad_norm_), one Adam step (torch.optim.Adam: no weight decay, bias-corrected; *step_dev f32[1] is
- * incremented on the device), and refresh wb.  grad f32[CDA_MLP_PARAMS] and norm2 f64[1] are scratch outputs (the gradient before
- * clipping and its squared norm). */
+/* step 4: reduce the partials to the gradient of theta, clip its global norm to max_norm (torch.nn.utils.clip_grad_norm_), one Adam step
+ * (torch.optim.Adam: no weight decay, bias-corrected; *step_dev f32[1] is incremented on the device), and refresh wb: two launches.
+ * loss_sums5 (f64[5], may be NULL): the sums cda_ppo_loss32 accumulated for this minibatch (clear = finish = 0): [3..4] are d loss / d log_std;
+ * the means go to loss_out6 (f32[6], may be NULL: what finish = 1 would have written, loss_samples = rows * agents_per_row) and the sums are
+ * CLEARED for the next minibatch - no memset, no finishing launch between the steps of an update.
+ * grad f32[CDA_MLP_PARAMS] receives the gradient before clipping (its never-written entries - the heads' rows 25..31 - must be zero: allocate
+ * it zeroed); scratch3 f64[3] must be zero before the FIRST call and is kept consistent by the kernels ([0] accumulator, zero between calls;
+ * [1] a counter; [2] = the squared norm of this call's gradient). */
 int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* step_dev, void* wb,
-                 const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles, const float* loss_out6,
-                 float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* norm2, void* stream);
+                 const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
+                 double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float* loss_out6,
+                 float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* scratch3, void* stream);
 
 /* cda_ppo_loss (cda.h) for int32 action arrays - the env's own action tensors as the rollout kernel wrote them.  norm_rows > 0:
  * the means (and the gradient's 1/B) are over norm_rows * agents_per_row samples instead of rows * agents_per_row (a minibatch

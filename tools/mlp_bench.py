@@ -55,13 +55,13 @@ def main():
     res["forward_train_us"] = timed(lambda: check(L.cda_mlp_forward_train(p.wb.data_ptr(), p.theta.data_ptr(), upd.x_rm.data_ptr(), R, upd.h1p.data_ptr(), upd.h2p.data_ptr(), upd.out.data_ptr(), st), "fwd"), a.iters)
     res["loss_us"] = timed(lambda: check(L.cda_ppo_loss32(upd.out.data_ptr(), p.theta.data_ptr() + mlp.OFF_LS * 4, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(), acts[3].data_ptr(),
                                                          lp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), upd.perm.data_ptr(), R, A, 32, 0.2, 0.5, 0.01, upd.d_out.data_ptr(),
-                                                         upd.sums5.data_ptr(), upd.out6.data_ptr(), 0, 1, 1, st), "loss"), a.iters)
+                                                         upd.sums5.data_ptr(), upd.out6.data_ptr(), 0, 0, 0, st), "loss"), a.iters)
     res["backward_us"] = timed(lambda: check(L.cda_mlp_backward(p.wb.data_ptr(), upd.d_out.data_ptr(), upd.h1p.data_ptr(), upd.h2p.data_ptr(), R, upd.dz1p.data_ptr(), upd.dz2p.data_ptr(),
                                                                upd.doutp.data_ptr(), upd.bias_slab.data_ptr(), st), "bwd"), a.iters)
     res["wgrad_us"] = timed(lambda: check(L.cda_mlp_wgrad(upd.x_pk.data_ptr(), upd.h1p.data_ptr(), upd.h2p.data_ptr(), upd.dz1p.data_ptr(), upd.dz2p.data_ptr(), upd.doutp.data_ptr(), R, chunks,
                                                          upd.slab.data_ptr(), st), "wgrad"), a.iters)
     res["adam_us"] = timed(lambda: check(L.cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), upd.slab.data_ptr(), chunks,
-                                                       upd.bias_slab.data_ptr(), tiles, upd.out6.data_ptr(), 0.0, 0.9, 0.999, 1e-8, 0.5, upd.grad.data_ptr(), upd.norm2.data_ptr(), st), "adam"), a.iters)
+                                                       upd.bias_slab.data_ptr(), tiles, upd.sums5.data_ptr(), R * A, 0.5, 0.01, upd.out6.data_ptr(), 0.0, 0.9, 0.999, 1e-8, 0.5, upd.grad.data_ptr(), upd.norm2.data_ptr(), st), "adam"), a.iters)
     res["minibatch_step_us"] = timed(lambda: upd.minibatch_step(0, R, acts, lp_old, adv, ret, 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5), a.iters)
     # useful work per row (MACs): layer 1 168 x 512, layer 2 two 256 x 256 blocks, heads 24 x 256 + 1 x 256
     fwd = 168 * 512 + 2 * 256 * 256 + 25 * 256
