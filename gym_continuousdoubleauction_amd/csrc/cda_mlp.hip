@@ -53,28 +53,39 @@ __device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int r = 0; r < 16; r
 // ---- the observation tile: M rows -> LDS image [row][XS_LD] bf16, columns 168 .. 175 zero --------------------------------------
 template <int M>
 __device__ __forceinline__ void load_x_bf16(const __bf16* __restrict__ x_rm, long long row0, long long rows_end, __bf16* xs) {
-    constexpr int CH = KX / 8;                                            // 22 chunks of 16 B per row
-    for (int c = (int)threadIdx.x; c < M * CH; c += 256) {
-        const int r = c / CH, q = c - r * CH;
-        long long gr = row0 + r; if (gr >= rows_end) gr = rows_end - 1;   // clamp: rows past the end repeat the last one (never stored)
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x_rm + gr * KX + q * 8);
-        *reinterpret_cast<bf16x8*>(xs + r * XS_LD + q * 8) = v;
+    constexpr int CH = KX / 8, N = M * CH, PER = (N + 255) / 256;                // 22 chunks of 16 B per row; PER chunks per thread
+    bf16x8 v[PER];
+    #pragma unroll
+    for (int u = 0; u < PER; u++) {                                             // every request first ...
+        const int c = (int)threadIdx.x + 256 * u, cc = c < N ? c : N - 1, r = cc / CH, q = cc - r * CH;
+        long long gr = row0 + r; if (gr >= rows_end) gr = rows_end - 1;         // clamp: rows past the end repeat the last one (never used)
+        v[u] = *reinterpret_cast<const bf16x8*>(x_rm + gr * KX + q * 8);
+    }
+    #pragma unroll
+    for (int u = 0; u < PER; u++) {                                             // ... then the LDS image
+        const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
+        if (c < N) *reinterpret_cast<bf16x8*>(xs + r * XS_LD + q * 8) = v[u];
     }
 }
 template <int M>
 __device__ __forceinline__ void load_x_f32(const float* __restrict__ obs, long long row0, long long rows_end, __bf16* xs) {
-    constexpr int CH = KX / 4;                                            // 44 chunks of 4 values per row (42 real + 2 of zeros)
-    for (int c = (int)threadIdx.x; c < M * CH; c += 256) {
-        const int r = c / CH, q = c - r * CH;
+    constexpr int CH = KX / 4, N = M * CH, PER = (N + 255) / 256;                // 44 chunks of 4 values per row (42 real + 2 of zeros)
+    float4 v[PER];
+    #pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int c = (int)threadIdx.x + 256 * u, cc = c < N ? c : N - 1, r = cc / CH, q = cc - r * CH;
         long long gr = row0 + r; if (gr >= rows_end) gr = rows_end - 1;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (q < OBS / 4) v = *reinterpret_cast<const float4*>(obs + gr * OBS + q * 4);
-        bf16x4 b; b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(xs + r * XS_LD + q * 4) = b;
+        v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (q < OBS / 4) v[u] = *reinterpret_cast<const float4*>(obs + gr * OBS + q * 4);
+    }
+    #pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
+        bf16x4 b; b[0] = (__bf16)v[u].x; b[1] = (__bf16)v[u].y; b[2] = (__bf16)v[u].z; b[3] = (__bf16)v[u].w;
+        if (c < N) *reinterpret_cast<bf16x4*>(xs + r * XS_LD + q * 4) = b;
     }
 }
 
-// ---- one layer for one wave: acc[it][jt] += A(LDS, rows 32 it .., K) x B(global, features f0 + 32 jt .., K) --------------------
 // The B operand (weights) of a layer goes through a register ring of RING k-steps, statically indexed (the loops are unrolled): a layer is
 // PRIMED - its first RING steps requested - before the previous layer's epilogue and barrier, and while step ks multiplies, step ks + RING
 // is requested.  hipcc on its own looks ONE step ahead and sinks every other request to just before its use, which leaves a wave with
@@ -217,6 +228,17 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const long long row0 = A.first_row + (long long)blockIdx.x * M, rows_end = A.first_row + A.n_rows;
     MLP_MARK(0);
+    // every bias this lane will add, requested before anything else (a request placed later retires behind a whole ring of weight
+    // requests: vmcnt counts in order)
+    float b1s[2][2], b2s[2][2];
+    #pragma unroll
+    for (int hf = 0; hf < 2; hf++)
+        #pragma unroll
+        for (int jt = 0; jt < 2; jt++) {
+            b1s[hf][jt] = A.theta[CDA_MLP_OFF_B1 + 256 * hf + 64 * w + 2 * j + jt] * TWO_LOG2E;
+            b2s[hf][jt] = A.theta[CDA_MLP_OFF_B2 + 256 * hf + 64 * w + 2 * j + jt] * TWO_LOG2E;
+        }
+    const float bo = A.theta[CDA_MLP_OFF_BO + j];
     if (MODE == MODE_TRAIN) load_x_bf16<M>(A.x_rm, row0, rows_end, xs); else load_x_f32<M>(A.obs, row0, rows_end, xs);
     __syncthreads();
     MLP_MARK(1);
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             MLP_MARK(2 + 8 * half);
             R2.prime(W2b + ((size_t)half * HID + 64 * w) * HID, HID, lane);     // (in flight across the epilogue and its barrier)
             if (half == 1) __syncthreads();                                     // the heads of half 0 still read `act`
-            const float bias0 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j] * TWO_LOG2E, bias1 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j + 1] * TWO_LOG2E;
+            const float bias0 = half ? b1s[1][0] : b1s[0][0], bias1 = half ? b1s[1][1] : b1s[0][1];
             #pragma unroll
             for (int it = 0; it < MT; it++) {
                 float v0[16], v1[16];
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             MLP_MARK(5 + 8 * half);
             RO.prime(Wob + (size_t)half * NOUT * HID, HID, lane);
             __syncthreads();                                                    // every wave has read h1: h2 takes its place
-            const float bias0 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j] * TWO_LOG2E, bias1 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j + 1] * TWO_LOG2E;
+            const float bias0 = half ? b2s[1][0] : b2s[0][0], bias1 = half ? b2s[1][1] : b2s[0][1];
             #pragma unroll
             for (int it = 0; it < MT; it++) {
                 float v0[16], v1[16];
@@ -284,7 +306,6 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     }
     // outputs: column j of rows rowmap(r, h) of row tile w
     if (w < MT) {
-        const float bo = A.theta[CDA_MLP_OFF_BO + j];
         #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = 32 * w + rowmap(r, h);
@@ -561,7 +582,7 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
 // (16-B loads, a wave reads 1 KB per chunk, eight chunks in flight), mapped back to the parameter index (the slab's paddings and the heads'
 // masked blocks have none).  Biases (+ log_std): 64 entries per block, the row tiles split over 16 threads each.
 constexpr int RED_DENSE_BLOCKS = CDA_MLP_SLAB / 4 / 256;                          // 240
-constexpr int RED_BIAS_BLOCKS = (CDA_MLP_BSLAB + 1 + 63) / 64;                    // 17 (entry 1056 = the log_std pair)
+constexpr int RED_BIAS_BLOCKS = (CDA_MLP_BSLAB + 1 + 15) / 16;                    // 67 (entry 1056 = the log_std pair)
 __device__ __forceinline__ int param_of_dense(int d) {
     if (d < CDA_MLP_SLAB_W2) { const int o = d / (32 * XT), i = d - o * (32 * XT); return i < OBS ? CDA_MLP_OFF_W1 + o * OBS + i : -1; }
     if (d < CDA_MLP_SLAB_WO) return CDA_MLP_OFF_W2 + (d - CDA_MLP_SLAB_W2);
@@ -600,15 +621,24 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
             for (int e = 0; e < 4; e++) { grad[p + e] = g[e]; sq += g[e] * g[e]; }
         }
     } else {
-        const int e = ((int)blockIdx.x - RED_DENSE_BLOCKS) * 64 + ((int)threadIdx.x & 63), part = (int)threadIdx.x >> 6;   // entry of the bias slab (+ 2 for log_std)
-        float s = 0.0f;
+        // 16 entries of the bias slab per block, the row tiles split 16 ways (a serial walk over hundreds of 4-KB strided partials by a
+        // handful of threads was latency bound: 60 us)
+        const int e = ((int)blockIdx.x - RED_DENSE_BLOCKS) * 16 + ((int)threadIdx.x & 15), part = (int)threadIdx.x >> 4;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         if (e < CDA_MLP_BSLAB) {
-            for (int t = part; t < n_tiles; t += 4) s += bslab[(size_t)t * CDA_MLP_BSLAB + e];
+            const float* src = bslab + e;
+            int t = part;
+            for (; t + 48 < n_tiles; t += 64) {
+                s0 += src[(size_t)t * CDA_MLP_BSLAB]; s1 += src[(size_t)(t + 16) * CDA_MLP_BSLAB]; s2 += src[(size_t)(t + 32) * CDA_MLP_BSLAB]; s3 += src[(size_t)(t + 48) * CDA_MLP_BSLAB];
+            }
+            for (; t < n_tiles; t += 16) s0 += src[(size_t)t * CDA_MLP_BSLAB];
         }
-        red[part][threadIdx.x & 63] = s;
+        red[part][threadIdx.x & 15] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (part == 0) {
-            float g = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            float g = 0.0f;
+            #pragma unroll
+            for (int q = 0; q < 16; q++) g += red[q][threadIdx.x];
             int p = -1;
             if (e < CDA_MLP_FEAT) p = CDA_MLP_OFF_B1 + e;
             else if (e < 2 * CDA_MLP_FEAT) p = CDA_MLP_OFF_B2 + (e - CDA_MLP_FEAT);

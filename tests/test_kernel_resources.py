@@ -66,3 +66,15 @@ def test_step_kernels_keep_four_waves_per_simd_and_spill_no_vgpr():
     for n, v in ks.items():
         if "k_run_random" in n or "k_reset" in n:                 # (the episode kernel keeps more state live and spills a few VGPRs)
             assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 16, (n, v)
+
+
+@pytest.mark.skipif(not (os.path.exists(READELF) and os.path.exists(OBJDUMP) and shutil.which(os.environ.get("HIPCC", "hipcc"))),
+                    reason="needs hipcc and the ROCm LLVM tools")
+def test_network_kernels_spill_nothing():
+    """The MFMA kernels of csrc/cda_mlp.hip keep accumulators, operand rings and epilogue values in the 512-entry register file: a spill there
+    is scratch traffic inside the k-loop (round 4: 137 spilled VGPRs made the training forward 1.5 x slower until its tail predicates went)."""
+    ks, _ = _kernels()
+    net = {n: v for n, v in ks.items() if any(k in n for k in ("k_mlp_fwd", "k_mlp_bwd", "k_mlp_wgrad"))}
+    assert len(net) >= 10, sorted(ks)                      # forward: 3 tile sizes x 4 modes; backward: 3 tile sizes; one weight-gradient kernel
+    for n, v in net.items():
+        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (n, v)

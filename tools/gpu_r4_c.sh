@@ -33,3 +33,11 @@ for sub in ("pmc1", "pmc2", "pmc3", "pmc4"):
             print(f"{sub} {k[0]:42s} {k[1]:34s} {acc[k]/cnt[k]:16.1f} (n={cnt[k]})")
 PY
 tail -3 $O/pmc2.err
+for mt in 4 2; do
+  CDA_MLP_MT=$mt timeout 300 python -m gym_continuousdoubleauction_amd.ppo --markets 4096 --agents 4 --horizon 64 --iters 8 --out $O/ppo_fused_mt$mt.json > $O/ppo_fused_mt$mt.log 2>&1
+  python - <<PY
+import json
+d=json.load(open("$O/ppo_fused_mt$mt.json")); h=d["iterations"][2:]
+print("MT=$mt e2e %.1f M agent-steps/s; rollout %.2f ms update %.2f ms" % (d["value"]/1e6, 1e3*sum(x["rollout_s"] for x in h)/len(h), 1e3*sum(x["update_s"] for x in h)/len(h)))
+PY
+done
