@@ -31,6 +31,11 @@ What the line reports (one MI355X):
   value_one_launch           info on, the whole batch as ONE launch per step (--groups 1)
   value_ordered_per_step     info on, group chains, every step ordered after the caller's stream and the caller's stream
                              after it (CDAVecEnv.step's default: what a policy-in-the-loop consumer pays)
+  value_policy_in_loop       a CONSUMER between the steps: every chain runs {policy network forward + action sampling (one hand-written MFMA launch,
+                             csrc/cda_mlp.hip) -> env step -> auto reset} for its own markets on its own stream, K steps per HIP graph, no
+                             cross-stream edge inside the K steps (mlp.RolloutChains: the rollout of the PPO loop of BASELINE configs[4], random
+                             initial weights, no info tensors) - what a learner in the loop gets, where value_ordered_per_step is what it
+                             would get through per-step event edges
   roofline                   HIP event pairs on the chains' own streams around the k_step launches of the headline leg;
                              `traffic` / `issue_frac` only when a committed PMC pass of exactly this shape exists
                              (profiles/pmc/<markets>x<agents>_info<0|1>_g<groups>.json)
@@ -81,6 +86,10 @@ def parse():
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the hand-back (records all-gather + rebuild)")
     p.add_argument("--force-gather", action="store_true",
                    help="run the N>1 code path (process group, per-chain all-gather, rebuild) even with one rank; diagnostics")
+    p.add_argument("--transport", choices=["auto", "rccl", "torch"], default=os.environ.get("CDA_BENCH_TRANSPORT", "auto"),
+                   help="N>1 hand-back: 'rccl' = ncclAllGather issued natively per chain (cda_step_groups_handback), 'torch' = torch.distributed collectives per chain, "
+                        "'auto' = rccl when the process group runs on RCCL and the start-up self-check passes (env: CDA_BENCH_TRANSPORT)")
+    p.add_argument("--no-policy-leg", action="store_true", help="skip value_policy_in_loop")
     p.add_argument("--fused", type=int, default=0, metavar="T",
                    help="not the headline run: T steps per launch through cda_run_random (random agents sampled in the kernel, "
                         "market state resident in LDS across steps, no per-step barrier between markets)")
@@ -132,15 +141,17 @@ def cpu_baseline(markets, agents, budget_s, max_step, first_market):
     lib = O.lib()
     seeds = np.arange(SEED_BASE + first_market, SEED_BASE + first_market + n, dtype=np.uint64)
 
-    def timed(n_markets, n_threads, steps):
+    def timed(n_markets, n_threads, steps, with_info=True):
         env = O.OracleEnv(cfg, n_markets=n_markets)
         env.reset(seeds=seeds[:n_markets])
         bounds = [(i * n_markets // n_threads, (i + 1) * n_markets // n_threads) for i in range(n_threads)]
         bounds = [(lo, hi) for lo, hi in bounds if hi > lo]
+        import ctypes as C
+        info = C.byref(env._info_ptrs) if with_info else None          # every info tensor of Info_Helper.set_info, like the GPU headline leg
 
         def work(lo, hi):      # ONE foreign call per thread; ctypes releases the GIL for its duration
-            lib.oracle_run_random_range(env.h, lo, hi - lo, 0, steps, ACTION_SEED, first_market, env.obs.ctypes.data, env.reward.ctypes.data,
-                                        env.term.ctypes.data, env.trunc.ctypes.data)
+            lib.oracle_run_random_range_info(env.h, lo, hi - lo, 0, steps, ACTION_SEED, first_market, env.obs.ctypes.data, env.reward.ctypes.data,
+                                             env.term.ctypes.data, env.trunc.ctypes.data, info)
         th = [threading.Thread(target=work, args=b) for b in bounds]
         t0 = time.perf_counter()
         for x in th:
@@ -152,19 +163,31 @@ def cpu_baseline(markets, agents, budget_s, max_step, first_market):
         return dt, len(bounds)
 
     threads = min(cores, n)
+    phys = physical_cores()
     dt, _ = timed(n, threads, 8)                                   # calibration on a throw-away env
-    steps = int(max(16, min(max_step - 1, 0.8 * budget_s / max(dt / 8, 1e-6))))
+    steps = int(max(16, min(max_step - 1, 0.55 * budget_s / max(dt / 8, 1e-6))))
     dt, used = timed(n, threads, steps)                            # steps 0 .. steps-1 of the GPU leg's stream
     value = n * agents * steps / dt
+    # one thread per PHYSICAL core (the SMT siblings idle): the figure a core count should be read against
+    value_phys = None
+    if isinstance(phys, int) and 0 < phys < threads:
+        stp = int(max(8, steps * 0.35))
+        dtp, usedp = timed(n, phys, stp)
+        value_phys = n * agents * stp / dtp
     n1 = min(n, 64)
     dt1, _ = timed(n1, 1, 4)
-    steps1 = int(max(8, min(max_step - 1, 0.2 * budget_s / max(dt1 / 4, 1e-6))))
+    steps1 = int(max(8, min(max_step - 1, 0.15 * budget_s / max(dt1 / 4, 1e-6))))
     dt1, _ = timed(n1, 1, steps1)
     value1 = n1 * agents * steps1 / dt1
-    return {"value": value, "unit": "agent-steps/s", "cores": used, "cores_note": f"{used} hardware threads ({physical_cores()} physical cores, SMT)",
-            "kind": "port", "value_1thread": value1, "cpu_model": cpu_model(),
+    dtn, _ = timed(n, threads, max(8, steps // 4), with_info=False)
+    value_noinfo = n * agents * max(8, steps // 4) / dtn
+    return {"value": value, "unit": "agent-steps/s", "cores": used, "cores_note": f"{used} hardware threads ({phys} physical cores, SMT)",
+            "kind": "port", "outputs": "obs + reward + flags + every info tensor (as the GPU headline leg)",
+            "value_physical_cores": value_phys, "physical_cores": phys if isinstance(phys, int) else None,
+            "value_without_info": value_noinfo, "value_1thread": value1, "cpu_model": cpu_model(),
             "sample": f"{n} markets x {agents} agents x steps 0..{steps - 1} of the GPU leg's action stream ({dt:.1f} s wall), C oracle, "
-                      f"{used} threads, obs+reward outputs only; 1 thread: {n1} markets x {steps1} steps ({dt1:.1f} s)"}
+                      f"{used} threads, info tensors ON; one thread per physical core ({phys}): {'%.3g' % value_phys if value_phys else 'n/a'} agent-steps/s; "
+                      f"without info tensors: {value_noinfo:.3g}; 1 thread: {n1} markets x {steps1} steps ({dt1:.1f} s)"}
 
 
 def pmc_entry(n, a, info, groups):
@@ -247,7 +270,7 @@ def main():
         def __init__(self, with_info, n_groups, handback=False, ordered=False):
             self.with_info, self.ordered, self.handback = with_info, ordered, handback
             if handback:
-                self.sh = ShardedVecEnv(cfg, world * N, device=str(device), groups=n_groups, handback=True, force_collective=args.force_gather,
+                self.sh = ShardedVecEnv(cfg, world * N, device=str(device), groups=n_groups, handback=True, force_collective=args.force_gather, transport=args.transport,
                                         env_factory=lambda c, n, d, g: CDAVecEnv(c, n_markets=n, device=d, with_info=with_info, groups=g, handback=True))
                 self.env = self.sh.env
                 self.sh.reset(seed_base=SEED_BASE)
@@ -359,9 +382,10 @@ def main():
     env = head.env
     n_flagged = int((env.flags() != 0).sum().item())
     peak_orders = int(env.book_peak().max().item())
-    tile, spill = env.book_capacity, env.book_spill
+    tile, spill, spill_wanted = env.book_capacity, env.book_spill, env.book_spill_wanted
     head_groups, head_ranges = env.groups, list(env.group_ranges)
     head_transport = None if head.sh is None else ("ncclAllGather issued by cda_step_groups_handback" if head.sh.transport == "rccl" else "torch.distributed")
+    head_transport_note = None if head.sh is None else getattr(head.sh, "transport_note", None)
     head.close()
 
     extras = {}
@@ -375,6 +399,33 @@ def main():
         if groups != 1:
             extra("one_launch", with_info=headline_info, n_groups=1)
             extra("ordered_per_step", with_info=headline_info, n_groups=groups, ordered=True)
+
+    # the consumer-facing leg: policy network in the loop, per chain (see the module docstring)
+    policy_leg = None
+    if world == 1 and not args.no_extra_legs and not args.no_policy_leg and not args.fused and not gather and cfg.get("n_hist", 4) == 4:
+        try:
+            from gym_continuousdoubleauction_amd.mlp import FusedPolicy, RolloutChains
+            pcfg = dict(cfg, auto_reset=True)
+            penv = CDAVecEnv(pcfg, n_markets=N, device=str(device), with_info=False)
+            penv.reset(seed=seeds)
+            pol = FusedPolicy(device, seed=0)
+            chains = max(1, min(4, N))
+            roll = RolloutChains(penv, pol, K, groups=chains, seed=ACTION_SEED, use_graphs=True)
+            for _ in range(max(2, min(4, W // max(K, 1) + 2))):        # warm-up rollouts (the first one captures the chains' graphs)
+                roll.run()
+            ptook = []
+            for _ in range(max(R, 3)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                roll.run()
+                torch.cuda.synchronize()
+                ptook.append(time.perf_counter() - t0)
+            policy_leg = {"elapsed": statistics.median(ptook), "min": min(ptook), "max": max(ptook), "chains": chains, "graphs": roll.graphs is not None,
+                          "flagged": int((penv.flags() != 0).sum().item())}
+            penv.close()
+            del roll, pol
+        except Exception as ex:  # noqa: BLE001 - an extra leg never fails the headline
+            policy_leg = {"error": repr(ex)}
 
     if rank == 0:
         total_agent_steps = float(world) * N * A * K
@@ -419,9 +470,11 @@ def main():
                                    f"most held by any market in this run: {peak_orders}); global {world * N} markets"
                                    + (f"; FUSED: {args.fused} steps per launch (cda_run_random)" if args.fused else ""),
                        "markets_per_gpu": N, "agents": A, "info_outputs": bool(headline_info), "groups": head_groups,
+                       "book_tile": tile, "book_spill": spill, "book_spill_wanted": spill_wanted, "spill_halved": bool(spill < spill_wanted),
                        "actions": f"cda_random_actions(seed {ACTION_SEED}, step, global market, agent), resident in HBM",
                        "clock_primer": f"{primer_steps} untimed steps on a scratch env before the measured envs' resets",
-                       "collective": (f"{head_groups} all-gathers per step (one per chain, own stream + communicator; transport: {head_transport}) of {handback_stride(A)}-B records "
+                       "collective": (f"{head_groups} all-gathers per step (one per chain, own stream + communicator; transport: {head_transport}"
+                                      + (f" [{head_transport_note}]" if head_transport_note else "") + f"; asked: {args.transport}) of {handback_stride(A)}-B records "
                                       f"(newest frame | reward | flags), rebuilt into [global markets, ...] arrays by cda_handback_unpack") if gather else "none",
                        "flagged_markets": n_flagged, "peak_resting_orders": peak_orders},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -431,6 +484,17 @@ def main():
                          "algorithmic_bytes_per_launch": B * markets_per_launch[0], "achieved_per_launch": per_launch_gbps[0] if per_launch_gbps else None,
                          "issue_frac": issue_frac, "valu_busy_frac": valu_busy},
         }
+        if policy_leg is not None:
+            if "error" in policy_leg:
+                out["value_policy_in_loop"] = None
+                out["config"]["policy_in_loop"] = f"failed: {policy_leg['error']}"
+            else:
+                out["value_policy_in_loop"] = total_agent_steps / policy_leg["elapsed"]
+                out["ms_per_step_policy_in_loop"] = policy_leg["elapsed"] / K * 1e3
+                out["config"]["policy_in_loop"] = (f"{policy_leg['chains']} chains x {{168-512-512-32 bf16 MFMA policy/value forward + sampling -> k_step -> auto reset}}, "
+                                                   f"{K} steps per HIP graph" + ("" if policy_leg["graphs"] else " (graph capture failed: direct launches)")
+                                                   + f", no info tensors; min / max over the repeats: {total_agent_steps / policy_leg['max']:.4g} / {total_agent_steps / policy_leg['min']:.4g}")
+                out["config"]["flagged_markets_policy_in_loop"] = policy_leg["flagged"]
         for name, ex in extras.items():
             out[f"value_{name}"] = total_agent_steps / ex["elapsed"]
             out[f"ms_per_step_{name}"] = ex["elapsed"] / K * 1e3

@@ -19,7 +19,7 @@ SYMBOLS = [
     "cda_selftest_dec", "cda_selftest_rng", "cda_strerror", "cda_num_markets", "cda_obs_dim",
     "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host", "cda_nav_conservation",
     "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants", "cda_selftest_libm", "cda_selftest_libm_host", "cda_book_capacity",
-    "cda_get_book", "cda_book_spill", "cda_num_agents", "cda_handback_stride", "cda_set_handback", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
+    "cda_get_book", "cda_book_spill", "cda_book_spill_wanted", "cda_num_agents", "cda_handback_stride", "cda_set_handback", "cda_set_handback_geometry", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
 ]
 
 
@@ -86,6 +86,7 @@ def lib():
     L.cda_num_agents.argtypes = [vp]
     L.cda_book_capacity.argtypes = [vp]
     L.cda_book_spill.argtypes = [vp]
+    L.cda_book_spill_wanted.argtypes = [vp]
     L.cda_policy_sample.argtypes = [vp, i32, vp, vp, i64, i32, u64, vp] + [vp] * 10 + [vp]
     L.cda_gae.argtypes = [vp, vp, vp, vp, i32, i64, C.c_float, C.c_float, vp, vp, vp]
     L.cda_ppo_loss.argtypes = [vp] * 11 + [i64, i32, i32, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp]
@@ -94,7 +95,8 @@ def lib():
     L.cda_handback_groups.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp)] + [vp] * 4
     L.cda_handback_stride.argtypes = [i32]
     L.cda_set_handback.argtypes = [vp, vp]
-    L.cda_handback_unpack.argtypes = [vp, i32, i32, i64, i64, i32, i32, vp, vp, vp, vp, vp]
+    L.cda_handback_unpack.argtypes = [vp, i32, i32, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp]
+    L.cda_set_handback_geometry.argtypes = [vp, i64, i64]
     L.cda_get_book.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
     L.cda_obs_dim.argtypes = [vp]
     L.cda_state_bytes_per_market.argtypes = [vp]

@@ -286,13 +286,17 @@ __global__ void k_random_actions(uint64_t seed, uint64_t market_base, int step0,
 }
 // receiving side of the hand-back: one wave per record.  Lane l < 42 holds column l of every frame of its row in registers, so
 // the shift by one frame has no read-after-write hazard; restarted rows are filled with the new frame.
+// n_rows_total > 0: uneven shards - segment s owns seg_row_stride rows, the LAST one the remainder (n_rows_total - s * seg_row_stride); records
+// beyond a segment's rows are padding (every rank sends the same count) and are skipped.
 __global__ __launch_bounds__(256) void k_handback_unpack(const uint8_t* rec, int n_seg, int seg_records, long long seg_row_stride, long long row0, int A, int H, int stride,
-                                                          float* obs_full, double* reward_full, uint8_t* term_full, uint8_t* trunc_full) {
+                                                          long long n_rows_total, float* obs_full, double* reward_full, uint8_t* term_full, uint8_t* trunc_full) {
     const long long r = (long long)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = (int)(threadIdx.x & 63);
     if (r >= (long long)n_seg * seg_records) return;
     const uint8_t* p = rec + (size_t)r * (size_t)stride;
-    const size_t row = (size_t)(row0 + (r / seg_records) * seg_row_stride + (r % seg_records));
+    const long long seg = r / seg_records, local = row0 + (r % seg_records);
+    if (n_rows_total > 0 && local >= (seg == n_seg - 1 ? n_rows_total - seg * seg_row_stride : seg_row_stride)) return;
+    const size_t row = (size_t)(seg * seg_row_stride + local);
     const uint8_t* fl = p + CDA_SNAPSHOT_DIM * 4 + A * 8;
     const bool restarted = fl[2] != 0;
     if (lane < CDA_SNAPSHOT_DIM) {
@@ -369,6 +373,8 @@ struct cda_env {
     size_t arena_bytes;
     uint8_t* done_buf;       // auto_reset: u8[N] behind the market records - terminated | truncated of the last step
     uint8_t* handback;       // cda_set_handback: caller-owned [N, handback_stride(A)] bytes, or NULL
+    int64_t hb_row_stride, hb_rows_total;   // cda_set_handback_geometry: rows between two ranks' first markets / global row count (0, 0 = equal shards of N)
+    int32_t spill_wanted;    // orders per side the spill ring was asked to hold (automatic: num_agents * max_step rounded up); P.lay.spill_cap is what it got
 };
 static inline int32_t handback_stride_of(int32_t num_agents) { return (CDA_SNAPSHOT_DIM * 4 + num_agents * 8 + 3 + 7) & ~7; }
 
@@ -458,18 +464,22 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     P.lay.stride = (off + 255) & ~255;
     // HBM tier of the book: a ring of spill_cap orders per side behind every market's tile.  Automatic size: a side gains at
     // most one resting order per agent and step, so num_agents * max_step (+ the tile) can never be exceeded inside an episode -
-    // the unbounded OrderTree of the reference (ordertree.py:5-58), priced in HBM: 32 B per order slot and market, untouched
-    // (not even paged in) by a market whose book fits its tile.  Halved while the rings would take more than a quarter of the
-    // device's free memory.
+    // the unbounded OrderTree of the reference (ordertree.py:5-58), priced in HBM: 32 B per order slot and market (hipMalloc'd
+    // memory is physically backed whether a market ever touches it or not).  The automatic size is halved while the rings would
+    // take more than a quarter of the device's free memory - down to CDA_SPILL_MIN if it must: an env that fitted without the tier
+    // still fits with it.  cda_book_spill() reports what was granted, cda_book_spill_wanted() what "unbounded inside an episode"
+    // needs: a caller learns at construction when the two differ (the Python env warns).
     P.lay.spill_cap = 0;
+    e->spill_wanted = 0;
     if (cfg->book_spill >= 0) {
         int64_t want = cfg->book_spill > 0 ? (int64_t)cfg->book_spill : (int64_t)cfg->num_agents * (int64_t)cfg->max_step;
         if (cfg->book_spill == 0 && want < 1024) want = 1024;
         int64_t capv = CDA_SPILL_MIN;
         while (capv < want && capv < CDA_SPILL_MAX) capv <<= 1;
+        e->spill_wanted = (int32_t)capv;
         size_t free_b = 0, total_b = 0;
         if (cfg->book_spill == 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (capv > 1024 && spill_region_bytes((int32_t)capv) * (size_t)n_markets > free_b / 4) capv >>= 1;
+            while (capv > CDA_SPILL_MIN && spill_region_bytes((int32_t)capv) * (size_t)n_markets > free_b / 4) capv >>= 1;
         // a price level's size is summed in int32 (the observation's raw snapshot): the largest decodable order size times the
         // orders one side can hold must stay below 2^31 - the same rule cfg_ok applies to the tile alone
         const int64_t scale = (int64_t)cfg->mkt_max_size * (int64_t)cfg->limit_size_multiple + (int64_t)cfg->min_size;
@@ -620,7 +630,8 @@ static int handback_chain(cda_env* e, int32_t first, int32_t count, hipStream_t 
         src = (const uint8_t*)gathered;
     }
     hipLaunchKernelGGL(k_handback_unpack, dim3((unsigned)(((size_t)world * count + 3) / 4)), dim3(256), 0, stream, src, (int)world, (int)count,
-                       (long long)e->P.n_markets, (long long)first, (int)A, (int)H, (int)stride, obs_full, reward_full, term_full, trunc_full);
+                       (long long)(e->hb_row_stride > 0 ? e->hb_row_stride : e->P.n_markets), (long long)first, (int)A, (int)H, (int)stride, (long long)e->hb_rows_total,
+                       obs_full, reward_full, term_full, trunc_full);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -712,10 +723,15 @@ int cda_set_handback(cda_env* e, void* records_dev) {
     e->handback = (uint8_t*)records_dev;
     return CDA_OK;
 }
+int cda_set_handback_geometry(cda_env* e, int64_t shard_row_stride, int64_t n_rows_total) {
+    if (!e || shard_row_stride < 0 || n_rows_total < 0 || (n_rows_total > 0 && shard_row_stride < 1)) return CDA_ERR_INVALID;
+    e->hb_row_stride = shard_row_stride; e->hb_rows_total = n_rows_total;
+    return CDA_OK;
+}
 int cda_handback_unpack(const void* records_dev, int32_t n_segments, int32_t seg_records, int64_t seg_row_stride, int64_t row0,
-                        int32_t num_agents, int32_t n_hist,
+                        int32_t num_agents, int32_t n_hist, int64_t n_rows_total,
                         float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full, void* stream) {
-    if (!records_dev || n_segments < 0 || seg_records < 0 || seg_row_stride < 0 || row0 < 0) return CDA_ERR_INVALID;
+    if (!records_dev || n_segments < 0 || seg_records < 0 || seg_row_stride < 0 || row0 < 0 || n_rows_total < 0) return CDA_ERR_INVALID;
     if (num_agents < 1 || num_agents > CDA_MAX_AGENTS || n_hist < 1 || n_hist > CDA_MAX_HIST) return CDA_ERR_INVALID;
     if (!obs_full || !reward_full || !terminated_full || !truncated_full) return CDA_ERR_INVALID;
     const int64_t count = (int64_t)n_segments * seg_records;
@@ -727,7 +743,7 @@ int cda_handback_unpack(const void* records_dev, int32_t n_segments, int32_t seg
     HIPCHK(hipSetDevice(dev));
     hipLaunchKernelGGL(k_handback_unpack, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)records_dev, (int)n_segments,
                        (int)seg_records, (long long)seg_row_stride, (long long)row0, (int)num_agents, (int)n_hist, (int)handback_stride_of(num_agents),
-                       obs_full, reward_full, terminated_full, truncated_full);
+                       (long long)n_rows_total, obs_full, reward_full, terminated_full, truncated_full);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -1056,6 +1072,7 @@ int32_t cda_book_capacity(const cda_env* e) { return e ? e->cap : 0; }
 int32_t cda_book_spill(const cda_env* e) { return e ? e->P.lay.spill_cap : 0; }
 int32_t cda_num_markets(const cda_env* e) { return e ? e->P.n_markets : 0; }
 int32_t cda_num_agents(const cda_env* e) { return e ? e->P.cfg.num_agents : 0; }
+int32_t cda_book_spill_wanted(const cda_env* e) { return e ? e->spill_wanted : 0; }
 int32_t cda_obs_dim(const cda_env* e) { return e ? e->P.cfg.n_hist * CDA_SNAPSHOT_DIM : 0; }
 int64_t cda_state_bytes_per_market(const cda_env* e) { return e ? (int64_t)e->P.lay.stride : 0; }
 

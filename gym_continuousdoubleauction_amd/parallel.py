@@ -93,12 +93,49 @@ def handback_stride(num_agents):
     return (42 * 4 + num_agents * 8 + 3 + 7) // 8 * 8
 
 
-def _hip_unpack(records, n_segments, seg_records, seg_row_stride, row0, num_agents, n_hist, obs, reward, term, trunc):
+def _hip_unpack(records, n_segments, seg_records, seg_row_stride, row0, num_agents, n_hist, obs, reward, term, trunc, n_rows_total=0):
     """the product's receiving side: one launch of cda_handback_unpack on the CURRENT stream"""
     from ._lib import check, lib
-    check(lib().cda_handback_unpack(records.data_ptr(), int(n_segments), int(seg_records), int(seg_row_stride), int(row0), int(num_agents), int(n_hist),
+    check(lib().cda_handback_unpack(records.data_ptr(), int(n_segments), int(seg_records), int(seg_row_stride), int(row0), int(num_agents), int(n_hist), int(n_rows_total),
                                     obs.data_ptr(), reward.data_ptr(), term.data_ptr(), trunc.data_ptr(),
                                     torch.cuda.current_stream(obs.device).cuda_stream), "cda_handback_unpack")
+
+
+HANDBACK_TIMEOUT_S = float(os.environ.get("CDA_HANDBACK_TIMEOUT_S", "60"))
+
+
+def _guarded(fn, what, streams=(), timeout=None):
+    """Run `fn` (a native call that enqueues collectives) under a host watchdog: the call itself in a worker thread (RCCL sets its
+    connections up lazily, inside the first collective, and that can block on the host), then every stream it enqueued on polled to
+    completion - both against one deadline.  A collective that never completes makes the process EXIT non-zero with a diagnostic inside
+    `timeout` seconds instead of hanging until somebody kills the job (torch.distributed's own timeout guards only ITS collectives)."""
+    import sys
+    import threading
+    import time
+    timeout = HANDBACK_TIMEOUT_S if timeout is None else float(timeout)
+    box = {}
+
+    def run():
+        try:
+            box["ret"] = fn()
+        except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread
+            box["err"] = e
+    t0 = time.monotonic()
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        print(f"[cda watchdog] {what}: the native call did not return within {timeout:.0f} s (a collective that cannot be set up or enqueued); exiting", file=sys.stderr, flush=True)
+        os._exit(3)
+    if "err" in box:
+        raise box["err"]
+    for s in streams:
+        while not s.query():
+            if time.monotonic() - t0 > timeout:
+                print(f"[cda watchdog] {what}: the device did not finish the enqueued collectives within {timeout:.0f} s; exiting", file=sys.stderr, flush=True)
+                os._exit(3)
+            time.sleep(0.002)
+    return box.get("ret")
 
 
 class _Rccl:
@@ -168,67 +205,144 @@ class ShardedVecEnv:
         self.n_total = int(n_markets_total)
         self.first, self.n_local = shard_range(self.rank, self.world, self.n_total)
         self.use_handback = bool(handback)
-        if self.use_handback and self.n_total % self.world:
-            raise ValueError("the hand-back path needs equal shards (n_markets_total divisible by the world size); use gather()")
+        # Uneven shards under the hand-back: every rank steps and sends the SAME number of records - the largest shard (the last rank's); the
+        # other ranks pad theirs with up to world - 1 markets nobody reads (seeded beyond the global range, fed pass actions), and the
+        # receiving side skips the padding (cda_set_handback_geometry).  Equal shards: nothing changes.
+        self.n_env = shard_pad(self.world, self.n_total) if self.use_handback else self.n_local
+        self.per = self.n_total // self.world
+        self.uneven = self.use_handback and self.n_env != self.per
         if env_factory is None:
             from .vec_env import CDAVecEnv
             env_factory = lambda cfg, n, dev, g: CDAVecEnv(cfg, n_markets=n, device=dev, with_info=False, groups=g, handback=self.use_handback)   # noqa: E731
-        self.env = env_factory(config, self.n_local, device, int(groups))
+        self.env = env_factory(config, self.n_env, device, int(groups))
         self.obs_dim = self.env.obs_dim
         self.num_agents = self.env.num_agents
         self.n_hist = self.obs_dim // 42
         self._packed = None
         self._padded = None
         self._gathered = None
+        self._pad_acts = None
         self.layout = slab_layout(self.n_local, self.obs_dim, self.num_agents)
         self.full = None
+        self.transport_note = None
         if self.use_handback:
             self._unpack = unpack or _hip_unpack
+            self._unpack_takes_total = unpack is None
             rec = self.env.handback
             dev = rec.device
-            self.group_ranges = list(getattr(self.env, "group_ranges", None) or [(0, self.n_local)])
+            self.group_ranges = list(getattr(self.env, "group_ranges", None) or [(0, self.n_env)])
             self.group_streams = list(getattr(self.env, "group_streams", None) or [])
             stride = rec.shape[1]
             self._gbuf = [torch.zeros((self.world, cnt, stride), dtype=torch.uint8, device=dev) for _, cnt in self.group_ranges]
+            self._rows_total = self.n_total if self.uneven else 0
+            native_ok = dev.type == "cuda" and unpack is None and hasattr(self.env, "_h")
+            if native_ok:
+                from ._lib import check, lib
+                check(lib().cda_set_handback_geometry(self.env._h, self.per if self.uneven else 0, self._rows_total), "cda_set_handback_geometry")
             # Transport.  "rccl" (the default on HIP devices when the process group runs on RCCL, or with one rank): the whole step -
             # every chain's k_step, ncclAllGather and rebuild - is ONE native call (cda_step_groups_handback); the library calls RCCL
             # itself on the chains' streams.  "torch": torch.distributed collectives issued from Python, chain by chain (~25 us of host
             # time per chain and step, tools/handback_host_probe.py) - the path of the gloo tests and of anything that is not RCCL.
-            # Either way one communicator per chain, so that the chains' collectives may be in flight together.
+            # Either way one communicator per chain, so that the chains' collectives may be in flight together.  "auto" = rccl where it
+            # is available AND its start-up self-check passes on every rank (below); CDA_HANDBACK_TRANSPORT overrides "auto".
+            asked = transport
+            if transport == "auto":
+                transport = os.environ.get("CDA_HANDBACK_TRANSPORT", "auto")
+            if transport not in ("auto", "rccl", "torch"):
+                raise ValueError(f"transport must be auto, rccl or torch, got {transport!r}")
             if transport == "auto":
                 on_rccl = self.world == 1 or self.dist.get_backend() == "nccl"
-                transport = "rccl" if (dev.type == "cuda" and unpack is None and hasattr(self.env, "_h") and on_rccl) else "torch"
+                transport = "rccl" if (native_ok and on_rccl) else "torch"
+            elif transport == "rccl" and not native_ok:
+                raise ValueError("transport 'rccl' needs the HIP env (the library issues ncclAllGather itself)")
             self.transport = transport
             self._pgs, self._comms = [], None
+            self.full = (torch.zeros((self.n_total, self.obs_dim), dtype=torch.float32, device=dev),
+                         torch.zeros((self.n_total, self.num_agents), dtype=torch.float64, device=dev),
+                         torch.zeros(self.n_total, dtype=torch.uint8, device=dev), torch.zeros(self.n_total, dtype=torch.uint8, device=dev))
             if transport == "rccl":
                 G = len(self.group_ranges)
                 if self.world > 1 or force_collective:       # (force_collective: a one-rank communicator, so that one GPU runs the real RCCL call)
                     comms, err = [], None
                     try:
                         rccl = _Rccl.get()
-                        comms = [rccl.new_comm(self.dist, self.rank, self.world) for _ in range(G)]
+                        comms = _guarded(lambda: [rccl.new_comm(self.dist, self.rank, self.world) for _ in range(G)], "ncclCommInitRank")
                     except Exception as e:  # noqa: BLE001 - every rank must take the same branch below
                         err = e
-                    ok = torch.tensor([0.0 if err else 1.0], device=dev)
-                    if self.world > 1:
-                        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
-                    if float(ok.item()) < 1.0:               # some rank could not build its communicators: all ranks use torch.distributed
+                    if self._all_ranks_agree(err is None, dev):
+                        self._comm_handles = comms
+                        self._comms = (C.c_void_p * G)(*[c.value for c in comms])
+                    else:                                    # some rank could not build its communicators: all ranks use torch.distributed
                         import sys
                         print(f"[ShardedVecEnv] rank {self.rank}: native RCCL communicators unavailable ({err}); falling back to torch.distributed", file=sys.stderr)
                         for c in comms:
                             _Rccl.get().lib.ncclCommDestroy(c)
                         transport = self.transport = "torch"
-                    else:
-                        self._comm_handles = comms
-                        self._comms = (C.c_void_p * G)(*[c.value for c in comms])
+                        self.transport_note = f"asked {asked}: RCCL communicators unavailable"
                 else:
                     _Rccl_optional_load()
                 self._gptrs = (C.c_void_p * G)(*[b.data_ptr() for b in self._gbuf])
-            if transport != "rccl":
+            if transport != "rccl" or (self.world > 1 and dev.type == "cuda"):
+                # (the torch groups also serve the self-check of the native transport)
                 self._pgs = [self.dist.new_group(ranks=list(range(self.world))) if self.world > 1 else None for _ in self.group_ranges]
-            self.full = (torch.zeros((self.n_total, self.obs_dim), dtype=torch.float32, device=dev),
-                         torch.zeros((self.n_total, self.num_agents), dtype=torch.float64, device=dev),
-                         torch.zeros(self.n_total, dtype=torch.uint8, device=dev), torch.zeros(self.n_total, dtype=torch.uint8, device=dev))
+            if transport == "rccl" and self._comms is not None:
+                ok = self._native_selfcheck(dev)
+                if not ok:
+                    import sys
+                    print(f"[ShardedVecEnv] rank {self.rank}: the native hand-back disagreed with torch.distributed on the self-check records; using torch.distributed",
+                          file=sys.stderr)
+                    for c in self._comm_handles:
+                        _Rccl.get().lib.ncclCommDestroy(c)
+                    self._comm_handles, self._comms = None, None
+                    self.transport = "torch"
+                    self.transport_note = f"asked {asked}: native self-check failed"
+                else:
+                    self.transport_note = "start-up self-check against torch.distributed passed on every rank"
+
+    def _all_ranks_agree(self, ok, dev):
+        t = torch.tensor([1.0 if ok else 0.0], device=dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item()) >= 1.0
+
+    def _native_selfcheck(self, dev):
+        """One hand-back of synthetic records through the native transport (under the host watchdog) and one through torch.distributed,
+        into two scratch sets of learner-side arrays; every rank compares and the verdicts are combined (MIN): a native path that hangs
+        exits the process inside a minute, one that delivers wrong bytes is replaced by torch.distributed - before anything is timed."""
+        from ._lib import check, lib
+        env = self.env
+        rec = env.handback
+        g = torch.Generator().manual_seed(1234 + self.rank)
+        saved = rec.clone()
+        rec.copy_(torch.randint(0, 256, rec.shape, dtype=torch.uint8, generator=g).to(dev))
+        a_set = tuple(torch.zeros_like(t) for t in self.full)
+        b_set = tuple(torch.zeros_like(t) for t in self.full)
+        streams = self.group_streams or [torch.cuda.current_stream(dev)]
+        torch.cuda.synchronize(dev)
+        ok = True
+        try:
+            arr = self._stream_array()
+            _guarded(lambda: check(lib().cda_handback_groups(env._h, len(self.group_ranges), arr, self._comms, self.world, self._gptrs,
+                                                             *[t.data_ptr() for t in a_set]), "cda_handback_groups"),
+                     "native hand-back self-check", streams=streams)
+            torch.cuda.synchronize(dev)
+            for gi, (first, cnt) in enumerate(self.group_ranges):
+                buf = torch.zeros_like(self._gbuf[gi])
+                mine = rec[first:first + cnt]
+                if self.world > 1:
+                    self.dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=self._pgs[gi])
+                else:
+                    buf[0].copy_(mine)
+                _hip_unpack(buf, self.world, cnt, self.per if self.uneven else self.n_env, first, self.num_agents, self.n_hist, *b_set, n_rows_total=self._rows_total)
+            torch.cuda.synchronize(dev)
+            ok = all(torch.equal(x.view(torch.uint8) if x.dtype != torch.uint8 else x, y.view(torch.uint8) if y.dtype != torch.uint8 else y) for x, y in zip(a_set, b_set))
+        except Exception as e:  # noqa: BLE001 - a failing native path is a verdict, not a crash
+            import sys
+            print(f"[ShardedVecEnv] rank {self.rank}: native hand-back self-check raised {e!r}", file=sys.stderr)
+            ok = False
+        rec.copy_(saved)
+        torch.cuda.synchronize(dev)
+        return self._all_ranks_agree(ok, dev)
 
     # ------------------------------------------------------------------ the hand-back
     def _stream_ctx(self, g):
@@ -246,7 +360,13 @@ class ShardedVecEnv:
             self.dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=self._pgs[g])
         else:
             buf[0].copy_(mine)
-        self._unpack(buf, self.world, cnt, self.n_local, first, self.num_agents, self.n_hist, *self.full)
+        stride_rows = self.per if self.uneven else self.n_env
+        if self._unpack_takes_total:
+            self._unpack(buf, self.world, cnt, stride_rows, first, self.num_agents, self.n_hist, *self.full, n_rows_total=self._rows_total)
+        elif self.uneven:
+            self._unpack(buf, self.world, cnt, stride_rows, first, self.num_agents, self.n_hist, *self.full, self._rows_total)
+        else:
+            self._unpack(buf, self.world, cnt, stride_rows, first, self.num_agents, self.n_hist, *self.full)
 
     def _stream_array(self):
         G = len(self.group_ranges)
@@ -272,21 +392,47 @@ class ShardedVecEnv:
 
     def reset(self, seed_base=0):
         """seed_base = s: global market i is seeded s + i; None: every market keeps its RNG stream (reset(seed=None))."""
-        obs = self.env.reset(seed=None if seed_base is None else global_seeds(seed_base, self.first, self.n_local))
+        seeds = None
+        if seed_base is not None:
+            seeds = global_seeds(seed_base, self.first, self.n_local)
+            if self.n_env > self.n_local:                  # padding markets: seeded beyond the global range, never read by anybody
+                seeds = torch.cat([seeds, global_seeds(seed_base, self.n_total + self.rank * self.world, self.n_env - self.n_local)])
+        obs = self.env.reset(seed=seeds)
         if self.use_handback:               # the reset wrote `restarted` records: the full observation restarts from them
             if self.group_streams:
                 self.env.fork()
             self.handback()
             self.join()
-        return obs
+        return obs[:self.n_local]
+
+    def _pad(self, acts, present):
+        """uneven shards: the local action rows followed by pass actions (absent agents) for the padding markets"""
+        if self.n_env == self.n_local:
+            return acts, present
+        n_extra = self.n_env - self.n_local
+        out = []
+        for x in acts:
+            x = torch.as_tensor(x)
+            out.append(torch.cat([x.reshape(self.n_local, self.num_agents), torch.zeros((n_extra, self.num_agents), dtype=x.dtype, device=x.device)]))
+        ref = out[0]
+        ps = torch.ones((self.n_local, self.num_agents), dtype=torch.uint8, device=ref.device) if present is None else torch.as_tensor(present).to(torch.uint8).reshape(self.n_local, self.num_agents)
+        ps = torch.cat([ps.to(ref.device), torch.zeros((n_extra, self.num_agents), dtype=torch.uint8, device=ref.device)])
+        return out, ps
+
+    def _local(self, out):
+        if self.n_env == self.n_local:
+            return out
+        obs, rew, term, trunc, info = out
+        return obs[:self.n_local], rew[:self.n_local], term[:self.n_local], trunc[:self.n_local], info
 
     def step(self, category, size_mean, size_sigma, price, price_offset, present=None, pipelined=False):
         """Actions for THIS rank's markets ([n_local, A]); returns the local outputs.  With hand-back the full arrays follow on the
         chains' streams; pipelined=True leaves the fork / join with the caller's stream out (see CDAVecEnv.step)."""
         if not self.use_handback:
             return self.env.step(category, size_mean, size_sigma, price, price_offset, present)
+        (category, size_mean, size_sigma, price, price_offset), present = self._pad((category, size_mean, size_sigma, price, price_offset), present)
         if self.transport == "rccl":
-            return self._step_native(category, size_mean, size_sigma, price, price_offset, present, pipelined)
+            return self._local(self._step_native(category, size_mean, size_sigma, price, price_offset, present, pipelined))
         if self.group_streams:
             if not pipelined:
                 self.env.fork()             # the chains start after whatever the caller's stream holds (the actions a policy just wrote)
@@ -296,7 +442,7 @@ class ShardedVecEnv:
         self.handback()
         if not pipelined:
             self.join()
-        return out
+        return self._local(out)
 
     def _step_native(self, category, size_mean, size_sigma, price, price_offset, present, pipelined):
         """every chain's step, collective and rebuild in ONE host call (cda_step_groups_handback)"""
@@ -308,6 +454,9 @@ class ShardedVecEnv:
         ps = None if present is None else env._prep(present, _t.uint8)
         if self.group_streams and (not pipelined or env._need_fork):
             env.fork()
+        if len(env._views) > 1:                     # out_buffers > 1: the rotation CDAVecEnv.step performs
+            env._cur = (env._cur + 1) % len(env._views)
+            env._bind_outputs()
         if not hasattr(self, "_full_ptrs"):
             self._full_ptrs = [t.data_ptr() for t in self.full]
             self._streams_c = self._stream_array() if self.group_streams else None

@@ -42,6 +42,11 @@ class CDAVecEnv:
         self._h = h
         self.book_capacity = int(lib().cda_book_capacity(h))     # LDS book tile: 256 or 512 resting orders per market (config['book_capacity'])
         self.book_spill = int(lib().cda_book_spill(h))           # HBM spill ring behind it: orders per side (config['book_spill']; 0 = none)
+        self.book_spill_wanted = int(lib().cda_book_spill_wanted(h))   # ... and what an unbounded-inside-an-episode book needs
+        if self.book_spill < self.book_spill_wanted:
+            import warnings
+            warnings.warn(f"the HBM spill ring was cut to {self.book_spill} orders per side ({self.book_spill_wanted} needed for a book that can never overflow inside an "
+                          f"episode of {self.max_step} steps): device memory; a rest beyond tile + ring is dropped and flagged (CDA_FLAG_BOOK_OVERFLOW)", RuntimeWarning, stacklevel=2)
         N, A, dev = self.n_markets, self.num_agents, self.device
         # The per-step outputs of one launch live in ONE contiguous slab (obs | reward | terminated | truncated),
         # so a multi-GPU caller hands them to its peers with a single collective and no packing pass

@@ -82,7 +82,8 @@ typedef struct cda_config {
     int32_t book_spill;          /* extension: resting orders PER SIDE a market can hold in HBM behind its tile (the reference's
                                     OrderTree is unbounded, ordertree.py:5-58).  0 = automatic: num_agents * max_step rounded up to a
                                     power of two (at least 1024) - a side cannot grow faster than one order per agent and step, so
-                                    no order is ever dropped inside an episode; n > 0: rounded up to a power of two in
+                                    no order is ever dropped inside an episode (halved, down to CDA_SPILL_MIN, while the rings of all markets would take more than a
+                                    quarter of the free device memory: compare cda_book_spill / cda_book_spill_wanted); n > 0: rounded up to a power of two in
                                     [CDA_SPILL_MIN, CDA_SPILL_MAX]; -1: no HBM tier (the round-1/2 behaviour: the tile is the whole
                                     book).  A rest that fits neither is dropped and flagged (CDA_FLAG_BOOK_OVERFLOW), never silently */
     double  order_penalty;       /* 0.1  */
@@ -232,12 +233,18 @@ void cda_group_range(int32_t n_markets, int32_t n_groups, int32_t group, int32_t
  * the collective where the kernel left it.  cda_handback_unpack is the receiving side, for ANY process (it needs no env):
  * n_segments x seg_records records (an all-gathered buffer: one segment per rank), record k of segment s belonging to row
  * row0 + s * seg_row_stride + k of the learner's full arrays - the observation row is shifted by one frame and the new frame
- * appended (or, restarted, all frames set), reward / flags rows are overwritten.  One launch. */
+ * appended (or, restarted, all frames set), reward / flags rows are overwritten.  One launch.  (n_rows_total: see cda_set_handback_geometry.) */
 int32_t cda_handback_stride(int32_t num_agents);
 int cda_set_handback(cda_env* env, void* records_dev);
 int cda_handback_unpack(const void* records_dev, int32_t n_segments, int32_t seg_records, int64_t seg_row_stride, int64_t row0,
-                        int32_t num_agents, int32_t n_hist,
+                        int32_t num_agents, int32_t n_hist, int64_t n_rows_total,
                         float* obs_full, double* reward_full, uint8_t* terminated_full, uint8_t* truncated_full, void* stream);
+/* Uneven shards (n_rows_total not divisible by the rank count): every rank steps and sends the SAME number of records - the largest shard,
+ * the smaller ones padded with markets nobody reads - and the receiving side skips the padding: with n_rows_total > 0, segment s owns
+ * seg_row_stride rows (the last one n_rows_total - s * seg_row_stride) and record k of it is used only while row0 + k is below that.
+ * n_rows_total = 0: every record is used (equal shards).  cda_set_handback_geometry gives the native chains (cda_step_groups_handback,
+ * cda_handback_groups) the same two numbers: rows between two ranks' first markets, global row count (0, 0 = equal shards of N). */
+int cda_set_handback_geometry(cda_env* env, int64_t shard_row_stride, int64_t n_rows_total);
 
 /* cda_step_groups AND the hand-back of every chain in ONE host call (a Python loop over chains - stream context, collective, unpack -
  * costs ~25 us of host time per chain and step, more than the step itself): on streams[g], for the markets of group g,
@@ -301,8 +308,12 @@ int cda_set_state(cda_env* env, int32_t market, const cda_market_state* in_host)
 /* One side of one market's book, whole, in queue order (best price first, FIFO inside a level; ordertree.py / orderlist.py):
  * up to max_orders orders -> orders_out_host (host), the side's true length -> n_out_host.  side: 0 bids, 1 asks.  Synchronous. */
 int cda_get_book(cda_env* env, int32_t market, int32_t side, cda_order* orders_out_host, int32_t max_orders, int32_t* n_out_host);
-/* Orders per side the HBM spill ring of this env holds (0 = no HBM tier). */
+/* Orders per side the HBM spill ring of this env holds (0 = no HBM tier) - what cda_create GRANTED - and what was asked for (automatic:
+ * num_agents * max_step rounded up to a power of two, the size with which no order is ever dropped inside an episode).  The automatic size is
+ * halved while the rings would take more than a quarter of the free device memory; when granted < wanted the book is bounded by tile + ring and
+ * a rest beyond it is dropped and flagged (CDA_FLAG_BOOK_OVERFLOW) - a caller can tell at construction. */
 int32_t cda_book_spill(const cda_env* env);
+int32_t cda_book_spill_wanted(const cda_env* env);
 
 /* Pre-step raw top-10 snapshot agg_LOB_raw f32[N,40] (state_helper.py:159-160) -> device buffer. */
 int cda_get_raw_snapshot(cda_env* env, float* raw_out, void* stream);

@@ -934,9 +934,18 @@ int oracle_run_range(oracle_env* e, int32_t first, int32_t count, int32_t n_step
  * markets [first, first+count) play n_steps steps each; the action of (market i, step step0 + s, agent a) is
  * cda_random_action(action_seed, market_index_base + i, step0 + s, a) - the stream cda_random_actions() puts in HBM for
  * the GPU leg of bench.py, so both legs consume identical inputs.  Outputs are the last step's (global indexing). */
+int oracle_run_random_range_info(oracle_env* e, int32_t first, int32_t count, int32_t step0, int32_t n_steps,
+                                 uint64_t action_seed, uint64_t market_index_base,
+                                 float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out, const cda_info_ptrs* info);
 int oracle_run_random_range(oracle_env* e, int32_t first, int32_t count, int32_t step0, int32_t n_steps,
                             uint64_t action_seed, uint64_t market_index_base,
                             float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out) {
+    return oracle_run_random_range_info(e, first, count, step0, n_steps, action_seed, market_index_base, obs_out, reward_out, terminated_out, truncated_out, NULL);
+}
+/* ... with every info tensor of Info_Helper.set_info built each step (info_helper.py:30-116) - what the GPU headline leg of bench.py builds */
+int oracle_run_random_range_info(oracle_env* e, int32_t first, int32_t count, int32_t step0, int32_t n_steps,
+                                 uint64_t action_seed, uint64_t market_index_base,
+                                 float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out, const cda_info_ptrs* info) {
     if (!e || first < 0 || count < 0 || first + count > e->n || step0 < 0 || n_steps < 0) return CDA_ERR_INVALID;
     const int A = e->cfg.num_agents; const size_t od = (size_t)e->cfg.n_hist * CDA_SNAPSHOT_DIM;
     for (int i = first; i < first + count; i++) {
@@ -945,7 +954,7 @@ int oracle_run_random_range(oracle_env* e, int32_t first, int32_t count, int32_t
         for (int s = 0; s < n_steps; s++) {
             for (int a = 0; a < A; a++) cda_random_action(action_seed, market_index_base + (uint64_t)i, (uint32_t)(step0 + s), (uint32_t)a, &cat[a], &sm[a], &ss[a], &pr[a], &po[a]);
             market_step(e, &e->m[i], i, cat, sm, ss, pr, po, NULL, obs_out ? obs_out + od * (size_t)i : NULL, reward_out ? reward_out + o : NULL,
-                        terminated_out ? terminated_out + i : NULL, truncated_out ? truncated_out + i : NULL, NULL, NULL);
+                        terminated_out ? terminated_out + i : NULL, truncated_out ? truncated_out + i : NULL, info, NULL);
         }
     }
     return CDA_OK;

@@ -47,6 +47,10 @@ int oracle_run_range(oracle_env* env, int32_t first, int32_t count, int32_t n_st
 int oracle_run_random_range(oracle_env* env, int32_t first, int32_t count, int32_t step0, int32_t n_steps,
                             uint64_t action_seed, uint64_t market_index_base,
                             float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out);
+/* the same with every info tensor built each step (nullable info = oracle_run_random_range) */
+int oracle_run_random_range_info(oracle_env* env, int32_t first, int32_t count, int32_t step0, int32_t n_steps,
+                                 uint64_t action_seed, uint64_t market_index_base,
+                                 float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out, const cda_info_ptrs* info);
 /* Book capacity of the oracle: 0 = unbounded, as the reference's OrderTree (ordertree.py:5-58) - the default, and what the
  * product is with its HBM tier; an env created with cda_config.book_spill = -1 (the product without that tier) mirrors the
  * tile pool (cda_config.book_capacity; 256 up to 8 agents, 512 above) with its overflow flag.  oracle_book_peak: most resting orders each market

@@ -41,6 +41,7 @@ def lib():
         _lib.oracle_step_range.argtypes = [vp, C.c_int32, C.c_int32] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), vp]
         _lib.oracle_run_range.argtypes = [vp] + [C.c_int32] * 4 + [vp] * 9
         _lib.oracle_run_random_range.argtypes = [vp] + [C.c_int32] * 4 + [C.c_uint64] * 2 + [vp] * 4
+        _lib.oracle_run_random_range_info.argtypes = [vp] + [C.c_int32] * 4 + [C.c_uint64] * 2 + [vp] * 4 + [C.POINTER(K.InfoPtrs)]
         _lib.oracle_set_book_cap.argtypes = [vp, C.c_int32]
         _lib.oracle_book_peak.argtypes = [vp, vp]
         _lib.oracle_book_size.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

@@ -48,6 +48,14 @@ def test_bench_json_contract():
     assert c["kind"] == "port" and c["unit"] == "agent-steps/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert c["value_1thread"] > 0 and isinstance(c["cpu_model"], str) and c["cpu_model"]
     assert "GPU leg's action stream" in c["sample"] and "hardware threads" in c["cores_note"] and "physical cores" in c["cores_note"]
+    # the CPU leg builds the info tensors too (like the headline), says so, and carries the info-less and the
+    # one-thread-per-physical-core figures next to the SMT one
+    assert "info tensor" in c["outputs"] and c["value_without_info"] >= c["value"] * 0.8 and "value_physical_cores" in c and "physical_cores" in c
+    # ... the granted spill ring is in the config, with a flag when "unbounded inside an episode" was not affordable
+    cf = d["config"]
+    assert cf["book_tile"] == 256 and cf["book_spill"] >= 1024 and cf["book_spill_wanted"] >= cf["book_spill"] and cf["spill_halved"] == (cf["book_spill"] < cf["book_spill_wanted"])
+    # the consumer-facing number - a policy network between the steps, per chain, no cross-stream edge inside the horizon
+    assert d["value_policy_in_loop"] > 1e6 and d["ms_per_step_policy_in_loop"] > 0 and "MFMA" in cf["policy_in_loop"] and cf["flagged_markets_policy_in_loop"] == 0
 
 
 def test_bench_traffic_only_from_a_pmc_pass_of_the_same_shape():
@@ -93,6 +101,15 @@ def test_bench_multi_gpu_code_path_on_one_rank():
         assert d["n_gpus"] == 1 and d["value"] > 1e6 and "all-gathers per step" in d["config"]["collective"] and "208-B records" in d["config"]["collective"] and "ncclAllGather" in d["config"]["collective"]
         assert d["config"]["groups"] == (1 if extra else 2) and "hand-back" in d["metric"]
         assert d["config"]["flagged_markets"] == 0 and d["roofline"]["kernel_ms"] > 0
+        # the native transport was checked against torch.distributed on synthetic records before anything was timed
+        assert "self-check" in d["config"]["collective"] and "passed" in d["config"]["collective"]
+    # (a): the transport can be forced, by flag and by environment; the line records what ran and what was asked for
+    for how in (["--transport", "torch"], None):
+        e2 = dict(env) if how else dict(env, CDA_BENCH_TRANSPORT="torch")
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--markets", "256", "--no-cpu-baseline",
+                                       "--force-gather"] + (how or []), cwd=ROOT, env=e2, stderr=subprocess.STDOUT, text=True, timeout=600)
+        d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+        assert "transport: torch.distributed" in d["config"]["collective"] and "asked: torch" in d["config"]["collective"] and d["config"]["flagged_markets"] == 0
 
 
 def test_bench_fused_mode_reports_the_same_contract():
@@ -138,3 +155,56 @@ def test_rccl_refuses_two_ranks_on_one_device():
                           "--warmup", "4", "--markets", "64", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode != 0
     assert "Duplicate GPU detected" in out.stderr, out.stderr[-1500:]
+
+
+def _uneven_worker(rank, world, port, outdir, n_total):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv
+    cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 64, "is_render": False}
+    sh = ShardedVecEnv(cfg, n_total, device="cuda:0", groups=2, handback=True)       # the HIP env, the HIP unpack kernel; gloo carries the records
+    assert sh.transport == "torch" and sh.uneven and sh.n_env == n_total // world + n_total % world
+    sh.reset(seed_base=1000)
+    rec = []
+    for t in range(10):
+        rng = np.random.default_rng(700 + t)
+        full = (rng.integers(0, 9, (n_total, 4)).astype(np.int32), rng.uniform(-1, 1, (n_total, 4)).astype(np.float32), rng.uniform(0, 1, (n_total, 4)).astype(np.float32),
+                rng.integers(0, 10, (n_total, 4)).astype(np.int32), rng.integers(0, 3, (n_total, 4)).astype(np.int32))
+        acts = [torch.from_numpy(x[sh.first:sh.first + sh.n_local]).cuda() for x in full]
+        obs, rew, term, trunc, _ = sh.step(*acts)
+        torch.cuda.synchronize()
+        assert obs.shape[0] == sh.n_local
+        rec.append((sh.full[0].cpu().numpy().copy(), sh.full[1].cpu().numpy().copy()))
+    np.savez(os.path.join(outdir, f"uneven_{rank}.npz"), obs=np.stack([r[0] for r in rec]), rew=np.stack([r[1] for r in rec]))
+    dist.barrier()
+    sh.close()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_hand_back_on_the_hip_env_two_ranks_one_gpu(tmp_path):
+    """13 markets over two ranks (6 + 7): every rank steps and sends seven records per step (the smaller shard padded with a market
+    nobody reads), the HIP unpack kernel skips the padding; both ranks' learner-side arrays equal the oracle's single-process run, bit for bit."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    import oracle_lib as O
+    n_total = 13
+    mp.spawn(_uneven_worker, args=(2, 30100 + os.getpid() % 500, str(tmp_path), n_total), nprocs=2, join=True)
+    ora = O.OracleEnv({"num_of_agents": 4, "init_cash": 1000000, "max_step": 64, "is_render": False}, n_total)
+    ora.reset(seeds=(1000 + np.arange(n_total)).astype(np.uint64))
+    got = [np.load(tmp_path / f"uneven_{r}.npz") for r in range(2)]
+    for t in range(10):
+        rng = np.random.default_rng(700 + t)
+        full = (rng.integers(0, 9, (n_total, 4)).astype(np.int32), rng.uniform(-1, 1, (n_total, 4)).astype(np.float32), rng.uniform(0, 1, (n_total, 4)).astype(np.float32),
+                rng.integers(0, 10, (n_total, 4)).astype(np.int32), rng.integers(0, 3, (n_total, 4)).astype(np.int32))
+        oo, orw, _, _, _ = ora.step(*full)
+        for r in range(2):
+            assert np.array_equal(got[r]["obs"][t].view(np.uint32), oo.view(np.uint32)), (r, t)
+            assert np.array_equal(got[r]["rew"][t].view(np.uint64), orw.view(np.uint64)), (r, t)
+    ora.close()

@@ -11,10 +11,11 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "cda.h")
+MLP_HEADER = os.path.join(ROOT, "include", "cda_mlp.h")
 
 
-def _declared_symbols():
-    txt = open(HEADER).read()
+def _declared_symbols(header=HEADER):
+    txt = open(header).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(cda_[a-z_0-9]+)\s*\(", txt)))
 
@@ -35,6 +36,12 @@ def test_every_declared_symbol_is_exported(hip_lib):
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/cda.h but not exported by libcda_hip.so"
     assert sorted(_lib.SYMBOLS) == declared
+    # ... and every symbol of the network's header (include/cda_mlp.h)
+    declared_mlp = _declared_symbols(MLP_HEADER)
+    assert len(declared_mlp) >= 10
+    for name in declared_mlp:
+        assert hasattr(L, name), f"{name} declared in include/cda_mlp.h but not exported by libcda_hip.so"
+    assert sorted(_lib.MLP_SYMBOLS) == declared_mlp
 
 
 def test_ctypes_layout_matches_c(tmp_path):

@@ -62,14 +62,18 @@ def _actions(t):
             torch.from_numpy(rng.integers(0, 3, (N_TOTAL, A)).astype(np.int32)))
 
 
-def unpack_restated(records, n_segments, seg_records, seg_row_stride, row0, num_agents, n_hist, obs, reward, term, trunc):
+def unpack_restated(records, n_segments, seg_records, seg_row_stride, row0, num_agents, n_hist, obs, reward, term, trunc, n_rows_total=0):
     """cda_handback_unpack restated in numpy (the receiving side of the hand-back): shift the row by one frame, append the new one
-    (restarted: every frame = the new one), overwrite reward and flags."""
+    (restarted: every frame = the new one), overwrite reward and flags.  n_rows_total > 0 (uneven shards): segment s owns seg_row_stride
+    rows, the last one the remainder; records beyond a segment's rows are padding and are skipped."""
     rec = records.numpy().reshape(n_segments * seg_records, -1)
     o, r, te, tr = obs.numpy(), reward.numpy(), term.numpy(), trunc.numpy()
     a = num_agents
     for j in range(rec.shape[0]):
-        row = row0 + (j // seg_records) * seg_row_stride + j % seg_records
+        seg, local = j // seg_records, row0 + j % seg_records
+        if n_rows_total > 0 and local >= (n_rows_total - seg * seg_row_stride if seg == n_segments - 1 else seg_row_stride):
+            continue
+        row = seg * seg_row_stride + local
         frame = rec[j, :168].view(np.float32)
         if rec[j, 170 + 8 * a]:
             o[row] = np.tile(frame, n_hist)
@@ -137,8 +141,22 @@ def _worker_uneven(rank, world, port, outdir, n_total):
         g = env.gather(*env.step(*acts)[:4])
         assert g[0].shape[0] == n_total
         rec.append([x.clone().numpy() for x in g])
-    with pytest.raises(ValueError):                                # the hand-back path wants equal shards
-        ShardedVecEnv(CFG, n_total, device=None, env_factory=lambda c, n, d, g: _OracleStepper(c, n, d, g), handback=True, unpack=unpack_restated)
+    # the hand-back with uneven shards: every rank steps and sends the largest shard's record count (the smaller shards padded with markets
+    # nobody reads), the receiving side skips the padding; `full` equals the packed gather on every rank, every step
+    hb = ShardedVecEnv(CFG, n_total, device=None, env_factory=lambda c, n, d, g: _OracleStepper(c, n, d, g), groups=2, handback=True, unpack=unpack_restated)
+    assert hb.n_env == n_total // world + n_total % world and hb.n_local == shard_range(rank, world, n_total)[1] and hb.uneven
+    o0 = hb.reset(seed_base=1000)
+    assert o0.shape[0] == hb.n_local
+    for t in range(8):
+        rng = np.random.default_rng(500 + t)
+        full = (rng.integers(0, 9, (n_total, A)).astype(np.int32), rng.uniform(-1, 1, (n_total, A)).astype(np.float32),
+                rng.uniform(0, 1, (n_total, A)).astype(np.float32), rng.integers(0, 10, (n_total, A)).astype(np.int32),
+                rng.integers(0, 3, (n_total, A)).astype(np.int32))
+        acts = [torch.from_numpy(x[hb.first:hb.first + hb.n_local]) for x in full]
+        obs, rew, term, trunc, _ = hb.step(*acts)
+        assert obs.shape[0] == hb.n_local
+        assert np.array_equal(hb.full[0].numpy().view(np.uint32), rec[t][0].view(np.uint32)), (rank, t)
+        assert np.array_equal(hb.full[1].numpy().view(np.uint64), np.ascontiguousarray(rec[t][1]).view(np.uint64)), (rank, t)
     if rank == 0:
         np.savez(os.path.join(outdir, "uneven.npz"), obs=np.stack([r[0] for r in rec]), rew=np.stack([r[1] for r in rec]))
     dist.barrier()

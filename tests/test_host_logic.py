@@ -138,3 +138,28 @@ def test_lazy_info_dicts_are_real_dicts_once_touched():
         d = mk()
         d["extra"] = 1                                              # a consumer may add to it
         assert {k2: v for k2, v in d.items() if k2 != "extra"} == want
+
+
+def test_handback_watchdog_exits_instead_of_hanging():
+    """a native collective call that never returns, or whose work the device never finishes, ends the process with exit code 3
+    and a diagnostic inside the deadline (parallel._guarded) - it does not hang until somebody kills the job."""
+    import os
+    import subprocess
+    import sys
+    import time
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import time, sys; sys.path.insert(0, %r)\n"
+            "from gym_continuousdoubleauction_amd.parallel import _guarded\n"
+            "print(_guarded(lambda: 41 + 1, 'quick call', timeout=5), flush=True)\n"
+            "%s\n") % (ROOT, "%s")
+    t0 = time.time()
+    hang = subprocess.run([sys.executable, "-c", code % "_guarded(lambda: time.sleep(60), 'a collective that never returns', timeout=1.0)"], capture_output=True, text=True, timeout=120)
+    assert hang.returncode == 3 and "[cda watchdog]" in hang.stderr and "never returns" in hang.stderr and hang.stdout.strip() == "42"
+    assert time.time() - t0 < 45
+    code2 = code % ("class S:\n    def query(self):\n        return False\n_guarded(lambda: None, 'device never finishes', streams=[S()], timeout=1.0)")
+    stuck = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert stuck.returncode == 3 and "did not finish the enqueued collectives" in stuck.stderr
+    # an exception inside the guarded call comes back on the caller's thread
+    code3 = code % "try:\n    _guarded(lambda: 1 / 0, 'raises', timeout=5)\nexcept ZeroDivisionError:\n    print('raised')"
+    ok = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and ok.stdout.split() == ["42", "raised"]

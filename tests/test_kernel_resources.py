@@ -18,13 +18,15 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 def _kernels():
     """metadata of every kernel + the disassembled body of every function of the built library"""
     import __graft_entry__ as G
-    from kernel_resources import code_object
+    from kernel_resources import code_objects
     so = G.build_hip()
     co = os.path.join(ROOT, "gym_continuousdoubleauction_amd", "_kernel_resources.co")
+    notes = asm = ""
     try:
-        open(co, "wb").write(code_object(so))
-        notes = subprocess.run([READELF, "--notes", co], capture_output=True, text=True, check=True).stdout
-        asm = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        for blob in code_objects(so):                        # one code object per translation unit (env, PPO helpers, network)
+            open(co, "wb").write(blob)
+            notes += subprocess.run([READELF, "--notes", co], capture_output=True, text=True, check=True).stdout
+            asm += subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
     finally:
         if os.path.exists(co):
             os.remove(co)

@@ -12,19 +12,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def code_object(so):
-    """The AMDGPU ELF embedded in the host library's .hip_fatbin section."""
+def code_objects(so):
+    """Every AMDGPU ELF embedded in the host library's .hip_fatbin section (one per translation unit)."""
     d = open(so, "rb").read()
-    i = 0
+    out, i = [], 0
     while True:
         i = d.find(b"\x7fELF", i)
         if i < 0:
-            raise SystemExit("no AMDGPU code object in " + so)
+            break
         if struct.unpack_from("<H", d, i + 18)[0] == 224:                       # EM_AMDGPU
             shoff = struct.unpack_from("<Q", d, i + 40)[0]
             shentsize, shnum = struct.unpack_from("<HH", d, i + 58)
-            return d[i:i + shoff + shentsize * shnum]
-        i += 4
+            out.append(d[i:i + shoff + shentsize * shnum])
+            i += shoff + shentsize * shnum
+        else:
+            i += 4
+    if not out:
+        raise SystemExit("no AMDGPU code object in " + so)
+    return out
+
+
+def code_object(so):
+    """the first one (the env kernels: cda_hip.hip)"""
+    return code_objects(so)[0]
 
 
 def main():
@@ -34,9 +44,12 @@ def main():
     ap.add_argument("--filter", default="", help="only kernels whose mangled name contains this")
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as td:
-        co = os.path.join(td, "cda.co")
-        open(co, "wb").write(code_object(a.lib))
-        notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        notes, cos = "", []
+        for k, blob in enumerate(code_objects(a.lib)):
+            co = os.path.join(td, f"cda{k}.co")
+            open(co, "wb").write(blob)
+            cos.append(co)
+            notes += subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
         for blk in notes.split("- .agpr_count:")[1:]:
             name = re.search(r"\.name:\s+(\S+)", blk)
             if not name or a.filter not in name.group(1):
@@ -47,7 +60,8 @@ def main():
                 g("private_segment_fixed_size"), g("group_segment_fixed_size")))
         if a.asm:
             with open(a.asm, "w") as f:
-                subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co], stdout=f, check=True)
+                for co in cos:
+                    subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co], stdout=f, check=True)
 
 
 if __name__ == "__main__":
