@@ -9,7 +9,27 @@ package never touches the GPU, constructing an env does and fails loudly without
 """
 from . import _capi  # noqa: F401
 
-__all__ = ["CDAVecEnv", "CDAEnv", "CDAVecMultiAgentEnv", "run_random"]
+__all__ = ["CDAVecEnv", "CDAEnv", "CDAVecMultiAgentEnv", "run_random", "ENV_ID"]
+
+ENV_ID = "continuousDoubleAuction-v0"
+
+
+def _register_with_gymnasium():
+    """The reference registers its env with gymnasium at import (gym_continuousDoubleAuction/__init__.py:18-21: id
+    'continuousDoubleAuction-v0').  So does this package where gymnasium is importable - same id, the single-market facade as the entry
+    point (`gymnasium.make('continuousDoubleAuction-v0', config={...})`); without gymnasium there is nothing to register with."""
+    try:
+        from gymnasium.envs.registration import register
+    except Exception:  # noqa: BLE001 - gymnasium absent (this build image): fine
+        return False
+    try:
+        register(id=ENV_ID, entry_point="gym_continuousdoubleauction_amd.env:CDAEnv")
+    except Exception:  # noqa: BLE001 - e.g. the id is taken by the reference itself, imported next to this package
+        return False
+    return True
+
+
+GYMNASIUM_REGISTERED = _register_with_gymnasium()
 
 
 def __getattr__(name):

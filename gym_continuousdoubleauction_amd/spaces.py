@@ -5,7 +5,7 @@ stand-in with the same attributes (`shape`, `dtype`, `n`, `low`, `high`, `spaces
 `contains`) so the env is usable in images without gymnasium (this build image has none)."""
 import numpy as np
 
-try:  # pragma: no cover - gymnasium is absent from the build image
+try:  # (gymnasium is absent from the build image; tests/test_host_logic.py runs this branch under the stand-in of tests/golden/shim)
     from gymnasium import spaces as _gs
     Box, Discrete, Dict = _gs.Box, _gs.Discrete, _gs.Dict
     HAVE_GYMNASIUM = True

@@ -37,3 +37,8 @@ class Env:
 
     def close(self):
         pass
+
+
+def make(id, **kwargs):                            # noqa: A002
+    from .envs.registration import make as _make
+    return _make(id, **kwargs)
