@@ -19,7 +19,7 @@ SYMBOLS = [
     "cda_selftest_dec", "cda_selftest_rng", "cda_strerror", "cda_num_markets", "cda_obs_dim",
     "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host", "cda_nav_conservation",
     "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants", "cda_selftest_libm", "cda_selftest_libm_host", "cda_book_capacity",
-    "cda_get_book", "cda_step_specialised", "cda_book_spill", "cda_book_spill_wanted", "cda_num_agents", "cda_handback_stride", "cda_set_handback", "cda_set_handback_geometry", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
+    "cda_get_book", "cda_book_spill", "cda_book_spill_wanted", "cda_num_agents", "cda_handback_stride", "cda_set_handback", "cda_set_handback_geometry", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
 ]
 
 
@@ -85,7 +85,6 @@ def lib():
     L.cda_num_markets.argtypes = [vp]
     L.cda_num_agents.argtypes = [vp]
     L.cda_book_capacity.argtypes = [vp]
-    L.cda_step_specialised.argtypes = [vp]
     L.cda_book_spill.argtypes = [vp]
     L.cda_book_spill_wanted.argtypes = [vp]
     L.cda_policy_sample.argtypes = [vp, i32, vp, vp, i64, i32, u64, vp] + [vp] * 10 + [vp]

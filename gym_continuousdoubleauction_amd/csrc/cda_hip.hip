@@ -520,34 +520,10 @@ int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs
     return cda_reset_range(e, 0, e->P.n_markets, seeds, mask, obs_out, stream);
 }
 
-// The shape-specialised step kernels (cda_kernels.inc k_step<INFO, A, H>) bake the shape and the reference's default config in as constants:
-// they serve an env only when every one of those constants EQUALS its Params.  0 = the generic kernel.  CDA_STEP_GENERIC=1 in the
-// environment forces the generic kernel (A/B measurements).
-static int spec_agents(const cda_env* e) {
-    static int forced = -1;
-    if (forced < 0) { const char* v = getenv("CDA_STEP_GENERIC"); forced = (v && v[0] == '1') ? 1 : 0; }
-    if (forced) return 0;
-    const Params& P = e->P; const cda_config& c = P.cfg;
-    if (e->cap != 256 || (c.num_agents != 4 && c.num_agents != 8) || c.n_hist != SPEC_N_HIST || c.tick_size != 1 || c.min_size != SPEC_MIN_SIZE) return 0;
-    if (P.mkt_mul != SPEC_MKT_MUL || P.lim_mul != SPEC_LIM_MUL) return 0;
-    if (c.order_penalty != SPEC_ORDER_PENALTY || c.trade_penalty != SPEC_TRADE_PENALTY || c.drawdown_penalty != SPEC_DRAWDOWN_PENALTY ||
-        c.passive_bonus != SPEC_PASSIVE_BONUS || c.loss_multiplier != SPEC_LOSS_MULTIPLIER) return 0;
-    const Layout l = record_layout(c.num_agents, c.n_hist, 256);
-    if (l.acc_off != P.lay.acc_off || l.hist_off != P.lay.hist_off || l.book_off != P.lay.book_off || l.stride != P.lay.stride) return 0;
-    return c.num_agents;
-}
-extern "C" int32_t cda_step_specialised(const cda_env* e) { return e ? spec_agents(e) : 0; }
-
 // one launch of k_step (+ the auto-reset pass) over [first, first + n) on `stream`; arguments validated by the callers
 static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0, hipStream_t stream) {
     const size_t smem = smem_for(e, CDA_WPB) + ZIG_LDS_BYTES;
-    const int spec = spec_agents(e);
-    if (spec) {
-        cda::cap256::StepKernArgs K; K.arena = e->arena; K.P = e->P; K.S = S0; K.S.first_market = first; K.S.end_market = first + n;
-        const dim3 g = grid_for(n), b = dim3(64 * CDA_WPB);
-        if (spec == 4) { if (K.S.has_info) hipLaunchKernelGGL((cda::cap256::k_step<true, 4, SPEC_N_HIST>), g, b, smem, stream, K); else hipLaunchKernelGGL((cda::cap256::k_step<false, 4, SPEC_N_HIST>), g, b, smem, stream, K); }
-        else { if (K.S.has_info) hipLaunchKernelGGL((cda::cap256::k_step<true, 8, SPEC_N_HIST>), g, b, smem, stream, K); else hipLaunchKernelGGL((cda::cap256::k_step<false, 8, SPEC_N_HIST>), g, b, smem, stream, K); }
-    } else if (e->cap == 512) {
+    if (e->cap == 512) {
         cda::cap512::StepKernArgs K; K.arena = e->arena; K.P = e->P; K.S = S0; K.S.first_market = first; K.S.end_market = first + n;
         if (K.S.has_info) hipLaunchKernelGGL(cda::cap512::k_step<true>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
         else hipLaunchKernelGGL(cda::cap512::k_step<false>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);

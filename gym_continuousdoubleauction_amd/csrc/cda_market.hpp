@@ -76,8 +76,7 @@ struct Layout {                  // byte offsets inside a market record
     int32_t spill_cap;           // orders per side the market's HBM spill ring holds (a power of two; 0 = no HBM tier)
 };
 
-// the record layout of an env with `num_agents` agents, `n_hist` frames and a book tile of `cap` orders: ONE definition, used by cda_create
-// (run time) and by the shape-specialised step kernels (compile time)
+// the record layout of an env with `num_agents` agents, `n_hist` frames and a book tile of `cap` orders
 __host__ __device__ constexpr Layout record_layout(int num_agents, int n_hist, int cap) {
     Layout l{};
     int off = HEADER_BYTES;
@@ -95,11 +94,6 @@ struct Params {
     int32_t n_markets;
     float mkt_mul, lim_mul;
 };
-
-// The constants of the shape-specialised step kernels (k_step<INFO, A, H>): the reference's defaults (config/env_defaults.json:8-27).
-constexpr int SPEC_MIN_SIZE = 1, SPEC_MKT_MAX_SIZE = 100, SPEC_LIMIT_MULTIPLE = 10, SPEC_N_HIST = 4;
-constexpr float SPEC_MKT_MUL = 49.5f, SPEC_LIM_MUL = 499.5f;            // (mkt_max_size - min_size) / 2, (mkt_max_size * limit_size_multiple - min_size) / 2
-constexpr double SPEC_ORDER_PENALTY = 0.1, SPEC_TRADE_PENALTY = 0.05, SPEC_DRAWDOWN_PENALTY = 0.2, SPEC_PASSIVE_BONUS = 0.1, SPEC_LOSS_MULTIPLIER = 1.5;
 
 // ---- uniform (per-wave) market scalars kept in registers -----------------------------------
 struct Mkt {

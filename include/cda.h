@@ -408,9 +408,6 @@ const char* cda_strerror(int status);
 int32_t cda_num_markets(const cda_env* env);
 int32_t cda_num_agents(const cda_env* env);
 int32_t cda_book_capacity(const cda_env* env);   /* 256 or 512: the LDS tile this env was built with */
-/* 4 / 8: this env is stepped by a shape-specialised build of the step kernel (agent count, history depth, record layout and the reference's
- * default size / reward constants compiled in); 0: by the generic one (any other shape or config; CDA_STEP_GENERIC=1 forces it). */
-int32_t cda_step_specialised(const cda_env* env);
 int32_t cda_obs_dim(const cda_env* env);
 /* Bytes the arena keeps per market in HBM. */
 int64_t cda_state_bytes_per_market(const cda_env* env);
