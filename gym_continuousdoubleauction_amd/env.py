@@ -254,9 +254,21 @@ class _DictSurface(_Base):
         terminateds["__all__"] = bool(term[i])
         truncateds["__all__"] = bool(trunc[i])
         lob = info["lob_actions"][i]
-        # env.LOB_actions (continuousDoubleAuction_env.py:284-285): the decoded orders in the order of the action dict, passes left out
+        # env.LOB_actions (continuousDoubleAuction_env.py:284-285): the decoded orders in the order of the action dict, passes left out.
+        # Keys are mapped to the canonical agent ids the way _encode resolves them (a key like "agent_02" or "trader_2" addresses agent_2:
+        # its order and its model_action must not disappear from the outputs)
         index = {a: k for k, a in enumerate(agents)}
-        listed = [a for a in actions if a in index] if actions is not None else agents
+        if actions is not None:
+            canon = {}
+            for key in actions:
+                k = index.get(key)
+                if k is None:
+                    k = int(str(key).split("_")[1])
+                canon[agents[k]] = key
+            listed = list(canon)
+            actions = {a: actions[key] for a, key in canon.items()}
+        else:
+            listed = agents
         lob_actions = [
             {"ID": a, "side": ("bid", "ask")[int(row[0])], "type": ("market", "limit", "modify", "cancel")[int(row[1])],
              "size": int(row[2]), "price": float(row[3])}
@@ -309,10 +321,10 @@ class CDAEnv(_DictSurface):
 
     def book(self):
         """(bids, asks): lists of dicts in queue order (best price first, FIFO inside a level)."""
-        s = self._vec.get_state(0)
-        conv = lambda o: {"price": o.price, "quantity": o.qty, "trade_id": o.owner, "order_id": o.order_id,  # noqa: E731
-                          "timestamp": o.timestamp}
-        return [conv(o) for o in s.bids[: s.n_bids]], [conv(o) for o in s.asks[: s.n_asks]]
+        conv = lambda o: {"price": int(o[0]), "quantity": int(o[1]), "trade_id": int(o[2]), "order_id": int(o[3]),  # noqa: E731
+                          "timestamp": int(o[4])}
+        bids, asks = self._vec.get_book(0)              # the WHOLE book (cda_get_book), not the first CDA_BOOK_CAP_MAX orders of the state dump
+        return [conv(o) for o in bids], [conv(o) for o in asks]
 
     # -- reset / step ---------------------------------------------------------------------
     def reset(self, *, seed=None, options=None):

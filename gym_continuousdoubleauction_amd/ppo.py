@@ -343,7 +343,7 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
     x_all = obs.to(torch.bfloat16) if amp else obs
     rows_mb = max(1, minibatch // A)
     stats = {}
-    graph_key = (R, A, obs.shape[1], x_all.dtype, rows_mb, clip, vf_coef, ent_coef)
+    graph_key = (R, A, obs.shape[1], x_all.dtype, rows_mb, clip, vf_coef, ent_coef, id(model), id(opt))     # (the captured graphs hold raw references to THIS model and optimiser)
     use_graphs = graphs is not None and fused and obs.is_cuda
     if use_graphs and graphs.get("key") == graph_key:
         stats = graphs["update"].run(x_all, actions, logp_old, adv, ret, epochs)

@@ -146,8 +146,10 @@ typedef struct cda_account_state {
     int32_t num_trades_step, num_passive_fills_step, order_step_placed, num_rejected_step;
 } cda_account_state;
 
-/* The dump holds the first CDA_BOOK_CAP_MAX orders of each side; n_bids / n_asks are the TRUE counts (they may be larger:
- * cda_get_book reads a side of any length). */
+/* The dump holds the first CDA_BOOK_CAP_MAX orders of each side; n_bids / n_asks are the TRUE counts and MAY EXCEED the arrays (since round 3:
+ * the book is unbounded; cda_get_book reads a side of any length).  A C caller walking the arrays must stop at
+ * min(n_bids, CDA_BOOK_CAP_MAX) / min(n_asks, CDA_BOOK_CAP_MAX).  cda_set_state with a count above CDA_BOOK_CAP_MAX means "keep the book as it is"
+ * (the counts must equal the market's current ones) and restores everything else of the dump. */
 typedef struct cda_market_state {
     uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;  /* numpy PCG64 */
     uint32_t rng_has_uint32, rng_uinteger;

@@ -392,6 +392,10 @@ def test_lob_actions_hold_the_decoded_orders():              # test_new_action_s
     assert got["agent_2"]["type"] == "cancel" and got["agent_2"]["side"] == "ask" and got["agent_2"]["price"] > 0
     env.reset(seed=5)
     assert env.LOB_actions is None
+    # keys that only RESOLVE to an agent ("agent_02" -> agent 2: _encode's fallback) address that agent in every output too
+    _, _, _, _, infos = env.step({"agent_02": one(2, price=1), "agent_0": one(1)})
+    assert [a["ID"] for a in env.LOB_actions] == ["agent_2", "agent_0"]          # dict order, canonical ids
+    assert infos["agent_2"]["model_action"] is not None and infos["agent_0"]["model_action"] is not None and "model_action" not in infos["agent_1"]
     env.close()
 
 
