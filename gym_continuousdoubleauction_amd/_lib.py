@@ -25,7 +25,7 @@ SYMBOLS = [
 
 # every symbol include/cda_mlp.h declares
 MLP_SYMBOLS = [
-    "cda_mlp_tile_rows", "cda_mlp_pack", "cda_mlp_policy_step", "cda_mlp_forward", "cda_mlp_prep_rows", "cda_mlp_forward_train", "cda_mlp_backward",
+    "cda_mlp_tile_rows", "cda_mlp_permutation", "cda_mlp_pack", "cda_mlp_policy_step", "cda_mlp_forward", "cda_mlp_prep_rows", "cda_mlp_forward_train", "cda_mlp_backward",
     "cda_mlp_wgrad", "cda_mlp_adam", "cda_ppo_loss32", "cda_mlp_rollout_chain", "cda_mlp_selftest_mfma",
 ]
 
@@ -105,6 +105,7 @@ def lib():
     L.cda_mlp_tile_rows.argtypes = []
     L.cda_mlp_tile_rows.restype = i32
     L.cda_mlp_pack.argtypes = [vp, vp, vp]
+    L.cda_mlp_permutation.argtypes = [u64, i64, vp, vp]
     L.cda_mlp_policy_step.argtypes = [vp, vp, vp, i32, i32, i32, u64, vp, i64] + [vp] * 8 + [vp]
     L.cda_mlp_forward.argtypes = [vp, vp, vp, i64, i64, vp, vp]
     L.cda_mlp_prep_rows.argtypes = [vp, vp, i64, vp, vp, vp]

@@ -182,10 +182,12 @@ struct FwdArgs {
     // MODE_SAMPLE
     int agents; unsigned long long seed; const long long* counter; long long draw;
     int* env_cat; float* env_mean; float* env_sigma; int* env_price; int* env_off; float* a_cont; float* logp; float* value;
+    int split_halves;            // 1: gridDim.y = 2, workgroup (x, y) runs network half y only (policy | value: independent networks; the rollout's launches);
+                                 // 2: the value half only (the bootstrap value); 0: both halves, one after the other
     unsigned long long* dbg; int dbg_block;       // CDA_MLP_TIMING builds (tools/libcda_tools.so) only: cycle stamps of one workgroup, [4 waves][32]
 };
 #ifdef CDA_MLP_TIMING
-#define MLP_MARK(i) do { if (A.dbg && (int)blockIdx.x == A.dbg_block && lane == 0) A.dbg[w * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define MLP_MARK(i) do { if (A.dbg && (int)blockIdx.x == A.dbg_block && blockIdx.y == 0 && lane == 0) A.dbg[w * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MLP_MARK(i) do {} while (0)
 #endif
@@ -245,9 +247,12 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
     f32x16 acc3[1][1]; acc3[0][0] = zero16();                                   // heads: wave w owns row tile w (waves >= MT idle there)
     WRing<2, KX / 16, PF, true> R1; WRing<2, HID / 16, PF, true> R2; WRing<1, HID / 16, PF> RO;
-    R1.prime(W1b + (size_t)(64 * w) * KX, KX, lane);
+    // The two halves are independent networks: a rollout launch gives each its own workgroup (half the serial chain, half the weight bytes
+    // through one CU's L1); the update's launches run both in one workgroup (the observation tile is staged once).
+    const int half_begin = A.split_halves == 1 ? (int)blockIdx.y : (A.split_halves == 2 ? 1 : 0), half_end = A.split_halves ? half_begin + 1 : 2;
+    R1.prime(W1b + (size_t)(256 * half_begin + 64 * w) * KX, KX, lane);
     #pragma unroll 1
-    for (int half = 0; half < 2; half++) {
+    for (int half = half_begin; half < half_end; half++) {
         const int f0 = 256 * half + 64 * w;                                     // this wave's first feature (of 512)
         {   // layer 1: [M, 176] x W1[f0 .. f0 + 63]^T
             f32x16 acc[MT][2];
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             layer_mma(xs, XS_LD, R1, lane, acc);
             MLP_MARK(2 + 8 * half);
             R2.prime(W2b + ((size_t)half * HID + 64 * w) * HID, HID, lane);     // (in flight across the epilogue and its barrier)
-            if (half == 1) __syncthreads();                                     // the heads of half 0 still read `act`
+            if (half != half_begin) __syncthreads();                            // the heads of the previous half still read `act`
             const float bias0 = half ? b1s[1][0] : b1s[0][0], bias1 = half ? b1s[1][1] : b1s[0][1];
             #pragma unroll
             for (int it = 0; it < MT; it++) {
@@ -297,26 +302,28 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             }
         }
         MLP_MARK(6 + 8 * half);
-        if (half == 0) R1.prime(W1b + (size_t)(256 + 64 * w) * KX, KX, lane);   // the value half's first layer, requested across the heads
+        if (half + 1 < half_end) R1.prime(W1b + (size_t)(256 + 64 * w) * KX, KX, lane);   // the value half's first layer, requested across the heads
         __syncthreads();
         MLP_MARK(7 + 8 * half);
         // heads: [32 rows of tile w, 256] x Wob[half]^T (the other half's rows of Wob are zero); waves >= MT multiply a tile nobody reads
         layer_mma(act + (w < MT ? 32 * w : 0) * ACT_LD, ACT_LD, RO, lane, acc3);
         MLP_MARK(8 + 8 * half);
     }
-    // outputs: column j of rows rowmap(r, h) of row tile w
+    // outputs: column j of rows rowmap(r, h) of row tile w.  A workgroup that ran one half only owns that half's columns (policy: 0 .. 23 and the
+    // zero padding; value: 24)
+    const bool own_col = !A.split_halves || (half_begin == 0 ? j != N_LOGITS : j == N_LOGITS);
     if (w < MT) {
         #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = 32 * w + rowmap(r, h);
             const float o = acc3[0][0][r] + bo;
-            if (MODE == MODE_SAMPLE) outs[row * OUTS_LD + j] = o;
+            if (MODE == MODE_SAMPLE) { if (half_begin == 0) outs[row * OUTS_LD + j] = o; else if (j == N_LOGITS && row0 + row < rows_end) A.value[row0 + row] = o; }
             else if (MODE == MODE_VALUE) { if (j == N_LOGITS && row0 + row < rows_end) A.value[row0 + row] = o; }
-            else if (MODE == MODE_TRAIN || row0 + row < rows_end) A.out[(row0 + row) * NOUT + j] = o;
+            else if (own_col && (MODE == MODE_TRAIN || row0 + row < rows_end)) A.out[(row0 + row) * NOUT + j] = o;
         }
     }
     MLP_MARK(18);
-    if (MODE == MODE_SAMPLE) {
+    if (MODE == MODE_SAMPLE && half_begin == 0) {
         __syncthreads();
         // one thread per (row, agent) sample: three categorical heads by inverse CDF, two Gaussian heads by Box-Muller, the action's
         // log-probability, and the env's five action words (size_mean = tanh, size_sigma = sigmoid: the Box bounds of
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             float l[N_LOGITS];
             #pragma unroll
             for (int q = 0; q < N_LOGITS; q++) l[q] = outs[row * OUTS_LD + q];
-            if (a == 0) A.value[grow] = outs[row * OUTS_LD + N_LOGITS];
+            if (a == 0 && !A.split_halves) A.value[grow] = outs[row * OUTS_LD + N_LOGITS];
             const unsigned long long w0 = mix64(key + (unsigned long long)i), w1 = mix64(w0), w2 = mix64(w1);
             float lp = 0.0f;
             const int c = sample_head<N_CAT>(l, u01(w0, 0), lp);
@@ -351,6 +358,30 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
         }
     }
     MLP_MARK(19);
+}
+
+// ---- update: the epoch's shuffle as a keyed bijection (no sort) -----------------------------------------------------------------------
+// perm[i] = walk(i): a bijective mixer on [0, 2^bits) (add, odd multiply, xor-shift: each step invertible), iterated until the value falls
+// below n (cycle walking: < 2 rounds on average, since 2^bits < 2 n).  torch.randperm is a device sort: ~10 launches, 130 us per epoch.
+__device__ __forceinline__ unsigned int perm_mix(unsigned int x, int bits, unsigned long long key) {
+    const unsigned int mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    const int s1 = (bits + 1) / 2, s2 = (2 * bits + 2) / 3;
+    #pragma unroll
+    for (int r = 0; r < 4; r++) {
+        x = (x + (unsigned int)(key >> (16 * r))) & mask;
+        x = (x * 0x9E3779B1u) & mask;
+        x ^= x >> s1;
+        x = (x * 0x85EBCA6Bu) & mask;
+        x ^= x >> s2;
+    }
+    return x;
+}
+__global__ void k_make_perm(unsigned long long key, long long n, int bits, long long* __restrict__ perm) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned int x = (unsigned int)i;
+    do { x = perm_mix(x, bits, key); } while ((long long)x >= n);
+    perm[i] = (long long)x;
 }
 
 // ---- update, step 0: gather + convert + both images of the observation rows ---------------------------------------------------
@@ -582,6 +613,7 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
 // (16-B loads, a wave reads 1 KB per chunk, eight chunks in flight), mapped back to the parameter index (the slab's paddings and the heads'
 // masked blocks have none).  Biases (+ log_std): 64 entries per block, the row tiles split over 16 threads each.
 constexpr int RED_DENSE_BLOCKS = CDA_MLP_SLAB / 4 / 256;                          // 240
+constexpr int NORM_PARTIALS = 8;                                                 // scratch[8 + block]: the blocks' shares of the squared gradient norm
 constexpr int RED_BIAS_BLOCKS = (CDA_MLP_BSLAB + 1 + 15) / 16;                    // 67 (entry 1056 = the log_std pair)
 __device__ __forceinline__ int param_of_dense(int d) {
     if (d < CDA_MLP_SLAB_W2) { const int o = d / (32 * XT), i = d - o * (32 * XT); return i < OBS ? CDA_MLP_OFF_W1 + o * OBS + i : -1; }
@@ -593,7 +625,7 @@ __device__ __forceinline__ int param_of_dense(int d) {
 }
 struct LossFinish { double* sums5; long long samples; float vf_coef, ent_coef; float* out6; };
 __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slab, int n_chunks, const float* __restrict__ bslab, int n_tiles,
-                                                     LossFinish LF, float* __restrict__ grad, double* __restrict__ norm2) {
+                                                     LossFinish LF, float* __restrict__ grad, double* __restrict__ norm2, float* __restrict__ step) {
     __shared__ float red[16][64];
     float sq = 0.0f;
     if ((int)blockIdx.x < RED_DENSE_BLOCKS) {
@@ -665,7 +697,9 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
     __shared__ float wsum[4];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(norm2, (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3]);
+    // this block's share of the squared norm: a plain store (no atomic accumulator to clear between calls); k_adam sums the shares
+    if (threadIdx.x == 0) norm2[NORM_PARTIALS + blockIdx.x] = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
+    if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1.0f;                   // nobody reads it in this launch; k_adam (next on the stream) sees t
 }
 __device__ __forceinline__ void pack_one(int p, float v, __bf16* __restrict__ wb) {
     const __bf16 b = (__bf16)v;
@@ -687,13 +721,21 @@ __global__ void k_pack(const float* __restrict__ theta, __bf16* __restrict__ wb)
     const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (p < CDA_MLP_PARAMS) pack_one(p, theta[p], wb);
 }
-// scratch f64[3]: [0] the squared-norm accumulator (zero between calls: the last block to finish clears it), [1] the finished-block counter
-// (as an integer), [2] the squared norm of this call's gradient (output)
-__global__ __launch_bounds__(256) void k_adam(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v, float* __restrict__ step, __bf16* __restrict__ wb,
+// scratch f64[CDA_MLP_SCRATCH]: [2] = the squared norm of this call's gradient (output), [8 + b] = block b's share of it (k_grad_reduce)
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step, __bf16* __restrict__ wb,
                                               const float* __restrict__ grad, double* __restrict__ scratch, float lr, float b1, float b2, float eps, float max_norm) {
     const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const float t = step[0] + 1.0f;
-    const double n2 = scratch[0];
+    // every block sums the shares itself (307 doubles from L2): no grid-wide accumulator, nothing to clear, no fence
+    __shared__ double part[4];
+    double acc = 0.0;
+    for (int b = (int)threadIdx.x; b < RED_DENSE_BLOCKS + RED_BIAS_BLOCKS; b += 256) acc += scratch[NORM_PARTIALS + b];
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const double n2 = (part[0] + part[1]) + (part[2] + part[3]);
+    if (p == 0) scratch[2] = n2;
+    const float t = step[0];                                                    // (already counts this step: k_grad_reduce raised it)
     if (p < CDA_MLP_PARAMS) {
         const float coef = fminf(1.0f, max_norm / ((float)sqrt(n2) + 1e-6f));    // torch.nn.utils.clip_grad_norm_
         const float g = grad[p] * coef;
@@ -703,12 +745,6 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ theta, float* 
         const float th = theta[p] - (lr / c1) * mm / (sqrtf(vv) / sqrtf(c2) + eps);
         theta[p] = th;
         pack_one(p, th, wb);
-    }
-    __syncthreads();                                                            // every thread of the block has read step and the norm
-    if (threadIdx.x == 0) {
-        __threadfence();
-        unsigned int* done = reinterpret_cast<unsigned int*>(scratch + 1);
-        if (atomicAdd(done, 1u) == gridDim.x - 1) { scratch[2] = n2; scratch[0] = 0.0; *done = 0u; step[0] = t; }
     }
 }
 
@@ -862,11 +898,11 @@ int allow_lds(K kern, size_t bytes) {
 template <int MODE>
 int launch_fwd(const FwdArgs& A, int mt, hipStream_t st) {
     const size_t lds = fwd_lds(mt, MODE);
-    const unsigned grid = (unsigned)((A.n_rows + 32 * mt - 1) / (32 * mt));
+    const dim3 grid((unsigned)((A.n_rows + 32 * mt - 1) / (32 * mt)), A.split_halves == 1 ? 2u : 1u);
     int rc = CDA_OK;
-    if (mt == 4) { rc = allow_lds(k_mlp_fwd<4, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<4, MODE>), dim3(grid), dim3(256), lds, st, A); }
-    else if (mt == 2) { rc = allow_lds(k_mlp_fwd<2, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<2, MODE>), dim3(grid), dim3(256), lds, st, A); }
-    else { rc = allow_lds(k_mlp_fwd<1, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<1, MODE>), dim3(grid), dim3(256), lds, st, A); }
+    if (mt == 4) { rc = allow_lds(k_mlp_fwd<4, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<4, MODE>), grid, dim3(256), lds, st, A); }
+    else if (mt == 2) { rc = allow_lds(k_mlp_fwd<2, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<2, MODE>), grid, dim3(256), lds, st, A); }
+    else { rc = allow_lds(k_mlp_fwd<1, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<1, MODE>), grid, dim3(256), lds, st, A); }
     if (rc) return rc;
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
@@ -884,6 +920,7 @@ extern "C" int cda_tools_mlp_fwd_timing(const void* wb, const float* theta, cons
         A.agents = agents; A.seed = 1; A.counter = (const long long*)counter; A.draw = 0;
         A.env_cat = (int*)s; A.env_price = (int*)(s + 4 * NA); A.env_off = (int*)(s + 8 * NA); A.env_mean = (float*)(s + 12 * NA); A.env_sigma = (float*)(s + 16 * NA);
         A.a_cont = (float*)(s + 20 * NA); A.logp = (float*)(s + 28 * NA); A.value = (float*)(s + 32 * NA);
+        A.split_halves = 1;                              // as the rollout launches it: the stamps are the policy half's workgroup
         return launch_fwd<MODE_SAMPLE>(A, mt, (hipStream_t)stream);
     }
     return launch_fwd<MODE_TRAIN>(A, mt, (hipStream_t)stream);
@@ -910,6 +947,7 @@ extern "C" int cda_mlp_policy_step(const void* wb, const float* theta, const flo
     A.agents = num_agents; A.seed = seed; A.counter = (const long long*)counter_dev; A.draw = draw;
     A.env_cat = env_category; A.env_mean = env_size_mean; A.env_sigma = env_size_sigma; A.env_price = env_price; A.env_off = env_price_offset;
     A.a_cont = a_cont; A.logp = logp; A.value = value;
+    A.split_halves = 1;
     return launch_fwd<MODE_SAMPLE>(A, rollout_mt(), (hipStream_t)stream);
 }
 
@@ -917,7 +955,16 @@ extern "C" int cda_mlp_forward(const void* wb, const float* theta, const float* 
     if (!wb || !theta || !obs || !out || first_row < 0 || n_rows < 1) return CDA_ERR_INVALID;
     FwdArgs A; memset(&A, 0, sizeof A);
     A.obs = obs; A.first_row = first_row; A.n_rows = n_rows; A.wb = (const __bf16*)wb; A.theta = theta; A.out = out;
+    A.split_halves = n_rows >= 32768 ? 0 : 1;
     return launch_fwd<MODE_OUT>(A, n_rows >= 32768 ? train_mt() : rollout_mt(), (hipStream_t)stream);
+}
+
+extern "C" int cda_mlp_permutation(uint64_t key, int64_t n, int64_t* perm, void* stream) {
+    if (!perm || n < 1 || n > ((int64_t)1 << 31)) return CDA_ERR_INVALID;
+    int bits = 1;
+    while (((int64_t)1 << bits) < n) bits++;
+    hipLaunchKernelGGL(k_make_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (unsigned long long)key, (long long)n, bits, (long long*)perm);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
 extern "C" int cda_mlp_prep_rows(const float* obs, const int64_t* perm, int64_t n_rows, void* x_rm, void* x_pk, void* stream) {
@@ -966,8 +1013,8 @@ extern "C" int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* s
     if (!theta || !adam_m || !adam_v || !step_dev || !wb || !slab || !bias_slab || !grad || !scratch3 || n_chunks < 1 || n_bias_tiles < 1 || (loss_sums5 && loss_samples < 1)) return CDA_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     LossFinish LF; LF.sums5 = loss_sums5; LF.samples = loss_samples; LF.vf_coef = vf_coef; LF.ent_coef = ent_coef; LF.out6 = loss_out6;
-    hipLaunchKernelGGL(k_grad_reduce, dim3(RED_DENSE_BLOCKS + RED_BIAS_BLOCKS), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, LF, grad, scratch3);
-    hipLaunchKernelGGL(k_adam, dim3((CDA_MLP_PARAMS + 255) / 256), dim3(256), 0, st, theta, adam_m, adam_v, step_dev, (__bf16*)wb, (const float*)grad, scratch3,
+    hipLaunchKernelGGL(k_grad_reduce, dim3(RED_DENSE_BLOCKS + RED_BIAS_BLOCKS), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, LF, grad, scratch3, step_dev);
+    hipLaunchKernelGGL(k_adam, dim3((CDA_MLP_PARAMS + 255) / 256), dim3(256), 0, st, theta, adam_m, adam_v, (const float*)step_dev, (__bf16*)wb, (const float*)grad, scratch3,
                        lr, beta1, beta2, eps, max_norm);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
@@ -1017,6 +1064,7 @@ extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* 
     FwdArgs V; memset(&V, 0, sizeof V);
     V.obs = B->obs + (size_t)n_steps * N * OBS; V.first_row = first_market; V.n_rows = n_markets; V.wb = (const __bf16*)wb; V.theta = theta;
     V.value = B->value + (size_t)n_steps * N;
+    V.split_halves = 2;                                  // the value network alone
     return launch_fwd<MODE_VALUE>(V, rollout_mt(), st);
 }
 #endif

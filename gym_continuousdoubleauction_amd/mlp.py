@@ -325,9 +325,10 @@ class FusedUpdate:
         self.doutp = e(pad * NOUT, bf)
         self.out, self.d_out = e(pad * NOUT, f32).view(-1, NOUT), e(pad * NOUT, f32).view(-1, NOUT)
         self.slab, self.bias_slab = e(self.chunks * SLAB, f32), e(self.n_tiles * BSLAB, f32)
-        self.grad, self.norm2 = e(PARAMS, f32), e(3, torch.float64)          # (norm2[2] = the squared gradient norm of the last step)
+        self.grad, self.norm2 = e(PARAMS, f32), e(512, torch.float64)        # (norm2[2] = the squared gradient norm of the last step)
         self.sums5, self.out6 = e(5, torch.float64), e(6, f32)
         self.perm = torch.zeros(self.R, dtype=torch.int64, device=dev)
+        self.shuffle_seed, self._epochs_done = 0x5DEECE66D, 0
 
     def minibatch_step(self, s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, apply=True):
         """rows [s, s + rows) of the prepared (shuffled) observations: one optimiser step"""
@@ -364,8 +365,10 @@ class FusedUpdate:
             assert t.is_contiguous()
         assert acts[0].dtype == torch.int32 and acts[3].dtype == torch.float32 and adv.dtype == torch.float32
         for ep in range(epochs):
-            if perms is None:
-                torch.randperm(self.R, device=dev, out=self.perm)
+            if perms is None:                                   # a keyed bijection per epoch (one launch; torch.randperm is a device sort)
+                self._epochs_done += 1
+                key = (self.shuffle_seed * 0x9E3779B97F4A7C15 + self._epochs_done * 0xD1342543DE82EF95) & (2 ** 64 - 1)
+                _check(L.cda_mlp_permutation(key, self.R, self.perm.data_ptr(), _stream(dev)), "cda_mlp_permutation")
             else:
                 self.perm.copy_(perms[ep])
             _check(L.cda_mlp_prep_rows(obs_rows.data_ptr(), self.perm.data_ptr(), self.R, self.x_rm.data_ptr(), self.x_pk.data_ptr(), _stream(dev)), "cda_mlp_prep_rows")

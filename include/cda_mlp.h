@@ -64,6 +64,7 @@ extern "C" {
 #define CDA_MLP_SLAB      245760
 /* bias partial sums of one row tile of the backward kernel: db1 [512] | db2 [512] | dbo [32]  (f32) */
 #define CDA_MLP_BSLAB     1056
+#define CDA_MLP_SCRATCH   512                    /* f64 words of cda_mlp_adam's scratch */
 
 /* rows per workgroup of the update's forward / backward kernels (32, 64 or 128: CDA_MLP_MT in the environment, default 128) = rows per
  * bias partial of cda_mlp_backward */
@@ -85,6 +86,10 @@ int cda_mlp_policy_step(const void* wb, const float* theta, const float* obs, in
                         float* a_cont, float* logp, float* value, void* stream);
 /* The network outputs alone for rows [first_row, first_row + n_rows) of obs f32[*,168] -> out f32[*,32] (same row indexing). */
 int cda_mlp_forward(const void* wb, const float* theta, const float* obs, int64_t first_row, int64_t n_rows, float* out, void* stream);
+
+/* An epoch's shuffle: perm i64[n] = a pseudo-random PERMUTATION of 0 .. n-1 determined by `key` (a keyed bijective mixer + cycle walking, one
+ * launch; the sort behind torch.randperm is ~10 launches). */
+int cda_mlp_permutation(uint64_t key, int64_t n, int64_t* perm, void* stream);
 
 /* Update, step 0: rows of obs f32[*,168] selected by perm i64[n_rows] (NULL = identity) -> x_rm bf16[n_rows][176] (row-major, zero
  * padded) and x_pk (packed, 6 feature tiles).  n_rows % 32 == 0. */
@@ -108,12 +113,11 @@ int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p, const void
  * the means go to loss_out6 (f32[6], may be NULL: what finish = 1 would have written, loss_samples = rows * agents_per_row) and the sums are
  * CLEARED for the next minibatch - no memset, no finishing launch between the steps of an update.
  * grad f32[CDA_MLP_PARAMS] receives the gradient before clipping (its never-written entries - the heads' rows 25..31 - must be zero: allocate
- * it zeroed); scratch3 f64[3] must be zero before the FIRST call and is kept consistent by the kernels ([0] accumulator, zero between calls;
- * [1] a counter; [2] = the squared norm of this call's gradient). */
+ * it zeroed); scratch f64[CDA_MLP_SCRATCH]: [2] = the squared norm of this call's gradient (output), the rest is the kernels' own. */
 int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* step_dev, void* wb,
                  const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
                  double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float* loss_out6,
-                 float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* scratch3, void* stream);
+                 float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* scratch, void* stream);
 
 /* cda_ppo_loss (cda.h) for int32 action arrays - the env's own action tensors as the rollout kernel wrote them.  norm_rows > 0:
  * the means (and the gradient's 1/B) are over norm_rows * agents_per_row samples instead of rows * agents_per_row (a minibatch
