@@ -533,7 +533,10 @@ static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0,
         else hipLaunchKernelGGL(cda::cap256::k_step<false>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
     }
     HIPCHK(hipGetLastError());
-    if (e->P.cfg.auto_reset) {            // same stream: every market-wave of it exits at once unless its episode just ended
+    // auto_reset: in the info-less kernel a market whose episode ended resets itself as the kernel's last act (reset_after_step in
+    // cda_kernels.inc); with info tensors the pass is a launch of its own behind the step (every market-wave of it exits at once unless its
+    // episode just ended)
+    if (e->P.cfg.auto_reset && S0.has_info) {
         LAUNCH_CAP(e, k_reset, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), stream, e->arena, e->P,
                            (const uint64_t*)NULL, (const uint8_t*)e->done_buf, S0.obs_out, (int)first, (int)(first + n),
                            e->handback, handback_stride_of(e->P.cfg.num_agents), 1);
