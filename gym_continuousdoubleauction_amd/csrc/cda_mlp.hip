@@ -27,6 +27,16 @@
 // The env kernels are built with -ffp-contract=off (their f64 sums must match CPython's); nothing here has such a constraint.
 #pragma clang fp contract(fast)
 
+#ifndef CDA_MLP_PF8
+#define CDA_MLP_PF8 4
+#endif
+#ifndef CDA_MLP_PF4
+#define CDA_MLP_PF4 4
+#endif
+#ifndef CDA_MLP_AD
+#define CDA_MLP_AD 2
+#endif
+
 namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -51,19 +61,19 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __
 __device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int r = 0; r < 16; r++) z[r] = 0.0f; return z; }
 
 // ---- the observation tile: M rows -> LDS image [row][XS_LD] bf16, columns 168 .. 175 zero --------------------------------------
-template <int M>
+template <int M, int NT = 256>
 __device__ __forceinline__ void load_x_bf16(const __bf16* __restrict__ x_rm, long long row0, long long rows_end, __bf16* xs) {
-    constexpr int CH = KX / 8, N = M * CH, PER = (N + 255) / 256;                // 22 chunks of 16 B per row; PER chunks per thread
+    constexpr int CH = KX / 8, N = M * CH, PER = (N + NT - 1) / NT;              // 22 chunks of 16 B per row; PER chunks per thread
     bf16x8 v[PER];
     #pragma unroll
     for (int u = 0; u < PER; u++) {                                             // every request first ...
-        const int c = (int)threadIdx.x + 256 * u, cc = c < N ? c : N - 1, r = cc / CH, q = cc - r * CH;
+        const int c = (int)threadIdx.x + NT * u, cc = c < N ? c : N - 1, r = cc / CH, q = cc - r * CH;
         long long gr = row0 + r; if (gr >= rows_end) gr = rows_end - 1;         // clamp: rows past the end repeat the last one (never used)
         v[u] = *reinterpret_cast<const bf16x8*>(x_rm + gr * KX + q * 8);
     }
     #pragma unroll
     for (int u = 0; u < PER; u++) {                                             // ... then the LDS image
-        const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
+        const int c = (int)threadIdx.x + NT * u, r = c / CH, q = c - r * CH;
         if (c < N) *reinterpret_cast<bf16x8*>(xs + r * XS_LD + q * 8) = v[u];
     }
 }
@@ -90,21 +100,24 @@ __device__ __forceinline__ void load_x_f32(const float* __restrict__ obs, long l
 // PRIMED - its first RING steps requested - before the previous layer's epilogue and barrier, and while step ks multiplies, step ks + RING
 // is requested.  hipcc on its own looks ONE step ahead and sinks every other request to just before its use, which leaves a wave with
 // 2 .. 8 MFMAs per step waiting ~600 cycles for L2 each time: hence the sched_barriers.
-// PAIRED (two column tiles): tile jt, lane j multiplies weight row 2 j + jt - a lane then holds two NEIGHBOURING output features of the
-// same rows, which is one dword of the row-major LDS image of the activations (no cross-lane exchange) - see feature_of().
+// The weights live in HBM in OPERAND ORDER (cda_mlp_pack / k_adam write them so): for a wave's group of 32 JT output features, column tile jt and
+// k-step ks, the 64 lanes' 16-byte pieces are 1 KB of CONTIGUOUS memory - a wave request is eight whole cache lines.  (Read from nn.Linear's
+// row-major [out][in] instead, a request touched 32 rows 512 B apart and used 32 B of every 128-B line; four waves' working set does not fit
+// the 32-KB L1, so every k-step re-fetched four times its bytes from L2: ~400 cycles per k-step however many MFMAs it held.)
+// PAIRED (two column tiles): tile jt, lane j holds weight row 2 j + jt of the group - a lane then holds two NEIGHBOURING output features of the
+// same rows, which is one dword of the row-major LDS image of the activations (no cross-lane exchange) - see feature_of() and pack_one().
 template <int JT, int KSTEPS, int PF, bool PAIRED = false>
 struct WRing {
     static constexpr int RING = PF < KSTEPS ? PF : KSTEPS;
-    static constexpr int TILE_STEP = PAIRED ? 1 : 32;                            // weight rows between the column tiles of one lane
     bf16x8 b[RING][JT];
-    const __bf16* base;                                                          // this lane's first 16 bytes: row, half-step (h)
-    int ld;
-    __device__ __forceinline__ void prime(const __bf16* __restrict__ b_glob, int b_ld, int lane) {
-        base = b_glob + (size_t)((PAIRED ? 2 : 1) * (lane & 31)) * b_ld + 8 * (lane >> 5); ld = b_ld;
+    const __bf16* base;                                                          // the group's image + this lane's 16 bytes
+    __device__ __forceinline__ const bf16x8* piece(int jt, int ks) const { return reinterpret_cast<const bf16x8*>(base + (size_t)(jt * KSTEPS + ks) * 512); }
+    __device__ __forceinline__ void prime(const __bf16* __restrict__ group, int /*ld*/, int lane) {
+        base = group + lane * 8;
         #pragma unroll
         for (int ks = 0; ks < RING; ks++)
             #pragma unroll
-            for (int jt = 0; jt < JT; jt++) b[ks][jt] = *reinterpret_cast<const bf16x8*>(base + (size_t)(TILE_STEP * jt) * ld + 16 * ks);
+            for (int jt = 0; jt < JT; jt++) b[ks][jt] = *piece(jt, ks);
         __builtin_amdgcn_sched_barrier(0);
     }
 };
@@ -114,27 +127,33 @@ __host__ __device__ __forceinline__ constexpr int feature_of(int ft, int q) { re
 template <int MT, int JT, int KSTEPS, int PF, bool PAIRED>
 __device__ __forceinline__ void layer_mma(const __bf16* a_lds, int a_ld, WRing<JT, KSTEPS, PF, PAIRED>& W, int lane, f32x16 (&acc)[MT][JT]) {
     constexpr int RING = WRing<JT, KSTEPS, PF, PAIRED>::RING;
-    constexpr int TILE_STEP = WRing<JT, KSTEPS, PF, PAIRED>::TILE_STEP;
     const __bf16* a_base = a_lds + (lane & 31) * a_ld + 8 * (lane >> 5);
-    bf16x8 a[2][MT];                                                            // the A operand (LDS) one step ahead as well: its read
-    #pragma unroll                                                              // latency hides under this step's MFMAs
-    for (int it = 0; it < MT; it++) a[0][it] = *reinterpret_cast<const bf16x8*>(a_base + 32 * it * a_ld);
+    // the A operand (LDS) runs AD steps ahead as well: with one step the read was issued a few dozen cycles before its use (a wave issues its
+    // step's MFMAs back to back) and every k-step ended in an exposed LDS round trip, ~200 cycles
+    constexpr int AD = CDA_MLP_AD, AR = AD + 1;
+    bf16x8 a[AR][MT];
+    #pragma unroll
+    for (int s0 = 0; s0 < AD && s0 < KSTEPS; s0++)
+        #pragma unroll
+        for (int it = 0; it < MT; it++) a[s0][it] = *reinterpret_cast<const bf16x8*>(a_base + 32 * it * a_ld + 16 * s0);
+    __builtin_amdgcn_s_setprio(1);                                              // a wave in its MFMA loop goes first: its SIMD may host a wave in a VALU epilogue
     #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) {
-        if (ks + 1 < KSTEPS) {
+        if (ks + AD < KSTEPS) {
             #pragma unroll
-            for (int it = 0; it < MT; it++) a[(ks + 1) & 1][it] = *reinterpret_cast<const bf16x8*>(a_base + 32 * it * a_ld + 16 * (ks + 1));
+            for (int it = 0; it < MT; it++) a[(ks + AD) % AR][it] = *reinterpret_cast<const bf16x8*>(a_base + 32 * it * a_ld + 16 * (ks + AD));
         }
         #pragma unroll
         for (int it = 0; it < MT; it++)
             #pragma unroll
-            for (int jt = 0; jt < JT; jt++) acc[it][jt] = mfma(a[ks & 1][it], W.b[ks % RING][jt], acc[it][jt]);
+            for (int jt = 0; jt < JT; jt++) acc[it][jt] = mfma(a[ks % AR][it], W.b[ks % RING][jt], acc[it][jt]);
         if (ks + RING < KSTEPS) {
             #pragma unroll
-            for (int jt = 0; jt < JT; jt++) W.b[ks % RING][jt] = *reinterpret_cast<const bf16x8*>(W.base + (size_t)(TILE_STEP * jt) * W.ld + 16 * (ks + RING));
+            for (int jt = 0; jt < JT; jt++) W.b[ks % RING][jt] = *W.piece(jt, ks + RING);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // One accumulator tile -> its packed HBM image: two 16-B stores per lane, 1 KB per wave and store.
@@ -188,8 +207,10 @@ struct FwdArgs {
 };
 #ifdef CDA_MLP_TIMING
 #define MLP_MARK(i) do { if (A.dbg && (int)blockIdx.x == A.dbg_block && blockIdx.y == 0 && lane == 0) A.dbg[w * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define MLP_MARK8(i) do { if (A.dbg && (int)blockIdx.x == A.dbg_block && lane == 0) A.dbg[w8 * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MLP_MARK(i) do {} while (0)
+#define MLP_MARK8(i) do {} while (0)
 #endif
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
@@ -222,7 +243,7 @@ __device__ __forceinline__ int sample_head(const float* l, float u, float& logp)
 
 template <int MT, int MODE>
 __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
-    constexpr int M = 32 * MT, PF = MT == 1 ? 16 : (MT == 2 ? 3 : 4);
+    constexpr int M = 32 * MT, PF = MT == 1 ? 16 : (MT == 2 ? 3 : CDA_MLP_PF4);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* xs = reinterpret_cast<__bf16*>(smem);                               // [M][XS_LD]
     __bf16* act = xs + M * XS_LD;                                               // [M][ACT_LD]
@@ -360,6 +381,90 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     MLP_MARK(19);
 }
 
+// ---- the update's forward with BOTH halves in flight: 8 waves, the value half one stage behind the policy half ---------------------------
+// A tile's time in k_mlp_fwd is MFMA loops + tanh epilogues (VALU: two transcendentals per value, ~56 cycles) one after the other, with one wave
+// per SIMD: the matrix pipe idles during every epilogue.  Here waves 0-3 run the policy network and waves 4-7 the value network of the same rows,
+// each half through its own LDS buffer, and the value half simply starts ONE STAGE LATER (an extra barrier at its start, one at the policy
+// half's end): while one half multiplies, the other one's epilogue runs on the same SIMDs' vector units.
+//     stage        0     1     2     3     4     5
+//     policy      M1    E1    M2    E2    MH     -
+//     value        -    M1    E1    M2    E2    MH
+template <int MT>
+__global__ __launch_bounds__(512) void k_mlp_fwd8(FwdArgs A) {
+    constexpr int M = 32 * MT, PF = CDA_MLP_PF8;         // weight requests in flight: L2 answers in ~1000 cycles under load, a k-step multiplies for 128
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* xs = reinterpret_cast<__bf16*>(smem);                               // [M][XS_LD]
+    const int lane = (int)threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int w8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), half = w8 >> 2, w = w8 & 3;
+    __bf16* act = xs + M * XS_LD + half * (M * ACT_LD);                         // this half's [M][ACT_LD]
+    const long long row0 = (long long)blockIdx.x * M, rows_end = A.n_rows;
+    const int f0 = 256 * half + 64 * w;
+    const float b1_0 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j] * TWO_LOG2E, b1_1 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j + 1] * TWO_LOG2E;
+    const float b2_0 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j] * TWO_LOG2E, b2_1 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j + 1] * TWO_LOG2E;
+    const float bo = A.theta[CDA_MLP_OFF_BO + j];
+    MLP_MARK8(0);
+    load_x_bf16<M, 512>(A.x_rm, row0, rows_end, xs);
+    const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
+    WRing<2, KX / 16, PF, true> R1; WRing<2, HID / 16, PF, true> R2; WRing<1, HID / 16, PF> RO;
+    R1.prime(W1b + (size_t)f0 * KX, KX, lane);
+    __syncthreads();                                                            // the observation tile is in LDS
+    MLP_MARK8(1);
+    if (half == 1) __syncthreads();                                             // stage 0: the value half waits
+    MLP_MARK8(2);
+    f32x16 acc[MT][2];
+    #pragma unroll
+    for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+    layer_mma(xs, XS_LD, R1, lane, acc);                                        // M1
+    MLP_MARK8(3);
+    R2.prime(W2b + ((size_t)half * HID + 64 * w) * HID, HID, lane);
+    __syncthreads();
+    MLP_MARK8(4);
+    #pragma unroll
+    for (int it = 0; it < MT; it++) {                                           // E1
+        float v0[16], v1[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], b1_0); v1[r] = tanh_biased(acc[it][1][r], b1_1); }
+        store_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5), lane, v0);
+        store_packed(A.h1p, row0 / 32 + it, 16, (f0 >> 5) + 1, lane, v1);
+        store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    MLP_MARK8(5);
+    __syncthreads();
+    MLP_MARK8(6);
+    #pragma unroll
+    for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+    layer_mma(act, ACT_LD, R2, lane, acc);                                      // M2
+    MLP_MARK8(7);
+    RO.prime(Wob + (size_t)half * NOUT * HID, HID, lane);
+    __syncthreads();                                                            // every wave of the half has read h1: h2 takes its place
+    MLP_MARK8(8);
+    #pragma unroll
+    for (int it = 0; it < MT; it++) {                                           // E2
+        float v0[16], v1[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], b2_0); v1[r] = tanh_biased(acc[it][1][r], b2_1); }
+        store_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5), lane, v0);
+        store_packed(A.h2p, row0 / 32 + it, 16, (f0 >> 5) + 1, lane, v1);
+        store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    MLP_MARK8(9);
+    __syncthreads();
+    MLP_MARK8(10);
+    f32x16 acc3[1][1]; acc3[0][0] = zero16();                                   // MH: wave w of the half owns row tile w (waves >= MT multiply a tile nobody reads)
+    layer_mma(act + (w < MT ? 32 * w : 0) * ACT_LD, ACT_LD, RO, lane, acc3);
+    MLP_MARK8(11);
+    const bool own_col = half == 0 ? j != N_LOGITS : j == N_LOGITS;             // policy: columns 0 .. 23 and the zero padding; value: column 24
+    if (w < MT && own_col) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) A.out[(row0 + 32 * w + rowmap(r, h)) * NOUT + j] = acc3[0][0][r] + bo;
+    }
+    MLP_MARK8(12);
+    if (half == 0) __syncthreads();                                             // stage 5: the policy half's matching barrier
+    MLP_MARK8(13);
+}
+
 // ---- update: the epoch's shuffle as a keyed bijection (no sort) -----------------------------------------------------------------------
 // perm[i] = walk(i): a bijective mixer on [0, 2^bits) (add, odd multiply, xor-shift: each step invertible), iterated until the value falls
 // below n (cycle walking: < 2 rounds on average, since 2^bits < 2 n).  torch.randperm is a device sort: ~10 launches, 130 us per epoch.
@@ -423,7 +528,7 @@ struct BwdArgs {
 };
 template <int MT>
 __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
-    constexpr int M = 32 * MT, PF = MT == 1 ? 16 : (MT == 2 ? 3 : 4);
+    constexpr int M = 32 * MT, PF = MT == 1 ? 16 : (MT == 2 ? 3 : CDA_MLP_PF4);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* dos = reinterpret_cast<__bf16*>(smem);                              // [M][DO_LD]   d_out, bf16 (the A operand)
     __bf16* dact = dos + M * DO_LD;                                             // [M][ACT_LD]  dz2 of the current half
@@ -519,6 +624,102 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(BwdArgs A) {
             if (h == 0) { bs[f0 + 2 * j] = colsum0; bs[f0 + 2 * j + 1] = colsum1; }
         }
     }
+}
+
+// The backward kernel in the same arrangement: 8 waves, the value half one stage behind.
+//     stage        0          1          2       3
+//     policy   MdH2 + E2     MdH1        E1      -
+//     value        -       MdH2 + E2    MdH1     E1
+template <int MT>
+__global__ __launch_bounds__(512) void k_mlp_bwd8(BwdArgs A) {
+    constexpr int M = 32 * MT, PF = CDA_MLP_PF8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* dos = reinterpret_cast<__bf16*>(smem);                              // [M][DO_LD]   d_out, bf16 (the A operand)
+    float* dof = reinterpret_cast<float*>(dos + M * DO_LD);                     // [M][OUTS_LD] d_out, f32 (bias sums)
+    const int lane = (int)threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int w8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), half = w8 >> 2, w = w8 & 3;
+    __bf16* dact = reinterpret_cast<__bf16*>(dof + M * OUTS_LD) + half * (M * ACT_LD);   // this half's [M][ACT_LD]
+    const long long row0 = (long long)blockIdx.x * M;
+    float* bs = A.bias_slab + (size_t)blockIdx.x * CDA_MLP_BSLAB;
+    for (int c = (int)threadIdx.x; c < M * (NOUT / 4); c += 512) {
+        const int r = c / (NOUT / 4), q = c - r * (NOUT / 4);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row0 + r < A.n_rows) v = *reinterpret_cast<const float4*>(A.d_out + (row0 + r) * NOUT + 4 * q);
+        bf16x4 b; b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(dos + r * DO_LD + 4 * q) = b;
+        dof[r * OUTS_LD + 4 * q] = v.x; dof[r * OUTS_LD + 4 * q + 1] = v.y; dof[r * OUTS_LD + 4 * q + 2] = v.z; dof[r * OUTS_LD + 4 * q + 3] = v.w;
+    }
+    const int f0 = 256 * half + 64 * w, ft0 = f0 >> 5;
+    const __bf16* W2T = A.wb + CDA_MLP_WB_W2T; const __bf16* WoT = A.wb + CDA_MLP_WB_WOT;
+    WRing<2, NOUT / 16, PF, true> RO; WRing<2, HID / 16, PF, true> R2;
+    RO.prime(WoT + (size_t)f0 * NOUT, NOUT, lane);
+    __syncthreads();
+    if (w8 < MT) {                                                              // d_out in the packed layout (lane = output column, slots = rows)
+        __bf16 v[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = dos[(32 * w8 + rowmap(r, h)) * DO_LD + j];
+        store_packed_bf(A.doutp, row0 / 32 + w8, 1, 0, lane, v);
+    }
+    if (threadIdx.x >= 448 && threadIdx.x < 448 + NOUT) {                        // (the last wave: not one that stores doutp)
+        const int o = (int)threadIdx.x - 448;
+        float sum = 0.0f;
+        for (int r = 0; r < M; r++) sum += dof[r * OUTS_LD + o];
+        bs[2 * CDA_MLP_FEAT + o] = sum;
+    }
+    if (half == 1) __syncthreads();                                             // stage 0: the value half waits
+    {   // MdH2 + E2
+        bf16x8 hp[MT][2][2];
+        #pragma unroll
+        for (int it = 0; it < MT; it++) { load_packed(A.h2p, row0 / 32 + it, 16, ft0, lane, hp[it][0]); load_packed(A.h2p, row0 / 32 + it, 16, ft0 + 1, lane, hp[it][1]); }
+        f32x16 acc[MT][2];
+        #pragma unroll
+        for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+        layer_mma(dos, DO_LD, RO, lane, acc);
+        R2.prime(W2T + ((size_t)half * HID + 64 * w) * HID, HID, lane);
+        float colsum0 = 0.0f, colsum1 = 0.0f;
+        #pragma unroll
+        for (int it = 0; it < MT; it++) {
+            float v0[16], v1[16];
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float h0 = (float)hp[it][0][r >> 3][r & 7], h1 = (float)hp[it][1][r >> 3][r & 7];
+                v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
+                colsum0 += v0[r]; colsum1 += v1[r];
+            }
+            store_packed(A.dz2p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz2p, row0 / 32 + it, 16, ft0 + 1, lane, v1);
+            store_lds_pair(dact, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
+        if (h == 0) { bs[CDA_MLP_FEAT + f0 + 2 * j] = colsum0; bs[CDA_MLP_FEAT + f0 + 2 * j + 1] = colsum1; }
+    }
+    __syncthreads();
+    {   // MdH1, then E1
+        bf16x8 hp[MT][2][2];
+        #pragma unroll
+        for (int it = 0; it < MT; it++) { load_packed(A.h1p, row0 / 32 + it, 16, ft0, lane, hp[it][0]); load_packed(A.h1p, row0 / 32 + it, 16, ft0 + 1, lane, hp[it][1]); }
+        f32x16 acc[MT][2];
+        #pragma unroll
+        for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+        layer_mma(dact, ACT_LD, R2, lane, acc);
+        __syncthreads();
+        float colsum0 = 0.0f, colsum1 = 0.0f;
+        #pragma unroll
+        for (int it = 0; it < MT; it++) {
+            float v0[16], v1[16];
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float h0 = (float)hp[it][0][r >> 3][r & 7], h1 = (float)hp[it][1][r >> 3][r & 7];
+                v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
+                colsum0 += v0[r]; colsum1 += v1[r];
+            }
+            store_packed(A.dz1p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz1p, row0 / 32 + it, 16, ft0 + 1, lane, v1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
+        if (h == 0) { bs[f0 + 2 * j] = colsum0; bs[f0 + 2 * j + 1] = colsum1; }
+    }
+    if (half == 0) __syncthreads();                                             // stage 3: the policy half's matching barrier
 }
 
 // ---- update, step 3: weight gradients ------------------------------------------------------------------------------------------
@@ -701,19 +902,25 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
     if (threadIdx.x == 0) norm2[NORM_PARTIALS + blockIdx.x] = (double)wsum[0] + (double)wsum[1] + (double)wsum[2] + (double)wsum[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1.0f;                   // nobody reads it in this launch; k_adam (next on the stream) sees t
 }
+// element index inside a group's operand image: column tile jt, k-step ks, lane (position q in the tile, k-half hh), slot e
+__device__ __forceinline__ size_t op_index(int ksteps, int jt, int k, int q) { return ((size_t)(jt * ksteps + (k >> 4)) * 64 + q + 32 * ((k & 15) >> 3)) * 8 + (k & 7); }
+// one parameter -> its places in the bf16 operand blob (operand order, see WRing).  A PAIRED group = 64 consecutive output features of one half:
+// feature 64 w + 2 q + jt sits in column tile jt at position q.
 __device__ __forceinline__ void pack_one(int p, float v, __bf16* __restrict__ wb) {
     const __bf16 b = (__bf16)v;
-    if (p < CDA_MLP_OFF_B1) { const int o = p / OBS, i = p - o * OBS; wb[CDA_MLP_WB_W1 + o * KX + i] = b; }
-    else if (p >= CDA_MLP_OFF_W2 && p < CDA_MLP_OFF_B2) {
+    if (p < CDA_MLP_OFF_B1) {                                                    // W1[o][i] -> W1p: group o / 64 (8 groups of 64 x 176)
+        const int o = p / OBS, i = p - o * OBS, g = o >> 6, f = o & 63;
+        wb[CDA_MLP_WB_W1 + (size_t)g * 64 * KX + op_index(KX / 16, f & 1, i, f >> 1)] = b;
+    } else if (p >= CDA_MLP_OFF_W2 && p < CDA_MLP_OFF_B2) {                      // W2[blk][o][i] -> W2p (rows = outputs) and W2Tp (rows = inputs, k = outputs)
         const int q = p - CDA_MLP_OFF_W2, blk = q / (HID * HID), o = (q / HID) % HID, i = q % HID;
-        wb[CDA_MLP_WB_W2 + q] = b;
-        wb[CDA_MLP_WB_W2T + ((size_t)blk * HID + i) * HID + o] = b;
-    } else if (p >= CDA_MLP_OFF_WO && p < CDA_MLP_OFF_BO) {
+        wb[CDA_MLP_WB_W2 + ((size_t)blk * 4 + (o >> 6)) * 64 * HID + op_index(HID / 16, o & 1, i, (o & 63) >> 1)] = b;
+        wb[CDA_MLP_WB_W2T + ((size_t)blk * 4 + (i >> 6)) * 64 * HID + op_index(HID / 16, i & 1, o, (i & 63) >> 1)] = b;
+    } else if (p >= CDA_MLP_OFF_WO && p < CDA_MLP_OFF_BO) {                      // Wo[o][i] -> Wop (one tile of 32 outputs per half) and WoTp (rows = features, k = outputs)
         const int q = p - CDA_MLP_OFF_WO, o = q / HID, i = q - o * HID;
         if (o <= N_LOGITS) {
             const int hf = o == N_LOGITS ? 1 : 0;
-            wb[CDA_MLP_WB_WO + ((size_t)hf * NOUT + o) * HID + i] = b;
-            wb[CDA_MLP_WB_WOT + ((size_t)hf * HID + i) * NOUT + o] = b;
+            wb[CDA_MLP_WB_WO + (size_t)hf * NOUT * HID + op_index(HID / 16, 0, i, o)] = b;
+            wb[CDA_MLP_WB_WOT + ((size_t)hf * 4 + (i >> 6)) * 64 * NOUT + op_index(NOUT / 16, i & 1, o, (i & 63) >> 1)] = b;
         }
     }
 }
@@ -876,12 +1083,24 @@ __global__ void k_selftest_mfma(const float* __restrict__ a, const float* __rest
     for (int r = 0; r < 16; r++) d[rowmap(r, h) * 32 + j] = acc[r];
 }
 
-// tile size of the forward / backward kernels of the update: 32 * MT rows per workgroup (CDA_MLP_MT = 1, 2 or 4; default 4)
+// The update's forward / backward kernels: CDA_MLP_WAVES = 8 (default): the 8-wave kernels with both network halves in flight, 64 rows per
+// workgroup; CDA_MLP_WAVES = 4: the 4-wave kernels, 32 * CDA_MLP_MT rows per workgroup (CDA_MLP_MT = 1, 2 or 4; default 4).
+int train_waves() {
+    static int wv = 0;
+    if (!wv) { const char* e = getenv("CDA_MLP_WAVES"); wv = e ? atoi(e) : 8; if (wv != 4 && wv != 8) wv = 8; }
+    return wv;
+}
 int train_mt() {
     static int mt = 0;
-    if (!mt) { const char* e = getenv("CDA_MLP_MT"); mt = e ? atoi(e) : 4; if (mt != 1 && mt != 2 && mt != 4) mt = 4; }
+    if (!mt) {
+        const char* e = getenv("CDA_MLP_MT"); mt = e ? atoi(e) : (train_waves() == 8 ? 2 : 4);
+        if (mt != 1 && mt != 2 && mt != 4) mt = train_waves() == 8 ? 2 : 4;
+        if (train_waves() == 8 && mt == 4) mt = 2;                               // (two activation buffers of 128 rows do not fit the LDS)
+    }
     return mt;
 }
+size_t fwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + 2 * M * ACT_LD * 2; }
+size_t bwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * OUTS_LD * 4 + 2 * M * ACT_LD * 2; }
 int rollout_mt() {
     static int mt = 0;
     if (!mt) { const char* e = getenv("CDA_MLP_ROLLOUT_MT"); mt = e ? atoi(e) : 1; if (mt != 1 && mt != 2 && mt != 4) mt = 1; }
@@ -915,6 +1134,12 @@ extern "C" int cda_tools_mlp_fwd_timing(const void* wb, const float* theta, cons
     FwdArgs A; memset(&A, 0, sizeof A);
     A.x_rm = (const __bf16*)x_rm; A.obs = obs; A.first_row = 0; A.n_rows = n_rows; A.wb = (const __bf16*)wb; A.theta = theta;
     A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.out = out; A.dbg = (unsigned long long*)dbg; A.dbg_block = block;
+    if (sample == 2) {                                   // the 8-wave training forward
+        const size_t lds = fwd8_lds(2);
+        int rc = allow_lds(k_mlp_fwd8<2>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(k_mlp_fwd8<2>, dim3((unsigned)((n_rows + 63) / 64)), dim3(512), lds, (hipStream_t)stream, A);
+        return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+    }
     if (sample) {
         const size_t NA = (size_t)n_rows * agents; char* s = (char*)scratch_i32x3_f32x5;
         A.agents = agents; A.seed = 1; A.counter = (const long long*)counter; A.draw = 0;
@@ -955,8 +1180,8 @@ extern "C" int cda_mlp_forward(const void* wb, const float* theta, const float* 
     if (!wb || !theta || !obs || !out || first_row < 0 || n_rows < 1) return CDA_ERR_INVALID;
     FwdArgs A; memset(&A, 0, sizeof A);
     A.obs = obs; A.first_row = first_row; A.n_rows = n_rows; A.wb = (const __bf16*)wb; A.theta = theta; A.out = out;
-    A.split_halves = n_rows >= 32768 ? 0 : 1;
-    return launch_fwd<MODE_OUT>(A, n_rows >= 32768 ? train_mt() : rollout_mt(), (hipStream_t)stream);
+    A.split_halves = 1;
+    return launch_fwd<MODE_OUT>(A, n_rows >= 32768 ? 4 : rollout_mt(), (hipStream_t)stream);
 }
 
 extern "C" int cda_mlp_permutation(uint64_t key, int64_t n, int64_t* perm, void* stream) {
@@ -978,6 +1203,16 @@ extern "C" int cda_mlp_forward_train(const void* wb, const float* theta, const v
     FwdArgs A; memset(&A, 0, sizeof A);
     A.x_rm = (const __bf16*)x_rm; A.first_row = 0; A.n_rows = n_rows; A.wb = (const __bf16*)wb; A.theta = theta;
     A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.out = out;
+    if (train_waves() == 8) {
+        const int mt = train_mt();
+        const size_t lds = fwd8_lds(mt);
+        const unsigned grid = (unsigned)((n_rows + 32 * mt - 1) / (32 * mt));
+        int rc;
+        if (mt == 2) { rc = allow_lds(k_mlp_fwd8<2>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_fwd8<2>, dim3(grid), dim3(512), lds, (hipStream_t)stream, A); }
+        else { rc = allow_lds(k_mlp_fwd8<1>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_fwd8<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, A); }
+        if (rc) return rc;
+        return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+    }
     return launch_fwd<MODE_TRAIN>(A, train_mt(), (hipStream_t)stream);
 }
 
@@ -987,9 +1222,16 @@ extern "C" int cda_mlp_backward(const void* wb, const float* d_out, const void* 
     BwdArgs A; A.wb = (const __bf16*)wb; A.d_out = d_out; A.h1p = (const __bf16*)h1p; A.h2p = (const __bf16*)h2p; A.n_rows = n_rows;
     A.dz1p = (__bf16*)dz1p; A.dz2p = (__bf16*)dz2p; A.doutp = (__bf16*)doutp; A.bias_slab = bias_slab;
     const int mt = train_mt();
-    const size_t lds = bwd_lds(mt);
     const unsigned grid = (unsigned)((n_rows + 32 * mt - 1) / (32 * mt));
     int rc;
+    if (train_waves() == 8) {
+        const size_t lds8 = bwd8_lds(mt);
+        if (mt == 2) { rc = allow_lds(k_mlp_bwd8<2>, lds8); if (!rc) hipLaunchKernelGGL(k_mlp_bwd8<2>, dim3(grid), dim3(512), lds8, (hipStream_t)stream, A); }
+        else { rc = allow_lds(k_mlp_bwd8<1>, lds8); if (!rc) hipLaunchKernelGGL(k_mlp_bwd8<1>, dim3(grid), dim3(512), lds8, (hipStream_t)stream, A); }
+        if (rc) return rc;
+        return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+    }
+    const size_t lds = bwd_lds(mt);
     if (mt == 4) { rc = allow_lds(k_mlp_bwd<4>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_bwd<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, A); }
     else if (mt == 2) { rc = allow_lds(k_mlp_bwd<2>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_bwd<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, A); }
     else { rc = allow_lds(k_mlp_bwd<1>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_bwd<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, A); }

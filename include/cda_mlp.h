@@ -18,8 +18,10 @@
  *     W1 [512][168] | b1 [512] | W2 [2][256][256] | b2 [512] | Wo [32][256] | bo [32] | log_std [2]
  * rows 0..255 of W1 / b1 / b2 and block 0 of W2 are the policy network, the rest the value network; Wo rows 0..23 are the policy
  * heads (reading the policy half), row 24 the value head (reading the value half), rows 25..31 unused (zero, never updated).
- * cda_mlp_pack derives the bf16 operand copies `wb` (CDA_MLP_WB_ELEMS bf16) the kernels multiply with:
- *     W1b [512][176] | W2b [2][256][256] | Wob [2][32][256] | W2T [2][256][256] | WoT [2][256][32]
+ * cda_mlp_pack derives the bf16 operand copies `wb` (CDA_MLP_WB_ELEMS bf16) the kernels multiply with - five matrices of the sizes
+ *     W1 [512][176] | W2 [2][256][256] | Wo [2][32][256] | W2^T [2][256][256] | Wo^T [2][256][32]
+ * each stored in MFMA OPERAND ORDER: per group of 64 (heads: 32) output rows, per column tile and k-step, the 64 lanes' 16-byte pieces are 1 KB of
+ * contiguous memory (csrc/cda_mlp.hip WRing / pack_one), so that a wave's weight request is eight whole cache lines.
  *
  * Tensors of the update live in HBM in the MFMA's own register layout ("packed": [rows/32][feature tiles of 32][2][64 lanes][8 bf16],
  * lane = (feature, row-half), the 8 slots = 8 rows) so that the weight-gradient kernel reads its operands with no transposition.

@@ -112,3 +112,39 @@ def test_config4_ppo_iteration_at_4096x4_with_oracle_replay():
     env.close(); ora.close()
     del model
     torch.cuda.synchronize()
+
+
+def test_config4_fused_ppo_iteration_at_4096x4_with_oracle_replay():
+    """BASELINE configs[4] on the hand-written network (ppo.train_fused): one iteration at full size - four rollout chains x 64 steps, 16
+    minibatch steps of 262 144 samples.  The rollout's OWN buffers are the evidence: the recorded actions of 32 markets replayed through the CPU
+    oracle reproduce the recorded observations and rewards bit for bit; losses finite, no flags, invariants and NAV conservation hold; the
+    update moved the parameters and the first minibatch step's loss statistics are those of an on-policy batch (entropy of a fresh policy)."""
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecEnv, ppo
+    import oracle_lib as O
+    n, a, horizon = 4096, 4, 64
+    cfg = {"num_of_agents": a, "init_cash": 1000000, "max_step": 4096, "is_render": False, "auto_reset": True}
+    env = CDAVecEnv(cfg, n, with_info=False)
+    keep, logs = {}, []
+    pol, hist = ppo.train_fused(env, iters=1, horizon=horizon, seed=11, log=logs.append, keep=keep)
+    h = hist[0]
+    assert all(math.isfinite(h[k]) for k in ("pg_loss", "v_loss", "entropy", "mean_reward")) and h["agent_steps"] == n * a * horizon
+    assert 6.0 < h["entropy"] < 8.0                              # log 9 + log 10 + log 3 + two Gaussians at log_std -0.5: 7.4 for a fresh policy
+    assert float(pol.adam_step.item()) == 16 and torch.isfinite(pol.theta).all()
+    assert (env.flags() == 0).all() and (env.check_invariants() == 0).all()
+    _, bad = env.nav_conservation()
+    assert not bad.any()
+    b = {k: v.cpu().numpy() for k, v in keep["buffers"].items()}
+    idx = np.arange(0, n, n // 32)
+    ora = O.OracleEnv({k: v for k, v in cfg.items() if k != "auto_reset"}, len(idx))
+    o0 = ora.reset(seeds=(11 + idx).astype(np.uint64))            # env.reset(seed=11): market i is seeded 11 + i
+    assert np.array_equal(b["obs"][0][idx].view(np.uint32), o0.view(np.uint32))
+    for t in range(horizon):
+        cat, mean, sigma = b["category"][t][idx], b["size_mean"][t][idx], b["size_sigma"][t][idx]
+        assert cat.min() >= 0 and cat.max() <= 8 and np.abs(mean).max() <= 1 and sigma.min() >= 0 and sigma.max() <= 1
+        oo, orw, _, _, _ = ora.step(cat, mean, sigma, b["price"][t][idx], b["price_offset"][t][idx])
+        assert np.array_equal(b["reward"][t][idx].view(np.uint64), orw.view(np.uint64)), t
+        assert np.array_equal(b["obs"][t + 1][idx].view(np.uint32), oo.view(np.uint32)), t
+    env.close(); ora.close()
+    del pol
+    torch.cuda.synchronize()

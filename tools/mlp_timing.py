@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--mt", type=int, default=4)
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--sample", action="store_true")
+    ap.add_argument("--waves8", action="store_true", help="the 8-wave training forward (both halves in flight, 64 rows per workgroup)")
     ap.add_argument("--block", type=int, default=7)
     a = ap.parse_args()
     T = C.CDLL(os.path.join(ROOT, "tools", "libcda_tools.so"))
@@ -33,16 +34,24 @@ def main():
     obs = torch.randn(R, 168, device=dev)
     from gym_continuousdoubleauction_amd._lib import check, lib
     check(lib().cda_mlp_prep_rows(obs.data_ptr(), None, R, upd.x_rm.data_ptr(), upd.x_pk.data_ptr(), torch.cuda.current_stream().cuda_stream), "prep")
-    dbg = torch.zeros(4 * 32, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(8 * 32, dtype=torch.int64, device=dev)
     scratch = torch.zeros(R * 4 * 40, dtype=torch.uint8, device=dev)
     counter = torch.zeros(1, dtype=torch.int64, device=dev)
     vp = C.c_void_p
     T.cda_tools_mlp_fwd_timing.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp, C.c_int32, vp]
     for rep in range(3):
         rc = T.cda_tools_mlp_fwd_timing(p.wb.data_ptr(), p.theta.data_ptr(), upd.x_rm.data_ptr(), obs.data_ptr(), R, 4, upd.h1p.data_ptr(), upd.h2p.data_ptr(), upd.out.data_ptr(),
-                                        scratch.data_ptr(), counter.data_ptr(), a.mt, int(a.sample), dbg.data_ptr(), a.block, torch.cuda.current_stream().cuda_stream)
+                                        scratch.data_ptr(), counter.data_ptr(), a.mt, 2 if a.waves8 else int(a.sample), dbg.data_ptr(), a.block, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, rc
         torch.cuda.synchronize()
+    if a.waves8:
+        d = dbg.cpu().view(8, 32)
+        names = ["x tile in LDS", "stagger barrier", "M1", "barrier", "E1", "barrier", "M2", "barrier", "E2", "barrier", "MH", "outputs", "final barrier"]
+        print(f"8-wave training forward, 64 rows per workgroup, {R} rows; workgroup {a.block}; shader cycles per segment, waves 0..7 (0-3 policy, 4-7 value)")
+        for k, nm in enumerate(names):
+            print(f"  {nm:20s} " + " ".join(f"{int(d[w, k + 1] - d[w, k]):7d}" for w in range(8)))
+        print(f"  {'total':20s} " + " ".join(f"{int(d[w, 13] - d[w, 0]):7d}" for w in range(8)))
+        return
     d = dbg.cpu().view(4, 32)
     print(f"forward kernel, {'sampling' if a.sample else 'training'} mode, {32 * a.mt} rows per workgroup, {R} rows; workgroup {a.block}; shader cycles per segment, waves 0..3")
     keys = sorted(NAMES)
