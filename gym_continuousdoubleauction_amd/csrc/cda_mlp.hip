@@ -262,16 +262,16 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             b2s[hf][jt] = A.theta[CDA_MLP_OFF_B2 + 256 * hf + 64 * w + 2 * j + jt] * TWO_LOG2E;
         }
     const float bo = A.theta[CDA_MLP_OFF_BO + j];
-    if (MODE == MODE_TRAIN) load_x_bf16<M>(A.x_rm, row0, rows_end, xs); else load_x_f32<M>(A.obs, row0, rows_end, xs);
-    __syncthreads();
-    MLP_MARK(1);
     const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
     f32x16 acc3[1][1]; acc3[0][0] = zero16();                                   // heads: wave w owns row tile w (waves >= MT idle there)
     WRing<2, KX / 16, PF, true> R1; WRing<2, HID / 16, PF, true> R2; WRing<1, HID / 16, PF> RO;
     // The two halves are independent networks: a rollout launch gives each its own workgroup (half the serial chain, half the weight bytes
     // through one CU's L1); the update's launches run both in one workgroup (the observation tile is staged once).
     const int half_begin = A.split_halves == 1 ? (int)blockIdx.y : (A.split_halves == 2 ? 1 : 0), half_end = A.split_halves ? half_begin + 1 : 2;
-    R1.prime(W1b + (size_t)(256 * half_begin + 64 * w) * KX, KX, lane);
+    R1.prime(W1b + (size_t)(256 * half_begin + 64 * w) * KX, KX, lane);         // (layer 1's weights fly while the observation tile is staged)
+    if (MODE == MODE_TRAIN) load_x_bf16<M>(A.x_rm, row0, rows_end, xs); else load_x_f32<M>(A.obs, row0, rows_end, xs);
+    __syncthreads();
+    MLP_MARK(1);
     #pragma unroll 1
     for (int half = half_begin; half < half_end; half++) {
         const int f0 = 256 * half + 64 * w;                                     // this wave's first feature (of 512)
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             const float x0 = l[22] + __expf(ls0) * n0, x1 = l[23] + __expf(ls1) * n1;
             lp += -0.5f * n0 * n0 - ls0 - HALF_LOG_2PI - 0.5f * n1 * n1 - ls1 - HALF_LOG_2PI;
             A.env_cat[i] = c; A.env_price[i] = p; A.env_off[i] = o;
-            A.env_mean[i] = tanhf(x0);
+            A.env_mean[i] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x0) + 1.0f), 1.0f);      // tanh(x0): 1 - 2 / (e^(2 x0) + 1); libm's tanhf is a call of ~100 instructions
             A.env_sigma[i] = 1.0f / (1.0f + __expf(-x1));
             A.a_cont[2 * i] = x0; A.a_cont[2 * i + 1] = x1;
             A.logp[i] = lp;

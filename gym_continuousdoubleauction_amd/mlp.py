@@ -309,8 +309,12 @@ class FusedUpdate:
     """The PPO update on the kernels of include/cda_mlp.h: per epoch one gather / convert pass over the R unique observations (shuffled),
     per minibatch {forward, loss, back-propagation, weight gradients, reduce + clip + Adam}: eight launches, no autograd, no GEMM library."""
 
-    def __init__(self, policy, n_rows, rows_mb, num_agents, chunks=None):
+    def __init__(self, policy, n_rows, rows_mb, num_agents, chunks=None, sub_batches=1):
+        """sub_batches > 1: a minibatch step runs {forward, loss, backward, weight gradients} once per sub-batch of rows_mb / sub_batches rows and
+        reduces all their partial sums in one optimiser step - the same step, with activations of a sub-batch small enough to stay in the
+        256-MB Infinity Cache between the kernel that writes them and the ones that read them."""
         self.p, self.R, self.rows_mb, self.A = policy, int(n_rows), int(rows_mb), int(num_agents)
+        self.sub = max(1, int(sub_batches))
         if self.R % 32 or self.rows_mb % 32 or self.rows_mb > self.R:
             raise ValueError("rows and minibatch rows must be multiples of 32")
         dev = policy.device
@@ -324,7 +328,7 @@ class FusedUpdate:
         self.h1p, self.h2p, self.dz1p, self.dz2p = (e(pad * FEAT, bf) for _ in range(4))
         self.doutp = e(pad * NOUT, bf)
         self.out, self.d_out = e(pad * NOUT, f32).view(-1, NOUT), e(pad * NOUT, f32).view(-1, NOUT)
-        self.slab, self.bias_slab = e(self.chunks * SLAB, f32), e(self.n_tiles * BSLAB, f32)
+        self.slab, self.bias_slab = e(self.sub * self.chunks * SLAB, f32), e((self.n_tiles + self.sub) * BSLAB, f32)
         self.grad, self.norm2 = e(PARAMS, f32), e(512, torch.float64)        # (norm2[2] = the squared gradient norm of the last step)
         self.sums5, self.out6 = e(5, torch.float64), e(6, f32)
         self.perm = torch.zeros(self.R, dtype=torch.int64, device=dev)
@@ -334,19 +338,26 @@ class FusedUpdate:
         """rows [s, s + rows) of the prepared (shuffled) observations: one optimiser step"""
         L, p, dev = _lib(), self.p, self.p.device
         st = _stream(dev)
-        tiles = (rows + self.tile_rows - 1) // self.tile_rows
-        chunks = max(1, min(self.chunks, rows // 32))
-        x_rm = self.x_rm.data_ptr() + s * KX * 2
-        x_pk = self.x_pk.data_ptr() + s * 32 * XT * 2
-        _check(L.cda_mlp_forward_train(p.wb.data_ptr(), p.theta.data_ptr(), x_rm, rows, self.h1p.data_ptr(), self.h2p.data_ptr(), self.out.data_ptr(), st), "cda_mlp_forward_train")
-        _check(L.cda_ppo_loss32(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(), acts[3].data_ptr(),
-                                logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), self.perm.data_ptr() + s * 8, rows, self.A, NOUT,
-                                float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(), self.sums5.data_ptr(), self.out6.data_ptr(), 0, 0 if apply else 1, 0 if apply else 1, st),
-               "cda_ppo_loss32")            # (apply: the sums are finished and cleared by cda_mlp_adam)
-        _check(L.cda_mlp_backward(p.wb.data_ptr(), self.d_out.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), rows, self.dz1p.data_ptr(), self.dz2p.data_ptr(),
-                                  self.doutp.data_ptr(), self.bias_slab.data_ptr(), st), "cda_mlp_backward")
-        _check(L.cda_mlp_wgrad(x_pk, self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(), rows, chunks,
-                               self.slab.data_ptr(), st), "cda_mlp_wgrad")
+        sub = self.sub if (rows % (32 * self.sub) == 0 and rows // self.sub >= 32) else 1
+        rs = rows // sub                                           # rows per sub-batch
+        tiles_sub = (rs + self.tile_rows - 1) // self.tile_rows
+        chunks = max(1, min(self.chunks, rs // 32))
+        for k in range(sub):
+            o = s + k * rs
+            x_rm = self.x_rm.data_ptr() + o * KX * 2
+            x_pk = self.x_pk.data_ptr() + o * 32 * XT * 2
+            _check(L.cda_mlp_forward_train(p.wb.data_ptr(), p.theta.data_ptr(), x_rm, rs, self.h1p.data_ptr(), self.h2p.data_ptr(), self.out.data_ptr(), st), "cda_mlp_forward_train")
+            last = k == sub - 1
+            _check(L.cda_ppo_loss32(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(), acts[3].data_ptr(),
+                                    logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), self.perm.data_ptr() + o * 8, rs, self.A, NOUT,
+                                    float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(), self.sums5.data_ptr(), self.out6.data_ptr(), rows,
+                                    0 if (apply or k) else 1, 0 if (apply or not last) else 1, st),
+                   "cda_ppo_loss32")            # (apply: the sums are finished and cleared by cda_mlp_adam; they accumulate over the sub-batches)
+            _check(L.cda_mlp_backward(p.wb.data_ptr(), self.d_out.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), rs, self.dz1p.data_ptr(), self.dz2p.data_ptr(),
+                                      self.doutp.data_ptr(), self.bias_slab.data_ptr() + k * tiles_sub * BSLAB * 4, st), "cda_mlp_backward")
+            _check(L.cda_mlp_wgrad(x_pk, self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(), rs, chunks,
+                                   self.slab.data_ptr() + k * chunks * SLAB * 4, st), "cda_mlp_wgrad")
+        chunks, tiles = chunks * sub, tiles_sub * sub
         if apply:
             _check(L.cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), self.slab.data_ptr(), chunks,
                                   self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A, float(vf_coef), float(ent_coef), self.out6.data_ptr(),

@@ -465,7 +465,7 @@ def _capture_rollout_step(model, env, N, A, T, seed=0, shared=True):
 
 
 def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, chains=4, minibatch=262144,
-                gamma=0.99, lam=0.95, clip=0.2, vf_coef=0.5, ent_coef=0.01, policy=None, keep=None):
+                gamma=0.99, lam=0.95, clip=0.2, vf_coef=0.5, ent_coef=0.01, policy=None, keep=None, sub_batches=None):
     """The PPO loop on the hand-written network kernels (mlp.py, include/cda_mlp.h): rollouts as `chains` independent per-chain launch
     sequences (policy forward + sampling -> env step -> auto reset, one HIP graph per chain, no cross-stream edge inside the horizon), the
     update as {forward, loss, back-propagation, weight gradients, clip + Adam} launches per minibatch step - no autograd, no GEMM library.
@@ -480,7 +480,9 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, 
     roll = RolloutChains(env, policy, T, groups=chains, seed=seed, use_graphs=use_graph)
     R = T * N
     rows_mb = max(32, min(R, (max(1, minibatch // A) // 32) * 32))
-    upd = FusedUpdate(policy, R, rows_mb, A)
+    import os
+    sub_batches = int(os.environ.get("CDA_PPO_SUB_BATCHES", "1")) if sub_batches is None else int(sub_batches)
+    upd = FusedUpdate(policy, R, rows_mb, A, sub_batches=sub_batches)
     history = []
     for it in range(iters):
         torch.cuda.synchronize(dev)

@@ -283,6 +283,30 @@ def test_keyed_permutation_is_a_permutation(n):
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
 
 
+def test_sub_batched_minibatch_step_gives_the_same_gradient():
+    """FusedUpdate(sub_batches=2): the same optimiser step from two half-size passes (loss sums and partial gradients accumulate)."""
+    from gym_continuousdoubleauction_amd import mlp
+    from gym_continuousdoubleauction_amd._lib import lib, check
+    R, A = 512, 4
+    x = _obs(R, seed=3) * 0.5
+    g = torch.Generator().manual_seed(12)
+    B = R * A
+    acts = (torch.randint(0, 9, (B,), generator=g).int().to(DEV), torch.randint(0, 10, (B,), generator=g).int().to(DEV), torch.randint(0, 3, (B,), generator=g).int().to(DEV),
+            torch.randn(B, 2, generator=g).to(DEV))
+    lp, adv, ret = (torch.randn(B, generator=g) * 0.1 - 7).to(DEV), torch.randn(B, generator=g).to(DEV), torch.randn(B, generator=g).to(DEV)
+    grads, outs = [], []
+    for sub in (1, 2):
+        p = _policy(seed=13)
+        upd = mlp.FusedUpdate(p, R, R, A, chunks=2, sub_batches=sub)
+        upd.perm.copy_(torch.randperm(R, generator=torch.Generator().manual_seed(1)))
+        xd = x.to(DEV)
+        check(lib().cda_mlp_prep_rows(xd.data_ptr(), upd.perm.data_ptr(), R, upd.x_rm.data_ptr(), upd.x_pk.data_ptr(), torch.cuda.current_stream().cuda_stream), "prep")
+        upd.minibatch_step(0, R, acts, lp, adv, ret, 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5)
+        torch.cuda.synchronize()
+        grads.append(upd.grad.cpu().double()); outs.append(upd.out6.cpu().double())
+    assert (grads[0] - grads[1]).abs().max() <= 1e-5 * grads[0].abs().max() and (outs[0] - outs[1]).abs().max() <= 1e-5 * outs[0].abs().max()
+
+
 def test_policy_step_samples_what_it_reports():
     from gym_continuousdoubleauction_amd import mlp
     p = _policy(seed=23, scale=2.0)

@@ -52,7 +52,7 @@ def main():
             print(f"  {nm:20s} " + " ".join(f"{int(d[w, k + 1] - d[w, k]):7d}" for w in range(8)))
         print(f"  {'total':20s} " + " ".join(f"{int(d[w, 13] - d[w, 0]):7d}" for w in range(8)))
         return
-    d = dbg.cpu().view(4, 32)
+    d = dbg.cpu().view(8, 32)
     print(f"forward kernel, {'sampling' if a.sample else 'training'} mode, {32 * a.mt} rows per workgroup, {R} rows; workgroup {a.block}; shader cycles per segment, waves 0..3")
     keys = sorted(NAMES)
     for prev, k in zip(keys, keys[1:]):
