@@ -201,6 +201,7 @@ struct FwdArgs {
     // MODE_SAMPLE
     int agents; unsigned long long seed; const long long* counter; long long draw;
     int* env_cat; float* env_mean; float* env_sigma; int* env_price; int* env_off; float* a_cont; float* logp; float* value;
+    float* rec;                  // optional sample records [*, A][8 words] (include/cda_mlp.h CDA_REC_*): the words the update's loss reads, one line per row
     int split_halves;            // 1: gridDim.y = 2, workgroup (x, y) runs network half y only (policy | value: independent networks; the rollout's launches);
                                  // 2: the value half only (the bootstrap value); 0: both halves, one after the other
     unsigned long long* dbg; int dbg_block;       // CDA_MLP_TIMING builds (tools/libcda_tools.so) only: cycle stamps of one workgroup, [4 waves][32]
@@ -376,6 +377,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             A.env_sigma[i] = 1.0f / (1.0f + __expf(-x1));
             A.a_cont[2 * i] = x0; A.a_cont[2 * i + 1] = x1;
             A.logp[i] = lp;
+            if (A.rec) {
+                float4* rp = reinterpret_cast<float4*>(A.rec + 8 * i);
+                rp[0] = make_float4(__int_as_float(c), __int_as_float(p), __int_as_float(o), x0);
+                *reinterpret_cast<float2*>(A.rec + 8 * i + 4) = make_float2(x1, lp);
+            }
         }
     }
     MLP_MARK(19);
@@ -1067,6 +1073,126 @@ __global__ void k_ppo_finish32(const double* sums, long long B, float vf_coef, f
     }
 }
 
+// ---- the rollout's sample records: GAE straight into them, and the loss reading them -----------------------------------------------------
+// One thread per (market, agent) column walks its T steps backwards (ppo.gae's recursion) on the rollout's own buffers - reward f64 [T][N][A]
+// (scaled here), value f32 [T + 1][N] (slot T = the bootstrap value), terminated / truncated u8 [T][N] - and writes advantage and return into
+// words 6, 7 of the step's sample record.  The sums of the advantages and of their squares go to stats f64[2] (cleared by the caller): the
+// update normalises on the fly, (adv - mean) / (std + 1e-8) with the unbiased std, as ppo_update does with torch ops.
+__global__ __launch_bounds__(256) void k_gae_records(const double* __restrict__ reward, const float* __restrict__ value, const unsigned char* __restrict__ term,
+                                                     const unsigned char* __restrict__ trunc, int T, long long N, int Ag, float reward_scale, float gamma, float lam,
+                                                     float* __restrict__ rec, double* __restrict__ stats) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, B = N * Ag;
+    double s1 = 0.0, s2 = 0.0;
+    if (i < B) {
+        const long long n = i / Ag;
+        float nxt = value[(long long)T * N + n], run = 0.0f;
+        for (int t = T - 1; t >= 0; t--) {
+            const long long k = (long long)t * B + i, kn = (long long)t * N + n;
+            const float nd = (term[kn] | trunc[kn]) ? 0.0f : 1.0f, v = value[kn];
+            const float delta = (float)reward[k] * reward_scale + gamma * nxt * nd - v;
+            run = delta + gamma * lam * nd * run;
+            *reinterpret_cast<float2*>(rec + 8 * k + 6) = make_float2(run, run + v);
+            s1 += (double)run; s2 += (double)run * (double)run;
+            nxt = v;
+        }
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+    __shared__ double part[2][4];
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s1; part[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 2) atomicAdd(&stats[threadIdx.x], (part[threadIdx.x][0] + part[threadIdx.x][1]) + (part[threadIdx.x][2] + part[threadIdx.x][3]));
+}
+// k_ppo_loss32 on sample records: a row's A samples are ONE contiguous piece of A x 32 bytes (the seven separate per-sample arrays cost seven
+// scattered 16-byte gathers per row: 1.3 KB fetched per row for 128 B used)
+__global__ __launch_bounds__(256) void k_ppo_loss_rec(const float* __restrict__ outputs, const float* __restrict__ log_std, const float* __restrict__ rec,
+                                                      const double* __restrict__ adv_stats, long long n_stat, const long long* __restrict__ row_index,
+                                                      long long R, long long Rnorm, int agents, int stride, float clip, float vf_coef, float ent_coef,
+                                                      float* __restrict__ d_out, double* __restrict__ sums) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float invB = 1.0f / ((float)Rnorm * (float)agents);
+    float adv_mean = 0.0f, adv_rstd = 1.0f;
+    if (adv_stats) {
+        const double m = adv_stats[0] / (double)n_stat, var = (adv_stats[1] - (double)n_stat * m * m) / (double)(n_stat - 1);
+        adv_mean = (float)m; adv_rstd = 1.0f / ((float)sqrt(var > 0.0 ? var : 0.0) + 1e-8f);
+    }
+    float pg = 0.0f, vl = 0.0f, en = 0.0f, dls0 = 0.0f, dls1 = 0.0f;
+    if (r < R) {
+        float l[N_LOGITS], d[N_LOGITS], p[N_CAT + N_PRICE + N_OFF], lp[N_CAT + N_PRICE + N_OFF];
+        const float4* lp4 = reinterpret_cast<const float4*>(outputs + r * stride);
+        #pragma unroll
+        for (int q = 0; q < N_LOGITS / 4; q++) { const float4 v = lp4[q]; l[4 * q] = v.x; l[4 * q + 1] = v.y; l[4 * q + 2] = v.z; l[4 * q + 3] = v.w; }
+        const float ls0 = log_std[0], ls1 = log_std[1];
+        const float is0 = __expf(-ls0), is1 = __expf(-ls1);
+        const float HALF_LOG_2PI = 0.918938533204672742f;
+        float h0, h1, h2;
+        head_probs<N_CAT>(l, p, lp, h0);
+        head_probs<N_PRICE>(l + N_CAT, p + N_CAT, lp + N_CAT, h1);
+        head_probs<N_OFF>(l + N_CAT + N_PRICE, p + N_CAT + N_PRICE, lp + N_CAT + N_PRICE, h2);
+        const float ent = h0 + h1 + h2 + 1.0f + 2.0f * HALF_LOG_2PI + ls0 + ls1;
+        const float es = ent_coef * invB;
+        #pragma unroll
+        for (int q = 0; q < N_LOGITS; q++) d[q] = 0.0f;
+        const float val = outputs[r * stride + N_LOGITS];
+        float G = 0.0f, dval = 0.0f;
+        const long long src_row = row_index ? row_index[r] : r;
+        const float4* rp = reinterpret_cast<const float4*>(rec + src_row * agents * 8);
+        for (int a = 0; a < agents; a++) {
+            const float4 w0 = rp[2 * a], w1 = rp[2 * a + 1];
+            const int ac = __float_as_int(w0.x), ap = __float_as_int(w0.y), ao = __float_as_int(w0.z);
+            const float z0 = (w0.w - l[22]) * is0, z1 = (w1.x - l[23]) * is1;
+            const float logp = -0.5f * z0 * z0 - ls0 - HALF_LOG_2PI - 0.5f * z1 * z1 - ls1 - HALF_LOG_2PI +
+                               pick<N_CAT>(lp, ac) + pick<N_PRICE>(lp + N_CAT, ap) + pick<N_OFF>(lp + N_CAT + N_PRICE, ao);
+            const float Av = (w1.z - adv_mean) * adv_rstd, ratio = __expf(logp - w1.y);
+            const float un = ratio * Av, cl = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip) * Av;
+            pg -= fminf(un, cl);
+            const float g_logp = (un <= cl) ? -un * invB : 0.0f;
+            const float dv = val - w1.w;
+            vl += dv * dv;
+            dval += 2.0f * vf_coef * dv * invB;
+            en += ent;
+            G += g_logp;
+            #pragma unroll
+            for (int q = 0; q < N_CAT; q++) d[q] += (q == ac) ? g_logp : 0.0f;
+            #pragma unroll
+            for (int q = 0; q < N_PRICE; q++) d[N_CAT + q] += (q == ap) ? g_logp : 0.0f;
+            #pragma unroll
+            for (int q = 0; q < N_OFF; q++) d[N_CAT + N_PRICE + q] += (q == ao) ? g_logp : 0.0f;
+            d[22] += g_logp * z0 * is0;
+            d[23] += g_logp * z1 * is1;
+            dls0 += g_logp * (z0 * z0 - 1.0f) - es;
+            dls1 += g_logp * (z1 * z1 - 1.0f) - es;
+        }
+        const float esA = es * (float)agents;
+        #pragma unroll
+        for (int q = 0; q < N_CAT; q++) d[q] += -G * p[q] + esA * p[q] * (lp[q] + h0);
+        #pragma unroll
+        for (int q = 0; q < N_PRICE; q++) d[N_CAT + q] += -G * p[N_CAT + q] + esA * p[N_CAT + q] * (lp[N_CAT + q] + h1);
+        #pragma unroll
+        for (int q = 0; q < N_OFF; q++) d[N_CAT + N_PRICE + q] += -G * p[N_CAT + N_PRICE + q] + esA * p[N_CAT + N_PRICE + q] * (lp[N_CAT + N_PRICE + q] + h2);
+        float4* dp4 = reinterpret_cast<float4*>(d_out + r * stride);
+        #pragma unroll
+        for (int q = 0; q < N_LOGITS / 4; q++) dp4[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+        dp4[N_LOGITS / 4] = make_float4(dval, 0.0f, 0.0f, 0.0f);
+        for (int q = N_LOGITS / 4 + 1; q < stride / 4; q++) dp4[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    float v5[5] = {pg, vl, en, dls0, dls1};
+    __shared__ float part[5][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    #pragma unroll
+    for (int q = 0; q < 5; q++) {
+        float x = v5[q];
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+        if (lane == 0) part[q][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const double t = (double)part[threadIdx.x][0] + (double)part[threadIdx.x][1] + (double)part[threadIdx.x][2] + (double)part[threadIdx.x][3];
+        atomicAdd(&sums[threadIdx.x], t);
+    }
+}
+
 __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, long long n4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
@@ -1276,6 +1402,31 @@ extern "C" int cda_ppo_loss32(const float* outputs, const float* log_std, const 
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
+extern "C" int cda_gae_records(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
+                               int32_t num_agents, float reward_scale, float gamma, float lam, float* rec, double* stats2, void* stream) {
+    if (!reward || !value || !terminated || !truncated || !rec || !stats2 || n_steps < 1 || n_markets < 1 || num_agents < 1 || num_agents > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
+    const long long B = (long long)n_markets * num_agents;
+    hipLaunchKernelGGL(k_gae_records, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, reward, value, (const unsigned char*)terminated, (const unsigned char*)truncated,
+                       (int)n_steps, (long long)n_markets, (int)num_agents, reward_scale, gamma, lam, rec, stats2);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+extern "C" int cda_ppo_loss_records(const float* outputs, const float* log_std, const float* rec, const double* adv_stats2, int64_t adv_count, const int64_t* row_index,
+                                    int64_t rows, int32_t agents_per_row, int32_t out_stride, float clip, float vf_coef, float ent_coef,
+                                    float* d_outputs, double* sums5, float* out6, int64_t norm_rows, int32_t clear, int32_t finish, void* stream) {
+    if (!outputs || !log_std || !rec || !d_outputs || !sums5 || !out6 || rows < 1 || agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS ||
+        out_stride <= N_LOGITS || (out_stride & 3) || norm_rows < 0 || (adv_stats2 && adv_count < 2)) return CDA_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rn = norm_rows > 0 ? norm_rows : rows;
+    if (clear && hipMemsetAsync(sums5, 0, 5 * sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
+    hipLaunchKernelGGL(k_ppo_loss_rec, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, outputs, log_std, rec, adv_stats2, (long long)adv_count,
+                       (const long long*)row_index, (long long)rows, rn, (int)agents_per_row, (int)out_stride, clip, vf_coef, ent_coef, d_outputs, sums5);
+    if (finish) hipLaunchKernelGGL(k_ppo_finish32, dim3(1), dim3(64), 0, st, (const double*)sums5, rn * agents_per_row, vf_coef, ent_coef, out6);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
 #ifndef CDA_MLP_TIMING          /* (the tools build holds the network kernels only, not the env) */
 extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
                                      uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* B, int32_t copy_first_obs, void* stream) {
@@ -1294,9 +1445,14 @@ extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* 
     }
     for (int32_t t = 0; t < n_steps; t++) {
         const size_t o = (size_t)t * NA;
-        int rc = cda_mlp_policy_step(wb, theta, B->obs + (size_t)t * N * OBS, first_market, n_markets, A, seed, counter_dev, t,
-                                     B->category + o, B->size_mean + o, B->size_sigma + o, B->price + o, B->price_offset + o,
-                                     B->a_cont + 2 * o, B->logp + o, B->value + (size_t)t * N, stream);
+        FwdArgs P; memset(&P, 0, sizeof P);
+        P.obs = B->obs + (size_t)t * N * OBS; P.first_row = first_market; P.n_rows = n_markets; P.wb = (const __bf16*)wb; P.theta = theta;
+        P.agents = A; P.seed = seed; P.counter = (const long long*)counter_dev; P.draw = t;
+        P.env_cat = B->category + o; P.env_mean = B->size_mean + o; P.env_sigma = B->size_sigma + o; P.env_price = B->price + o; P.env_off = B->price_offset + o;
+        P.a_cont = B->a_cont + 2 * o; P.logp = B->logp + o; P.value = B->value + (size_t)t * N;
+        P.rec = B->record ? B->record + 8 * o : NULL;
+        P.split_halves = 1;
+        int rc = launch_fwd<MODE_SAMPLE>(P, rollout_mt(), st);
         if (rc) return rc;
         rc = cda_step_range(env, first_market, n_markets, B->category + o, B->size_mean + o, B->size_sigma + o, B->price + o, B->price_offset + o, NULL,
                             B->obs + (size_t)(t + 1) * N * OBS, B->reward + o, B->terminated + (size_t)t * N, B->truncated + (size_t)t * N, NULL, stream);

@@ -230,7 +230,9 @@ class RolloutChains:
         self.buf = {"obs": e((T + 1, N, OBS), torch.float32), "category": e((T, N, A), torch.int32), "size_mean": e((T, N, A), torch.float32),
                     "size_sigma": e((T, N, A), torch.float32), "price": e((T, N, A), torch.int32), "price_offset": e((T, N, A), torch.int32),
                     "a_cont": e((T, N, A, 2), torch.float32), "logp": e((T, N, A), torch.float32), "value": e((T + 1, N), torch.float32),
-                    "reward": e((T, N, A), torch.float64), "terminated": e((T, N), torch.uint8), "truncated": e((T, N), torch.uint8)}
+                    "reward": e((T, N, A), torch.float64), "terminated": e((T, N), torch.uint8), "truncated": e((T, N), torch.uint8),
+                    "record": e((T, N, A, 8), torch.float32)}          # include/cda_mlp.h CDA_REC_*: what the update's loss reads, one line per row
+        self.adv_stats = torch.zeros(2, dtype=torch.float64, device=dev)
         self._cbufs = RolloutBufs(**{k: v.data_ptr() for k, v in self.buf.items()})
         self.seed = int(seed) & (2 ** 64 - 1)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -304,6 +306,14 @@ class RolloutChains:
                     cur.wait_event(self._joins[g])
         return self.buf
 
+    def gae(self, gamma=0.99, lam=0.95, reward_scale=1.0):
+        """advantages and returns of the last run() straight into the sample records (one launch; ppo.gae's recursion); returns
+        (records [T * N, A, 8], the sums the update normalises the advantages with, their count)"""
+        _check(_lib().cda_gae_records(self.buf["reward"].data_ptr(), self.buf["value"].data_ptr(), self.buf["terminated"].data_ptr(), self.buf["truncated"].data_ptr(),
+                                      self.T, self.N, self.A, float(reward_scale), float(gamma), float(lam), self.buf["record"].data_ptr(), self.adv_stats.data_ptr(),
+                                      _stream(self.device)), "cda_gae_records")
+        return self.buf["record"].view(self.T * self.N, self.A, 8), self.adv_stats, self.T * self.N * self.A
+
 
 class FusedUpdate:
     """The PPO update on the kernels of include/cda_mlp.h: per epoch one gather / convert pass over the R unique observations (shuffled),
@@ -334,8 +344,9 @@ class FusedUpdate:
         self.perm = torch.zeros(self.R, dtype=torch.int64, device=dev)
         self.shuffle_seed, self._epochs_done = 0x5DEECE66D, 0
 
-    def minibatch_step(self, s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, apply=True):
-        """rows [s, s + rows) of the prepared (shuffled) observations: one optimiser step"""
+    def minibatch_step(self, s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, apply=True, records=None):
+        """rows [s, s + rows) of the prepared (shuffled) observations: one optimiser step.  records = (rec f32 [R, A, 8], adv sums f64[2] or
+        None, their count): the loss reads sample records (RolloutChains.gae) instead of the seven per-sample arrays."""
         L, p, dev = _lib(), self.p, self.p.device
         st = _stream(dev)
         sub = self.sub if (rows % (32 * self.sub) == 0 and rows // self.sub >= 32) else 1
@@ -348,11 +359,18 @@ class FusedUpdate:
             x_pk = self.x_pk.data_ptr() + o * 32 * XT * 2
             _check(L.cda_mlp_forward_train(p.wb.data_ptr(), p.theta.data_ptr(), x_rm, rs, self.h1p.data_ptr(), self.h2p.data_ptr(), self.out.data_ptr(), st), "cda_mlp_forward_train")
             last = k == sub - 1
-            _check(L.cda_ppo_loss32(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(), acts[3].data_ptr(),
+            if records is not None:
+                rec, stats, count = records
+                _check(L.cda_ppo_loss_records(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, rec.data_ptr(), stats.data_ptr() if stats is not None else None, int(count),
+                                              self.perm.data_ptr() + o * 8, rs, self.A, NOUT, float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(),
+                                              self.sums5.data_ptr(), self.out6.data_ptr(), rows, 0 if (apply or k) else 1, 0 if (apply or not last) else 1, st),
+                       "cda_ppo_loss_records")
+            else:
+              _check(L.cda_ppo_loss32(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(), acts[3].data_ptr(),
                                     logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), self.perm.data_ptr() + o * 8, rs, self.A, NOUT,
                                     float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(), self.sums5.data_ptr(), self.out6.data_ptr(), rows,
                                     0 if (apply or k) else 1, 0 if (apply or not last) else 1, st),
-                   "cda_ppo_loss32")            # (apply: the sums are finished and cleared by cda_mlp_adam; they accumulate over the sub-batches)
+                     "cda_ppo_loss32")          # (apply: the sums are finished and cleared by cda_mlp_adam; they accumulate over the sub-batches)
             _check(L.cda_mlp_backward(p.wb.data_ptr(), self.d_out.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), rs, self.dz1p.data_ptr(), self.dz2p.data_ptr(),
                                       self.doutp.data_ptr(), self.bias_slab.data_ptr() + k * tiles_sub * BSLAB * 4, st), "cda_mlp_backward")
             _check(L.cda_mlp_wgrad(x_pk, self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(), rs, chunks,
@@ -365,16 +383,20 @@ class FusedUpdate:
                                   self.grad.data_ptr(), self.norm2.data_ptr(), st), "cda_mlp_adam")
         return chunks, tiles
 
-    def run(self, obs_rows, acts, logp_old, adv, ret, epochs=4, clip=0.2, vf_coef=0.5, ent_coef=0.01, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5,
-            perms=None):
+    def run(self, obs_rows, acts=None, logp_old=None, adv=None, ret=None, epochs=4, clip=0.2, vf_coef=0.5, ent_coef=0.01, lr=5e-5, betas=(0.9, 0.999), eps=1e-8,
+            max_norm=0.5, perms=None, records=None):
         """obs_rows f32 [R, 168] (one row per market-step); acts = (category i32, price i32, price_offset i32, a_cont f32[.., 2]) and logp_old / adv
         / ret f32, R * A entries each, sample r * A + a belonging to row r.  adv is expected normalised.  perms: optional i64 [epochs, R]
-        (tests); default torch.randperm per epoch."""
+        (tests); default a keyed permutation per epoch.  records = (rec, adv sums or None, count) replaces acts / logp_old / adv / ret (see
+        minibatch_step); with the sums given the advantages are normalised inside the loss."""
         L, dev = _lib(), self.p.device
         assert obs_rows.shape == (self.R, OBS) and obs_rows.dtype == torch.float32 and obs_rows.is_contiguous()
-        for t in (*acts, logp_old, adv, ret):
-            assert t.is_contiguous()
-        assert acts[0].dtype == torch.int32 and acts[3].dtype == torch.float32 and adv.dtype == torch.float32
+        if records is not None:
+            assert records[0].dtype == torch.float32 and records[0].is_contiguous() and records[0].numel() == self.R * self.A * 8
+        else:
+            for t in (*acts, logp_old, adv, ret):
+                assert t.is_contiguous()
+            assert acts[0].dtype == torch.int32 and acts[3].dtype == torch.float32 and adv.dtype == torch.float32
         for ep in range(epochs):
             if perms is None:                                   # a keyed bijection per epoch (one launch; torch.randperm is a device sort)
                 self._epochs_done += 1
@@ -385,5 +407,5 @@ class FusedUpdate:
             _check(L.cda_mlp_prep_rows(obs_rows.data_ptr(), self.perm.data_ptr(), self.R, self.x_rm.data_ptr(), self.x_pk.data_ptr(), _stream(dev)), "cda_mlp_prep_rows")
             for s in range(0, self.R, self.rows_mb):
                 rows = min(self.rows_mb, self.R - s)
-                self.minibatch_step(s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm)
+                self.minibatch_step(s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, records=records)
         return {"pg_loss": self.out6[0], "v_loss": self.out6[1], "entropy": self.out6[2]}

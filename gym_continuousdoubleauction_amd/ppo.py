@@ -488,22 +488,15 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, 
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         buf = roll.run()
-        val = buf["value"][:T].unsqueeze(-1).expand(T, N, A).reshape(T, N * A)
-        last_val = buf["value"][T].unsqueeze(-1).expand(N, A).reshape(N * A)
-        rew = (buf["reward"].float() * reward_scale).view(T, N * A)
-        dn = (buf["terminated"] | buf["truncated"]).unsqueeze(-1).expand(T, N, A).reshape(T, N * A).float()
-        adv, ret = gae(rew, val, last_val, dn, gamma=gamma, lam=lam)
-        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).reshape(-1).contiguous()
+        records = roll.gae(gamma=gamma, lam=lam, reward_scale=reward_scale)     # advantages + returns into the sample records, one launch
         torch.cuda.synchronize(dev)
         t_roll = time.perf_counter()
-        acts = (buf["category"].view(-1), buf["price"].view(-1), buf["price_offset"].view(-1), buf["a_cont"].view(-1, 2))
-        stats = upd.run(buf["obs"][:T].view(R, -1), acts, buf["logp"].view(-1), adv, ret.reshape(-1).contiguous(), epochs=epochs, clip=clip, vf_coef=vf_coef,
-                        ent_coef=ent_coef, lr=lr)
+        stats = upd.run(buf["obs"][:T].view(R, -1), epochs=epochs, clip=clip, vf_coef=vf_coef, ent_coef=ent_coef, lr=lr, records=records)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         stats = {k: float(v) for k, v in stats.items()}
-        stats.update(iter=it, mean_reward=float(rew.mean()) / reward_scale, agent_steps=N * A * T, agent_steps_per_s=N * A * T / (t1 - t0),
-                     rollout_s=t_roll - t0, update_s=t1 - t_roll)
+        stats.update(iter=it, mean_reward=float(buf["reward"].mean()), agent_steps=N * A * T, agent_steps_per_s=N * A * T / (t1 - t0),
+                     rollout_s=t_roll - t0, update_s=t1 - t_roll)           # (the reward mean is outside the timed region: logging only)
         history.append(stats)
         log(json.dumps(stats))
     if keep is not None:

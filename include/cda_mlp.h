@@ -148,9 +148,31 @@ typedef struct cda_rollout_bufs {
     double*  reward;         /* [T][N][A] */
     uint8_t* terminated;     /* [T][N] */
     uint8_t* truncated;      /* [T][N] */
+    float*   record;         /* [T][N][A][8] or NULL: the sample records below (words 0..5 written by the policy step) */
 } cda_rollout_bufs;
 int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
                           uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* bufs, int32_t copy_first_obs, void* stream);
+
+/* Sample records: what the update's loss reads of a sample, as ONE 32-byte record - a row's A samples are then one contiguous piece (the seven
+ * separate per-sample arrays cost seven scattered gathers per row).  Words: */
+#define CDA_REC_CATEGORY  0   /* i32 */
+#define CDA_REC_PRICE     1   /* i32 */
+#define CDA_REC_OFFSET    2   /* i32 */
+#define CDA_REC_CONT0     3   /* f32: the raw Gaussian samples */
+#define CDA_REC_CONT1     4
+#define CDA_REC_LOGP      5   /* f32: log-probability under the rollout's policy */
+#define CDA_REC_ADV       6   /* f32: advantage (unnormalised) */
+#define CDA_REC_RET       7   /* f32: return */
+/* Generalised advantage estimation of a whole rollout, straight from its buffers into the records (ppo.gae's recursion, one launch): reward f64
+ * [T][N][A] (scaled by reward_scale here), value f32 [T+1][N] (slot T = the bootstrap value), terminated / truncated u8 [T][N] -> words ADV, RET
+ * of rec [T][N][A][8]; stats2 f64[2] receives the sum of the advantages and of their squares. */
+int cda_gae_records(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
+                    int32_t num_agents, float reward_scale, float gamma, float lam, float* rec, double* stats2, void* stream);
+/* cda_ppo_loss32 reading sample records (rec = [all rows][A][8]; row_index as there).  adv_stats2 (may be NULL) + adv_count: the advantages are
+ * normalised on the fly, (adv - mean) / (std + 1e-8) with the unbiased std over the adv_count samples the sums were taken over. */
+int cda_ppo_loss_records(const float* outputs, const float* log_std, const float* rec, const double* adv_stats2, int64_t adv_count, const int64_t* row_index,
+                         int64_t rows, int32_t agents_per_row, int32_t out_stride, float clip, float vf_coef, float ent_coef,
+                         float* d_outputs, double* sums5, float* out6, int64_t norm_rows, int32_t clear, int32_t finish, void* stream);
 
 /* Device self-test of the operand / accumulator conventions this file is built on: D f32[32][32] = A bf16-rounded f32[32][16] x
  * B f32[16][32] through one v_mfma_f32_32x32x16_bf16 (host pointers; synchronous). */

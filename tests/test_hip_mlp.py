@@ -375,6 +375,10 @@ def test_rollout_chains_record_what_the_oracle_replays(groups, use_graphs):
             assert np.array_equal(b["reward"][t].numpy().view(np.uint64), orw.view(np.uint64)), (rnd, t)
             assert np.array_equal(b["obs"][t + 1].numpy().view(np.uint32), oo.view(np.uint32)), (rnd, t)
             assert not b["terminated"][t].any() and not b["truncated"][t].any()
+        rec = b["record"]                                    # the sample records hold the same words as the per-sample arrays
+        for w, k in enumerate(("category", "price", "price_offset")):
+            assert torch.equal(rec[..., w].contiguous().view(torch.int32), b[k])
+        assert torch.equal(rec[..., 3:5], b["a_cont"]) and torch.equal(rec[..., 5], b["logp"])
         cnt = roll.counter.clone()
         for t in (0, T // 2, T - 1):
             o = p.policy_step(buf["obs"][t], A, seed=99, counter=cnt, draw=t)
@@ -385,6 +389,48 @@ def test_rollout_chains_record_what_the_oracle_replays(groups, use_graphs):
         assert torch.equal(p.forward(buf["obs"][T])[:, 24].cpu(), b["value"][T])
     assert (env.flags() == 0).all() and (env.check_invariants() == 0).all()
     env.close(); ora.close()
+
+
+def test_gae_into_records_and_the_loss_on_records_equal_the_array_path():
+    """cda_gae_records = ppo.gae on the rollout's buffers (episode ends included), its sums = the normalisation ppo_update applies; the loss
+    reading records (normalising on the fly) = the loss reading the seven arrays with torch-normalised advantages."""
+    from gym_continuousdoubleauction_amd import CDAVecEnv, mlp, ppo
+    from gym_continuousdoubleauction_amd._lib import lib, check
+    N, A, T = 96, 4, 40
+    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 16, "is_render": False, "auto_reset": True}
+    env = CDAVecEnv(cfg, n_markets=N, with_info=False)
+    p = _policy(seed=31)
+    env.reset(seed=7)
+    roll = mlp.RolloutChains(env, p, T, groups=2, seed=5)
+    buf = roll.run()
+    rec, stats, count = roll.gae(gamma=0.97, lam=0.9, reward_scale=1e-3)
+    torch.cuda.synchronize()
+    assert count == T * N * A and bool((buf["terminated"] | buf["truncated"]).any())
+    val = buf["value"][:T].unsqueeze(-1).expand(T, N, A).reshape(T, N * A)
+    last_val = buf["value"][T].unsqueeze(-1).expand(N, A).reshape(N * A)
+    rew = (buf["reward"].float() * 1e-3).view(T, N * A)
+    dn = (buf["terminated"] | buf["truncated"]).unsqueeze(-1).expand(T, N, A).reshape(T, N * A).float()
+    adv, ret = ppo.gae(rew, val, last_val, dn, gamma=0.97, lam=0.9)
+    r4 = buf["record"]
+    assert torch.allclose(r4[..., 6].reshape(T, N * A), adv, rtol=1e-5, atol=1e-6) and torch.allclose(r4[..., 7].reshape(T, N * A), ret, rtol=1e-5, atol=1e-6)
+    a64 = r4[..., 6].double()
+    assert abs(float(stats[0]) - float(a64.sum())) <= 1e-6 * float(a64.abs().sum()) and abs(float(stats[1]) - float((a64 * a64).sum())) <= 1e-9 * float((a64 * a64).sum())
+    # the two loss kernels on the same rows
+    R = T * N
+    upd = mlp.FusedUpdate(p, R, R, A, chunks=2)
+    upd.perm.copy_(torch.randperm(R, generator=torch.Generator().manual_seed(2)))
+    check(lib().cda_mlp_prep_rows(buf["obs"][:T].view(R, -1).data_ptr(), upd.perm.data_ptr(), R, upd.x_rm.data_ptr(), upd.x_pk.data_ptr(), torch.cuda.current_stream().cuda_stream), "prep")
+    adv_n = ((r4[..., 6] - r4[..., 6].mean()) / (r4[..., 6].std() + 1e-8)).reshape(-1).contiguous()
+    acts = (buf["category"].view(-1), buf["price"].view(-1), buf["price_offset"].view(-1), buf["a_cont"].view(-1, 2))
+    upd.minibatch_step(0, R, acts, buf["logp"].view(-1), adv_n, r4[..., 7].reshape(-1).contiguous(), 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5)
+    torch.cuda.synchronize()
+    g0, o0, d0 = upd.grad.clone(), upd.out6.clone(), upd.d_out.clone()
+    upd.minibatch_step(0, R, None, None, None, None, 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5, records=(rec, stats, count))
+    torch.cuda.synchronize()
+    assert torch.allclose(upd.d_out, d0, rtol=2e-4, atol=1e-9) and torch.allclose(upd.out6, o0, rtol=1e-4, atol=1e-7)
+    assert (upd.grad - g0).abs().max() <= 2e-4 * g0.abs().max()
+    assert abs(float(o0[0])) < 1e-3 + 1e-3                   # the rollout's own policy: ratio 1, normalised advantages -> policy loss ~ 0
+    env.close()
 
 
 def test_fused_training_loop_runs_and_learns_something():
