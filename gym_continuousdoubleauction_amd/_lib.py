@@ -26,7 +26,7 @@ SYMBOLS = [
 # every symbol include/cda_mlp.h declares
 MLP_SYMBOLS = [
     "cda_mlp_tile_rows", "cda_mlp_permutation", "cda_mlp_pack", "cda_mlp_policy_step", "cda_mlp_forward", "cda_mlp_prep_rows", "cda_mlp_forward_train", "cda_mlp_backward",
-    "cda_mlp_wgrad", "cda_mlp_adam", "cda_ppo_loss32", "cda_gae_records", "cda_ppo_loss_records", "cda_mlp_rollout_chain", "cda_mlp_selftest_mfma",
+    "cda_mlp_wgrad", "cda_mlp_adam", "cda_ppo_loss32", "cda_gae_records", "cda_ppo_loss_records", "cda_mlp_forward_backward", "cda_mlp_rollout_chain", "cda_mlp_selftest_mfma",
 ]
 
 
@@ -116,6 +116,7 @@ def lib():
     L.cda_ppo_loss32.argtypes = [vp] * 10 + [i64, i32, i32, f32, f32, f32, vp, vp, vp, i64, i32, i32, vp]
     L.cda_gae_records.argtypes = [vp, vp, vp, vp, i32, i64, i32, f32, f32, f32, vp, vp, vp]
     L.cda_ppo_loss_records.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, f32, f32, f32, vp, vp, vp, i64, i32, i32, vp]
+    L.cda_mlp_forward_backward.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.cda_mlp_rollout_chain.argtypes = [vp, vp, vp, i32, i32, i32, u64, vp, C.POINTER(RolloutBufs), i32, vp]
     L.cda_mlp_selftest_mfma.argtypes = [i32, vp, vp, vp]
     for name in SYMBOLS:

@@ -48,6 +48,7 @@ constexpr int ACT_LD = HID + 8;      // LDS row of an activation tile: 264 bf16 
 constexpr int DO_LD = NOUT + 8;      // LDS row of the d_out tile: 40 bf16 = 80 B = 16 x 5
 constexpr int OUTS_LD = NOUT + 1;    // f32 row of the output tile kept in LDS for the sampling epilogue
 constexpr int N_CAT = 9, N_PRICE = 10, N_OFF = 3, N_LOGITS = 24;
+constexpr int LPS_LD = N_CAT + N_PRICE + N_OFF + 1;   // 23 floats: odd, conflict free
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 constexpr float TWO_LOG2E = 2.885390081777926814f;
@@ -728,6 +729,414 @@ __global__ __launch_bounds__(512) void k_mlp_bwd8(BwdArgs A) {
     if (half == 0) __syncthreads();                                             // stage 3: the policy half's matching barrier
 }
 
+// ---- update, steps 0 - 2 in ONE kernel: gather, forward, loss, back-propagation of a 64-row tile ---------------------------------------------
+// What the separate kernels pass through HBM stays on the chip: the observation rows are gathered (by the epoch's permutation) straight from the
+// rollout's f32 buffer and their packed image for the weight gradients is written from the LDS tile (k_prep_rows and its two images: gone);
+// the outputs and their gradients live in LDS (k_ppo_loss_rec's launch and four 8-MB round trips: gone); h1 / h2 of a wave's own 64 features
+// stay in its registers for tanh' (the backward's re-read of 134 MB: gone).  HBM sees: x (f32), the records, h1p / h2p / dz1p / dz2p / doutp /
+// x_pk (what the weight gradients read) and the bias sums.
+// The two networks are independent down to the loss (the policy's loss terms need the 24 policy outputs only, the value loss the value only):
+// a workgroup = 4 waves = ONE network half of one tile (blockIdx.y), 71 KB of LDS - two workgroups share a CU, any two: one's MFMA phases run
+// under the other's tanh / loss phases and its gather (two dependent trips to HBM for random 672-B rows, ~14 k cycles) under the other's
+// arithmetic, with no barrier between them.  (Both halves in one 8-wave workgroup, the value half one stage behind: 121 us, every stage as long
+// as its slower half, the gather exposed; persistent workgroups prefetching the next tile: 131 us - 40 more live registers or 89 spilled SGPRs.)
+//     per workgroup:  gather  [x_pk]  M1  E1 | M2 | E2 | MH | L | MdH2+E | MdH1  E          ( | = workgroup barrier)
+// L: one lane per row (wave 0), logits / value read from the LDS output tile, d_out written back in place (f32, for the bias sums) and as the
+// bf16 A operand of MdH2.  A row's d_out has two owners (columns != 24: policy, 24: value): each workgroup writes its own lanes of doutp.
+struct FbArgs {
+    const float* obs; const long long* perm; long long n_rows, norm_rows;
+    const __bf16* wb; const float* theta;
+    const float* rec; const double* adv_stats; long long adv_count; int agents; float clip, vf_coef, ent_coef;
+    __bf16* x_pk; __bf16* h1p; __bf16* h2p; __bf16* dz1p; __bf16* dz2p; __bf16* doutp; float* bias_slab;
+    float* out; float* d_out;        // optional f32 [rows][32] copies of the outputs and their gradients (tests, diagnostics)
+    double* sums5;
+    unsigned long long* dbg; int dbg_block;
+};
+__device__ __forceinline__ void store_packed_keep(__bf16* __restrict__ base, long long rt, int nft, int ft, int lane, const float (&v)[16], bf16x8 (&k)[2]) {
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    f32x8 f0, f1;
+    #pragma unroll
+    for (int r = 0; r < 8; r++) { f0[r] = v[r]; f1[r] = v[8 + r]; }
+    k[0] = __builtin_convertvector(f0, bf16x8); k[1] = __builtin_convertvector(f1, bf16x8);
+    bf16x8* dst = reinterpret_cast<bf16x8*>(base) + ((rt * nft + ft) * 2) * 64 + lane;
+    dst[0] = k[0]; dst[64] = k[1];
+}
+// softmax of one head: p[q], c = max + log(sum) (log p[q] = l[q] - c), entropy
+template <int N> __device__ __forceinline__ void head_probs_c(const float* l, float* p, float& c, float& ent) {
+    float mx = l[0];
+    #pragma unroll
+    for (int q = 1; q < N; q++) mx = fmaxf(mx, l[q]);
+    float s = 0.0f;
+    #pragma unroll
+    for (int q = 0; q < N; q++) { p[q] = __expf(l[q] - mx); s += p[q]; }
+    const float ls = __logf(s), inv = 1.0f / s;
+    float hh = 0.0f;
+    #pragma unroll
+    for (int q = 0; q < N; q++) { p[q] *= inv; hh -= p[q] * (l[q] - mx - ls); }
+    c = mx + ls; ent = hh;
+}
+// quad (four neighbouring lanes) exchanges: DPP quad_perm, one instruction each, no LDS
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false)); }
+__device__ __forceinline__ float quad_sum(float x) { x += dpp_f<0xB1>(x); x += dpp_f<0x4E>(x); return x; }          // [1,0,3,2] then [2,3,0,1]
+__device__ __forceinline__ float quad_max(float x) { x = fmaxf(x, dpp_f<0xB1>(x)); x = fmaxf(x, dpp_f<0x4E>(x)); return x; }
+template <int Q> __device__ __forceinline__ float quad_bcast(float x) { return dpp_f<Q * 0x55>(x); }
+template <int Q> __device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, Q * 0x55, 0xf, 0xf, false); }
+#ifdef CDA_MLP_TIMING
+#define MLP_MARKH(i) do { if (A.dbg && (int)blockIdx.x == A.dbg_block && lane == 0) A.dbg[(4 * half + w) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MLP_MARKH(i) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workgroups per CU: 256 registers per wave)
+    constexpr int MT = 2, M = 64, PF = CDA_MLP_PF8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* xs = reinterpret_cast<__bf16*>(smem);                               // [M][XS_LD]; once layer 1 has read it, its bytes hold:
+    float* outs = reinterpret_cast<float*>(smem);                               //   [M][OUTS_LD] f32: the outputs, then (in place) their gradients
+    __bf16* dos = reinterpret_cast<__bf16*>(smem + M * OUTS_LD * 4);            //   [M][DO_LD] bf16: the gradients as MdH2's A operand
+    static_assert(M * OUTS_LD * 4 + M * DO_LD * 2 <= M * XS_LD * 2, "the output tiles fit the observation tile's bytes");
+    const int lane = (int)threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), half = (int)blockIdx.y;
+    __bf16* act = xs + M * XS_LD;                                               // [M][ACT_LD]: h1, h2, then dz2
+    float* lps = reinterpret_cast<float*>(act + M * ACT_LD);                    // [M][LPS_LD] f32: a row's log-probabilities, indexed by the agents' actions
+    float* recs = lps + M * LPS_LD;                                             // [M][agents][8]: the tile's sample records
+    const long long row0 = (long long)blockIdx.x * M, rows_end = A.n_rows;
+    const int f0 = 256 * half + 64 * w, ft0 = f0 >> 5;
+    const float b1_0 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j] * TWO_LOG2E, b1_1 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j + 1] * TWO_LOG2E;
+    const float b2_0 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j] * TWO_LOG2E, b2_1 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j + 1] * TWO_LOG2E;
+    const float bo = A.theta[CDA_MLP_OFF_BO + j];
+    float* bs = A.bias_slab + (size_t)blockIdx.x * CDA_MLP_BSLAB;
+    const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
+    const __bf16* W2T = A.wb + CDA_MLP_WB_W2T; const __bf16* WoT = A.wb + CDA_MLP_WB_WOT;
+    WRing<2, KX / 16, PF, true> R1; WRing<2, HID / 16, PF, true> R2; WRing<1, HID / 16, PF> RO;
+    MLP_MARKH(0);
+    {   // the tile's rows, gathered.  Their source rows first (one lane each, through LDS): with the index known every request below is
+        // unconditional and independent - the compiler issues them back to back (behind a per-request `perm ? perm[i] : i` it waited for each
+        // index, then for each row: 14 round trips in a row)
+        long long* srow = reinterpret_cast<long long*>(lps);                    // (the log-probabilities' bytes: used by the loss, long after)
+        if (threadIdx.x < M) {
+            long long gr = row0 + (int)threadIdx.x; if (gr >= rows_end) gr = rows_end - 1;   // rows past the end repeat the last one (their loss terms are masked)
+            srow[threadIdx.x] = A.perm ? A.perm[gr] : gr;
+        }
+        R1.prime(W1b + (size_t)f0 * KX, KX, lane);
+        __syncthreads();
+        constexpr int CH = KX / 4, N = M * CH, PER = (N + 255) / 256;           // 44 chunks of 4 values per row (42 real + 2 of zeros): 11 per thread
+        float4 v[PER];
+        #pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
+            v[u] = *reinterpret_cast<const float4*>(A.obs + srow[r] * OBS + (q < OBS / 4 ? q : OBS / 4 - 1) * 4);
+        }
+        const int rec_pieces = M * A.agents * 2;                                // the records: [agents][8] f32 per row = 2 agents' 16-B pieces
+        for (int c = (int)threadIdx.x; c < rec_pieces; c += 256) {
+            const int r = c / (2 * A.agents), q = c - r * (2 * A.agents);
+            reinterpret_cast<float4*>(recs)[c] = reinterpret_cast<const float4*>(A.rec + srow[r] * A.agents * 8)[q];
+        }
+        #pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
+            bf16x4 b; b[0] = (__bf16)v[u].x; b[1] = (__bf16)v[u].y; b[2] = (__bf16)v[u].z; b[3] = (__bf16)v[u].w;
+            if (q >= OBS / 4) { b[0] = b[1] = b[2] = b[3] = (__bf16)0.0f; }
+            *reinterpret_cast<bf16x4*>(xs + r * XS_LD + q * 4) = b;
+        }
+    }
+    __syncthreads();                                                            // the observation tile is in LDS
+    MLP_MARKH(1);
+    if (half == 1) {                                                            // value half: the packed image of x for the weight gradients
+        #pragma unroll
+        for (int u = 0; u < MT * XT * 2 / 4; u++) {                             // 24 pieces (row tile, feature tile, k-step), 6 per wave
+            const int pc = w + 4 * u, it = pc / (XT * 2), rem = pc - it * (XT * 2), ft = rem >> 1, ks = rem & 1;
+            bf16x8 v;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (32 * ft + j < KX) ? xs[(32 * it + rowmap(8 * ks + e, h)) * XS_LD + 32 * ft + j] : (__bf16)0.0f;
+            reinterpret_cast<bf16x8*>(A.x_pk)[(((row0 / 32 + it) * XT + ft) * 2 + ks) * 64 + lane] = v;
+        }
+    }
+    MLP_MARKH(2);
+    bf16x8 k1[MT][2][2], k2[MT][2][2];                                          // h1, h2 of this wave's 64 features, as stored: tanh' comes from them
+    f32x16 acc[MT][2];
+    #pragma unroll
+    for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+    layer_mma(xs, XS_LD, R1, lane, acc);                                        // M1
+    MLP_MARKH(3);
+    R2.prime(W2b + ((size_t)half * HID + 64 * w) * HID, HID, lane);
+    #pragma unroll
+    for (int it = 0; it < MT; it++) {                                           // E1
+        float v0[16], v1[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], b1_0); v1[r] = tanh_biased(acc[it][1][r], b1_1); }
+        store_packed_keep(A.h1p, row0 / 32 + it, 16, ft0, lane, v0, k1[it][0]);
+        store_packed_keep(A.h1p, row0 / 32 + it, 16, ft0 + 1, lane, v1, k1[it][1]);
+        store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    MLP_MARKH(4);
+    __syncthreads();
+    MLP_MARKH(5);
+    #pragma unroll
+    for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+    layer_mma(act, ACT_LD, R2, lane, acc);                                      // M2
+    MLP_MARKH(6);
+    RO.prime(Wob + (size_t)half * NOUT * HID, HID, lane);
+    __syncthreads();                                                            // every wave has read h1: h2 takes its place
+    MLP_MARKH(7);
+    #pragma unroll
+    for (int it = 0; it < MT; it++) {                                           // E2
+        float v0[16], v1[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], b2_0); v1[r] = tanh_biased(acc[it][1][r], b2_1); }
+        store_packed_keep(A.h2p, row0 / 32 + it, 16, ft0, lane, v0, k2[it][0]);
+        store_packed_keep(A.h2p, row0 / 32 + it, 16, ft0 + 1, lane, v1, k2[it][1]);
+        store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    MLP_MARKH(8);
+    __syncthreads();
+    MLP_MARKH(9);
+    const bool own_col = half == 0 ? j != N_LOGITS : j == N_LOGITS;             // policy: columns 0 .. 23 and the zero padding; value: column 24
+    {   // MH: wave w owns row tile w (waves >= MT multiply a tile nobody reads); the outputs go to LDS (the observation tile is dead)
+        f32x16 acc3[1][1]; acc3[0][0] = zero16();
+        layer_mma(act + (w < MT ? 32 * w : 0) * ACT_LD, ACT_LD, RO, lane, acc3);
+        if (w < MT) {
+            #pragma unroll
+            for (int r = 0; r < 16; r++) outs[(32 * w + rowmap(r, h)) * OUTS_LD + j] = own_col ? acc3[0][0][r] + bo : 0.0f;
+        }
+    }
+    MLP_MARKH(10);
+    WRing<2, NOUT / 16, PF, true> RT; WRing<2, HID / 16, PF, true> R2T;
+    RT.prime(WoT + (size_t)f0 * NOUT, NOUT, lane);
+    __syncthreads();                                                            // the outputs are in LDS
+    MLP_MARKH(11);
+    // ---- the loss of this half's outputs: lane = row, wave 0 --------------------------------------------------------------------------------
+    const float invB = 1.0f / ((float)A.norm_rows * (float)A.agents);
+    if (half == 0) {
+        // the policy's loss terms, FOUR lanes per row (every wave: rows 16 w .. + 15): lane s of a row's quad holds the six outputs 6 s .. 6 s + 5
+        // (heads: category 0 .. 8, price 9 .. 18, offset 19 .. 21, the two means 22, 23), the softmax reductions run over the quad (DPP), the
+        // row's agents are dealt round the quad and each agent's terms broadcast back.  (One lane per row on one wave: ~1000 instructions,
+        // 7.5 k cycles with the other three waves waiting.)
+        const int row = 16 * w + (lane >> 2), sq = lane & 3, i0 = 6 * sq;
+        const bool live = row0 + row < rows_end;
+        const float* rr = recs + (size_t)row * A.agents * 8;
+        float* orow = outs + row * OUTS_LD;
+        __bf16* drow = dos + row * DO_LD;
+        float adv_mean = 0.0f, adv_rstd = 1.0f;
+        if (A.adv_stats) {
+            const double m = A.adv_stats[0] / (double)A.adv_count, var = (A.adv_stats[1] - (double)A.adv_count * m * m) / (double)(A.adv_count - 1);
+            adv_mean = (float)m; adv_rstd = 1.0f / ((float)sqrt(var > 0.0 ? var : 0.0) + 1e-8f);
+        }
+        float l[6], d[6], pr[6], lp[6]; int hid[6];
+        #pragma unroll
+        for (int k = 0; k < 6; k++) { l[k] = orow[i0 + k]; d[k] = 0.0f; const int i = i0 + k; hid[k] = i < N_CAT ? 0 : (i < N_CAT + N_PRICE ? 1 : (i < N_CAT + N_PRICE + N_OFF ? 2 : 3)); }
+        const float NEG = -3.0e38f;
+        float mx[3], sm[3], cc[3], hh[3];
+        #pragma unroll
+        for (int t = 0; t < 3; t++) {
+            float m = NEG;
+            #pragma unroll
+            for (int k = 0; k < 6; k++) m = fmaxf(m, hid[k] == t ? l[k] : NEG);
+            mx[t] = quad_max(m);
+        }
+        #pragma unroll
+        for (int k = 0; k < 6; k++) pr[k] = hid[k] < 3 ? __expf(l[k] - (hid[k] == 0 ? mx[0] : (hid[k] == 1 ? mx[1] : mx[2]))) : 0.0f;
+        #pragma unroll
+        for (int t = 0; t < 3; t++) {
+            float x = 0.0f;
+            #pragma unroll
+            for (int k = 0; k < 6; k++) x += hid[k] == t ? pr[k] : 0.0f;
+            sm[t] = quad_sum(x);
+        }
+        float inv[3];
+        #pragma unroll
+        for (int t = 0; t < 3; t++) { cc[t] = mx[t] + __logf(sm[t]); inv[t] = 1.0f / sm[t]; }
+        #pragma unroll
+        for (int k = 0; k < 6; k++) {
+            pr[k] *= hid[k] == 0 ? inv[0] : (hid[k] == 1 ? inv[1] : inv[2]);
+            lp[k] = hid[k] < 3 ? l[k] - (hid[k] == 0 ? cc[0] : (hid[k] == 1 ? cc[1] : cc[2])) : 0.0f;
+        }
+        #pragma unroll
+        for (int t = 0; t < 3; t++) {
+            float x = 0.0f;
+            #pragma unroll
+            for (int k = 0; k < 6; k++) x -= hid[k] == t ? pr[k] * lp[k] : 0.0f;
+            hh[t] = quad_sum(x);
+        }
+        const float mean0 = quad_bcast<3>(l[4]), mean1 = quad_bcast<3>(l[5]);   // outputs 22, 23: lane 3's last two
+        const float ls0 = A.theta[CDA_MLP_OFF_LS], ls1 = A.theta[CDA_MLP_OFF_LS + 1];
+        const float is0 = __expf(-ls0), is1 = __expf(-ls1);
+        const float HALF_LOG_2PI = 0.918938533204672742f;
+        const float ent = hh[0] + hh[1] + hh[2] + 1.0f + 2.0f * HALF_LOG_2PI + ls0 + ls1;
+        const float es = A.ent_coef * invB;
+        float* lrow = lps + row * LPS_LD;                                       // the row's log-probabilities, indexed by the agents' actions
+        #pragma unroll
+        for (int k = 0; k < 6; k++) lrow[i0 + k < LPS_LD ? i0 + k : LPS_LD - 1] = lp[k];    // (22 real entries; the means' two slots land on the row's spare word)
+        float pg = 0.0f, en = 0.0f, dls0 = 0.0f, dls1 = 0.0f, G = 0.0f, dm0 = 0.0f, dm1 = 0.0f;
+        for (int a4 = 0; a4 < A.agents; a4 += 4) {                              // agent a4 + s on lane s of the quad
+            const int a = a4 + sq;
+            float g = 0.0f, gz0 = 0.0f, gz1 = 0.0f; int ac = -1, ap = -1, ao = -1;
+            if (a < A.agents) {
+                const float4 w0 = reinterpret_cast<const float4*>(rr)[2 * a], w1 = reinterpret_cast<const float4*>(rr)[2 * a + 1];
+                ac = __float_as_int(w0.x); ap = __float_as_int(w0.y); ao = __float_as_int(w0.z);
+                const float z0 = (w0.w - mean0) * is0, z1 = (w1.x - mean1) * is1;
+                const float logp = -0.5f * z0 * z0 - ls0 - HALF_LOG_2PI - 0.5f * z1 * z1 - ls1 - HALF_LOG_2PI +
+                                   lrow[min(max(ac, 0), N_CAT - 1)] + lrow[N_CAT + min(max(ap, 0), N_PRICE - 1)] + lrow[N_CAT + N_PRICE + min(max(ao, 0), N_OFF - 1)];
+                const float Av = (w1.z - adv_mean) * adv_rstd, ratio = __expf(logp - w1.y);
+                const float un = ratio * Av, cl = fminf(fmaxf(ratio, 1.0f - A.clip), 1.0f + A.clip) * Av;
+                pg -= fminf(un, cl);
+                g = (un <= cl) ? -un * invB : 0.0f;
+                en += ent;
+                gz0 = g * z0 * is0; gz1 = g * z1 * is1;
+                dls0 += g * (z0 * z0 - 1.0f) - es;
+                dls1 += g * (z1 * z1 - 1.0f) - es;
+            }
+            // agent Q of this group, broadcast: its three actions as slot numbers of THIS lane (head ranges are disjoint: at most one of the
+            // three can name a slot; an absent agent adds g = 0)
+            #define CDA_FB_AGENT(Q) { \
+                const float gq = quad_bcast<Q>(g); \
+                const int r0 = quad_bcast_i<Q>(ac) - i0, r1 = N_CAT + quad_bcast_i<Q>(ap) - i0, r2 = N_CAT + N_PRICE + quad_bcast_i<Q>(ao) - i0; \
+                G += gq; dm0 += quad_bcast<Q>(gz0); dm1 += quad_bcast<Q>(gz1); \
+                _Pragma("unroll") for (int k = 0; k < 6; k++) d[k] += ((r0 == k) | (r1 == k) | (r2 == k)) ? gq : 0.0f; }
+            CDA_FB_AGENT(0) CDA_FB_AGENT(1) CDA_FB_AGENT(2) CDA_FB_AGENT(3)
+            #undef CDA_FB_AGENT
+        }
+        const float esA = es * (float)A.agents;
+        #pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const float hk = hid[k] == 0 ? hh[0] : (hid[k] == 1 ? hh[1] : hh[2]);
+            d[k] += -G * pr[k] + esA * pr[k] * (lp[k] + hk);                    // (the means' slots: pr = 0)
+        }
+        if (sq == 3) { d[4] = dm0; d[5] = dm1; }
+        if (A.out && live) {
+            #pragma unroll
+            for (int k = 0; k < 6; k++) A.out[(row0 + row) * NOUT + i0 + k] = l[k];
+            if (sq != 0) A.out[(row0 + row) * NOUT + N_LOGITS + 2 * sq] = 0.0f;
+            A.out[(row0 + row) * NOUT + N_LOGITS + 2 * sq + 1] = 0.0f;
+        }
+        if (!live) {
+            pg = en = dls0 = dls1 = 0.0f;
+            #pragma unroll
+            for (int k = 0; k < 6; k++) d[k] = 0.0f;
+        }
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        #pragma unroll
+        for (int k = 0; k < 6; k += 2) {
+            orow[i0 + k] = d[k]; orow[i0 + k + 1] = d[k + 1];
+            f32x2 f; f[0] = d[k]; f[1] = d[k + 1];
+            *reinterpret_cast<bf16x2*>(drow + i0 + k) = __builtin_convertvector(f, bf16x2);
+        }
+        orow[N_LOGITS + 2 * sq] = 0.0f; orow[N_LOGITS + 2 * sq + 1] = 0.0f;     // columns 24 .. 31: zero (24 is the value workgroup's, in its own tile)
+        { f32x2 f; f[0] = 0.0f; f[1] = 0.0f; *reinterpret_cast<bf16x2*>(drow + N_LOGITS + 2 * sq) = __builtin_convertvector(f, bf16x2); }
+        if (A.d_out && live) {
+            #pragma unroll
+            for (int k = 0; k < 6; k++) A.d_out[(row0 + row) * NOUT + i0 + k] = d[k];
+            if (sq != 0) A.d_out[(row0 + row) * NOUT + N_LOGITS + 2 * sq] = 0.0f;
+            A.d_out[(row0 + row) * NOUT + N_LOGITS + 2 * sq + 1] = 0.0f;
+        }
+        float v4[4] = {pg, en, dls0, dls1};
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float x = v4[q];
+            #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+            v4[q] = x;
+        }
+        double* slot = A.sums5 + 8 * ((4 * (int)blockIdx.x + w) & (CDA_MLP_LOSS_SLOTS - 1));   // a slot (one cache line) per wave mod 64: one hot line stalls every CU's memory pipeline behind its atomics
+        if (lane == 0) { atomicAdd(&slot[0], (double)v4[0]); atomicAdd(&slot[2], (double)v4[1]); atomicAdd(&slot[3], (double)v4[2]); atomicAdd(&slot[4], (double)v4[3]); }
+    } else if (w == 0) {                                                        // the value loss: a lane per row
+        const int row = lane;
+        const bool live = row0 + row < rows_end;
+        const float* rr = recs + (size_t)row * A.agents * 8;
+        float* orow = outs + row * OUTS_LD;
+        __bf16* drow = dos + row * DO_LD;
+        const float val = orow[N_LOGITS];
+        float vl = 0.0f, dval = 0.0f;
+        for (int a = 0; a < A.agents; a++) {
+            const float dv = val - rr[8 * a + 7];
+            vl += dv * dv;
+            dval += 2.0f * A.vf_coef * dv * invB;
+        }
+        if (A.out && live) A.out[(row0 + row) * NOUT + N_LOGITS] = val;
+        if (!live) { vl = 0.0f; dval = 0.0f; }
+        #pragma unroll
+        for (int q = 0; q < NOUT; q++) { orow[q] = q == N_LOGITS ? dval : 0.0f; drow[q] = (__bf16)(q == N_LOGITS ? dval : 0.0f); }
+        if (A.d_out && live) A.d_out[(row0 + row) * NOUT + N_LOGITS] = dval;
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vl += __shfl_down(vl, o, 64);
+        if (lane == 0) atomicAdd(&A.sums5[8 * ((int)blockIdx.x & (CDA_MLP_LOSS_SLOTS - 1)) + 1], (double)vl);
+    }
+    MLP_MARKH(12);
+    __syncthreads();                                                            // d_out is in LDS
+    MLP_MARKH(13);
+    if (w >= MT) {                                                              // d_out's packed image and column sums: this half's columns (waves 2, 3: a row tile each)
+        const int it = w - MT;
+        if (own_col) {
+            bf16x8 v0, v1;
+            #pragma unroll
+            for (int r = 0; r < 8; r++) { v0[r] = dos[(32 * it + rowmap(r, h)) * DO_LD + j]; v1[r] = dos[(32 * it + rowmap(8 + r, h)) * DO_LD + j]; }
+            bf16x8* dst = reinterpret_cast<bf16x8*>(A.doutp) + ((row0 / 32 + it) * 2) * 64 + lane;
+            dst[0] = v0; dst[64] = v1;
+        }
+        float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                 // lane (column j, row half h) of wave 2 + it: 16 rows each, four running sums
+        #pragma unroll
+        for (int r = 0; r < 16; r++) s4[r & 3] += outs[(32 * it + 16 * h + r) * OUTS_LD + j];
+        float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        sum += __shfl_xor(sum, 32, 64);
+        float* part = reinterpret_cast<float*>(lps);                            // (the log-probabilities are dead)
+        if (h == 0) part[32 * it + j] = sum;
+    }
+    {   // MdH2 + E: dz2 = (d_out x Wo) tanh'(h2)
+        #pragma unroll
+        for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+        layer_mma(dos, DO_LD, RT, lane, acc);
+        MLP_MARKH(21);
+        R2T.prime(W2T + ((size_t)half * HID + 64 * w) * HID, HID, lane);
+        float colsum0 = 0.0f, colsum1 = 0.0f;
+        #pragma unroll
+        for (int it = 0; it < MT; it++) {
+            float v0[16], v1[16];
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float h0 = (float)k2[it][0][r >> 3][r & 7], h1 = (float)k2[it][1][r >> 3][r & 7];
+                v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
+                colsum0 += v0[r]; colsum1 += v1[r];
+            }
+            store_packed(A.dz2p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz2p, row0 / 32 + it, 16, ft0 + 1, lane, v1);
+            store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);         // (h2's image was last read by MH, two barriers ago)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
+        if (h == 0) { bs[CDA_MLP_FEAT + f0 + 2 * j] = colsum0; bs[CDA_MLP_FEAT + f0 + 2 * j + 1] = colsum1; }
+    }
+    MLP_MARKH(14);
+    __syncthreads();
+    MLP_MARKH(15);
+    if (w == 0 && h == 0 && own_col) {                                          // d_out's column sums: the two row tiles' shares
+        const float* part = reinterpret_cast<const float*>(lps);
+        bs[2 * CDA_MLP_FEAT + j] = part[j] + part[32 + j];
+    }
+    {   // MdH1, then E: dz1 = (dz2 x W2) tanh'(h1)
+        #pragma unroll
+        for (int it = 0; it < MT; it++) { acc[it][0] = zero16(); acc[it][1] = zero16(); }
+        layer_mma(act, ACT_LD, R2T, lane, acc);
+        MLP_MARKH(16);
+        float colsum0 = 0.0f, colsum1 = 0.0f;
+        #pragma unroll
+        for (int it = 0; it < MT; it++) {
+            float v0[16], v1[16];
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float h0 = (float)k1[it][0][r >> 3][r & 7], h1 = (float)k1[it][1][r >> 3][r & 7];
+                v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
+                colsum0 += v0[r]; colsum1 += v1[r];
+            }
+            store_packed(A.dz1p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz1p, row0 / 32 + it, 16, ft0 + 1, lane, v1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
+        if (h == 0) { bs[f0 + 2 * j] = colsum0; bs[f0 + 2 * j + 1] = colsum1; }
+    }
+    MLP_MARKH(17);
+}
+
 // ---- update, step 3: weight gradients ------------------------------------------------------------------------------------------
 // dW[i][j] = sum over rows of dz[row][i] h[row][j]: both operands come out of HBM in the packed layout, 16 B per lane, straight into
 // the MFMA (no LDS).  One workgroup = one JOB (an output panel) x one row chunk; the chunk's partial sum goes to the slab.
@@ -888,12 +1297,14 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
                 // statistics (out6, what k_ppo_finish32 would write) and clears the sums for the next minibatch - no memset, no extra launch
                 float g0 = 0.0f, g1 = 0.0f;
                 if (LF.sums5) {
-                    const double pg = LF.sums5[0] / (double)LF.samples, vl = LF.sums5[1] / (double)LF.samples, en = LF.sums5[2] / (double)LF.samples;
-                    g0 = (float)LF.sums5[3]; g1 = (float)LF.sums5[4];
+                    double t5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+                    for (int sl = 0; sl < CDA_MLP_LOSS_SLOTS; sl++)
+                        #pragma unroll
+                        for (int q = 0; q < 5; q++) { t5[q] += LF.sums5[8 * sl + q]; LF.sums5[8 * sl + q] = 0.0; }
+                    const double pg = t5[0] / (double)LF.samples, vl = t5[1] / (double)LF.samples, en = t5[2] / (double)LF.samples;
+                    g0 = (float)t5[3]; g1 = (float)t5[4];
                     if (LF.out6) { LF.out6[0] = (float)pg; LF.out6[1] = (float)vl; LF.out6[2] = (float)en; LF.out6[3] = (float)(pg + (double)LF.vf_coef * vl - (double)LF.ent_coef * en);
                                    LF.out6[4] = g0; LF.out6[5] = g1; }
-                    #pragma unroll
-                    for (int q = 0; q < 5; q++) LF.sums5[q] = 0.0;
                 }
                 grad[CDA_MLP_OFF_LS] = g0; grad[CDA_MLP_OFF_LS + 1] = g1; sq = g0 * g0 + g1 * g1;
             }
@@ -1073,6 +1484,17 @@ __global__ void k_ppo_finish32(const double* sums, long long B, float vf_coef, f
     }
 }
 
+__global__ void k_ppo_finish_slots(const double* sums, long long B, float vf_coef, float ent_coef, float* out) {      // the same over CDA_MLP_LOSS_SLOTS slots
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int sl = 0; sl < CDA_MLP_LOSS_SLOTS; sl++)
+            for (int q = 0; q < 5; q++) t5[q] += sums[8 * sl + q];
+        const double pg = t5[0] / (double)B, vl = t5[1] / (double)B, en = t5[2] / (double)B;
+        out[0] = (float)pg; out[1] = (float)vl; out[2] = (float)en; out[3] = (float)(pg + (double)vf_coef * vl - (double)ent_coef * en);
+        out[4] = (float)t5[3]; out[5] = (float)t5[4];
+    }
+}
+
 // ---- the rollout's sample records: GAE straight into them, and the loss reading them -----------------------------------------------------
 // One thread per (market, agent) column walks its T steps backwards (ppo.gae's recursion) on the rollout's own buffers - reward f64 [T][N][A]
 // (scaled here), value f32 [T + 1][N] (slot T = the bootstrap value), terminated / truncated u8 [T][N] - and writes advantage and return into
@@ -1227,6 +1649,12 @@ int train_mt() {
 }
 size_t fwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + 2 * M * ACT_LD * 2; }
 size_t bwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * OUTS_LD * 4 + 2 * M * ACT_LD * 2; }
+int compute_units() {
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; if (n < 1) n = 256; }
+    return n;
+}
+size_t fb_lds(int agents) { return (size_t)64 * XS_LD * 2 + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * agents * 32; }
 int rollout_mt() {
     static int mt = 0;
     if (!mt) { const char* e = getenv("CDA_MLP_ROLLOUT_MT"); mt = e ? atoi(e) : 1; if (mt != 1 && mt != 2 && mt != 4) mt = 1; }
@@ -1362,6 +1790,33 @@ extern "C" int cda_mlp_backward(const void* wb, const float* d_out, const void* 
     else if (mt == 2) { rc = allow_lds(k_mlp_bwd<2>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_bwd<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, A); }
     else { rc = allow_lds(k_mlp_bwd<1>, lds); if (!rc) hipLaunchKernelGGL(k_mlp_bwd<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, A); }
     if (rc) return rc;
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
+#ifdef CDA_MLP_TIMING
+static unsigned long long* g_fb_dbg = NULL; static int g_fb_dbg_block = 0;
+extern "C" void cda_tools_mlp_fb_dbg(void* dbg_u64x8x32, int32_t block) { g_fb_dbg = (unsigned long long*)dbg_u64x8x32; g_fb_dbg_block = block; }
+#endif
+extern "C" int cda_mlp_forward_backward(const void* wb, const float* theta, const float* obs, const int64_t* perm, int64_t n_rows, int64_t norm_rows,
+                                        const float* rec, const double* adv_stats2, int64_t adv_count, int32_t agents_per_row, float clip, float vf_coef, float ent_coef,
+                                        void* x_pk, void* h1p, void* h2p, void* dz1p, void* dz2p, void* doutp, float* bias_slab,
+                                        double* sums5, float* out6, int32_t clear, int32_t finish, float* out, float* d_out, void* stream) {
+    if (!wb || !theta || !obs || !rec || !x_pk || !h1p || !h2p || !dz1p || !dz2p || !doutp || !bias_slab || !sums5 || n_rows < 32 || (n_rows & 31) || norm_rows < 0 ||
+        agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS || (adv_stats2 && adv_count < 2) || (finish && !out6)) return CDA_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    FbArgs A; memset(&A, 0, sizeof A);
+    A.obs = obs; A.perm = (const long long*)perm; A.n_rows = n_rows; A.norm_rows = norm_rows > 0 ? norm_rows : n_rows; A.wb = (const __bf16*)wb; A.theta = theta;
+    A.rec = rec; A.adv_stats = adv_stats2; A.adv_count = adv_count; A.agents = agents_per_row; A.clip = clip; A.vf_coef = vf_coef; A.ent_coef = ent_coef;
+    A.x_pk = (__bf16*)x_pk; A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.dz1p = (__bf16*)dz1p; A.dz2p = (__bf16*)dz2p; A.doutp = (__bf16*)doutp; A.bias_slab = bias_slab;
+    A.out = out; A.d_out = d_out; A.sums5 = sums5;
+#ifdef CDA_MLP_TIMING
+    A.dbg = g_fb_dbg; A.dbg_block = g_fb_dbg_block;
+#endif
+    if (clear && hipMemsetAsync(sums5, 0, (size_t)CDA_MLP_LOSS_SLOTS * 8 * sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
+    const size_t lds = fb_lds(agents_per_row);
+    int rc = allow_lds(k_mlp_fb, lds); if (rc) return rc;
+    hipLaunchKernelGGL(k_mlp_fb, dim3((unsigned)((n_rows + 63) / 64), 2), dim3(256), lds, st, A);
+    if (finish) hipLaunchKernelGGL(k_ppo_finish_slots, dim3(1), dim3(64), 0, st, (const double*)sums5, A.norm_rows * agents_per_row, vf_coef, ent_coef, out6);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 

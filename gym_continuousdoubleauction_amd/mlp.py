@@ -319,12 +319,16 @@ class FusedUpdate:
     """The PPO update on the kernels of include/cda_mlp.h: per epoch one gather / convert pass over the R unique observations (shuffled),
     per minibatch {forward, loss, back-propagation, weight gradients, reduce + clip + Adam}: eight launches, no autograd, no GEMM library."""
 
-    def __init__(self, policy, n_rows, rows_mb, num_agents, chunks=None, sub_batches=1):
-        """sub_batches > 1: a minibatch step runs {forward, loss, backward, weight gradients} once per sub-batch of rows_mb / sub_batches rows and
+    def __init__(self, policy, n_rows, rows_mb, num_agents, chunks=None, sub_batches=1, fused=True):
+        """fused (default; used when run() is given sample records): gather, forward, loss and back-propagation of a minibatch are ONE launch
+        (cda_mlp_forward_backward) - a minibatch step is {that, weight gradients, reduce, Adam}; otherwise the separate kernels run (prep_rows per
+        epoch, forward, loss, backward).
+        sub_batches > 1 (separate kernels only): a minibatch step runs {forward, loss, backward, weight gradients} once per sub-batch of rows_mb / sub_batches rows and
         reduces all their partial sums in one optimiser step - the same step, with activations of a sub-batch small enough to stay in the
         256-MB Infinity Cache between the kernel that writes them and the ones that read them."""
         self.p, self.R, self.rows_mb, self.A = policy, int(n_rows), int(rows_mb), int(num_agents)
         self.sub = max(1, int(sub_batches))
+        self.fused = bool(fused) and self.sub == 1
         if self.R % 32 or self.rows_mb % 32 or self.rows_mb > self.R:
             raise ValueError("rows and minibatch rows must be multiples of 32")
         dev = policy.device
@@ -340,15 +344,35 @@ class FusedUpdate:
         self.out, self.d_out = e(pad * NOUT, f32).view(-1, NOUT), e(pad * NOUT, f32).view(-1, NOUT)
         self.slab, self.bias_slab = e(self.sub * self.chunks * SLAB, f32), e((self.n_tiles + self.sub) * BSLAB, f32)
         self.grad, self.norm2 = e(PARAMS, f32), e(512, torch.float64)        # (norm2[2] = the squared gradient norm of the last step)
-        self.sums5, self.out6 = e(5, torch.float64), e(6, f32)
+        self.sums5, self.out6 = e(64 * 8, torch.float64), e(6, f32)       # CDA_MLP_LOSS_SLOTS x 8: the loss sums (slot 0, words 0..4 for the separate loss kernels)
         self.perm = torch.zeros(self.R, dtype=torch.int64, device=dev)
+        pad64 = ((self.rows_mb + 63) // 64) * 64
+        self.x_pk_mb = e(pad64 * 32 * XT, bf) if self.fused else None         # the fused kernel's packed image of the minibatch's observations
         self.shuffle_seed, self._epochs_done = 0x5DEECE66D, 0
 
-    def minibatch_step(self, s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, apply=True, records=None):
-        """rows [s, s + rows) of the prepared (shuffled) observations: one optimiser step.  records = (rec f32 [R, A, 8], adv sums f64[2] or
+    def minibatch_step(self, s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, apply=True, records=None, obs_rows=None,
+                       debug_outputs=False):
+        """rows [s, s + rows) of the prepared (shuffled) observations: one optimiser step.  obs_rows (with records, fused=True): the unshuffled f32
+        observation rows - the fused kernel gathers rows perm[s .. s + rows) itself, no prepared images needed.  records = (rec f32 [R, A, 8], adv sums f64[2] or
         None, their count): the loss reads sample records (RolloutChains.gae) instead of the seven per-sample arrays."""
         L, p, dev = _lib(), self.p, self.p.device
         st = _stream(dev)
+        if obs_rows is not None and records is not None and self.fused:
+            rec, stats, count = records
+            chunks, tiles = max(1, min(self.chunks, rows // 32)), (rows + 63) // 64
+            _check(L.cda_mlp_forward_backward(p.wb.data_ptr(), p.theta.data_ptr(), obs_rows.data_ptr(), self.perm.data_ptr() + s * 8, rows, rows, rec.data_ptr(),
+                                              stats.data_ptr() if stats is not None else None, int(count), self.A, float(clip), float(vf_coef), float(ent_coef),
+                                              self.x_pk_mb.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(),
+                                              self.bias_slab.data_ptr(), self.sums5.data_ptr(), self.out6.data_ptr(), 0 if apply else 1, 0 if apply else 1,
+                                              self.out.data_ptr() if debug_outputs else None, self.d_out.data_ptr() if debug_outputs else None, st), "cda_mlp_forward_backward")
+            _check(L.cda_mlp_wgrad(self.x_pk_mb.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(), rows, chunks,
+                                   self.slab.data_ptr(), st), "cda_mlp_wgrad")
+            if apply:
+                _check(L.cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), self.slab.data_ptr(), chunks,
+                                      self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A, float(vf_coef), float(ent_coef), self.out6.data_ptr(),
+                                      float(lr), float(betas[0]), float(betas[1]), float(eps), float(max_norm),
+                                      self.grad.data_ptr(), self.norm2.data_ptr(), st), "cda_mlp_adam")
+            return chunks, tiles
         sub = self.sub if (rows % (32 * self.sub) == 0 and rows // self.sub >= 32) else 1
         rs = rows // sub                                           # rows per sub-batch
         tiles_sub = (rs + self.tile_rows - 1) // self.tile_rows
@@ -404,8 +428,11 @@ class FusedUpdate:
                 _check(L.cda_mlp_permutation(key, self.R, self.perm.data_ptr(), _stream(dev)), "cda_mlp_permutation")
             else:
                 self.perm.copy_(perms[ep])
-            _check(L.cda_mlp_prep_rows(obs_rows.data_ptr(), self.perm.data_ptr(), self.R, self.x_rm.data_ptr(), self.x_pk.data_ptr(), _stream(dev)), "cda_mlp_prep_rows")
+            fused = self.fused and records is not None
+            if not fused:
+                _check(L.cda_mlp_prep_rows(obs_rows.data_ptr(), self.perm.data_ptr(), self.R, self.x_rm.data_ptr(), self.x_pk.data_ptr(), _stream(dev)), "cda_mlp_prep_rows")
             for s in range(0, self.R, self.rows_mb):
                 rows = min(self.rows_mb, self.R - s)
-                self.minibatch_step(s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, records=records)
+                self.minibatch_step(s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, records=records,
+                                    obs_rows=obs_rows if fused else None)
         return {"pg_loss": self.out6[0], "v_loss": self.out6[1], "entropy": self.out6[2]}

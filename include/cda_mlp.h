@@ -111,11 +111,13 @@ int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p, const void
                   int64_t n_rows, int32_t n_chunks, float* slab, void* stream);
 /* step 4: reduce the partials to the gradient of theta, clip its global norm to max_norm (torch.nn.utils.clip_grad_norm_), one Adam step
  * (torch.optim.Adam: no weight decay, bias-corrected; *step_dev f32[1] is incremented on the device), and refresh wb: two launches.
- * loss_sums5 (f64[5], may be NULL): the sums cda_ppo_loss32 accumulated for this minibatch (clear = finish = 0): [3..4] are d loss / d log_std;
+ * loss_sums5 (f64[CDA_MLP_LOSS_SLOTS][8], may be NULL): the sums the loss accumulated for this minibatch (clear = finish = 0) - cda_ppo_loss32 /
+ * cda_ppo_loss_records add into words 0..4 of slot 0, cda_mlp_forward_backward into every slot; words [3..4] are d loss / d log_std;
  * the means go to loss_out6 (f32[6], may be NULL: what finish = 1 would have written, loss_samples = rows * agents_per_row) and the sums are
  * CLEARED for the next minibatch - no memset, no finishing launch between the steps of an update.
  * grad f32[CDA_MLP_PARAMS] receives the gradient before clipping (its never-written entries - the heads' rows 25..31 - must be zero: allocate
  * it zeroed); scratch f64[CDA_MLP_SCRATCH]: [2] = the squared norm of this call's gradient (output), the rest is the kernels' own. */
+#define CDA_MLP_LOSS_SLOTS 64
 int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* step_dev, void* wb,
                  const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
                  double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float* loss_out6,
@@ -173,6 +175,19 @@ int cda_gae_records(const double* reward, const float* value, const uint8_t* ter
 int cda_ppo_loss_records(const float* outputs, const float* log_std, const float* rec, const double* adv_stats2, int64_t adv_count, const int64_t* row_index,
                          int64_t rows, int32_t agents_per_row, int32_t out_stride, float clip, float vf_coef, float ent_coef,
                          float* d_outputs, double* sums5, float* out6, int64_t norm_rows, int32_t clear, int32_t finish, void* stream);
+
+/* The update's per-row work in ONE launch: the n_rows observation rows obs[perm[i]] (perm NULL: obs[i]) are gathered from the rollout's f32 buffer,
+ * run forward, their loss taken from the sample records rec[perm[i]] (cda_ppo_loss_records' rule, advantages normalised on the fly when adv_stats2
+ * is given) and back-propagated to the pre-activations - what cda_mlp_prep_rows, cda_mlp_forward_train, cda_ppo_loss_records and cda_mlp_backward do
+ * in four launches, without their round trips through HBM (outputs and their gradients stay in LDS, h1 / h2 in registers for tanh').  Written: the
+ * packed images x_pk / h1p / h2p / dz1p / dz2p / doutp cda_mlp_wgrad reads, the bias sums (one CDA_MLP_BSLAB row per 64-row tile) and the five loss
+ * sums; out / d_out (may be NULL): f32 [n_rows][32] copies of the outputs and their gradients.  Buffers are padded to whole 64-row tiles.
+ * clear / finish / out6 / norm_rows: as cda_ppo_loss32, except that the loss sums are f64[CDA_MLP_LOSS_SLOTS][8] (a tile adds into slot `tile mod SLOTS`, words
+ * 0..4: one hot cache line would stall every CU's memory pipeline behind its atomics). */
+int cda_mlp_forward_backward(const void* wb, const float* theta, const float* obs, const int64_t* perm, int64_t n_rows, int64_t norm_rows,
+                             const float* rec, const double* adv_stats2, int64_t adv_count, int32_t agents_per_row, float clip, float vf_coef, float ent_coef,
+                             void* x_pk, void* h1p, void* h2p, void* dz1p, void* dz2p, void* doutp, float* bias_slab,
+                             double* sums5, float* out6, int32_t clear, int32_t finish, float* out, float* d_out, void* stream);
 
 /* Device self-test of the operand / accumulator conventions this file is built on: D f32[32][32] = A bf16-rounded f32[32][16] x
  * B f32[16][32] through one v_mfma_f32_32x32x16_bf16 (host pointers; synchronous). */

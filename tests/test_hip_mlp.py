@@ -433,6 +433,46 @@ def test_gae_into_records_and_the_loss_on_records_equal_the_array_path():
     env.close()
 
 
+@pytest.mark.parametrize("N,T", [(96, 40), (100, 40)])          # 3840 rows = 60 whole tiles; 4000 rows: the last tile is half empty
+def test_fused_forward_loss_backward_equals_the_separate_kernels(N, T):
+    """cda_mlp_forward_backward (one launch: gather, forward, loss, back-propagation) against prep_rows + forward_train + loss_records + backward on the
+    same minibatch: outputs bit for bit, gradients to float32 rounding of the loss arithmetic."""
+    from gym_continuousdoubleauction_amd import CDAVecEnv, mlp
+    from gym_continuousdoubleauction_amd._lib import lib, check
+    A = 4
+    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 16, "is_render": False, "auto_reset": True}
+    env = CDAVecEnv(cfg, n_markets=N, with_info=False)
+    p = _policy(seed=37)
+    env.reset(seed=11)
+    roll = mlp.RolloutChains(env, p, T, groups=2, seed=6)
+    buf = roll.run()
+    records = roll.gae(gamma=0.99, lam=0.95, reward_scale=1e-3)
+    R = T * N
+    obs = buf["obs"][:T].view(R, -1)
+    perm = torch.randperm(R, generator=torch.Generator().manual_seed(3))
+    res = []
+    for fused in (False, True):
+        upd = mlp.FusedUpdate(p, R, R, A, chunks=3, fused=fused)
+        upd.perm.copy_(perm)
+        if not fused:
+            check(lib().cda_mlp_prep_rows(obs.data_ptr(), upd.perm.data_ptr(), R, upd.x_rm.data_ptr(), upd.x_pk.data_ptr(), torch.cuda.current_stream().cuda_stream), "prep")
+        upd.minibatch_step(0, R, None, None, None, None, 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5, records=records, obs_rows=obs if fused else None, debug_outputs=True)
+        torch.cuda.synchronize()
+        xpk = (upd.x_pk_mb if fused else upd.x_pk)[:R * 192].clone()
+        res.append(dict(out=upd.out[:R].clone(), d_out=upd.d_out[:R].clone(), grad=upd.grad.clone(), out6=upd.out6.clone(), xpk=xpk,
+                        h1=upd.h1p[:R * 512].clone(), h2=upd.h2p[:R * 512].clone(), dz2=upd.dz2p[:R * 512].float().clone(), dz1=upd.dz1p[:R * 512].float().clone()))
+    a, b = res
+    assert torch.equal(a["xpk"].view(torch.int16), b["xpk"].view(torch.int16))
+    assert torch.equal(a["h1"].view(torch.int16), b["h1"].view(torch.int16)) and torch.equal(a["h2"].view(torch.int16), b["h2"].view(torch.int16))
+    assert torch.equal(a["out"][:, :25], b["out"][:, :25])
+    assert torch.allclose(a["d_out"], b["d_out"], rtol=2e-4, atol=1e-10)
+    for k in ("dz2", "dz1"):
+        assert (a[k] - b[k]).abs().max() <= 2e-2 * a[k].abs().max()          # (a float32 ulp in d_out now and then moves a bf16 rounding)
+    assert torch.allclose(a["out6"], b["out6"], rtol=1e-4, atol=1e-7)
+    assert (a["grad"] - b["grad"]).abs().max() <= 1e-3 * a["grad"].abs().max()
+    env.close()
+
+
 def test_fused_training_loop_runs_and_learns_something():
     from gym_continuousdoubleauction_amd import CDAVecEnv, ppo
     cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 48, "is_render": False, "auto_reset": True}
