@@ -638,7 +638,8 @@ def main(argv=None):
                "config": {"workload": f"{args.markets} markets x {args.agents} agents, PyTorch-ROCm PPO policy in the loop (256x256 tanh actor and critic, "
                                       f"4 epochs, 262144-sample minibatches), horizon {args.horizon}, {args.iters} iterations, auto_reset on",
                           "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters, "env_groups": p_groups,
-                          "loop": "legacy (PyTorch network)" if args.legacy else f"fused: hand-written bf16 MFMA network (csrc/cda_mlp.hip), {args.chains} rollout chains",
+                          "loop": "legacy (PyTorch network)" if args.legacy else (f"fused: hand-written bf16 MFMA network (csrc/cda_mlp.hip), {args.chains} rollout chains; GAE straight into the sample records (one launch); "
+                                                                                      "a minibatch step = {gather + forward + loss + backward in one launch, weight gradients, reduce, Adam}"),
                           "hip_graphs": "none" if args.no_graphs else ("one graph per rollout step (policy + env step + buffer writes), one per minibatch step of the update"
                                                                       if args.legacy else "one graph per rollout chain (the whole horizon); the update is plain launches"),
                           "update_dtype": "float32" if args.fp32_update else "bfloat16 operands, float32 accumulation (float32 parameters, Adam state, softmax and losses)",

@@ -433,13 +433,13 @@ def test_gae_into_records_and_the_loss_on_records_equal_the_array_path():
     env.close()
 
 
-@pytest.mark.parametrize("N,T", [(96, 40), (100, 40)])          # 3840 rows = 60 whole tiles; 4000 rows: the last tile is half empty
-def test_fused_forward_loss_backward_equals_the_separate_kernels(N, T):
+@pytest.mark.parametrize("N,T,A", [(96, 40, 4), (100, 40, 4),    # 3840 rows = 60 whole tiles; 4000 rows: the last tile is half empty
+                                   (64, 8, 8), (64, 8, 2), (64, 8, 1), (32, 9, 16), (40, 8, 5)])   # other agent counts: the quad deals agents round four lanes
+def test_fused_forward_loss_backward_equals_the_separate_kernels(N, T, A):
     """cda_mlp_forward_backward (one launch: gather, forward, loss, back-propagation) against prep_rows + forward_train + loss_records + backward on the
     same minibatch: outputs bit for bit, gradients to float32 rounding of the loss arithmetic."""
     from gym_continuousdoubleauction_amd import CDAVecEnv, mlp
     from gym_continuousdoubleauction_amd._lib import lib, check
-    A = 4
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 16, "is_render": False, "auto_reset": True}
     env = CDAVecEnv(cfg, n_markets=N, with_info=False)
     p = _policy(seed=37)
@@ -465,7 +465,8 @@ def test_fused_forward_loss_backward_equals_the_separate_kernels(N, T):
     assert torch.equal(a["xpk"].view(torch.int16), b["xpk"].view(torch.int16))
     assert torch.equal(a["h1"].view(torch.int16), b["h1"].view(torch.int16)) and torch.equal(a["h2"].view(torch.int16), b["h2"].view(torch.int16))
     assert torch.equal(a["out"][:, :25], b["out"][:, :25])
-    assert torch.allclose(a["d_out"], b["d_out"], rtol=2e-4, atol=1e-10)
+    # (the two loss kernels order a row's float32 sums differently: entries that are differences of much larger terms agree to the terms' rounding)
+    assert torch.allclose(a["d_out"], b["d_out"], rtol=2e-4, atol=2e-5 * float(a["d_out"].abs().max()))
     for k in ("dz2", "dz1"):
         assert (a[k] - b[k]).abs().max() <= 2e-2 * a[k].abs().max()          # (a float32 ulp in d_out now and then moves a bf16 rounding)
     assert torch.allclose(a["out6"], b["out6"], rtol=1e-4, atol=1e-7)
