@@ -1282,6 +1282,15 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
             for (; t < n_tiles; t += 16) s0 += src[(size_t)t * CDA_MLP_BSLAB];
         }
         red[part][threadIdx.x & 15] = (s0 + s1) + (s2 + s3);
+        __shared__ double lred[16][5];                                           // the loss sums' slots, split the same 16 ways (one thread walking all 64: +5 us on the kernel)
+        if (e == CDA_MLP_BSLAB && LF.sums5) {
+            double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int sl = part; sl < CDA_MLP_LOSS_SLOTS; sl += 16)
+                #pragma unroll
+                for (int q = 0; q < 5; q++) { t[q] += LF.sums5[8 * sl + q]; LF.sums5[8 * sl + q] = 0.0; }
+            #pragma unroll
+            for (int q = 0; q < 5; q++) lred[part][q] = t[q];
+        }
         __syncthreads();
         if (part == 0) {
             float g = 0.0f;
@@ -1293,14 +1302,14 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
             else if (e < CDA_MLP_BSLAB) { const int o = e - 2 * CDA_MLP_FEAT; p = CDA_MLP_OFF_BO + o; if (o > N_LOGITS) g = 0.0f; }
             if (p >= 0) { grad[p] = g; sq = g * g; }
             if (e == CDA_MLP_BSLAB) {
-                // log_std: its gradient comes with the loss sums (cda_ppo_loss32's sums5[3..4]); this one thread also finishes the loss
-                // statistics (out6, what k_ppo_finish32 would write) and clears the sums for the next minibatch - no memset, no extra launch
+                // log_std: its gradient comes with the loss sums (words 3, 4); this one thread also finishes the loss statistics (out6, what
+                // k_ppo_finish32 would write); the sums are cleared for the next minibatch above - no memset, no extra launch
                 float g0 = 0.0f, g1 = 0.0f;
                 if (LF.sums5) {
                     double t5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-                    for (int sl = 0; sl < CDA_MLP_LOSS_SLOTS; sl++)
+                    for (int k = 0; k < 16; k++)
                         #pragma unroll
-                        for (int q = 0; q < 5; q++) { t5[q] += LF.sums5[8 * sl + q]; LF.sums5[8 * sl + q] = 0.0; }
+                        for (int q = 0; q < 5; q++) t5[q] += lred[k][q];
                     const double pg = t5[0] / (double)LF.samples, vl = t5[1] / (double)LF.samples, en = t5[2] / (double)LF.samples;
                     g0 = (float)t5[3]; g1 = (float)t5[4];
                     if (LF.out6) { LF.out6[0] = (float)pg; LF.out6[1] = (float)vl; LF.out6[2] = (float)en; LF.out6[3] = (float)(pg + (double)LF.vf_coef * vl - (double)LF.ent_coef * en);
