@@ -8,15 +8,20 @@
 //     B operand, lane l: column j = l & 31, the same 8 k
 //     D, lane l, register r (16 f32): column j = l & 31, row i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
 //   Every product here is "activations x weights^T": i = batch row, j = output feature, so A comes from a row-major bf16 image of the
-//   activations in LDS ([row][k], 16-B reads, rows padded by 16 B: conflict free) and B straight from global memory, because
-//   nn.Linear's [out][in] layout IS k-contiguous per output feature.  The accumulator then holds, per lane, ONE feature and 16 rows -
+//   activations in LDS ([row][k], 16-B reads, rows padded by 16 B: conflict free) and B from global memory, where the weights are kept in
+//   OPERAND ORDER (cda_mlp_pack / k_adam: a wave's request for one k-step of one feature tile is 1 KB of contiguous memory - see WRing).
+//   The accumulator then holds, per lane, ONE feature and 16 rows -
 //   which is exactly an operand of the weight-gradient product (dW[i][j] = sum over ROWS of dz[row][i] h[row][j]: lane = feature,
 //   the 8 slots = 8 rows; the pairing of slots between A and B is all that matters, not which rows they are).  So activations and
 //   pre-activation gradients are written to HBM as the accumulators stand ("packed": 16 B per lane, 1 KB per wave store) and the
 //   weight-gradient kernel loads them as MFMA operands with no transposition at all.
 //
-// Workgroup = 4 waves = M rows (M = 32 MT) x the 256 features of one network half at a time: wave w owns features 64 w .. 64 w + 63
-// (2 feature tiles) for all MT row tiles; the two halves (policy, value) run one after the other through the same LDS buffers.
+// The kernels:
+//   k_mlp_fwd<MT, MODE>   4 waves = 32 MT rows x one network half (256 features: wave w owns 64, two paired tiles); the rollout's policy step
+//                         (MODE_SAMPLE: forward + sampling + records, halves in separate workgroups), the bootstrap value, plain outputs
+//   k_mlp_fb              the update: gather + forward + loss + back-propagation of a 64-row tile half, one launch (the default path)
+//   k_mlp_fwd8 / k_mlp_bwd8 / k_mlp_bwd / k_ppo_loss*   the same steps as separate kernels (FusedUpdate(fused=False); the tests hold both equal)
+//   k_mlp_wgrad, k_grad_reduce, k_adam, k_make_perm, k_prep_rows, k_gae_records
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1658,11 +1663,6 @@ int train_mt() {
 }
 size_t fwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + 2 * M * ACT_LD * 2; }
 size_t bwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * OUTS_LD * 4 + 2 * M * ACT_LD * 2; }
-int compute_units() {
-    static int n = 0;
-    if (!n) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; if (n < 1) n = 256; }
-    return n;
-}
 size_t fb_lds(int agents) { return (size_t)64 * XS_LD * 2 + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * agents * 32; }
 int rollout_mt() {
     static int mt = 0;
