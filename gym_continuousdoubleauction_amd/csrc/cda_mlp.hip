@@ -1522,14 +1522,28 @@ __global__ __launch_bounds__(256) void k_gae_records(const double* __restrict__ 
     if (i < B) {
         const long long n = i / Ag;
         float nxt = value[(long long)T * N + n], run = 0.0f;
-        for (int t = T - 1; t >= 0; t--) {
-            const long long k = (long long)t * B + i, kn = (long long)t * N + n;
-            const float nd = (term[kn] | trunc[kn]) ? 0.0f : 1.0f, v = value[kn];
-            const float delta = (float)reward[k] * reward_scale + gamma * nxt * nd - v;
-            run = delta + gamma * lam * nd * run;
-            *reinterpret_cast<float2*>(rec + 8 * k + 6) = make_float2(run, run + v);
-            s1 += (double)run; s2 += (double)run * (double)run;
-            nxt = v;
+        // eight steps' operands requested together, then the recursion over them (one step at a time, every iteration paid a memory round trip:
+        // 39 us for 64 steps)
+        for (int t0 = T - 1; t0 >= 0; t0 -= 8) {
+            float rw[8], vv[8], nd[8];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t0 - u >= 0 ? t0 - u : 0;
+                const long long k = (long long)t * B + i, kn = (long long)t * N + n;
+                rw[u] = (float)reward[k] * reward_scale; vv[u] = value[kn]; nd[u] = (term[kn] | trunc[kn]) ? 0.0f : 1.0f;
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t0 - u;
+                if (t >= 0) {
+                    const long long k = (long long)t * B + i;
+                    const float delta = rw[u] + gamma * nxt * nd[u] - vv[u];
+                    run = delta + gamma * lam * nd[u] * run;
+                    *reinterpret_cast<float2*>(rec + 8 * k + 6) = make_float2(run, run + vv[u]);
+                    s1 += (double)run; s2 += (double)run * (double)run;
+                    nxt = vv[u];
+                }
+            }
         }
     }
     #pragma unroll

@@ -391,13 +391,14 @@ def test_rollout_chains_record_what_the_oracle_replays(groups, use_graphs):
     env.close(); ora.close()
 
 
-def test_gae_into_records_and_the_loss_on_records_equal_the_array_path():
+@pytest.mark.parametrize("T", [40, 13])                     # (the kernel walks eight steps at a time: a horizon that is not a multiple of 8 as well)
+def test_gae_into_records_and_the_loss_on_records_equal_the_array_path(T):
     """cda_gae_records = ppo.gae on the rollout's buffers (episode ends included), its sums = the normalisation ppo_update applies; the loss
     reading records (normalising on the fly) = the loss reading the seven arrays with torch-normalised advantages."""
     from gym_continuousdoubleauction_amd import CDAVecEnv, mlp, ppo
     from gym_continuousdoubleauction_amd._lib import lib, check
-    N, A, T = 96, 4, 40
-    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 16, "is_render": False, "auto_reset": True}
+    N, A = 96, 4
+    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 8, "is_render": False, "auto_reset": True}
     env = CDAVecEnv(cfg, n_markets=N, with_info=False)
     p = _policy(seed=31)
     env.reset(seed=7)
