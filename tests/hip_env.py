@@ -6,8 +6,8 @@ from gym_continuousdoubleauction_amd.vec_env import CDAVecEnv, DEC_DTYPE
 
 
 class HipEnv:
-    def __init__(self, config=None, n_markets=1):
-        self.env = CDAVecEnv(config, n_markets=n_markets, device="cuda:0", with_info=True)
+    def __init__(self, config=None, n_markets=1, with_info=True):
+        self.env = CDAVecEnv(config, n_markets=n_markets, device="cuda:0", with_info=with_info)
         self.n, self.A = self.env.n_markets, self.env.num_agents
 
     def close(self):
@@ -19,7 +19,7 @@ class HipEnv:
     def step(self, cat, mean, sigma, price, off, present=None):
         obs, rew, term, trunc, info = self.env.step(cat, mean, sigma, price, off, present)
         out = {}
-        for k, v in info.items():
+        for k, v in (info or {}).items():
             a = v.cpu().numpy()
             out[k] = a.view(DEC_DTYPE).reshape(self.n, self.A) if k == "nav" else a
         return (obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy().astype(np.uint8),

@@ -126,7 +126,8 @@ def test_book_capacity_overflow_is_flagged_not_silent():
     env.close(); ora.close()
 
 
-def test_auto_reset_equals_step_then_masked_reset():
+@pytest.mark.parametrize("with_info", [True, False])     # with info tensors: a k_reset launch behind the step; without: the step kernel's own last act
+def test_auto_reset_equals_step_then_masked_reset(with_info):
     """cda_config.auto_reset: a market whose episode ended is reset on the device right after the step (seed=None
     semantics).  Equivalent to the oracle's step followed by reset(mask=terminated|truncated): same rewards and
     flags for the finished step, the new episode's first observation in the obs row, same states afterwards."""
@@ -134,7 +135,7 @@ def test_auto_reset_equals_step_then_masked_reset():
     import oracle_lib as O
     n, a, steps = 96, 4, 70
     cfg = {"num_of_agents": a, "init_cash": 1000000, "max_step": 16, "is_render": False}
-    hip = HipEnv(dict(cfg, auto_reset=True), n)
+    hip = HipEnv(dict(cfg, auto_reset=True), n, with_info=with_info)
     orc = O.OracleEnv(cfg, n_markets=n)
     seeds = np.arange(900, 900 + n, dtype=np.uint64)
     assert np.array_equal(hip.reset(seeds), orc.reset(seeds))
