@@ -162,6 +162,47 @@ def test_auto_reset_equals_step_then_masked_reset(with_info):
     hip.close(); orc.close()
 
 
+@pytest.mark.parametrize("with_info", [True, False])
+def test_auto_reset_of_markets_whose_books_outgrew_the_tile(with_info):
+    """The same equivalence where the general build steps the market (books of 2 x 400 resting orders: the HBM tier): the episode's end resets
+    a deep book too - inside slow_step's own tail in the info-less kernel."""
+    from hip_env import HipEnv
+    from fuzz_cases import prefill_book
+    import oracle_lib as O
+    n, a = 12, 4
+    cfg = {"num_of_agents": a, "init_cash": 1000000, "max_step": 5, "is_render": False}
+    hip = HipEnv(dict(cfg, auto_reset=True), n, with_info=with_info)
+    orc = O.OracleEnv(cfg, n_markets=n)
+    seeds = np.arange(40, 40 + n, dtype=np.uint64)
+    assert np.array_equal(hip.reset(seeds), orc.reset(seeds))
+    rng = np.random.default_rng(9)
+    n_resets = 0
+    for t in range(12):
+        if t in (0, 6):                                   # deep books in four markets at the start of two episodes
+            for i in range(0, n, 3):
+                for e in (hip, orc):
+                    prefill_book(e, i, np.random.default_rng(70 + i + t), a, 400, 400)
+        acts = (rng.integers(0, 9, (n, a)).astype(np.int32), rng.uniform(-0.01, 0.01, (n, a)).astype(np.float32), rng.uniform(0, 1, (n, a)).astype(np.float32),
+                rng.integers(0, 10, (n, a)).astype(np.int32), rng.integers(0, 3, (n, a)).astype(np.int32))
+        ho, hr, ht, hu, _ = hip.step(*acts)
+        oo, orw, ot, ou, _ = orc.step(*acts)
+        oo, orw, ot, ou = oo.copy(), orw.copy(), ot.copy(), ou.copy()
+        done = ((ot != 0) | (ou != 0)).astype(np.uint8)
+        if done.any():
+            oo[done == 1] = orc.reset(None, done)[done == 1]
+            n_resets += int(done.sum())
+        assert np.array_equal(hr.view(np.uint64), orw.view(np.uint64)), t
+        assert np.array_equal(ht, ot) and np.array_equal(hu, ou), t
+        assert np.array_equal(ho.view(np.uint32), oo.view(np.uint32)), t
+    assert n_resets >= 2 * n
+    for i in range(n):
+        assert bytes(hip.get_state(i)) == bytes(orc.get_state(i)), f"state of market {i}"
+        for side in (0, 1):
+            assert np.array_equal(hip.get_book(i, side), orc.get_book(i, side))
+    assert int((hip.flags() != 0).sum()) == 0
+    hip.close(); orc.close()
+
+
 def test_fused_random_agent_episode_equals_stepwise_and_oracle():
     """cda_run_random: a whole random-agent episode per launch (state in LDS from step to step, every market at its own
     pace) must be bit-identical to stepping the same markets one launch per step on the same actions, and to the oracle."""
