@@ -335,6 +335,7 @@ class FusedUpdate:
         self.tile_rows = int(_lib().cda_mlp_tile_rows())
         self.n_tiles = (self.rows_mb + self.tile_rows - 1) // self.tile_rows
         pad = self.n_tiles * self.tile_rows                            # the kernels write whole workgroup tiles
+        pad = ((pad + 63) // 64) * 64                                  # (the fused kernel's are 64 rows whatever CDA_MLP_MT says)
         self.chunks = int(chunks) if chunks else max(1, min(51, self.rows_mb // 512))      # 5 jobs x 51 chunks = 255 workgroups: one wave of the 256 CUs
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)                      # noqa: E731
@@ -342,7 +343,7 @@ class FusedUpdate:
         self.h1p, self.h2p, self.dz1p, self.dz2p = (e(pad * FEAT, bf) for _ in range(4))
         self.doutp = e(pad * NOUT, bf)
         self.out, self.d_out = e(pad * NOUT, f32).view(-1, NOUT), e(pad * NOUT, f32).view(-1, NOUT)
-        self.slab, self.bias_slab = e(self.sub * self.chunks * SLAB, f32), e((self.n_tiles + self.sub) * BSLAB, f32)
+        self.slab, self.bias_slab = e(self.sub * self.chunks * SLAB, f32), e((max(self.n_tiles, pad // 64) + self.sub) * BSLAB, f32)
         self.grad, self.norm2 = e(PARAMS, f32), e(512, torch.float64)        # (norm2[2] = the squared gradient norm of the last step)
         self.sums5, self.out6 = e(64 * 8, torch.float64), e(6, f32)       # CDA_MLP_LOSS_SLOTS x 8: the loss sums (slot 0, words 0..4 for the separate loss kernels)
         self.perm = torch.zeros(self.R, dtype=torch.int64, device=dev)
