@@ -1686,10 +1686,18 @@ int rollout_mt() {
 size_t fwd_lds(int mt, int mode) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + M * ACT_LD * 2 + (mode == MODE_SAMPLE ? M * OUTS_LD * 4 : 0); }
 size_t bwd_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * ACT_LD * 2 + M * OUTS_LD * 4; }
 
+// more than 64 KB of dynamic LDS needs the function attribute raised, once per (kernel, device): remembered here (a launch path, not a setup path)
 template <typename K>
 int allow_lds(K kern, size_t bytes) {
     if (bytes <= 64 * 1024) return CDA_OK;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+    struct Granted { const void* fn; int dev; size_t bytes; };
+    static Granted granted[64]; static int n_granted = 0;
+    const void* fn = reinterpret_cast<const void*>(kern);
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return CDA_ERR_HIP;
+    for (int i = 0; i < n_granted; i++) if (granted[i].fn == fn && granted[i].dev == dev && granted[i].bytes >= bytes) return CDA_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return CDA_ERR_HIP;
+    if (n_granted < 64) { granted[n_granted].fn = fn; granted[n_granted].dev = dev; granted[n_granted].bytes = bytes; n_granted++; }
+    return CDA_OK;
 }
 template <int MODE>
 int launch_fwd(const FwdArgs& A, int mt, hipStream_t st) {
