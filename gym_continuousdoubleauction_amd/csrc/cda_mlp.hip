@@ -787,7 +787,7 @@ __device__ __forceinline__ float quad_max(float x) { x = fmaxf(x, dpp_f<0xB1>(x)
 template <int Q> __device__ __forceinline__ float quad_bcast(float x) { return dpp_f<Q * 0x55>(x); }
 template <int Q> __device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, Q * 0x55, 0xf, 0xf, false); }
 #ifdef CDA_MLP_TIMING
-#define MLP_MARKH(i) do { if (A.dbg && (int)blockIdx.x == A.dbg_block && lane == 0) A.dbg[(4 * half + w) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define MLP_MARKH(i) do { if (A.dbg && tile_id == A.dbg_block && lane == 0) A.dbg[(4 * half + w) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MLP_MARKH(i) do {} while (0)
 #endif
@@ -800,16 +800,21 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
     __bf16* dos = reinterpret_cast<__bf16*>(smem + M * OUTS_LD * 4);            //   [M][DO_LD] bf16: the gradients as MdH2's A operand
     static_assert(M * OUTS_LD * 4 + M * DO_LD * 2 <= M * XS_LD * 2, "the output tiles fit the observation tile's bytes");
     const int lane = (int)threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), half = (int)blockIdx.y;
+    // Workgroup -> (tile, half), XCD-aware: workgroup ids go round the eight XCDs, so ids 8 apart share an L2.  The two halves of a tile gather
+    // the same rows and records: id = 16 g + 8 half + k is tile 8 g + k - its sibling is dispatched 8 ids later, on the same XCD, and finds them
+    // in that L2 (half, tile as the grid's y, x: siblings a thousand ids apart, every row fetched twice - 132 MB instead of 82 per launch).
+    const int wg = (int)blockIdx.x, half = (wg >> 3) & 1, tile_id = 8 * (wg >> 4) + (wg & 7);
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if ((long long)tile_id * M >= A.n_rows) return;                             // (the last group of eight may be short; whole workgroups leave)
     __bf16* act = xs + M * XS_LD;                                               // [M][ACT_LD]: h1, h2, then dz2
     float* lps = reinterpret_cast<float*>(act + M * ACT_LD);                    // [M][LPS_LD] f32: a row's log-probabilities, indexed by the agents' actions
     float* recs = lps + M * LPS_LD;                                             // [M][agents][8]: the tile's sample records
-    const long long row0 = (long long)blockIdx.x * M, rows_end = A.n_rows;
+    const long long row0 = (long long)tile_id * M, rows_end = A.n_rows;
     const int f0 = 256 * half + 64 * w, ft0 = f0 >> 5;
     const float b1_0 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j] * TWO_LOG2E, b1_1 = A.theta[CDA_MLP_OFF_B1 + f0 + 2 * j + 1] * TWO_LOG2E;
     const float b2_0 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j] * TWO_LOG2E, b2_1 = A.theta[CDA_MLP_OFF_B2 + f0 + 2 * j + 1] * TWO_LOG2E;
     const float bo = A.theta[CDA_MLP_OFF_BO + j];
-    float* bs = A.bias_slab + (size_t)blockIdx.x * CDA_MLP_BSLAB;
+    float* bs = A.bias_slab + (size_t)tile_id * CDA_MLP_BSLAB;
     const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
     const __bf16* W2T = A.wb + CDA_MLP_WB_W2T; const __bf16* WoT = A.wb + CDA_MLP_WB_WOT;
     WRing<2, KX / 16, PF, true> R1; WRing<2, HID / 16, PF, true> R2; WRing<1, HID / 16, PF> RO;
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
             v4[q] = x;
         }
-        double* slot = A.sums5 + 8 * ((4 * (int)blockIdx.x + w) & (CDA_MLP_LOSS_SLOTS - 1));   // a slot (one cache line) per wave mod 64: one hot line stalls every CU's memory pipeline behind its atomics
+        double* slot = A.sums5 + 8 * ((4 * tile_id + w) & (CDA_MLP_LOSS_SLOTS - 1));   // a slot (one cache line) per wave mod 64: one hot line stalls every CU's memory pipeline behind its atomics
         if (lane == 0) { atomicAdd(&slot[0], (double)v4[0]); atomicAdd(&slot[2], (double)v4[1]); atomicAdd(&slot[3], (double)v4[2]); atomicAdd(&slot[4], (double)v4[3]); }
     } else if (w == 0) {                                                        // the value loss: a lane per row
         const int row = lane;
@@ -1066,7 +1071,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
         if (A.d_out && live) A.d_out[(row0 + row) * NOUT + N_LOGITS] = dval;
         #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vl += __shfl_down(vl, o, 64);
-        if (lane == 0) atomicAdd(&A.sums5[8 * ((int)blockIdx.x & (CDA_MLP_LOSS_SLOTS - 1)) + 1], (double)vl);
+        if (lane == 0) atomicAdd(&A.sums5[8 * (tile_id & (CDA_MLP_LOSS_SLOTS - 1)) + 1], (double)vl);
     }
     MLP_MARKH(12);
     __syncthreads();                                                            // d_out is in LDS
@@ -1846,7 +1851,8 @@ extern "C" int cda_mlp_forward_backward(const void* wb, const float* theta, cons
     if (clear && hipMemsetAsync(sums5, 0, (size_t)CDA_MLP_LOSS_SLOTS * 8 * sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
     const size_t lds = fb_lds(agents_per_row);
     int rc = allow_lds(k_mlp_fb, lds); if (rc) return rc;
-    hipLaunchKernelGGL(k_mlp_fb, dim3((unsigned)((n_rows + 63) / 64), 2), dim3(256), lds, st, A);
+    const long long tiles = (n_rows + 63) / 64;
+    hipLaunchKernelGGL(k_mlp_fb, dim3((unsigned)(16 * ((tiles + 7) / 8))), dim3(256), lds, st, A);
     if (finish) hipLaunchKernelGGL(k_ppo_finish_slots, dim3(1), dim3(64), 0, st, (const double*)sums5, A.norm_rows * agents_per_row, vf_coef, ent_coef, out6);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
