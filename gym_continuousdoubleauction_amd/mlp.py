@@ -316,8 +316,9 @@ class RolloutChains:
 
 
 class FusedUpdate:
-    """The PPO update on the kernels of include/cda_mlp.h: per epoch one gather / convert pass over the R unique observations (shuffled),
-    per minibatch {forward, loss, back-propagation, weight gradients, reduce + clip + Adam}: eight launches, no autograd, no GEMM library."""
+    """The PPO update on the kernels of include/cda_mlp.h: per epoch a keyed permutation of the R unique observation rows, per minibatch
+    {gather + forward + loss + back-propagation (one launch), weight gradients, reduce, clip + Adam}: four launches, no autograd, no GEMM
+    library.  fused=False: the same step as separate kernels (a gather / convert pass per epoch, then forward, loss, backward, ...)."""
 
     def __init__(self, policy, n_rows, rows_mb, num_agents, chunks=None, sub_batches=1, fused=True):
         """fused (default; used when run() is given sample records): gather, forward, loss and back-propagation of a minibatch are ONE launch

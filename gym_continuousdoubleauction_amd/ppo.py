@@ -468,7 +468,8 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, 
                 gamma=0.99, lam=0.95, clip=0.2, vf_coef=0.5, ent_coef=0.01, policy=None, keep=None, sub_batches=None):
     """The PPO loop on the hand-written network kernels (mlp.py, include/cda_mlp.h): rollouts as `chains` independent per-chain launch
     sequences (policy forward + sampling -> env step -> auto reset, one HIP graph per chain, no cross-stream edge inside the horizon), the
-    update as {forward, loss, back-propagation, weight gradients, clip + Adam} launches per minibatch step - no autograd, no GEMM library.
+    sample records completed by one GAE launch, the update as {gather + forward + loss + back-propagation, weight gradients, reduce, clip + Adam}
+    per minibatch step - no autograd, no GEMM library.
     Needs a HIP CDAVecEnv with auto_reset and 168-float observations.  Returns (FusedPolicy, history); `keep` (a dict) receives the last
     rollout's buffers and the RolloutChains object."""
     from .mlp import FusedPolicy, FusedUpdate, RolloutChains
