@@ -23,8 +23,21 @@ def _register_with_gymnasium():
     except Exception:  # noqa: BLE001 - gymnasium absent (this build image): fine
         return False
     try:
-        register(id=ENV_ID, entry_point="gym_continuousdoubleauction_amd.env:CDAEnv")
-    except Exception:  # noqa: BLE001 - e.g. the id is taken by the reference itself, imported next to this package
+        from gymnasium.envs.registration import registry
+        if ENV_ID in registry:              # the id is taken (the reference itself, imported next to this package): real gymnasium would only warn and override,
+            return False                    # and the import order would silently decide what gymnasium.make returns - leave the first registration alone
+    except Exception:  # noqa: BLE001 - a gymnasium without the registry mapping: register() below decides
+        pass
+    kw = {"id": ENV_ID, "entry_point": "gym_continuousdoubleauction_amd.env:CDAEnv"}
+    try:
+        # a multi-agent dict API is not what gymnasium's passive checker / order enforcer wrap: make() must hand the env over as it is
+        register(disable_env_checker=True, order_enforce=False, **kw)
+    except TypeError:
+        try:
+            register(**kw)                  # (a registration function without those keywords)
+        except Exception:  # noqa: BLE001
+            return False
+    except Exception:  # noqa: BLE001
         return False
     return True
 

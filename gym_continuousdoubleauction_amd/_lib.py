@@ -20,6 +20,7 @@ SYMBOLS = [
     "cda_state_bytes_per_market", "cda_run_random", "cda_random_actions_host", "cda_nav_conservation",
     "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants", "cda_selftest_libm", "cda_selftest_libm_host", "cda_book_capacity",
     "cda_get_book", "cda_book_spill", "cda_book_spill_wanted", "cda_num_agents", "cda_handback_stride", "cda_set_handback", "cda_set_handback_geometry", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
+    "cda_step_range_capture",
 ]
 
 
@@ -27,13 +28,25 @@ SYMBOLS = [
 MLP_SYMBOLS = [
     "cda_mlp_tile_rows", "cda_mlp_permutation", "cda_mlp_pack", "cda_mlp_policy_step", "cda_mlp_forward", "cda_mlp_prep_rows", "cda_mlp_forward_train", "cda_mlp_backward",
     "cda_mlp_wgrad", "cda_mlp_adam", "cda_ppo_loss32", "cda_gae_records", "cda_ppo_loss_records", "cda_mlp_forward_backward", "cda_mlp_rollout_chain", "cda_mlp_selftest_mfma",
+    "cda_mlp_reduce", "cda_mlp_apply", "cda_gae_records_bootstrap", "cda_mlp_values", "cda_episode_returns", "cda_mlp_league_step", "cda_mlp_league_rollout_chain",
+    "cda_gae_records_league", "cda_league_assign",
 ]
 
 
 class RolloutBufs(C.Structure):
     """cda_rollout_bufs (include/cda_mlp.h)"""
     _fields_ = [(n, C.c_void_p) for n in ("obs", "category", "size_mean", "size_sigma", "price", "price_offset", "a_cont", "logp", "value", "reward",
-                                          "terminated", "truncated", "record")]
+                                          "terminated", "truncated", "record", "dist", "info_steps", "fin_index", "fin_obs", "fin_count")] + [("fin_cap", C.c_int32)]
+
+
+class League(C.Structure):
+    """cda_league (include/cda_mlp.h)"""
+    _fields_ = [("wb_bank", C.c_void_p), ("theta_bank", C.c_void_p), ("slot_net", C.c_void_p), ("n_nets", C.c_int32), ("n_trainable", C.c_int32), ("random_seed", C.c_uint64)]
+
+
+class PpoExtra(C.Structure):
+    """cda_ppo_extra (include/cda_mlp.h)"""
+    _fields_ = [("rec_stride", C.c_int32), ("kl_coef", C.c_float), ("vf_clip", C.c_float), ("dist_old", C.c_void_p), ("log_std_old", C.c_void_p)]
 
 
 class CDAError(RuntimeError):
@@ -112,11 +125,21 @@ def lib():
     L.cda_mlp_forward_train.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
     L.cda_mlp_backward.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]
     L.cda_mlp_wgrad.argtypes = [vp] * 6 + [i64, i32, vp, vp]
-    L.cda_mlp_adam.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i64, f32, f32, vp, f32, f32, f32, f32, f32, vp, vp, vp]
+    L.cda_mlp_adam.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i64, f32, f32, f32, vp, f32, f32, f32, f32, f32, vp, vp, vp]
+    L.cda_mlp_reduce.argtypes = [vp, i32, vp, i32, vp, i64, f32, f32, f32, vp, vp, vp, vp, vp]
+    L.cda_mlp_apply.argtypes = [vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp, vp]
+    L.cda_gae_records_bootstrap.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, f32, f32, f32, vp, vp, i64, vp, vp, vp]
+    L.cda_gae_records_league.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, f32, f32, f32, vp, vp, vp]
+    L.cda_mlp_values.argtypes = [vp, vp, i32, vp, i64, vp, i64, vp]
+    L.cda_episode_returns.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp]
+    L.cda_mlp_league_step.argtypes = [C.POINTER(League), vp, i32, i32, i32, u64, vp, i64] + [vp] * 8 + [i64, vp, vp, i64, vp]
+    L.cda_mlp_league_rollout_chain.argtypes = [vp, C.POINTER(League), i32, i32, i32, u64, vp, C.POINTER(RolloutBufs), i32, vp]
+    L.cda_league_assign.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp]
+    L.cda_step_range_capture.argtypes = [vp, i32, i32] + [vp] * 6 + [vp] * 4 + [C.POINTER(K.InfoPtrs), vp, i32, vp, vp, vp]
     L.cda_ppo_loss32.argtypes = [vp] * 10 + [i64, i32, i32, f32, f32, f32, vp, vp, vp, i64, i32, i32, vp]
     L.cda_gae_records.argtypes = [vp, vp, vp, vp, i32, i64, i32, f32, f32, f32, vp, vp, vp]
     L.cda_ppo_loss_records.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, f32, f32, f32, vp, vp, vp, i64, i32, i32, vp]
-    L.cda_mlp_forward_backward.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.cda_mlp_forward_backward.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i32, f32, f32, f32, C.POINTER(PpoExtra), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.cda_mlp_rollout_chain.argtypes = [vp, vp, vp, i32, i32, i32, u64, vp, C.POINTER(RolloutBufs), i32, vp]
     L.cda_mlp_selftest_mfma.argtypes = [i32, vp, vp, vp]
     for name in SYMBOLS:

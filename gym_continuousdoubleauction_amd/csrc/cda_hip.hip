@@ -120,6 +120,7 @@ __device__ __forceinline__ void stage_tables_commit(const TablePrefetch& q) {
 // step - the hot kernel
 // ------------------------------------------------------------------------------------------
 
+struct FinCapture { float* obs; int32_t* count; int32_t* index_out; int32_t cap; };      // episode-end capture: see capture_final_obs (cda_kernels.inc)
 struct StepArgs {
     const int32_t* category; const float* size_mean; const float* size_sigma;
     const int32_t* price; const int32_t* price_offset; const uint8_t* present;
@@ -128,6 +129,7 @@ struct StepArgs {
     cda_info_ptrs info; int has_info;
     int first_market, end_market;       // this launch steps the markets [first_market, end_market); every array argument is the full [N, ...] one
     uint8_t* handback; int32_t handback_stride;   // cda_set_handback: compact per-market records of what is new this step (NULL = off)
+    float* fin_obs; int32_t* fin_count; int32_t* fin_index_out; int32_t fin_cap;   // episode-end capture (cda_step_range_capture; NULL = off): read in the cold reset paths only
     unsigned long long* phase_cycles;   // debug builds only (CDA_PHASE_TIMING): [N,40] cycle stamps
     int dbg_skip;                       // debug builds only (CDA_DEBUG_SKIP): phases to leave out (tools/fixed_cost_probe.py); results are then wrong
 };
@@ -511,7 +513,7 @@ int cda_reset_range(cda_env* e, int32_t first_market, int32_t n_markets, const u
     if (!e || !range_ok(e, first_market, n_markets)) return CDA_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     LAUNCH_CAP(e, k_reset, grid_for(n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), (hipStream_t)stream, e->arena, e->P, seeds, mask, obs_out,
-                       (int)first_market, (int)(first_market + n_markets), e->handback, handback_stride_of(e->P.cfg.num_agents), 0);
+                       (int)first_market, (int)(first_market + n_markets), e->handback, handback_stride_of(e->P.cfg.num_agents), 0, FinCapture{NULL, NULL, NULL, 0});
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -539,7 +541,7 @@ static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0,
     if (e->P.cfg.auto_reset && S0.has_info) {
         LAUNCH_CAP(e, k_reset, grid_for(n), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB), stream, e->arena, e->P,
                            (const uint64_t*)NULL, (const uint8_t*)e->done_buf, S0.obs_out, (int)first, (int)(first + n),
-                           e->handback, handback_stride_of(e->P.cfg.num_agents), 1);
+                           e->handback, handback_stride_of(e->P.cfg.num_agents), 1, FinCapture{S0.fin_obs, S0.fin_count, S0.fin_index_out, S0.fin_cap});
         HIPCHK(hipGetLastError());
     }
     return CDA_OK;
@@ -557,6 +559,7 @@ static int fill_step_args(cda_env* e, StepArgs& S, const int32_t* category, cons
     S.done_out = e->P.cfg.auto_reset ? e->done_buf : NULL;
     S.handback = e->handback; S.handback_stride = handback_stride_of(e->P.cfg.num_agents);
     S.first_market = 0; S.end_market = e->P.n_markets;
+    S.fin_obs = NULL; S.fin_count = NULL; S.fin_index_out = NULL; S.fin_cap = 0;
     return CDA_OK;
 }
 
@@ -569,6 +572,23 @@ int cda_step_range(cda_env* e, int32_t first_market, int32_t n_markets,
     int rc = fill_step_args(e, S, category, size_mean, size_sigma, price, price_offset, present, obs_out, reward_out, terminated_out, truncated_out, info_out);
     if (rc) return rc;
     if (!range_ok(e, first_market, n_markets)) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    return launch_step(e, first_market, n_markets, S, (hipStream_t)stream);
+}
+
+int cda_step_range_capture(cda_env* e, int32_t first_market, int32_t n_markets,
+                           const int32_t* category, const float* size_mean, const float* size_sigma,
+                           const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                           float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                           const cda_info_ptrs* info_out, float* fin_obs, int32_t fin_cap, int32_t* fin_count, int32_t* fin_index_out, void* stream) {
+    StepArgs S;
+    int rc = fill_step_args(e, S, category, size_mean, size_sigma, price, price_offset, present, obs_out, reward_out, terminated_out, truncated_out, info_out);
+    if (rc) return rc;
+    if (!range_ok(e, first_market, n_markets)) return CDA_ERR_INVALID;
+    if (fin_index_out) {
+        if (!e->P.cfg.auto_reset || !fin_obs || !fin_count || fin_cap < 1) return CDA_ERR_INVALID;
+        S.fin_obs = fin_obs; S.fin_count = fin_count; S.fin_index_out = fin_index_out; S.fin_cap = fin_cap;
+    }
     HIPCHK(hipSetDevice(e->device));
     return launch_step(e, first_market, n_markets, S, (hipStream_t)stream);
 }

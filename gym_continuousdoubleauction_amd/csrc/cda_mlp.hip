@@ -28,6 +28,7 @@
 #include <string.h>
 #include <type_traits>
 #include "../../include/cda_mlp.h"
+#include "../../include/cda_random_agents.h"
 
 // The env kernels are built with -ffp-contract=off (their f64 sums must match CPython's); nothing here has such a constraint.
 #pragma clang fp contract(fast)
@@ -196,7 +197,7 @@ __device__ __forceinline__ void store_lds_pair(__bf16* act, int ld, int row_base
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------------
-enum { MODE_TRAIN = 0, MODE_OUT = 1, MODE_SAMPLE = 2, MODE_VALUE = 3 };
+enum { MODE_TRAIN = 0, MODE_OUT = 1, MODE_SAMPLE = 2, MODE_VALUE = 3, MODE_LEAGUE = 4 };
 struct FwdArgs {
     const __bf16* x_rm;          // MODE_TRAIN: [n_rows][176] bf16
     const float* obs;            // otherwise: f32 [*][168]
@@ -210,6 +211,12 @@ struct FwdArgs {
     float* rec;                  // optional sample records [*, A][8 words] (include/cda_mlp.h CDA_REC_*): the words the update's loss reads, one line per row
     int split_halves;            // 1: gridDim.y = 2, workgroup (x, y) runs network half y only (policy | value: independent networks; the rollout's launches);
                                  // 2: the value half only (the bootstrap value); 0: both halves, one after the other
+    float* dist;                 // optional, MODE_SAMPLE / MODE_LEAGUE: the policy's distribution per ROW, f32 [*][24] = the 22 normalised log-probabilities of the three
+                                 // categorical heads | the two Gaussian means (what the KL term of the update needs of the rollout's policy)
+    // MODE_LEAGUE (and MODE_VALUE with n_train > 0): wb / theta are BANKS of n_nets networks (nets 0 .. n_train - 1 trainable); gridDim.y enumerates
+    // (net, half) jobs: y < 2 n_train: net y / 2, half y & 1; above: the policy half of net n_train + (y - 2 n_train).  slot_net i32 [*, A]: the net that
+    // plays (market, slot), < 0 = the uniform random module (drawn by net 0's policy workgroup).  value / dist of net p live p * value_stride / p * dist_stride further on.
+    int n_train; const int* slot_net; long long value_stride, dist_stride; unsigned long long random_seed;
     unsigned long long* dbg; int dbg_block;       // CDA_MLP_TIMING builds (tools/libcda_tools.so) only: cycle stamps of one workgroup, [4 waves][32]
 };
 #ifdef CDA_MLP_TIMING
@@ -248,6 +255,21 @@ __device__ __forceinline__ int sample_head(const float* l, float u, float& logp)
     return a;
 }
 
+// softmax of one head: p[q], c = max + log(sum) (log p[q] = l[q] - c), entropy
+template <int N> __device__ __forceinline__ void head_probs_c(const float* l, float* p, float& c, float& ent) {
+    float mx = l[0];
+    #pragma unroll
+    for (int q = 1; q < N; q++) mx = fmaxf(mx, l[q]);
+    float s = 0.0f;
+    #pragma unroll
+    for (int q = 0; q < N; q++) { p[q] = __expf(l[q] - mx); s += p[q]; }
+    const float ls = __logf(s), inv = 1.0f / s;
+    float hh = 0.0f;
+    #pragma unroll
+    for (int q = 0; q < N; q++) { p[q] *= inv; hh -= p[q] * (l[q] - mx - ls); }
+    c = mx + ls; ent = hh;
+}
+
 template <int MT, int MODE>
 __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     constexpr int M = 32 * MT, PF = MT == 1 ? 16 : (MT == 2 ? 3 : CDA_MLP_PF4);
@@ -258,6 +280,22 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const long long row0 = A.first_row + (long long)blockIdx.x * M, rows_end = A.first_row + A.n_rows;
     MLP_MARK(0);
+    // A league launch (MODE_LEAGUE; the bootstrap values of its trainable nets: MODE_VALUE with n_train > 0): blockIdx.y names the (net, half) job
+    // and the net's parameters are its row of the banks.  Uniform per workgroup: scalar registers.
+    int net = 0, job_half = 0;
+    if (MODE == MODE_LEAGUE) { const int y = (int)blockIdx.y; net = y < 2 * A.n_train ? y >> 1 : A.n_train + (y - 2 * A.n_train); job_half = y < 2 * A.n_train ? (y & 1) : 0; }
+    if (MODE == MODE_VALUE && A.n_train > 0) net = (int)blockIdx.y;
+    const float* theta = A.theta + (size_t)net * CDA_MLP_PARAMS;
+    const __bf16* wb = A.wb + (size_t)net * CDA_MLP_WB_ELEMS;
+    if (MODE == MODE_LEAGUE && net >= A.n_train) {
+        // a frozen snapshot (champion) is only needed where one of the tile's (market, slot) pairs is played by it: whole workgroups leave otherwise
+        int mine = 0;
+        for (int s = (int)threadIdx.x; s < M * A.agents; s += 256) {
+            const long long grow = row0 + s / A.agents;
+            if (grow < rows_end) mine |= A.slot_net[grow * A.agents + (s % A.agents)] == net;
+        }
+        if (!__syncthreads_or(mine)) return;
+    }
     // every bias this lane will add, requested before anything else (a request placed later retires behind a whole ring of weight
     // requests: vmcnt counts in order)
     float b1s[2][2], b2s[2][2];
@@ -265,16 +303,18 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     for (int hf = 0; hf < 2; hf++)
         #pragma unroll
         for (int jt = 0; jt < 2; jt++) {
-            b1s[hf][jt] = A.theta[CDA_MLP_OFF_B1 + 256 * hf + 64 * w + 2 * j + jt] * TWO_LOG2E;
-            b2s[hf][jt] = A.theta[CDA_MLP_OFF_B2 + 256 * hf + 64 * w + 2 * j + jt] * TWO_LOG2E;
+            b1s[hf][jt] = theta[CDA_MLP_OFF_B1 + 256 * hf + 64 * w + 2 * j + jt] * TWO_LOG2E;
+            b2s[hf][jt] = theta[CDA_MLP_OFF_B2 + 256 * hf + 64 * w + 2 * j + jt] * TWO_LOG2E;
         }
-    const float bo = A.theta[CDA_MLP_OFF_BO + j];
-    const __bf16* W1b = A.wb + CDA_MLP_WB_W1; const __bf16* W2b = A.wb + CDA_MLP_WB_W2; const __bf16* Wob = A.wb + CDA_MLP_WB_WO;
+    const float bo = theta[CDA_MLP_OFF_BO + j];
+    const __bf16* W1b = wb + CDA_MLP_WB_W1; const __bf16* W2b = wb + CDA_MLP_WB_W2; const __bf16* Wob = wb + CDA_MLP_WB_WO;
     f32x16 acc3[1][1]; acc3[0][0] = zero16();                                   // heads: wave w owns row tile w (waves >= MT idle there)
     WRing<2, KX / 16, PF, true> R1; WRing<2, HID / 16, PF, true> R2; WRing<1, HID / 16, PF> RO;
     // The two halves are independent networks: a rollout launch gives each its own workgroup (half the serial chain, half the weight bytes
     // through one CU's L1); the update's launches run both in one workgroup (the observation tile is staged once).
-    const int half_begin = A.split_halves == 1 ? (int)blockIdx.y : (A.split_halves == 2 ? 1 : 0), half_end = A.split_halves ? half_begin + 1 : 2;
+    const int half_begin = MODE == MODE_LEAGUE ? job_half : (A.split_halves == 1 ? (int)blockIdx.y : (A.split_halves == 2 ? 1 : 0));
+    const int half_end = (MODE == MODE_LEAGUE || A.split_halves) ? half_begin + 1 : 2;
+    float* const value_out = A.value ? A.value + (size_t)net * A.value_stride : nullptr;
     R1.prime(W1b + (size_t)(256 * half_begin + 64 * w) * KX, KX, lane);         // (layer 1's weights fly while the observation tile is staged)
     if (MODE == MODE_TRAIN) load_x_bf16<M>(A.x_rm, row0, rows_end, xs); else load_x_f32<M>(A.obs, row0, rows_end, xs);
     __syncthreads();
@@ -345,30 +385,50 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
         for (int r = 0; r < 16; r++) {
             const int row = 32 * w + rowmap(r, h);
             const float o = acc3[0][0][r] + bo;
-            if (MODE == MODE_SAMPLE) { if (half_begin == 0) outs[row * OUTS_LD + j] = o; else if (j == N_LOGITS && row0 + row < rows_end) A.value[row0 + row] = o; }
-            else if (MODE == MODE_VALUE) { if (j == N_LOGITS && row0 + row < rows_end) A.value[row0 + row] = o; }
+            if (MODE == MODE_SAMPLE || MODE == MODE_LEAGUE) { if (half_begin == 0) outs[row * OUTS_LD + j] = o; else if (j == N_LOGITS && row0 + row < rows_end) value_out[row0 + row] = o; }
+            else if (MODE == MODE_VALUE) { if (j == N_LOGITS && row0 + row < rows_end) value_out[row0 + row] = o; }
             else if (own_col && (MODE == MODE_TRAIN || row0 + row < rows_end)) A.out[(row0 + row) * NOUT + j] = o;
         }
     }
     MLP_MARK(18);
-    if (MODE == MODE_SAMPLE && half_begin == 0) {
+    if ((MODE == MODE_SAMPLE || MODE == MODE_LEAGUE) && half_begin == 0) {
         __syncthreads();
         // one thread per (row, agent) sample: three categorical heads by inverse CDF, two Gaussian heads by Box-Muller, the action's
         // log-probability, and the env's five action words (size_mean = tanh, size_sigma = sigmoid: the Box bounds of
         // action_helper.py:126-138)
         const int ag = A.agents;
         const unsigned long long key = mix64(A.seed + (unsigned long long)A.counter[0] * 0xd1342543de82ef95ull + (unsigned long long)A.draw * 0x2545f4914f6cdd1dull);
-        const float ls0 = A.theta[CDA_MLP_OFF_LS], ls1 = A.theta[CDA_MLP_OFF_LS + 1];
+        const float ls0 = theta[CDA_MLP_OFF_LS], ls1 = theta[CDA_MLP_OFF_LS + 1];
         const float HALF_LOG_2PI = 0.918938533204672742f;
         for (int s = (int)threadIdx.x; s < M * ag; s += 256) {
             const int row = s / ag, a = s - row * ag;
             const long long grow = row0 + row;
             if (grow >= rows_end) continue;
             const long long i = grow * ag + a;
+            if (MODE == MODE_LEAGUE) {
+                // the slot's module: this net -> sampled below; the uniform random module (RandomRLModule's law, train/model/model_handler.py:38-53;
+                // the counter-based stream of include/cda_random_agents.h keyed (random_seed + rollout counter, market, step, slot)) -> drawn by net 0's
+                // workgroup; any other net -> that net's workgroup writes the slot
+                const int mod = A.slot_net[i];
+                if (mod != net) {
+                    if (net == 0 && mod < 0) {
+                        int c, p, o; float sm, ss;
+                        cda_random_action(A.random_seed + (unsigned long long)A.counter[0] * 0x9e3779b97f4a7c15ull, (unsigned long long)grow, (unsigned int)A.draw, (unsigned int)a, &c, &sm, &ss, &p, &o);
+                        A.env_cat[i] = c; A.env_price[i] = p; A.env_off[i] = o; A.env_mean[i] = sm; A.env_sigma[i] = ss;
+                        A.a_cont[2 * i] = 0.0f; A.a_cont[2 * i + 1] = 0.0f; A.logp[i] = 0.0f;
+                        if (A.rec) {
+                            float4* rp = reinterpret_cast<float4*>(A.rec + 8 * i);
+                            rp[0] = make_float4(__int_as_float(c), __int_as_float(p), __int_as_float(o), 0.0f);
+                            *reinterpret_cast<float2*>(A.rec + 8 * i + 4) = make_float2(0.0f, 0.0f);
+                        }
+                    }
+                    continue;
+                }
+            }
             float l[N_LOGITS];
             #pragma unroll
             for (int q = 0; q < N_LOGITS; q++) l[q] = outs[row * OUTS_LD + q];
-            if (a == 0 && !A.split_halves) A.value[grow] = outs[row * OUTS_LD + N_LOGITS];
+            if (MODE == MODE_SAMPLE && a == 0 && !A.split_halves) A.value[grow] = outs[row * OUTS_LD + N_LOGITS];
             const unsigned long long w0 = mix64(key + (unsigned long long)i), w1 = mix64(w0), w2 = mix64(w1);
             float lp = 0.0f;
             const int c = sample_head<N_CAT>(l, u01(w0, 0), lp);
@@ -387,6 +447,24 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
                 float4* rp = reinterpret_cast<float4*>(A.rec + 8 * i);
                 rp[0] = make_float4(__int_as_float(c), __int_as_float(p), __int_as_float(o), x0);
                 *reinterpret_cast<float2*>(A.rec + 8 * i + 4) = make_float2(x1, lp);
+            }
+        }
+        if (A.dist && (MODE == MODE_SAMPLE || net < A.n_train)) {
+            // the rollout policy's distribution of every row, for the update's KL term: 22 normalised log-probabilities | 2 means (a thread per row)
+            float* dist = A.dist + (size_t)net * A.dist_stride;
+            for (int row = (int)threadIdx.x; row < M; row += 256) {
+                const long long grow = row0 + row;
+                if (grow >= rows_end) continue;
+                float l[N_LOGITS], p[N_CAT + N_PRICE + N_OFF], c0, c1, c2, e0;
+                #pragma unroll
+                for (int q = 0; q < N_LOGITS; q++) l[q] = outs[row * OUTS_LD + q];
+                head_probs_c<N_CAT>(l, p, c0, e0); head_probs_c<N_PRICE>(l + N_CAT, p + N_CAT, c1, e0); head_probs_c<N_OFF>(l + N_CAT + N_PRICE, p + N_CAT + N_PRICE, c2, e0);
+                float4* dp = reinterpret_cast<float4*>(dist + grow * N_LOGITS);
+                float o24[N_LOGITS];
+                #pragma unroll
+                for (int q = 0; q < N_LOGITS; q++) o24[q] = q < N_CAT ? l[q] - c0 : (q < N_CAT + N_PRICE ? l[q] - c1 : (q < N_CAT + N_PRICE + N_OFF ? l[q] - c2 : l[q]));
+                #pragma unroll
+                for (int q = 0; q < N_LOGITS / 4; q++) dp[q] = make_float4(o24[4 * q], o24[4 * q + 1], o24[4 * q + 2], o24[4 * q + 3]);
             }
         }
     }
@@ -752,6 +830,9 @@ struct FbArgs {
     const float* obs; const long long* perm; long long n_rows, norm_rows;
     const __bf16* wb; const float* theta;
     const float* rec; const double* adv_stats; long long adv_count; int agents; float clip, vf_coef, ent_coef;
+    int rec_stride;                  // floats between two rows' records (agents * 8 when a row's samples are all the row's agents; league: A * 8 with rec pointing at the trainable slot)
+    float kl_coef, vf_clip;          // the KL penalty (coefficient x mean KL(rollout policy || current policy), exact per row) and the clamp of the squared value error (<= 0: off)
+    const float* dist_old; const float* log_std_old;      // kl_coef != 0: the rollout policy's distribution per row, f32 [*][24] (FwdArgs::dist), and its two log_std
     __bf16* x_pk; __bf16* h1p; __bf16* h2p; __bf16* dz1p; __bf16* dz2p; __bf16* doutp; float* bias_slab;
     float* out; float* d_out;        // optional f32 [rows][32] copies of the outputs and their gradients (tests, diagnostics)
     double* sums5;
@@ -765,20 +846,6 @@ __device__ __forceinline__ void store_packed_keep(__bf16* __restrict__ base, lon
     k[0] = __builtin_convertvector(f0, bf16x8); k[1] = __builtin_convertvector(f1, bf16x8);
     bf16x8* dst = reinterpret_cast<bf16x8*>(base) + ((rt * nft + ft) * 2) * 64 + lane;
     dst[0] = k[0]; dst[64] = k[1];
-}
-// softmax of one head: p[q], c = max + log(sum) (log p[q] = l[q] - c), entropy
-template <int N> __device__ __forceinline__ void head_probs_c(const float* l, float* p, float& c, float& ent) {
-    float mx = l[0];
-    #pragma unroll
-    for (int q = 1; q < N; q++) mx = fmaxf(mx, l[q]);
-    float s = 0.0f;
-    #pragma unroll
-    for (int q = 0; q < N; q++) { p[q] = __expf(l[q] - mx); s += p[q]; }
-    const float ls = __logf(s), inv = 1.0f / s;
-    float hh = 0.0f;
-    #pragma unroll
-    for (int q = 0; q < N; q++) { p[q] *= inv; hh -= p[q] * (l[q] - mx - ls); }
-    c = mx + ls; ent = hh;
 }
 // quad (four neighbouring lanes) exchanges: DPP quad_perm, one instruction each, no LDS
 template <int CTRL> __device__ __forceinline__ float dpp_f(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false)); }
@@ -836,10 +903,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
             v[u] = *reinterpret_cast<const float4*>(A.obs + srow[r] * OBS + (q < OBS / 4 ? q : OBS / 4 - 1) * 4);
         }
-        const int rec_pieces = M * A.agents * 2;                                // the records: [agents][8] f32 per row = 2 agents' 16-B pieces
-        for (int c = (int)threadIdx.x; c < rec_pieces; c += 256) {
-            const int r = c / (2 * A.agents), q = c - r * (2 * A.agents);
-            reinterpret_cast<float4*>(recs)[c] = reinterpret_cast<const float4*>(A.rec + srow[r] * A.agents * 8)[q];
+        const int rp = 2 * A.agents, rpd = rp + (A.dist_old ? N_LOGITS / 4 : 0);    // the records: [agents][8] f32 per row = 2 16-B pieces per agent; then the row's old distribution (6 pieces)
+        for (int c = (int)threadIdx.x; c < M * rpd; c += 256) {
+            const int r = c / rpd, q = c - r * rpd;
+            reinterpret_cast<float4*>(recs)[c] = q < rp ? reinterpret_cast<const float4*>(A.rec + srow[r] * A.rec_stride)[q]
+                                                        : reinterpret_cast<const float4*>(A.dist_old + srow[r] * N_LOGITS)[q - rp];
         }
         #pragma unroll
         for (int u = 0; u < PER; u++) {
@@ -925,7 +993,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
         // 7.5 k cycles with the other three waves waiting.)
         const int row = 16 * w + (lane >> 2), sq = lane & 3, i0 = 6 * sq;
         const bool live = row0 + row < rows_end;
-        const float* rr = recs + (size_t)row * A.agents * 8;
+        const int rec_ld = A.agents * 8 + (A.dist_old ? N_LOGITS : 0);
+        const float* rr = recs + (size_t)row * rec_ld;
         float* orow = outs + row * OUTS_LD;
         __bf16* drow = dos + row * DO_LD;
         float adv_mean = 0.0f, adv_rstd = 1.0f;
@@ -1013,6 +1082,28 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             const float hk = hid[k] == 0 ? hh[0] : (hid[k] == 1 ? hh[1] : hh[2]);
             d[k] += -G * pr[k] + esA * pr[k] * (lp[k] + hk);                    // (the means' slots: pr = 0)
         }
+        float klsum = 0.0f;
+        if (A.dist_old) {
+            // KL(rollout policy || current policy) of the row, exact: the categorical heads from the old normalised log-probabilities, the Gaussian
+            // heads in closed form; every sample of the row carries it (the row's agents share the distribution), so the row's weight is `agents`
+            const float* od = rr + A.agents * 8 + i0;
+            const float klw = A.kl_coef * (float)A.agents * invB;
+            float kc = 0.0f, om[6];
+            #pragma unroll
+            for (int k = 0; k < 6; k++) {
+                om[k] = od[k];
+                const float po = hid[k] < 3 ? __expf(om[k]) : 0.0f;
+                kc += hid[k] < 3 ? po * (om[k] - lp[k]) : 0.0f;
+                d[k] += hid[k] < 3 ? klw * (pr[k] - po) : 0.0f;
+            }
+            kc = quad_sum(kc);
+            const float mo0 = quad_bcast<3>(om[4]), mo1 = quad_bcast<3>(om[5]);
+            const float lso0 = A.log_std_old[0], lso1 = A.log_std_old[1];
+            const float q0 = (__expf(2.0f * lso0) + (mo0 - mean0) * (mo0 - mean0)) * is0 * is0, q1 = (__expf(2.0f * lso1) + (mo1 - mean1) * (mo1 - mean1)) * is1 * is1;
+            const float kg = (ls0 - lso0) + 0.5f * q0 - 0.5f + (ls1 - lso1) + 0.5f * q1 - 0.5f;
+            dm0 += klw * (mean0 - mo0) * is0 * is0; dm1 += klw * (mean1 - mo1) * is1 * is1;
+            if (sq == 0) { dls0 += klw * (1.0f - q0); dls1 += klw * (1.0f - q1); klsum = (kc + kg) * (float)A.agents; }
+        }
         if (sq == 3) { d[4] = dm0; d[5] = dm1; }
         if (A.out && live) {
             #pragma unroll
@@ -1021,7 +1112,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             A.out[(row0 + row) * NOUT + N_LOGITS + 2 * sq + 1] = 0.0f;
         }
         if (!live) {
-            pg = en = dls0 = dls1 = 0.0f;
+            pg = en = dls0 = dls1 = klsum = 0.0f;
             #pragma unroll
             for (int k = 0; k < 6; k++) d[k] = 0.0f;
         }
@@ -1041,28 +1132,32 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             if (sq != 0) A.d_out[(row0 + row) * NOUT + N_LOGITS + 2 * sq] = 0.0f;
             A.d_out[(row0 + row) * NOUT + N_LOGITS + 2 * sq + 1] = 0.0f;
         }
-        float v4[4] = {pg, en, dls0, dls1};
+        float v4[5] = {pg, en, dls0, dls1, klsum};
         #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < 5; q++) {
             float x = v4[q];
             #pragma unroll
             for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
             v4[q] = x;
         }
         double* slot = A.sums5 + 8 * ((4 * tile_id + w) & (CDA_MLP_LOSS_SLOTS - 1));   // a slot (one cache line) per wave mod 64: one hot line stalls every CU's memory pipeline behind its atomics
-        if (lane == 0) { atomicAdd(&slot[0], (double)v4[0]); atomicAdd(&slot[2], (double)v4[1]); atomicAdd(&slot[3], (double)v4[2]); atomicAdd(&slot[4], (double)v4[3]); }
+        if (lane == 0) {
+            atomicAdd(&slot[0], (double)v4[0]); atomicAdd(&slot[2], (double)v4[1]); atomicAdd(&slot[3], (double)v4[2]); atomicAdd(&slot[4], (double)v4[3]);
+            if (A.dist_old) atomicAdd(&slot[5], (double)v4[4]);
+        }
     } else if (w == 0) {                                                        // the value loss: a lane per row
         const int row = lane;
         const bool live = row0 + row < rows_end;
-        const float* rr = recs + (size_t)row * A.agents * 8;
+        const float* rr = recs + (size_t)row * (A.agents * 8 + (A.dist_old ? N_LOGITS : 0));
         float* orow = outs + row * OUTS_LD;
         __bf16* drow = dos + row * DO_LD;
         const float val = orow[N_LOGITS];
         float vl = 0.0f, dval = 0.0f;
         for (int a = 0; a < A.agents; a++) {
-            const float dv = val - rr[8 * a + 7];
-            vl += dv * dv;
-            dval += 2.0f * A.vf_coef * dv * invB;
+            const float dv = val - rr[8 * a + 7], sqe = dv * dv;
+            const bool clamped = A.vf_clip > 0.0f && sqe > A.vf_clip;          // clamp(error^2, 0, vf_clip): the clamped samples carry no gradient
+            vl += clamped ? A.vf_clip : sqe;
+            dval += clamped ? 0.0f : 2.0f * A.vf_coef * dv * invB;
         }
         if (A.out && live) A.out[(row0 + row) * NOUT + N_LOGITS] = val;
         if (!live) { vl = 0.0f; dval = 0.0f; }
@@ -1249,7 +1344,7 @@ __device__ __forceinline__ int param_of_dense(int d) {
     if (o == N_LOGITS) return c >= HID ? CDA_MLP_OFF_WO + N_LOGITS * HID + (c - HID) : -1;
     return -1;
 }
-struct LossFinish { double* sums5; long long samples; float vf_coef, ent_coef; float* out6; };
+struct LossFinish { double* sums5; long long samples; float vf_coef, ent_coef, kl_coef; float* out6; };      // out6: f32[8] (CDA_LOSS_OUT_*)
 __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slab, int n_chunks, const float* __restrict__ bslab, int n_tiles,
                                                      LossFinish LF, float* __restrict__ grad, double* __restrict__ norm2, float* __restrict__ step) {
     __shared__ float red[16][64];
@@ -1292,14 +1387,14 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
             for (; t < n_tiles; t += 16) s0 += src[(size_t)t * CDA_MLP_BSLAB];
         }
         red[part][threadIdx.x & 15] = (s0 + s1) + (s2 + s3);
-        __shared__ double lred[16][5];                                           // the loss sums' slots, split the same 16 ways (one thread walking all 64: +5 us on the kernel)
+        __shared__ double lred[16][6];                                           // the loss sums' slots, split the same 16 ways (one thread walking all 64: +5 us on the kernel)
         if (e == CDA_MLP_BSLAB && LF.sums5) {
-            double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             for (int sl = part; sl < CDA_MLP_LOSS_SLOTS; sl += 16)
                 #pragma unroll
-                for (int q = 0; q < 5; q++) { t[q] += LF.sums5[8 * sl + q]; LF.sums5[8 * sl + q] = 0.0; }
+                for (int q = 0; q < 6; q++) { t[q] += LF.sums5[8 * sl + q]; LF.sums5[8 * sl + q] = 0.0; }
             #pragma unroll
-            for (int q = 0; q < 5; q++) lred[part][q] = t[q];
+            for (int q = 0; q < 6; q++) lred[part][q] = t[q];
         }
         __syncthreads();
         if (part == 0) {
@@ -1316,14 +1411,15 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
                 // k_ppo_finish32 would write); the sums are cleared for the next minibatch above - no memset, no extra launch
                 float g0 = 0.0f, g1 = 0.0f;
                 if (LF.sums5) {
-                    double t5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+                    double t5[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                     for (int k = 0; k < 16; k++)
                         #pragma unroll
-                        for (int q = 0; q < 5; q++) t5[q] += lred[k][q];
-                    const double pg = t5[0] / (double)LF.samples, vl = t5[1] / (double)LF.samples, en = t5[2] / (double)LF.samples;
+                        for (int q = 0; q < 6; q++) t5[q] += lred[k][q];
+                    const double pg = t5[0] / (double)LF.samples, vl = t5[1] / (double)LF.samples, en = t5[2] / (double)LF.samples, kl = t5[5] / (double)LF.samples;
                     g0 = (float)t5[3]; g1 = (float)t5[4];
-                    if (LF.out6) { LF.out6[0] = (float)pg; LF.out6[1] = (float)vl; LF.out6[2] = (float)en; LF.out6[3] = (float)(pg + (double)LF.vf_coef * vl - (double)LF.ent_coef * en);
-                                   LF.out6[4] = g0; LF.out6[5] = g1; }
+                    if (LF.out6) { LF.out6[0] = (float)pg; LF.out6[1] = (float)vl; LF.out6[2] = (float)en;
+                                   LF.out6[3] = (float)(pg + (double)LF.vf_coef * vl - (double)LF.ent_coef * en + (double)LF.kl_coef * kl);
+                                   LF.out6[4] = g0; LF.out6[5] = g1; LF.out6[6] = (float)kl; LF.out6[7] = 0.0f; }
                 }
                 grad[CDA_MLP_OFF_LS] = g0; grad[CDA_MLP_OFF_LS + 1] = g1; sq = g0 * g0 + g1 * g1;
             }
@@ -1503,14 +1599,14 @@ __global__ void k_ppo_finish32(const double* sums, long long B, float vf_coef, f
     }
 }
 
-__global__ void k_ppo_finish_slots(const double* sums, long long B, float vf_coef, float ent_coef, float* out) {      // the same over CDA_MLP_LOSS_SLOTS slots
+__global__ void k_ppo_finish_slots(const double* sums, long long B, float vf_coef, float ent_coef, float kl_coef, float* out) {      // the same over CDA_MLP_LOSS_SLOTS slots (out f32[8])
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double t5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        double t5[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int sl = 0; sl < CDA_MLP_LOSS_SLOTS; sl++)
-            for (int q = 0; q < 5; q++) t5[q] += sums[8 * sl + q];
-        const double pg = t5[0] / (double)B, vl = t5[1] / (double)B, en = t5[2] / (double)B;
-        out[0] = (float)pg; out[1] = (float)vl; out[2] = (float)en; out[3] = (float)(pg + (double)vf_coef * vl - (double)ent_coef * en);
-        out[4] = (float)t5[3]; out[5] = (float)t5[4];
+            for (int q = 0; q < 6; q++) t5[q] += sums[8 * sl + q];
+        const double pg = t5[0] / (double)B, vl = t5[1] / (double)B, en = t5[2] / (double)B, kl = t5[5] / (double)B;
+        out[0] = (float)pg; out[1] = (float)vl; out[2] = (float)en; out[3] = (float)(pg + (double)vf_coef * vl - (double)ent_coef * en + (double)kl_coef * kl);
+        out[4] = (float)t5[3]; out[5] = (float)t5[4]; out[6] = (float)kl; out[7] = 0.0f;
     }
 }
 
@@ -1519,30 +1615,40 @@ __global__ void k_ppo_finish_slots(const double* sums, long long B, float vf_coe
 // (scaled here), value f32 [T + 1][N] (slot T = the bootstrap value), terminated / truncated u8 [T][N] - and writes advantage and return into
 // words 6, 7 of the step's sample record.  The sums of the advantages and of their squares go to stats f64[2] (cleared by the caller): the
 // update normalises on the fly, (adv - mean) / (std + 1e-8) with the unbiased std, as ppo_update does with torch ops.
+// n_train > 0 (league self-play): slot p < n_train is played by trainable net p, whose values are value[p][T + 1][N] and whose sums go to stats[2 p ..];
+// the other slots' samples feed no update and are skipped.
 __global__ __launch_bounds__(256) void k_gae_records(const double* __restrict__ reward, const float* __restrict__ value, const unsigned char* __restrict__ term,
-                                                     const unsigned char* __restrict__ trunc, int T, long long N, int Ag, float reward_scale, float gamma, float lam,
+                                                     const unsigned char* __restrict__ trunc, int T, long long N, int Ag, int n_train, float reward_scale, float gamma, float lam,
+                                                     const int* __restrict__ fin_index, const float* __restrict__ fin_value, long long fin_value_stride,
                                                      float* __restrict__ rec, double* __restrict__ stats) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, B = N * Ag;
     double s1 = 0.0, s2 = 0.0;
-    if (i < B) {
+    const int slot = (int)(i % Ag);
+    if (i < B && (n_train <= 0 || slot < n_train)) {
         const long long n = i / Ag;
+        if (n_train > 0) { value += (long long)slot * (T + 1) * N; fin_value += (long long)slot * fin_value_stride; }
         float nxt = value[(long long)T * N + n], run = 0.0f;
         // eight steps' operands requested together, then the recursion over them (one step at a time, every iteration paid a memory round trip:
         // 39 us for 64 steps)
         for (int t0 = T - 1; t0 >= 0; t0 -= 8) {
-            float rw[8], vv[8], nd[8];
+            float rw[8], vv[8], nd[8], bv[8];
             #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int t = t0 - u >= 0 ? t0 - u : 0;
                 const long long k = (long long)t * B + i, kn = (long long)t * N + n;
-                rw[u] = (float)reward[k] * reward_scale; vv[u] = value[kn]; nd[u] = (term[kn] | trunc[kn]) ? 0.0f : 1.0f;
+                const bool tm = term[kn] != 0, tr = trunc[kn] != 0;
+                rw[u] = (float)reward[k] * reward_scale; vv[u] = value[kn]; nd[u] = (tm | tr) ? 0.0f : 1.0f;
+                // a time-limit truncation (not a termination) whose last observation was captured: the step bootstraps with V(that observation) - the value
+                // of the state the episode was cut in - instead of 0; nothing propagates across the episode boundary either way (nd = 0)
+                bv[u] = 0.0f;
+                if (fin_index && tr && !tm) { const int fi = fin_index[kn]; if (fi >= 0) bv[u] = fin_value[fi]; }
             }
             #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int t = t0 - u;
                 if (t >= 0) {
                     const long long k = (long long)t * B + i;
-                    const float delta = rw[u] + gamma * nxt * nd[u] - vv[u];
+                    const float delta = rw[u] + gamma * (nxt * nd[u] + bv[u]) - vv[u];
                     run = delta + gamma * lam * nd[u] * run;
                     *reinterpret_cast<float2*>(rec + 8 * k + 6) = make_float2(run, run + vv[u]);
                     s1 += (double)run; s2 += (double)run * (double)run;
@@ -1550,6 +1656,15 @@ __global__ __launch_bounds__(256) void k_gae_records(const double* __restrict__ 
                 }
             }
         }
+    }
+    if (n_train > 0) {                                                          // per net: a wave reduction and two atomics per (wave, net)
+        for (int p = 0; p < n_train; p++) {
+            double a1 = slot == p ? s1 : 0.0, a2 = slot == p ? s2 : 0.0;
+            #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64); }
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[2 * p], a1); atomicAdd(&stats[2 * p + 1], a2); }
+        }
+        return;
     }
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
@@ -1648,6 +1763,23 @@ __global__ __launch_bounds__(256) void k_ppo_loss_rec(const float* __restrict__ 
     }
 }
 
+// Returns of COMPLETED episodes from a rollout's buffers: running f64 [N][A] carries every (market, agent)'s return so far across rollouts; a step that ends
+// the market's episode adds the agent's total to done_sum f64 [A] (and 1 to done_count f64 [A]) and restarts it.  One thread per (market, agent), forwards in time.
+__global__ __launch_bounds__(256) void k_episode_returns(const double* __restrict__ reward, const unsigned char* __restrict__ term, const unsigned char* __restrict__ trunc,
+                                                         int T, long long N, int Ag, double* __restrict__ running, double* __restrict__ done_sum, double* __restrict__ done_count,
+                                                         double* __restrict__ per_slot) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, B = N * Ag;
+    if (i >= B) return;
+    const long long n = i / Ag; const int a = (int)(i - n * Ag);
+    double run = running[i], s = 0.0, c = 0.0;
+    for (int t = 0; t < T; t++) {
+        run += reward[(long long)t * B + i];
+        if (term[(long long)t * N + n] | trunc[(long long)t * N + n]) { s += run; c += 1.0; run = 0.0; }
+    }
+    running[i] = run;
+    if (c > 0.0) { atomicAdd(&done_sum[a], s); atomicAdd(&done_count[a], c); }
+    if (per_slot) { per_slot[2 * i] = s; per_slot[2 * i + 1] = c; }              // this rollout's completed episodes of (market, agent): sum of returns, number
+}
 __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, long long n4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
@@ -1682,13 +1814,13 @@ int train_mt() {
 }
 size_t fwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + 2 * M * ACT_LD * 2; }
 size_t bwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * OUTS_LD * 4 + 2 * M * ACT_LD * 2; }
-size_t fb_lds(int agents) { return (size_t)64 * XS_LD * 2 + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * agents * 32; }
+size_t fb_lds(int agents, bool with_dist) { return (size_t)64 * XS_LD * 2 + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * (agents * 32 + (with_dist ? N_LOGITS * 4 : 0)); }
 int rollout_mt() {
     static int mt = 0;
     if (!mt) { const char* e = getenv("CDA_MLP_ROLLOUT_MT"); mt = e ? atoi(e) : 1; if (mt != 1 && mt != 2 && mt != 4) mt = 1; }
     return mt;
 }
-size_t fwd_lds(int mt, int mode) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + M * ACT_LD * 2 + (mode == MODE_SAMPLE ? M * OUTS_LD * 4 : 0); }
+size_t fwd_lds(int mt, int mode) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + M * ACT_LD * 2 + ((mode == MODE_SAMPLE || mode == MODE_LEAGUE) ? M * OUTS_LD * 4 : 0); }
 size_t bwd_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * ACT_LD * 2 + M * OUTS_LD * 4; }
 
 // more than 64 KB of dynamic LDS needs the function attribute raised, once per (kernel, device): remembered here (a launch path, not a setup path)
@@ -1705,9 +1837,9 @@ int allow_lds(K kern, size_t bytes) {
     return CDA_OK;
 }
 template <int MODE>
-int launch_fwd(const FwdArgs& A, int mt, hipStream_t st) {
+int launch_fwd(const FwdArgs& A, int mt, hipStream_t st, unsigned grid_y = 0) {
     const size_t lds = fwd_lds(mt, MODE);
-    const dim3 grid((unsigned)((A.n_rows + 32 * mt - 1) / (32 * mt)), A.split_halves == 1 ? 2u : 1u);
+    const dim3 grid((unsigned)((A.n_rows + 32 * mt - 1) / (32 * mt)), grid_y ? grid_y : (A.split_halves == 1 ? 2u : 1u));
     int rc = CDA_OK;
     if (mt == 4) { rc = allow_lds(k_mlp_fwd<4, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<4, MODE>), grid, dim3(256), lds, st, A); }
     else if (mt == 2) { rc = allow_lds(k_mlp_fwd<2, MODE>, lds); if (!rc) hipLaunchKernelGGL((k_mlp_fwd<2, MODE>), grid, dim3(256), lds, st, A); }
@@ -1835,25 +1967,31 @@ extern "C" void cda_tools_mlp_fb_dbg(void* dbg_u64x8x32, int32_t block) { g_fb_d
 #endif
 extern "C" int cda_mlp_forward_backward(const void* wb, const float* theta, const float* obs, const int64_t* perm, int64_t n_rows, int64_t norm_rows,
                                         const float* rec, const double* adv_stats2, int64_t adv_count, int32_t agents_per_row, float clip, float vf_coef, float ent_coef,
+                                        const cda_ppo_extra* extra,
                                         void* x_pk, void* h1p, void* h2p, void* dz1p, void* dz2p, void* doutp, float* bias_slab,
                                         double* sums5, float* out6, int32_t clear, int32_t finish, float* out, float* d_out, void* stream) {
     if (!wb || !theta || !obs || !rec || !x_pk || !h1p || !h2p || !dz1p || !dz2p || !doutp || !bias_slab || !sums5 || n_rows < 32 || (n_rows & 31) || norm_rows < 0 ||
         agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS || (adv_stats2 && adv_count < 2) || (finish && !out6)) return CDA_ERR_INVALID;
+    if (extra && ((extra->rec_stride != 0 && extra->rec_stride < agents_per_row * 8) || (extra->rec_stride & 3) || (extra->kl_coef != 0.0f && (!extra->dist_old || !extra->log_std_old))))
+        return CDA_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     FbArgs A; memset(&A, 0, sizeof A);
     A.obs = obs; A.perm = (const long long*)perm; A.n_rows = n_rows; A.norm_rows = norm_rows > 0 ? norm_rows : n_rows; A.wb = (const __bf16*)wb; A.theta = theta;
     A.rec = rec; A.adv_stats = adv_stats2; A.adv_count = adv_count; A.agents = agents_per_row; A.clip = clip; A.vf_coef = vf_coef; A.ent_coef = ent_coef;
+    A.rec_stride = extra && extra->rec_stride ? extra->rec_stride : agents_per_row * 8;
+    A.kl_coef = extra ? extra->kl_coef : 0.0f; A.vf_clip = extra ? extra->vf_clip : 0.0f;
+    A.dist_old = extra && extra->kl_coef != 0.0f ? extra->dist_old : NULL; A.log_std_old = extra ? extra->log_std_old : NULL;
     A.x_pk = (__bf16*)x_pk; A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.dz1p = (__bf16*)dz1p; A.dz2p = (__bf16*)dz2p; A.doutp = (__bf16*)doutp; A.bias_slab = bias_slab;
     A.out = out; A.d_out = d_out; A.sums5 = sums5;
 #ifdef CDA_MLP_TIMING
     A.dbg = g_fb_dbg; A.dbg_block = g_fb_dbg_block;
 #endif
     if (clear && hipMemsetAsync(sums5, 0, (size_t)CDA_MLP_LOSS_SLOTS * 8 * sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
-    const size_t lds = fb_lds(agents_per_row);
+    const size_t lds = fb_lds(agents_per_row, A.dist_old != NULL);
     int rc = allow_lds(k_mlp_fb, lds); if (rc) return rc;
     const long long tiles = (n_rows + 63) / 64;
     hipLaunchKernelGGL(k_mlp_fb, dim3((unsigned)(16 * ((tiles + 7) / 8))), dim3(256), lds, st, A);
-    if (finish) hipLaunchKernelGGL(k_ppo_finish_slots, dim3(1), dim3(64), 0, st, (const double*)sums5, A.norm_rows * agents_per_row, vf_coef, ent_coef, out6);
+    if (finish) hipLaunchKernelGGL(k_ppo_finish_slots, dim3(1), dim3(64), 0, st, (const double*)sums5, A.norm_rows * agents_per_row, vf_coef, ent_coef, A.kl_coef, out6);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
@@ -1866,13 +2004,39 @@ extern "C" int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p,
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
+// squared norm of an (all-reduced) gradient as the per-block shares k_adam sums: block b's share to scratch[NORM_PARTIALS + b], the other shares zeroed
+__global__ __launch_bounds__(256) void k_grad_norm(const float* __restrict__ grad, double* __restrict__ scratch) {
+    double acc = 0.0;
+    for (int p = (int)(blockIdx.x * 256 + threadIdx.x); p < CDA_MLP_PARAMS; p += 256 * (RED_DENSE_BLOCKS + RED_BIAS_BLOCKS)) acc += (double)grad[p] * (double)grad[p];
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[NORM_PARTIALS + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+extern "C" int cda_mlp_reduce(const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
+                              double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float kl_coef, float* loss_out6, float* step_dev, float* grad, double* scratch3, void* stream) {
+    if (!step_dev || !slab || !bias_slab || !grad || !scratch3 || n_chunks < 1 || n_bias_tiles < 1 || (loss_sums5 && loss_samples < 1)) return CDA_ERR_INVALID;
+    LossFinish LF; LF.sums5 = loss_sums5; LF.samples = loss_samples; LF.vf_coef = vf_coef; LF.ent_coef = ent_coef; LF.kl_coef = kl_coef; LF.out6 = loss_out6;
+    hipLaunchKernelGGL(k_grad_reduce, dim3(RED_DENSE_BLOCKS + RED_BIAS_BLOCKS), dim3(256), 0, (hipStream_t)stream, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, LF, grad, scratch3, step_dev);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+extern "C" int cda_mlp_apply(float* theta, float* adam_m, float* adam_v, const float* step_dev, void* wb, const float* grad, int32_t recompute_norm,
+                             float lr, float beta1, float beta2, float eps, float max_norm, double* scratch3, void* stream) {
+    if (!theta || !adam_m || !adam_v || !step_dev || !wb || !grad || !scratch3) return CDA_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (recompute_norm) hipLaunchKernelGGL(k_grad_norm, dim3(RED_DENSE_BLOCKS + RED_BIAS_BLOCKS), dim3(256), 0, st, grad, scratch3);
+    hipLaunchKernelGGL(k_adam, dim3((CDA_MLP_PARAMS + 255) / 256), dim3(256), 0, st, theta, adam_m, adam_v, step_dev, (__bf16*)wb, grad, scratch3, lr, beta1, beta2, eps, max_norm);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
 extern "C" int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* step_dev, void* wb,
                             const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
-                            double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float* loss_out6,
+                            double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float kl_coef, float* loss_out6,
                             float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* scratch3, void* stream) {
     if (!theta || !adam_m || !adam_v || !step_dev || !wb || !slab || !bias_slab || !grad || !scratch3 || n_chunks < 1 || n_bias_tiles < 1 || (loss_sums5 && loss_samples < 1)) return CDA_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    LossFinish LF; LF.sums5 = loss_sums5; LF.samples = loss_samples; LF.vf_coef = vf_coef; LF.ent_coef = ent_coef; LF.out6 = loss_out6;
+    LossFinish LF; LF.sums5 = loss_sums5; LF.samples = loss_samples; LF.vf_coef = vf_coef; LF.ent_coef = ent_coef; LF.kl_coef = kl_coef; LF.out6 = loss_out6;
     hipLaunchKernelGGL(k_grad_reduce, dim3(RED_DENSE_BLOCKS + RED_BIAS_BLOCKS), dim3(256), 0, st, slab, (int)n_chunks, bias_slab, (int)n_bias_tiles, LF, grad, scratch3, step_dev);
     hipLaunchKernelGGL(k_adam, dim3((CDA_MLP_PARAMS + 255) / 256), dim3(256), 0, st, theta, adam_m, adam_v, (const float*)step_dev, (__bf16*)wb, (const float*)grad, scratch3,
                        lr, beta1, beta2, eps, max_norm);
@@ -1894,14 +2058,41 @@ extern "C" int cda_ppo_loss32(const float* outputs, const float* log_std, const 
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
-extern "C" int cda_gae_records(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
-                               int32_t num_agents, float reward_scale, float gamma, float lam, float* rec, double* stats2, void* stream) {
-    if (!reward || !value || !terminated || !truncated || !rec || !stats2 || n_steps < 1 || n_markets < 1 || num_agents < 1 || num_agents > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+static int gae_records(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
+                       int32_t num_agents, int32_t n_train, float reward_scale, float gamma, float lam, float* rec, double* stats, void* stream,
+                       const int32_t* fin_index = NULL, const float* fin_value = NULL, int64_t fin_value_stride = 0) {
+    if (!reward || !value || !terminated || !truncated || !rec || !stats || n_steps < 1 || n_markets < 1 || num_agents < 1 || num_agents > CDA_MAX_AGENTS ||
+        n_train < 0 || n_train > num_agents || (fin_index && !fin_value)) return CDA_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
+    if (hipMemsetAsync(stats, 0, 2 * sizeof(double) * (n_train > 0 ? n_train : 1), st) != hipSuccess) return CDA_ERR_HIP;
     const long long B = (long long)n_markets * num_agents;
     hipLaunchKernelGGL(k_gae_records, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, reward, value, (const unsigned char*)terminated, (const unsigned char*)truncated,
-                       (int)n_steps, (long long)n_markets, (int)num_agents, reward_scale, gamma, lam, rec, stats2);
+                       (int)n_steps, (long long)n_markets, (int)num_agents, (int)n_train, reward_scale, gamma, lam, (const int*)fin_index, fin_value, (long long)fin_value_stride, rec, stats);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+extern "C" int cda_gae_records(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
+                               int32_t num_agents, float reward_scale, float gamma, float lam, float* rec, double* stats2, void* stream) {
+    return gae_records(reward, value, terminated, truncated, n_steps, n_markets, num_agents, 0, reward_scale, gamma, lam, rec, stats2, stream);
+}
+// ... with the time-limit bootstrap: fin_index i32 [T][N] (slot of the step's captured last observation, -1 = none), fin_value f32 [max(n_trainable, 1)][fin_value_stride]
+// (cda_mlp_values on the captured list).  n_trainable = 0: one shared policy (cda_gae_records' layout), > 0: the league's (cda_gae_records_league's).
+extern "C" int cda_gae_records_bootstrap(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
+                                         int32_t num_agents, int32_t n_trainable, float reward_scale, float gamma, float lam,
+                                         const int32_t* fin_index, const float* fin_value, int64_t fin_value_stride, float* rec, double* stats, void* stream) {
+    return gae_records(reward, value, terminated, truncated, n_steps, n_markets, num_agents, n_trainable, reward_scale, gamma, lam, rec, stats, stream, fin_index, fin_value, fin_value_stride);
+}
+extern "C" int cda_gae_records_league(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
+                                      int32_t num_agents, int32_t n_trainable, float reward_scale, float gamma, float lam, float* rec, double* stats2k, void* stream) {
+    if (n_trainable < 1) return CDA_ERR_INVALID;
+    return gae_records(reward, value, terminated, truncated, n_steps, n_markets, num_agents, n_trainable, reward_scale, gamma, lam, rec, stats2k, stream);
+}
+
+extern "C" int cda_episode_returns(const double* reward, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets, int32_t num_agents,
+                                   double* running, double* done_sum, double* done_count, double* per_slot, void* stream) {
+    if (!reward || !terminated || !truncated || !running || !done_sum || !done_count || n_steps < 1 || n_markets < 1 || num_agents < 1 || num_agents > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+    const long long B = (long long)n_markets * num_agents;
+    hipLaunchKernelGGL(k_episode_returns, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reward, (const unsigned char*)terminated, (const unsigned char*)truncated,
+                       (int)n_steps, (long long)n_markets, (int)num_agents, running, done_sum, done_count, per_slot);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
@@ -1919,17 +2110,79 @@ extern "C" int cda_ppo_loss_records(const float* outputs, const float* log_std, 
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
+extern "C" int cda_mlp_league_step(const cda_league* L, const float* obs, int32_t first_market, int32_t n_markets, int32_t num_agents,
+                                   uint64_t seed, const int64_t* counter_dev, int64_t draw,
+                                   int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset,
+                                   float* a_cont, float* logp, float* value, int64_t value_stride, float* rec, float* dist, int64_t dist_stride, void* stream) {
+    if (!L || !L->wb_bank || !L->theta_bank || !L->slot_net || L->n_trainable < 1 || L->n_nets < L->n_trainable || L->n_nets > CDA_LEAGUE_MAX_NETS ||
+        !obs || !counter_dev || !env_category || !env_size_mean || !env_size_sigma || !env_price || !env_price_offset || !a_cont || !logp || !value ||
+        first_market < 0 || n_markets < 1 || num_agents < 1 || num_agents > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
+    FwdArgs A; memset(&A, 0, sizeof A);
+    A.obs = obs; A.first_row = first_market; A.n_rows = n_markets; A.wb = (const __bf16*)L->wb_bank; A.theta = L->theta_bank;
+    A.agents = num_agents; A.seed = seed; A.counter = (const long long*)counter_dev; A.draw = draw;
+    A.env_cat = env_category; A.env_mean = env_size_mean; A.env_sigma = env_size_sigma; A.env_price = env_price; A.env_off = env_price_offset;
+    A.a_cont = a_cont; A.logp = logp; A.value = value; A.rec = rec; A.dist = dist;
+    A.n_train = L->n_trainable; A.slot_net = L->slot_net; A.value_stride = value_stride; A.dist_stride = dist_stride; A.random_seed = L->random_seed;
+    A.split_halves = 1;
+    return launch_fwd<MODE_LEAGUE>(A, rollout_mt(), (hipStream_t)stream, (unsigned)(L->n_trainable + L->n_nets));     // 2 jobs per trainable net, 1 per frozen one
+}
+
+// The reference's agent-to-module mapping (train/callbk/league_based_self_play_callback.py:1286-1344) for every (market, pool slot) at once: slot s >= n_trainable
+// of a market draws np.random.RandomState((crc32(str(episode id)) + s) mod 2^32).choice(pool, p) - ONE random_sample() of a freshly seeded MT19937: the
+// init_genrand recurrence up to word 398, the twist + tempering of outputs 0 and 1, a 53-bit double, searchsorted(cdf, u, side = "right").  A thread per
+// (market, slot): 400 dependent integer steps (the host-side numpy restatement, league.mt19937_first_double, walks the same recurrence over all seeds at
+// once: tens of milliseconds at 2048 x 6 - longer than the episode it assigns).
+__global__ __launch_bounds__(256) void k_league_assign(const unsigned int* __restrict__ episode_crc, int N, int Ag, int n_train, const double* __restrict__ cdf,
+                                                       const int* __restrict__ pool_net, int P, int* __restrict__ slot_net, int* __restrict__ slot_pool) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= N * Ag) return;
+    const int n = i / Ag, s = i - n * Ag;
+    if (s < n_train) { slot_net[i] = s; if (slot_pool) slot_pool[i] = -1; return; }
+    unsigned int x = episode_crc[n] + (unsigned int)s;                          // (crc + slot) mod 2^32
+    unsigned int m0 = x, m1 = 0, m2 = 0, m397 = 0, m398 = 0;
+    for (unsigned int k = 1; k <= 398; k++) {
+        x = 1812433253u * (x ^ (x >> 30)) + k;
+        if (k == 1) m1 = x; else if (k == 2) m2 = x; else if (k == 397) m397 = x; else if (k == 398) m398 = x;
+    }
+    auto word = [](unsigned int a, unsigned int b, unsigned int c) {             // output k: twist of (mt[k], mt[k + 1], mt[k + 397]), tempered
+        const unsigned int y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        unsigned int v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        v ^= v >> 11; v ^= (v << 7) & 0x9d2c5680u; v ^= (v << 15) & 0xefc60000u; v ^= v >> 18;
+        return v;
+    };
+    const unsigned int w0 = word(m0, m1, m397) >> 5, w1 = word(m1, m2, m398) >> 6;
+    const double u = ((double)w0 * 67108864.0 + (double)w1) / 9007199254740992.0;
+    int idx = 0;
+    for (int q = 0; q < P; q++) idx += cdf[q] <= u ? 1 : 0;                      // searchsorted(..., side = "right")
+    if (idx >= P) idx = P - 1;
+    slot_net[i] = pool_net[idx];
+    if (slot_pool) slot_pool[i] = idx;
+}
+extern "C" int cda_league_assign(const uint32_t* episode_crc, int32_t n_markets, int32_t num_agents, int32_t n_trainable, const double* pool_cdf, const int32_t* pool_net,
+                                 int32_t pool_size, int32_t* slot_net, int32_t* slot_pool, void* stream) {
+    if (!episode_crc || !pool_cdf || !pool_net || !slot_net || n_markets < 1 || num_agents < 1 || num_agents > CDA_MAX_AGENTS || n_trainable < 0 || n_trainable > num_agents ||
+        pool_size < 1) return CDA_ERR_INVALID;
+    const int n = n_markets * num_agents;
+    hipLaunchKernelGGL(k_league_assign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned int*)episode_crc, (int)n_markets, (int)num_agents,
+                       (int)n_trainable, pool_cdf, (const int*)pool_net, (int)pool_size, (int*)slot_net, (int*)slot_pool);
+    return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
+}
+
 #ifndef CDA_MLP_TIMING          /* (the tools build holds the network kernels only, not the env) */
-extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
-                                     uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* B, int32_t copy_first_obs, void* stream) {
-    if (!env || !wb || !theta || !counter_dev || !B || n_steps < 1 || first_market < 0 || n_markets < 1) return CDA_ERR_INVALID;
+// One chain's rollout: the loop of {policy step, env step} launches; L != NULL: the league's policy step (banks of nets, per-slot modules)
+static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
+                         uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* B, int32_t copy_first_obs, void* stream) {
+    if (!env || !counter_dev || !B || n_steps < 1 || first_market < 0 || n_markets < 1) return CDA_ERR_INVALID;
+    if (L ? (!L->wb_bank || !L->theta_bank || !L->slot_net || L->n_trainable < 1 || L->n_nets < L->n_trainable || L->n_nets > CDA_LEAGUE_MAX_NETS) : (!wb || !theta)) return CDA_ERR_INVALID;
     if (!B->obs || !B->category || !B->size_mean || !B->size_sigma || !B->price || !B->price_offset || !B->a_cont || !B->logp || !B->value || !B->reward ||
         !B->terminated || !B->truncated) return CDA_ERR_INVALID;
+    if (B->fin_index && (!B->fin_obs || !B->fin_count || B->fin_cap < 1)) return CDA_ERR_INVALID;
     const int64_t N = cda_num_markets(env);
     if (cda_obs_dim(env) != OBS || (int64_t)first_market + n_markets > N) return CDA_ERR_INVALID;
     const int32_t A = cda_num_agents(env);
     hipStream_t st = (hipStream_t)stream;
     const size_t NA = (size_t)N * A;
+    const int n_train = L ? L->n_trainable : 0;
     if (copy_first_obs) {
         const long long n4 = (long long)n_markets * OBS / 4;
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, B->obs + ((size_t)n_steps * N + first_market) * OBS,
@@ -1938,26 +2191,56 @@ extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* 
     for (int32_t t = 0; t < n_steps; t++) {
         const size_t o = (size_t)t * NA;
         FwdArgs P; memset(&P, 0, sizeof P);
-        P.obs = B->obs + (size_t)t * N * OBS; P.first_row = first_market; P.n_rows = n_markets; P.wb = (const __bf16*)wb; P.theta = theta;
+        P.obs = B->obs + (size_t)t * N * OBS; P.first_row = first_market; P.n_rows = n_markets;
+        P.wb = (const __bf16*)(L ? L->wb_bank : wb); P.theta = L ? L->theta_bank : theta;
         P.agents = A; P.seed = seed; P.counter = (const long long*)counter_dev; P.draw = t;
         P.env_cat = B->category + o; P.env_mean = B->size_mean + o; P.env_sigma = B->size_sigma + o; P.env_price = B->price + o; P.env_off = B->price_offset + o;
         P.a_cont = B->a_cont + 2 * o; P.logp = B->logp + o; P.value = B->value + (size_t)t * N;
         P.rec = B->record ? B->record + 8 * o : NULL;
+        P.dist = B->dist ? B->dist + (size_t)t * N * N_LOGITS : NULL;
         P.split_halves = 1;
-        int rc = launch_fwd<MODE_SAMPLE>(P, rollout_mt(), st);
+        int rc;
+        if (L) {
+            P.n_train = n_train; P.slot_net = L->slot_net; P.random_seed = L->random_seed;
+            P.value_stride = (long long)(n_steps + 1) * N; P.dist_stride = (long long)n_steps * N * N_LOGITS;
+            rc = launch_fwd<MODE_LEAGUE>(P, rollout_mt(), st, (unsigned)(L->n_trainable + L->n_nets));
+        } else rc = launch_fwd<MODE_SAMPLE>(P, rollout_mt(), st);
         if (rc) return rc;
-        rc = cda_step_range(env, first_market, n_markets, B->category + o, B->size_mean + o, B->size_sigma + o, B->price + o, B->price_offset + o, NULL,
-                            B->obs + (size_t)(t + 1) * N * OBS, B->reward + o, B->terminated + (size_t)t * N, B->truncated + (size_t)t * N, NULL, stream);
+        rc = cda_step_range_capture(env, first_market, n_markets, B->category + o, B->size_mean + o, B->size_sigma + o, B->price + o, B->price_offset + o, NULL,
+                                    B->obs + (size_t)(t + 1) * N * OBS, B->reward + o, B->terminated + (size_t)t * N, B->truncated + (size_t)t * N,
+                                    B->info_steps ? &B->info_steps[t] : NULL,
+                                    B->fin_obs, B->fin_cap, B->fin_count, B->fin_index ? B->fin_index + (size_t)t * N : NULL, stream);
         if (rc) return rc;
     }
-    // the bootstrap value of the last observation
+    // the bootstrap value of the last observation (league: of every trainable net)
     FwdArgs V; memset(&V, 0, sizeof V);
-    V.obs = B->obs + (size_t)n_steps * N * OBS; V.first_row = first_market; V.n_rows = n_markets; V.wb = (const __bf16*)wb; V.theta = theta;
+    V.obs = B->obs + (size_t)n_steps * N * OBS; V.first_row = first_market; V.n_rows = n_markets;
+    V.wb = (const __bf16*)(L ? L->wb_bank : wb); V.theta = L ? L->theta_bank : theta;
     V.value = B->value + (size_t)n_steps * N;
+    V.n_train = n_train; V.value_stride = (long long)(n_steps + 1) * N;
     V.split_halves = 2;                                  // the value network alone
-    return launch_fwd<MODE_VALUE>(V, rollout_mt(), st);
+    return launch_fwd<MODE_VALUE>(V, rollout_mt(), st, L ? (unsigned)n_train : 0u);
+}
+extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
+                                     uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* B, int32_t copy_first_obs, void* stream) {
+    return rollout_chain(env, NULL, wb, theta, first_market, n_markets, n_steps, seed, counter_dev, B, copy_first_obs, stream);
+}
+extern "C" int cda_mlp_league_rollout_chain(cda_env* env, const cda_league* L, int32_t first_market, int32_t n_markets, int32_t n_steps,
+                                            uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* B, int32_t copy_first_obs, void* stream) {
+    if (!L) return CDA_ERR_INVALID;
+    return rollout_chain(env, L, NULL, NULL, first_market, n_markets, n_steps, seed, counter_dev, B, copy_first_obs, stream);
 }
 #endif
+
+// The values of captured last observations (cda_step_range_capture's list): value f32 [n_nets_trainable][cap] <- the value network(s) on fin_obs [cap][168].  Every
+// row of the list is evaluated (the count lives on the device; rows never written hold finite garbage nobody reads).
+extern "C" int cda_mlp_values(const void* wb_bank, const float* theta_bank, int32_t n_nets, const float* obs, int64_t n_rows, float* value, int64_t value_stride, void* stream) {
+    if (!wb_bank || !theta_bank || n_nets < 1 || n_nets > CDA_LEAGUE_MAX_NETS || !obs || !value || n_rows < 1) return CDA_ERR_INVALID;
+    FwdArgs V; memset(&V, 0, sizeof V);
+    V.obs = obs; V.first_row = 0; V.n_rows = n_rows; V.wb = (const __bf16*)wb_bank; V.theta = theta_bank; V.value = value;
+    V.n_train = n_nets; V.value_stride = value_stride; V.split_halves = 2;
+    return launch_fwd<MODE_VALUE>(V, n_rows >= 32768 ? 4 : rollout_mt(), (hipStream_t)stream, (unsigned)n_nets);
+}
 
 extern "C" int cda_mlp_selftest_mfma(int32_t device, const float* a_host, const float* b_host, float* d_host) {
     if (!a_host || !b_host || !d_host) return CDA_ERR_INVALID;

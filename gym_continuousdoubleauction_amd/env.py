@@ -29,9 +29,16 @@ from .vec_env import CDAVecEnv, DEC_DTYPE, ACTION_KEYS
 try:  # (ray is absent from the build image; tests/test_host_logic.py runs this branch under the stand-ins of tests/golden/shim)
     from ray.rllib.env.multi_agent_env import MultiAgentEnv as _Base
 except Exception:  # noqa: BLE001
-    class _Base:  # minimal stand-in so the class still constructs without RLlib
-        def __init__(self):
-            pass
+    try:  # gymnasium without ray: gymnasium.make() insists on a gymnasium.Env subclass (what RLlib's MultiAgentEnv is, too)
+        import gymnasium as _gym
+
+        class _Base(_gym.Env):
+            def __init__(self):
+                pass
+    except Exception:  # noqa: BLE001
+        class _Base:  # minimal stand-in so the class still constructs without either
+            def __init__(self):
+                pass
 
 _TERM_NAMES = ("nav_term", "order_penalty", "trade_penalty", "drawdown_penalty", "passive_bonus")
 _DEC_FIELDS = ("cash", "cash_on_hold", "position_val", "vwap", "nav", "prev_nav", "max_nav")

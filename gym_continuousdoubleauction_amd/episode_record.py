@@ -111,6 +111,66 @@ class BatchedEpisodeRecorder:
             step[name] = self._take(info[name])
         self._steps.append(step)
 
+    def record_rollout(self, roll, iteration=None):
+        """Feed the recorder from a fused rollout's buffers after the horizon (mlp.RolloutChains(info_markets=S): the last S markets of the env ran as a chain of
+        their own with the info tensors of every step) - one device->host copy per tensor per ROLLOUT, no per-step host call.  `markets` must be those S markets.
+        Episodes may span rollouts: rows accumulate until a step carries an episode end, which closes the episode (complete=True) and opens the next one
+        (ids from `episode_namer(market, ordinal)`, module ids from `module_namer(market)` when set).  The last step of an episode is recorded with the episode's own
+        last observation (the rollout's episode-end capture, when on) - obs[t + 1] already holds the next episode's first.  At every episode end the reference's
+        conservation check runs on the recorded NAVs (league_based_self_play_callback.py:679-704: sum of NAV == agents x init_cash, in Decimal):
+        `nav_checked` / `nav_violations` count episodes."""
+        import decimal
+        T, N, S, A = roll.T, roll.N, roll.info_markets, self.num_agents
+        if roll.info is None or S != len(self.markets) or not np.array_equal(self.markets, np.arange(N - S, N)):
+            raise ValueError("the recorder's markets must be the rollout's sampled chain (the last info_markets markets of the env)")
+        if iteration is not None:
+            self.iteration = iteration
+        b = roll.buf
+        host = lambda x: x[:, N - S:].detach().cpu().numpy()             # noqa: E731  [T, S, ...]
+        obs_next = b["obs"][1:, N - S:].detach().cpu().numpy()             # [T, S, 168]: the observation after step t
+        rew, term, trunc = host(b["reward"]), host(b["terminated"]), host(b["truncated"])
+        acts = [host(b[k]) for k in ("category", "size_mean", "size_sigma", "price", "price_offset")]
+        info = {k: v.detach().cpu().numpy() for k, v in roll.info.items()}   # already [T, S, ...]
+        fin_idx = fin_obs = None
+        if roll.capture_ends:
+            fin_idx, fin_obs = host(b["fin_index"]), b["fin_obs"].detach().cpu().numpy()
+        if not hasattr(self, "_ordinal"):
+            self._ordinal, self._t_in_episode = 0, 0
+            self.nav_checked = self.nav_violations = 0
+            self._name_episodes()
+        wall = time.time()
+        for t in range(T):
+            o = obs_next[t].copy()
+            done = (term[t] | trunc[t]).astype(bool)
+            if fin_idx is not None:
+                for j in np.nonzero(fin_idx[t] >= 0)[0]:
+                    o[j] = fin_obs[fin_idx[t][j]]
+            step = {"t": self._t_in_episode, "wall": wall, "obs": o.astype(np.float32, copy=False), "reward": rew[t].astype(np.float64, copy=False),
+                    "actions": [a[t] for a in acts]}
+            for name in {src for _, _, src in INFO_COLUMNS if src} | {"nav", "reward_terms"}:
+                step[name] = info[name][t]
+            self._steps.append(step)
+            self._t_in_episode += 1
+            if done.any():
+                if getattr(self, "init_cash", None) is not None:
+                    nav = np.ascontiguousarray(info["nav"][t]).view(K.DEC_DTYPE).reshape(S, A)
+                    for j in range(S):
+                        with decimal.localcontext() as ctx:
+                            ctx.prec = 28
+                            total = sum((K.dec_to_decimal(nav[j, a]) for a in range(A)), decimal.Decimal(0))
+                        self.nav_checked += 1
+                        if abs(total - decimal.Decimal(A) * decimal.Decimal(int(self.init_cash))) > decimal.Decimal(str(getattr(self, "nav_tolerance", 1e-6))):
+                            self.nav_violations += 1
+                self.finish(complete=bool(done.all()))
+                self._ordinal += 1
+                self._t_in_episode = 0
+                self._name_episodes()
+
+    def _name_episodes(self):
+        namer = getattr(self, "episode_namer", None) or (lambda m, k: f"market{m}-episode{k}")
+        mods = getattr(self, "module_namer", None)
+        self.begin_episodes([namer(int(m), self._ordinal) for m in self.markets], module_ids=None if mods is None else [mods(int(m)) for m in self.markets])
+
     def finish(self, complete=True):
         """The recorded markets' episodes ended (complete=False: sampling stopped before they did)."""
         if self._steps:

@@ -110,6 +110,40 @@ class LeagueSlotMapper:
         out[:, k:] = k + np.searchsorted(cdf, u, side="right").reshape(n, A - k)
         return out
 
+    def episode_crcs(self, episode_ids):
+        """zlib.crc32(str(id)) per episode: the host half of the seed rule (the generator half runs on the device, assign_device)"""
+        return np.array([zlib.crc32(str(e).encode("utf-8")) for e in episode_ids], dtype=np.uint32)
+
+    def assign_device(self, bank, episode_ids=None, crcs=None, net_of=None, slot_pool=None):
+        """assign() on the device (include/cda_mlp.h cda_league_assign), straight into `bank.slot_net` (mlp.PolicyBank): no host sync, one launch.
+        net_of: {module id: bank row} for the pool's network modules (champions); modules not named there play the uniform random law
+        (the reference's fixed opponents are RandomRLModules, train/model/model_handler.py:38-53).  slot_pool (optional i32 [N, A] device tensor)
+        receives the draw itself: available_modules[num_trainable + slot_pool] is the module's id (-1: the slot's own trainable policy)."""
+        import ctypes as C
+        import torch
+        from ._lib import check, lib
+        from .mlp import LEAGUE_RANDOM
+        if crcs is None:
+            crcs = self.episode_crcs(episode_ids)
+        N, A = bank.slot_net.shape
+        if len(crcs) != N or A != self.num_agents:
+            raise ValueError("one episode per market of the bank")
+        dev = bank.device
+        cand = self.pool()
+        if not cand:                                          # the reference's fallback for an empty pool: slot a plays policy_a (a random module here)
+            bank.slot_net[:, self.num_trainable:] = LEAGUE_RANDOM
+            return bank.slot_net
+        cdf = np.cumsum(self.pool_probabilities())
+        cdf /= cdf[-1]
+        nets = np.array([(net_of or {}).get(c, LEAGUE_RANDOM) for c in cand], dtype=np.int32)
+        keep = (torch.from_numpy(np.asarray(crcs, dtype=np.uint32).view(np.int32).copy()).to(dev, non_blocking=True), torch.from_numpy(cdf).to(dev, non_blocking=True),
+                torch.from_numpy(nets).to(dev, non_blocking=True))
+        with torch.cuda.device(dev):
+            check(lib().cda_league_assign(keep[0].data_ptr(), N, A, self.num_trainable, keep[1].data_ptr(), keep[2].data_ptr(), len(cand), bank.slot_net.data_ptr(),
+                                          slot_pool.data_ptr() if slot_pool is not None else None, torch.cuda.current_stream(dev).cuda_stream), "cda_league_assign")
+        self._keep = keep                                      # (the launch reads them asynchronously)
+        return bank.slot_net
+
     def names(self, assignment):
         mods = np.array(self.available_modules, dtype=object)
         return mods[assignment]

@@ -105,17 +105,186 @@ def train_league(env, iters=4, num_trainable=1, lr=5e-5, epochs=4, reward_scale=
     return model, mapper, history
 
 
+class League:
+    """The league's host state next to the device banks: who is in the pool, which bank row holds which champion, when the last one was promoted - the reference's
+    trigger (train/callbk/league_based_self_play_callback.py:780-880): a trainable policy becomes a champion when its mean episode return of the iteration exceeds
+    mean + std_dev_multiplier x std of all modules' returns, at most every `min_iterations_between_champions` iterations, the oldest champion leaving once
+    `max_champions` are held (config/train_config.json:60-64)."""
+
+    def __init__(self, mapper, bank, std_dev_multiplier=0.1, max_champions=8, min_iterations_between_champions=2):
+        self.mapper, self.bank = mapper, bank
+        self.std_dev_multiplier, self.max_champions, self.min_gap = float(std_dev_multiplier), int(max_champions), int(min_iterations_between_champions)
+        self.net_of = {}                                       # champion id -> bank row
+        self.history = []                                      # [{"id", "iteration", "return", "source"}]
+
+    def module_returns(self, per_slot, slot_pool):
+        """{module id: mean return of the episodes it completed this iteration}: per_slot f64 [N, A, 2] (mlp.EpisodeReturns), slot_pool i32 [N, A] (the draw per slot,
+        -1 = the slot's own trainable policy).  A handful of tiny device reductions + one small copy to the host."""
+        k, names = self.mapper.num_trainable, self.mapper.available_modules
+        N, A = slot_pool.shape
+        idx = torch.where(slot_pool < 0, torch.arange(A, device=slot_pool.device, dtype=torch.int32).expand(N, A), slot_pool + k).long().reshape(-1)
+        sums = torch.zeros((len(names), 2), dtype=torch.float64, device=per_slot.device).index_add_(0, idx, per_slot.reshape(-1, 2))
+        host = sums.cpu().numpy()
+        return {names[i]: host[i, 0] / host[i, 1] for i in range(len(names)) if host[i, 1] > 0}
+
+    def maybe_promote(self, returns, iteration):
+        """the reference's end-of-iteration decision; returns the new champion's id or None"""
+        import numpy as np
+        k = self.mapper.num_trainable
+        valid = [v for v in returns.values() if np.isfinite(v)]
+        if not valid:
+            return None
+        threshold = float(np.mean(valid)) + self.std_dev_multiplier * float(np.std(valid))
+        best, best_ret = None, -float("inf")
+        for p in range(k):
+            r = returns.get(self.mapper.available_modules[p])
+            if r is not None and r > best_ret:
+                best, best_ret = p, r
+        if best is None or not best_ret > threshold:
+            return None
+        if self.history and iteration - self.history[-1]["iteration"] < self.min_gap:
+            return None
+        slot = None
+        if len(self.net_of) >= self.max_champions:            # rolling window: the oldest champion leaves and its bank row is reused
+            oldest = next(c["id"] for c in self.history if c["id"] in self.net_of)
+            slot = self.net_of.pop(oldest) - k
+            self.mapper.remove(oldest)
+        cid = self.mapper.add_champion()
+        self.net_of[cid] = self.bank.snapshot(best, frozen_slot=slot)
+        self.history.append({"id": cid, "iteration": iteration, "return": best_ret, "source": self.mapper.available_modules[best]})
+        return cid
+
+
+def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epochs=4, seed=0, original_opponent_weight=1.0, champion_weight=3.0,
+                       std_dev_multiplier=0.1, max_champions=8, min_iterations_between_champions=2, chains=4, minibatch=262144, objective=None, use_graph=True,
+                       recorder=None, info_markets=0, run_id="league", log=print, keep=None):
+    """League self-play on the fused kernels (include/cda_mlp.h `cda_league`): the reference's training topology - `num_trainable` SEPARATELY trained policies
+    (policy_p plays slot p), every other slot drawn per episode from the pool of uniform random modules and frozen champions by the reference's mapping rule
+    (computed on the device, league.LeagueSlotMapper.assign_device) - at the speed of the fused loop: ONE policy launch per step serves every module of every
+    market, the rollout never leaves its HIP graphs, each trainable policy's update reads its own slot's sample records in place (record stride, no compaction).
+    env: CDAVecEnv with auto_reset; an episode = env.max_step steps = max_step / horizon iterations (horizon must divide it): all markets change opponents
+    together at the episode boundary.  Returns (bank, league, history)."""
+    import numpy as np
+    from . import ppo
+    from .mlp import EpisodeReturns, FusedUpdate, PolicyBank, RolloutChains
+    obj = dict(ppo.PPO_DEFAULTS)
+    obj.update(objective or {})
+    dev = env.obs.device
+    N, A, k = env.n_markets, env.num_agents, int(num_trainable)
+    T = int(horizon or env.max_step)
+    if int(env.max_step) % T:
+        raise ValueError("the horizon must divide the episode length (max_step)")
+    per_episode = int(env.max_step) // T
+    bank = PolicyBank(dev, N, A, k, max_frozen=max_champions, seed=seed, random_seed=seed + 12345)
+    mapper = LeagueSlotMapper(A, k, A - k, original_opponent_weight, champion_weight)
+    league = League(mapper, bank, std_dev_multiplier, max_champions, min_iterations_between_champions)
+    env.reset(seed=seed)
+    use_kl = obj["kl_coef"] > 0.0
+    roll = RolloutChains(env, bank, T, groups=chains, seed=seed, use_graphs=use_graph, with_dist=use_kl, capture_ends=bool(obj["bootstrap_truncation"]),
+                         info_markets=info_markets if recorder is not None else 0)
+    R = T * N
+    rows_mb = max(32, min(R, (max(1, minibatch) // 32) * 32))              # one sample per row: a minibatch of `minibatch` samples is that many rows
+    upds = [FusedUpdate(bank.policies[p], R, rows_mb, 1) for p in range(k)]
+    returns = EpisodeReturns(N, A, dev, per_slot=True)
+    slot_pool = torch.full((N, A), -1, dtype=torch.int32, device=dev)
+    kl_coefs = [float(obj["kl_coef"])] * k
+    episode_ids = lambda e: [f"{run_id}-episode{e}-market{i}" for i in range(N)]     # noqa: E731
+    next_crcs = mapper.episode_crcs(episode_ids(0))
+    if recorder is not None:
+        names = lambda: np.array(mapper.available_modules, dtype=object)             # noqa: E731
+        recorder.episode_namer = lambda m, e: f"{run_id}-episode{e}-market{m}"
+        recorder.init_cash = int(env.config.get("init_cash", 1000000))
+    history = []
+    for it in range(iters):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        if it % per_episode == 0:                                            # a new episode everywhere: new opponents (one launch; the crcs were computed while the GPU worked)
+            mapper.assign_device(bank, crcs=next_crcs, net_of=league.net_of, slot_pool=slot_pool)
+            if recorder is not None:
+                sp = slot_pool[N - roll.info_markets:].cpu().numpy() if roll.info_markets else None
+                mods = names()
+                recorder.module_namer = lambda m: [mods[a] if sp[m - (N - roll.info_markets), a] < 0 else mods[k + sp[m - (N - roll.info_markets), a]] for a in range(A)]
+                if hasattr(recorder, "_ordinal"):
+                    recorder._name_episodes()
+        buf = roll.run()
+        rec, stats, count = roll.gae(gamma=obj["gamma"], lam=obj["lam"], reward_scale=obj["reward_scale"])
+        torch.cuda.synchronize(dev)
+        t_roll = time.perf_counter()
+        obs_rows = buf["obs"][:T].view(R, -1)
+        outs = []
+        for p in range(k):                                                   # policy p learns from slot p's records only: rec + 8 p floats, a row every 8 A
+            upds[p].set_extra(rec_stride=8 * A, kl_coef=kl_coefs[p], vf_clip=obj["vf_clip"], dist_old=buf["dist"][p] if use_kl else None,
+                              log_std_old=roll.log_std_old[p] if use_kl else None)
+            outs.append(upds[p].run(obs_rows, epochs=epochs, clip=obj["clip"], vf_coef=obj["vf_coef"], ent_coef=obj["ent_coef"], lr=lr, max_norm=obj["max_norm"],
+                                    records=(rec.data_ptr() + 32 * p, stats[p], count)))
+        returns.update(buf, T)
+        if (it + 1) % per_episode == 0:                                      # host work under the GPU's: the next episode's ids
+            next_crcs = mapper.episode_crcs(episode_ids((it + 1) // per_episode))
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        stats_h = {"iter": it, "agent_steps": N * A * T, "agent_steps_per_s": N * A * T / (t1 - t0), "rollout_s": t_roll - t0, "update_s": t1 - t_roll}
+        for p, o in enumerate(outs):
+            stats_h[f"policy_{p}"] = {key: float(v) for key, v in o.items()}
+            kl_coefs[p] = ppo.adapt_kl_coef(kl_coefs[p], stats_h[f"policy_{p}"]["kl"], obj["kl_target"])
+        promoted = None
+        if (it + 1) % per_episode == 0:                                      # episodes just ended: credit the modules, run the reference's promotion rule
+            mr = league.module_returns(returns.per_slot, slot_pool)
+            promoted = league.maybe_promote(mr, it)
+            stats_h["module_returns"] = {m: float(v) for m, v in mr.items()}
+        stats_h.update(promoted=promoted, pool=list(mapper.pool()), mean_reward_trainable=float(buf["reward"][:, :, :k].mean()))
+        if recorder is not None and roll.info is not None:
+            recorder.record_rollout(roll, iteration=it)
+        history.append(stats_h)
+        log(json.dumps(stats_h))
+    if keep is not None:
+        keep.update(buffers=roll.buf, rollout=roll, updates=upds, slot_pool=slot_pool, returns=returns)
+    return bank, league, history
+
+
 def main(argv=None):
     p = argparse.ArgumentParser(description="League self-play (PPO vs random opponents and champion snapshots) on one MI355X.")
     p.add_argument("--markets", type=int, default=1024)
     p.add_argument("--agents", type=int, default=4)
     p.add_argument("--episode", type=int, default=64, help="episode length = max_step")
     p.add_argument("--iters", type=int, default=6)
+    p.add_argument("--fused", action="store_true", help="the league on the hand-written network kernels (train_league_fused): the reference's topology at the fused loop's speed")
+    p.add_argument("--trainable", type=int, default=None, help="separately trained policies (default: 2 with --fused, the reference's num_trained_agents; 1 otherwise)")
+    p.add_argument("--horizon", type=int, default=None, help="--fused: rollout length (divides --episode; default = --episode)")
+    p.add_argument("--chains", type=int, default=4)
+    p.add_argument("--objective", choices=("ppo", "rllib"), default="ppo")
+    p.add_argument("--out", default=None, help="write a JSON summary to this file")
     args = p.parse_args(argv)
     from .vec_env import CDAVecEnv
-    env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.episode, "is_render": False},
-                    n_markets=args.markets, device="cuda:0", with_info=False)
-    train_league(env, iters=args.iters)
+    from . import ppo
+    cfg = {"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.episode, "is_render": False}
+    if not args.fused:
+        env = CDAVecEnv(cfg, n_markets=args.markets, device="cuda:0", with_info=False)
+        train_league(env, iters=args.iters, num_trainable=args.trainable or 1)
+        env.close()
+        return
+    env = CDAVecEnv(dict(cfg, auto_reset=True), n_markets=args.markets, device="cuda:0", with_info=False)
+    k = args.trainable or 2
+    _, league, hist = train_league_fused(env, iters=args.iters, horizon=args.horizon, num_trainable=k, chains=args.chains,
+                                         objective=ppo.RLLIB_DEFAULTS if args.objective == "rllib" else None)
+    flags = env.flags()
+    _, bad = env.nav_conservation()
+    tail = hist[1:] or hist
+    summary = {"metric": "agent-steps/sec end to end (league rollout + one PPO update per trainable policy)",
+               "config": {"workload": f"{args.markets} markets x {args.agents} agents, {k} separately trained policies (policy_p plays slot p) against modules drawn per episode "
+                                      f"and slot from {args.agents - k} uniform random modules + up to 8 champion snapshots (the reference's mapping rule, on the device); episode "
+                                      f"{args.episode} steps, horizon {args.horizon or args.episode}, {args.iters} iterations; hand-written bf16 MFMA network kernels, one policy launch per step "
+                                      "for every module, 4 epochs per policy per iteration",
+                          "markets": args.markets, "agents": args.agents, "trainable": k, "episode": args.episode, "horizon": args.horizon or args.episode, "chains": args.chains,
+                          "objective": args.objective},
+               "iterations": hist,
+               "value": sum(h["agent_steps"] for h in tail) / sum(h["rollout_s"] + h["update_s"] for h in tail), "unit": "agent-steps/s",
+               "rollout_agent_steps_per_s": sum(h["agent_steps"] for h in tail) / sum(h["rollout_s"] for h in tail),
+               "champions": league.history, "flagged_markets": int((flags != 0).sum().item()), "nav_conservation_violations": int(bad.sum().item()),
+               "invariant_violations": int((env.check_invariants() != 0).sum().item())}
+    print(json.dumps(summary))
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump(summary, fh, indent=1)
     env.close()
 
 

@@ -148,9 +148,10 @@ def unpack_rows(packed, n_rows, n_feat, paired=False):
 
 
 class FusedPolicy:
-    """theta (f32 master copy), Adam state and the bf16 operand blob on one HIP device."""
+    """theta (f32 master copy), Adam state and the bf16 operand blob on one HIP device.  storage = (theta row, wb row): views into a PolicyBank's
+    banks instead of tensors of its own (the league's kernels address a net as a row of the banks)."""
 
-    def __init__(self, device, theta=None, seed=0):
+    def __init__(self, device, theta=None, seed=0, storage=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FusedPolicy needs a HIP device; the PyTorch statement of the network is ppo.ActorCritic")
@@ -158,11 +159,16 @@ class FusedPolicy:
             g = torch.Generator().manual_seed(int(seed))
             theta = init_theta(generator=g)
         assert theta.numel() == PARAMS
-        self.theta = theta.detach().float().to(self.device).contiguous()
+        if storage is None:
+            self.theta = theta.detach().float().to(self.device).contiguous()
+            self.wb = torch.zeros(WB_ELEMS, dtype=torch.bfloat16, device=self.device)
+        else:
+            self.theta, self.wb = storage
+            assert self.theta.shape == (PARAMS,) and self.theta.is_contiguous() and self.wb.shape == (WB_ELEMS,) and self.wb.is_contiguous()
+            self.theta.copy_(theta.detach().float())
         self.adam_m = torch.zeros_like(self.theta)
         self.adam_v = torch.zeros_like(self.theta)
         self.adam_step = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self.wb = torch.zeros(WB_ELEMS, dtype=torch.bfloat16, device=self.device)
         self.pack()
 
     @classmethod
@@ -209,39 +215,148 @@ class FusedPolicy:
         return outs
 
 
+LEAGUE_RANDOM, LEAGUE_MAX_NETS = -1, 16
+
+
+class PolicyBank:
+    """The league's networks as rows of two banks (include/cda_mlp.h `cda_league`): theta f32 [n_max, PARAMS], wb bf16 [n_max, WB_ELEMS]; rows
+    0 .. n_trainable - 1 are the trainable policies (FusedPolicy objects whose parameters ARE those rows: an optimiser step is seen by the next
+    rollout with no copy), the rows behind them frozen snapshots (champions: league_based_self_play_callback.py:938-1170).  slot_net i32 [N, A] names
+    the row that plays each (market, slot), LEAGUE_RANDOM = the uniform random module."""
+
+    def __init__(self, device, n_markets, num_agents, n_trainable, max_frozen=8, seed=0, random_seed=0):
+        from ._lib import League
+        self.device = torch.device(device)
+        self.n_trainable, self.max_frozen, self.n_frozen = int(n_trainable), int(max_frozen), 0
+        if not 1 <= self.n_trainable <= num_agents or self.n_trainable + self.max_frozen > LEAGUE_MAX_NETS:
+            raise ValueError(f"need 1 <= n_trainable <= num_agents and n_trainable + max_frozen <= {LEAGUE_MAX_NETS}")
+        n_max = self.n_trainable + self.max_frozen
+        self.theta = torch.zeros((n_max, PARAMS), dtype=torch.float32, device=self.device)
+        self.wb = torch.zeros((n_max, WB_ELEMS), dtype=torch.bfloat16, device=self.device)
+        self.policies = [FusedPolicy(self.device, seed=seed + 7919 * p, storage=(self.theta[p], self.wb[p])) for p in range(self.n_trainable)]
+        self.slot_net = torch.full((int(n_markets), int(num_agents)), LEAGUE_RANDOM, dtype=torch.int32, device=self.device)
+        self.slot_net[:, :self.n_trainable] = torch.arange(self.n_trainable, dtype=torch.int32, device=self.device)
+        self.random_seed = int(random_seed) & (2 ** 64 - 1)
+        self._struct = League()
+        self._refresh()
+
+    def _refresh(self):
+        s = self._struct
+        s.wb_bank, s.theta_bank, s.slot_net = self.wb.data_ptr(), self.theta.data_ptr(), self.slot_net.data_ptr()
+        s.n_nets, s.n_trainable, s.random_seed = self.n_trainable + self.n_frozen, self.n_trainable, self.random_seed
+
+    @property
+    def n_nets(self):
+        return self.n_trainable + self.n_frozen
+
+    def struct(self):
+        return self._struct
+
+    def snapshot(self, source, frozen_slot=None):
+        """freeze a copy of bank row `source` (a trainable net) as frozen net `frozen_slot` (default: the next free one); returns its bank row.
+        Device-side copies on the current stream: no host sync.  NOTE: a captured rollout graph bakes n_nets into its launches - RolloutChains
+        re-captures when the count changed."""
+        if frozen_slot is None:
+            if self.n_frozen >= self.max_frozen:
+                raise ValueError("the bank is full: overwrite a slot (frozen_slot=...)")
+            frozen_slot = self.n_frozen
+            self.n_frozen += 1
+        row = self.n_trainable + int(frozen_slot)
+        self.theta[row].copy_(self.theta[int(source)])
+        self.wb[row].copy_(self.wb[int(source)])
+        self._refresh()
+        return row
+
+    def set_slots(self, slot_net):
+        """slot_net: [N, A] integers (bank rows, LEAGUE_RANDOM for the random module); copied into the resident tensor (same address: graphs stay valid)"""
+        t = torch.as_tensor(slot_net).to(dtype=torch.int32)
+        if t.shape != self.slot_net.shape:
+            raise ValueError(f"need shape {tuple(self.slot_net.shape)}")
+        if int(t.max()) >= self.n_nets or int(t.min()) < LEAGUE_RANDOM:
+            raise ValueError("slot_net names a bank row that does not exist")
+        self.slot_net.copy_(t.to(self.device), non_blocking=True)
+
+
 class RolloutChains:
     """Whole rollouts of a CDAVecEnv (auto_reset on) under a FusedPolicy as G independent chains: chain g = the markets of group g, on
     its own stream: for every step {policy forward + sampling -> env step -> auto reset}, then the bootstrap value of the last
     observation.  Weights are frozen during a rollout and markets never interact, so no chain ever waits for another; the caller's
     stream forks into the chains before the first step and joins them after the last.  Buffers are [T(+1), N, ...] and every step's
     kernels read / write their own slot directly - nothing is copied between steps.  Each chain's launch sequence is captured into a HIP
-    graph once and replayed (use_graphs), or enqueued by one native call per chain (cda_mlp_rollout_chain)."""
+    graph once and replayed (use_graphs), or enqueued by one native call per chain (cda_mlp_rollout_chain).
 
-    def __init__(self, env, policy, horizon, groups=4, seed=0, use_graphs=True):
+    policy: a FusedPolicy (one shared policy plays every slot) or a PolicyBank (league self-play: per-slot modules, value / dist per trainable net).
+    with_dist: also record the rollout policy's distribution per market-step (the update's KL term).
+    capture_ends: episode-end capture (include/cda.h cda_step_range_capture): the last observation of every episode that ends inside the rollout is kept
+        (fin_obs / fin_index) - gae() then bootstraps time-limit truncations with V(that observation), as RLlib does.
+    info_markets = S > 0: the LAST S markets are a chain of their own that also writes the info tensors of every step into [T, S, ...] buffers
+        (`info`: what BatchedEpisodeRecorder.record_rollout reads; the reference records one episode in N, train/episode_record.py:197)."""
+
+    def __init__(self, env, policy, horizon, groups=4, seed=0, use_graphs=True, with_dist=False, capture_ends=False, info_markets=0):
         from ._lib import RolloutBufs
+        from . import _capi as K
         self.env, self.policy, self.T = env, policy, int(horizon)
+        self.bank = policy if isinstance(policy, PolicyBank) else None
         N, A, dev, T = env.n_markets, env.num_agents, env.device, int(horizon)
         if env.obs_dim != OBS:
             raise ValueError("the fused network is built for n_hist = 4 (168-float observations)")
         if not bool(env.config.get("auto_reset", False)):
             raise ValueError("RolloutChains needs an auto_reset env (episode ends are handled on the device)")
         self.N, self.A, self.device = N, A, dev
+        kn = self.bank.n_trainable if self.bank else 1
+        self.n_value_nets = kn
         e = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)             # noqa: E731
+        vshape = (kn, T + 1, N) if self.bank else (T + 1, N)
         self.buf = {"obs": e((T + 1, N, OBS), torch.float32), "category": e((T, N, A), torch.int32), "size_mean": e((T, N, A), torch.float32),
                     "size_sigma": e((T, N, A), torch.float32), "price": e((T, N, A), torch.int32), "price_offset": e((T, N, A), torch.int32),
-                    "a_cont": e((T, N, A, 2), torch.float32), "logp": e((T, N, A), torch.float32), "value": e((T + 1, N), torch.float32),
+                    "a_cont": e((T, N, A, 2), torch.float32), "logp": e((T, N, A), torch.float32), "value": e(vshape, torch.float32),
                     "reward": e((T, N, A), torch.float64), "terminated": e((T, N), torch.uint8), "truncated": e((T, N), torch.uint8),
                     "record": e((T, N, A, 8), torch.float32)}          # include/cda_mlp.h CDA_REC_*: what the update's loss reads, one line per row
-        self.adv_stats = torch.zeros(2, dtype=torch.float64, device=dev)
-        self._cbufs = RolloutBufs(**{k: v.data_ptr() for k, v in self.buf.items()})
+        ptrs = {k: v.data_ptr() for k, v in self.buf.items()}
+        if with_dist:
+            self.buf["dist"] = e((kn, T, N, N_LOGITS) if self.bank else (T, N, N_LOGITS), torch.float32)
+            self.log_std_old = e((kn, 2), torch.float32)               # the rollout policy's log_std (the update moves theta's)
+            ptrs["dist"] = self.buf["dist"].data_ptr()
+        self.with_dist = bool(with_dist)
+        self.capture_ends = bool(capture_ends)
+        if self.capture_ends:
+            cap = N * (T // max(1, int(env.max_step)) + 1)
+            self.fin_cap = cap
+            self.buf["fin_index"], self.buf["fin_obs"], self.buf["fin_count"] = torch.full((T, N), -1, dtype=torch.int32, device=dev), e((cap, OBS), torch.float32), e((1,), torch.int32)
+            self.fin_value = e((kn, cap), torch.float32)
+            ptrs.update(fin_index=self.buf["fin_index"].data_ptr(), fin_obs=self.buf["fin_obs"].data_ptr(), fin_count=self.buf["fin_count"].data_ptr(), fin_cap=cap)
+        self.adv_stats = torch.zeros((kn, 2), dtype=torch.float64, device=dev)
         self.seed = int(seed) & (2 ** 64 - 1)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
-        G = max(1, min(int(groups), N))
+        # the chains: G groups over the info-less markets (+ one chain of the sampled markets with info tensors)
+        S = max(0, min(int(info_markets), N - 1))
+        self.info_markets, n_plain = S, N - S
+        G = max(1, min(int(groups), n_plain))
+        if S and G >= 4:
+            G = 3                                                  # (the GPU runs four hardware queues by default: the sampled chain takes the fourth, streams.py)
         self.ranges = []
         for g in range(G):
             first, cnt = C.c_int32(), C.c_int32()
-            _lib().cda_group_range(N, G, g, C.byref(first), C.byref(cnt))
+            _lib().cda_group_range(n_plain, G, g, C.byref(first), C.byref(cnt))
             self.ranges.append((first.value, cnt.value))
+        self._cbufs = [RolloutBufs(**ptrs) for _ in range(G)]
+        self.info = None
+        if S:
+            self.ranges.append((n_plain, S))
+            self.info, self._info_steps = {}, (K.InfoPtrs * T)()
+            for name, ct, per_agent, dims in K.INFO_FIELDS:
+                shape = ((S, A) if per_agent else (S,)) + tuple(dims)
+                shape = shape + (16,) if ct is K.Dec else shape
+                dt = torch.uint8 if ct is K.Dec else {C.c_int32: torch.int32, C.c_double: torch.float64, C.c_uint8: torch.uint8}[ct]
+                t = e((T,) + shape, dt)
+                self.info[name] = t
+                per_market = t[0, 0].numel() * t.element_size()                  # the kernel indexes by GLOBAL market: shift the base so that market n_plain lands on row 0
+                for step in range(T):
+                    setattr(self._info_steps[step], name, t[step].data_ptr() - n_plain * per_market)
+            cb = RolloutBufs(**ptrs)
+            cb.info_steps = C.cast(self._info_steps, C.c_void_p)
+            self._cbufs.append(cb)
+        G = len(self.ranges)
         if G > 1:
             from .streams import concurrent_streams
             self.streams = list(concurrent_streams(dev, G))
@@ -250,16 +365,21 @@ class RolloutChains:
         self._fork = torch.cuda.Event()
         self._joins = [torch.cuda.Event() for _ in range(G)]
         self.graphs = None
+        self._graph_nets = None
         self._have_obs = False
         self.use_graphs = bool(use_graphs)
         self.join_mode = "events"
 
     def _enqueue(self, g, copy_first_obs):
         first, cnt = self.ranges[g]
+        st = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            _check(_lib().cda_mlp_rollout_chain(self.env._h, self.policy.wb.data_ptr(), self.policy.theta.data_ptr(), first, cnt, self.T, self.seed,
-                                                self.counter.data_ptr(), C.byref(self._cbufs), int(copy_first_obs), torch.cuda.current_stream(self.device).cuda_stream),
-                   "cda_mlp_rollout_chain")
+            if self.bank is not None:
+                _check(_lib().cda_mlp_league_rollout_chain(self.env._h, C.byref(self.bank.struct()), first, cnt, self.T, self.seed, self.counter.data_ptr(),
+                                                           C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_league_rollout_chain")
+            else:
+                _check(_lib().cda_mlp_rollout_chain(self.env._h, self.policy.wb.data_ptr(), self.policy.theta.data_ptr(), first, cnt, self.T, self.seed,
+                                                    self.counter.data_ptr(), C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_rollout_chain")
 
     def _capture(self):
         graphs = []
@@ -269,6 +389,7 @@ class RolloutChains:
                 self._enqueue(g, True)
             graphs.append(gr)
         self.graphs = graphs
+        self._graph_nets = self.bank.n_nets if self.bank else None
 
     def run(self):
         """one rollout of `horizon` steps; returns the buffer dict (views stay valid; the next run() overwrites them)"""
@@ -279,6 +400,13 @@ class RolloutChains:
             self.buf["obs"][self.T].copy_(self.env.obs)
             self._have_obs = True
         self.counter.add_(1)                                     # fresh draws for this rollout (on the caller's stream, before the fork)
+        if self.capture_ends:
+            self.buf["fin_count"].zero_(); self.buf["fin_index"].fill_(-1)
+        if self.with_dist:                                        # the log_std the rollout samples with (a row per trainable net)
+            src = self.bank.theta[:self.bank.n_trainable, OFF_LS:] if self.bank else self.policy.theta[OFF_LS:].view(1, 2)
+            self.log_std_old.copy_(src)
+        if self.graphs is not None and self.bank is not None and self._graph_nets != self.bank.n_nets:
+            self.graphs = None                                    # a snapshot joined the league: the launches' grids changed
         if self.use_graphs and self.graphs is None and len(self.streams) >= 1:
             torch.cuda.synchronize(dev)
             try:
@@ -307,12 +435,42 @@ class RolloutChains:
         return self.buf
 
     def gae(self, gamma=0.99, lam=0.95, reward_scale=1.0):
-        """advantages and returns of the last run() straight into the sample records (one launch; ppo.gae's recursion); returns
-        (records [T * N, A, 8], the sums the update normalises the advantages with, their count)"""
-        _check(_lib().cda_gae_records(self.buf["reward"].data_ptr(), self.buf["value"].data_ptr(), self.buf["terminated"].data_ptr(), self.buf["truncated"].data_ptr(),
-                                      self.T, self.N, self.A, float(reward_scale), float(gamma), float(lam), self.buf["record"].data_ptr(), self.adv_stats.data_ptr(),
-                                      _stream(self.device)), "cda_gae_records")
-        return self.buf["record"].view(self.T * self.N, self.A, 8), self.adv_stats, self.T * self.N * self.A
+        """advantages and returns of the last run() straight into the sample records (one launch; ppo.gae's recursion; with capture_ends a time-limit
+        truncation bootstraps with the value of the episode's captured last observation - one more value launch over the captured list).  Returns
+        (records [T * N, A, 8], the sums the update normalises the advantages with, their count); league: the sums are [n_trainable, 2] and the count is
+        per trainable net (T * N: one slot each)."""
+        L, st = _lib(), _stream(self.device)
+        k = self.bank.n_trainable if self.bank else 0
+        fin_index = fin_value = None
+        if self.capture_ends:
+            wb, th = (self.bank.wb, self.bank.theta) if self.bank else (self.policy.wb, self.policy.theta)
+            _check(L.cda_mlp_values(wb.data_ptr(), th.data_ptr(), max(k, 1), self.buf["fin_obs"].data_ptr(), self.fin_cap, self.fin_value.data_ptr(), self.fin_cap, st), "cda_mlp_values")
+            fin_index, fin_value = self.buf["fin_index"].data_ptr(), self.fin_value.data_ptr()
+        _check(L.cda_gae_records_bootstrap(self.buf["reward"].data_ptr(), self.buf["value"].data_ptr(), self.buf["terminated"].data_ptr(), self.buf["truncated"].data_ptr(),
+                                           self.T, self.N, self.A, k, float(reward_scale), float(gamma), float(lam), fin_index, fin_value, self.fin_cap if self.capture_ends else 0,
+                                           self.buf["record"].data_ptr(), self.adv_stats.data_ptr(), st), "cda_gae_records_bootstrap")
+        if self.bank:
+            return self.buf["record"].view(self.T * self.N, self.A, 8), self.adv_stats, self.T * self.N
+        return self.buf["record"].view(self.T * self.N, self.A, 8), self.adv_stats[0], self.T * self.N * self.A
+
+
+class EpisodeReturns:
+    """Returns of COMPLETED episodes, accumulated on the device from rollout to rollout (cda_episode_returns): what a learning curve is drawn from when the
+    horizon is shorter than an episode - the mean reward of a rollout slice depends on which part of the episodes the slice happens to cover."""
+
+    def __init__(self, n_markets, num_agents, device, per_slot=False):
+        self.N, self.A = int(n_markets), int(num_agents)
+        self.running = torch.zeros((self.N, self.A), dtype=torch.float64, device=device)
+        self.acc = torch.zeros((2, self.A), dtype=torch.float64, device=device)          # [0] sum of completed episodes' returns per slot, [1] their number
+        self.per_slot = torch.zeros((self.N, self.A, 2), dtype=torch.float64, device=device) if per_slot else None   # (sum, number) per (market, slot), this rollout
+        self.device = torch.device(device)
+
+    def update(self, buf, horizon):
+        self.acc.zero_()
+        _check(_lib().cda_episode_returns(buf["reward"].data_ptr(), buf["terminated"].data_ptr(), buf["truncated"].data_ptr(), int(horizon), self.N, self.A,
+                                          self.running.data_ptr(), self.acc[0].data_ptr(), self.acc[1].data_ptr(),
+                                          self.per_slot.data_ptr() if self.per_slot is not None else None, _stream(self.device)), "cda_episode_returns")
+        return self.acc                                                                   # (device tensor: read it with the iteration's other statistics)
 
 
 class FusedUpdate:
@@ -320,16 +478,20 @@ class FusedUpdate:
     {gather + forward + loss + back-propagation (one launch), weight gradients, reduce, clip + Adam}: four launches, no autograd, no GEMM
     library.  fused=False: the same step as separate kernels (a gather / convert pass per epoch, then forward, loss, backward, ...)."""
 
-    def __init__(self, policy, n_rows, rows_mb, num_agents, chunks=None, sub_batches=1, fused=True):
+    def __init__(self, policy, n_rows, rows_mb, num_agents, chunks=None, sub_batches=1, fused=True, allreduce=None, world=1):
         """fused (default; used when run() is given sample records): gather, forward, loss and back-propagation of a minibatch are ONE launch
         (cda_mlp_forward_backward) - a minibatch step is {that, weight gradients, reduce, Adam}; otherwise the separate kernels run (prep_rows per
         epoch, forward, loss, backward).
         sub_batches > 1 (separate kernels only): a minibatch step runs {forward, loss, backward, weight gradients} once per sub-batch of rows_mb / sub_batches rows and
         reduces all their partial sums in one optimiser step - the same step, with activations of a sub-batch small enough to stay in the
-        256-MB Infinity Cache between the kernel that writes them and the ones that read them."""
+        256-MB Infinity Cache between the kernel that writes them and the ones that read them.
+        allreduce (fused path; a data-parallel learner, one process per GPU each with its own shard of markets): callable(tensor) summing it in place over
+        the `world` ranks - called on the gradient (0.9 MB) between the reduce and the optimiser launches of every minibatch step, the only collective of
+        the loop; every rank's loss is normalised with the GLOBAL minibatch (rows x world) so the sum is the global gradient."""
         self.p, self.R, self.rows_mb, self.A = policy, int(n_rows), int(rows_mb), int(num_agents)
         self.sub = max(1, int(sub_batches))
         self.fused = bool(fused) and self.sub == 1
+        self.allreduce, self.world = allreduce, max(1, int(world))
         if self.R % 32 or self.rows_mb % 32 or self.rows_mb > self.R:
             raise ValueError("rows and minibatch rows must be multiples of 32")
         dev = policy.device
@@ -340,40 +502,63 @@ class FusedUpdate:
         self.chunks = int(chunks) if chunks else max(1, min(51, self.rows_mb // 512))      # 5 jobs x 51 chunks = 255 workgroups: one wave of the 256 CUs
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)                      # noqa: E731
-        self.x_rm, self.x_pk = e(self.R * KX, bf), e(self.R * 32 * XT, bf)
+        self.x_rm, self.x_pk = e(self.R * KX, bf), e(self.R * 32 * XT, bf)         # (the separate kernels' per-epoch images of the shuffled rows)
         self.h1p, self.h2p, self.dz1p, self.dz2p = (e(pad * FEAT, bf) for _ in range(4))
         self.doutp = e(pad * NOUT, bf)
         self.out, self.d_out = e(pad * NOUT, f32).view(-1, NOUT), e(pad * NOUT, f32).view(-1, NOUT)
         self.slab, self.bias_slab = e(self.sub * self.chunks * SLAB, f32), e((max(self.n_tiles, pad // 64) + self.sub) * BSLAB, f32)
         self.grad, self.norm2 = e(PARAMS, f32), e(512, torch.float64)        # (norm2[2] = the squared gradient norm of the last step)
-        self.sums5, self.out6 = e(64 * 8, torch.float64), e(6, f32)       # CDA_MLP_LOSS_SLOTS x 8: the loss sums (slot 0, words 0..4 for the separate loss kernels)
+        self.sums5, self.out6 = e(64 * 8, torch.float64), e(8, f32)       # CDA_MLP_LOSS_SLOTS x 8: the loss sums (slot 0, words 0..4 for the separate loss kernels); out6: CDA_LOSS_OUT_WORDS
         self.perm = torch.zeros(self.R, dtype=torch.int64, device=dev)
         pad64 = ((self.rows_mb + 63) // 64) * 64
         self.x_pk_mb = e(pad64 * 32 * XT, bf) if self.fused else None         # the fused kernel's packed image of the minibatch's observations
         self.shuffle_seed, self._epochs_done = 0x5DEECE66D, 0
+        self._extra = None
+
+    def set_extra(self, rec_stride=0, kl_coef=0.0, vf_clip=0.0, dist_old=None, log_std_old=None):
+        """what cda_ppo_extra carries (fused path): the record stride of a league update, RLlib's KL penalty and value-error clamp"""
+        from ._lib import PpoExtra
+        if not (rec_stride or kl_coef or vf_clip):
+            self._extra, self._kl = None, 0.0
+            return
+        x = PpoExtra()
+        x.rec_stride, x.kl_coef, x.vf_clip = int(rec_stride), float(kl_coef), float(vf_clip)
+        x.dist_old = dist_old.data_ptr() if (dist_old is not None and kl_coef) else None
+        x.log_std_old = log_std_old.data_ptr() if (log_std_old is not None and kl_coef) else None
+        self._extra, self._kl, self._extra_keep = x, float(kl_coef), (dist_old, log_std_old)
 
     def minibatch_step(self, s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, apply=True, records=None, obs_rows=None,
                        debug_outputs=False):
         """rows [s, s + rows) of the prepared (shuffled) observations: one optimiser step.  obs_rows (with records, fused=True): the unshuffled f32
-        observation rows - the fused kernel gathers rows perm[s .. s + rows) itself, no prepared images needed.  records = (rec f32 [R, A, 8], adv sums f64[2] or
-        None, their count): the loss reads sample records (RolloutChains.gae) instead of the seven per-sample arrays."""
+        observation rows - the fused kernel gathers rows perm[s .. s + rows) itself, no prepared images needed.  records = (rec f32 [R, A, 8] or its
+        address, adv sums f64[2] or None, their count): the loss reads sample records (RolloutChains.gae) instead of the seven per-sample arrays."""
         L, p, dev = _lib(), self.p, self.p.device
         st = _stream(dev)
+        ptr = lambda x: x if isinstance(x, int) else x.data_ptr()           # noqa: E731
         if obs_rows is not None and records is not None and self.fused:
             rec, stats, count = records
             chunks, tiles = max(1, min(self.chunks, rows // 32)), (rows + 63) // 64
-            _check(L.cda_mlp_forward_backward(p.wb.data_ptr(), p.theta.data_ptr(), obs_rows.data_ptr(), self.perm.data_ptr() + s * 8, rows, rows, rec.data_ptr(),
+            kl = getattr(self, "_kl", 0.0)
+            _check(L.cda_mlp_forward_backward(p.wb.data_ptr(), p.theta.data_ptr(), obs_rows.data_ptr(), self.perm.data_ptr() + s * 8, rows, rows * self.world, ptr(rec),
                                               stats.data_ptr() if stats is not None else None, int(count), self.A, float(clip), float(vf_coef), float(ent_coef),
+                                              C.byref(self._extra) if self._extra is not None else None,
                                               self.x_pk_mb.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(),
                                               self.bias_slab.data_ptr(), self.sums5.data_ptr(), self.out6.data_ptr(), 0 if apply else 1, 0 if apply else 1,
                                               self.out.data_ptr() if debug_outputs else None, self.d_out.data_ptr() if debug_outputs else None, st), "cda_mlp_forward_backward")
             _check(L.cda_mlp_wgrad(self.x_pk_mb.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(), rows, chunks,
                                    self.slab.data_ptr(), st), "cda_mlp_wgrad")
-            if apply:
+            if apply and self.allreduce is None:
                 _check(L.cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), self.slab.data_ptr(), chunks,
-                                      self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A, float(vf_coef), float(ent_coef), self.out6.data_ptr(),
+                                      self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A, float(vf_coef), float(ent_coef), kl, self.out6.data_ptr(),
                                       float(lr), float(betas[0]), float(betas[1]), float(eps), float(max_norm),
                                       self.grad.data_ptr(), self.norm2.data_ptr(), st), "cda_mlp_adam")
+            elif apply:
+                # data parallel: this rank's share of the gradient (its loss normalised by the global minibatch), summed over the ranks, then the same step everywhere
+                _check(L.cda_mlp_reduce(self.slab.data_ptr(), chunks, self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A * self.world, float(vf_coef), float(ent_coef), kl,
+                                        self.out6.data_ptr(), p.adam_step.data_ptr(), self.grad.data_ptr(), self.norm2.data_ptr(), st), "cda_mlp_reduce")
+                self.allreduce(self.grad)
+                _check(L.cda_mlp_apply(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), self.grad.data_ptr(), 1,
+                                       float(lr), float(betas[0]), float(betas[1]), float(eps), float(max_norm), self.norm2.data_ptr(), st), "cda_mlp_apply")
             return chunks, tiles
         sub = self.sub if (rows % (32 * self.sub) == 0 and rows // self.sub >= 32) else 1
         rs = rows // sub                                           # rows per sub-batch
@@ -387,7 +572,7 @@ class FusedUpdate:
             last = k == sub - 1
             if records is not None:
                 rec, stats, count = records
-                _check(L.cda_ppo_loss_records(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, rec.data_ptr(), stats.data_ptr() if stats is not None else None, int(count),
+                _check(L.cda_ppo_loss_records(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, ptr(rec), stats.data_ptr() if stats is not None else None, int(count),
                                               self.perm.data_ptr() + o * 8, rs, self.A, NOUT, float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(),
                                               self.sums5.data_ptr(), self.out6.data_ptr(), rows, 0 if (apply or k) else 1, 0 if (apply or not last) else 1, st),
                        "cda_ppo_loss_records")
@@ -404,7 +589,7 @@ class FusedUpdate:
         chunks, tiles = chunks * sub, tiles_sub * sub
         if apply:
             _check(L.cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), self.slab.data_ptr(), chunks,
-                                  self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A, float(vf_coef), float(ent_coef), self.out6.data_ptr(),
+                                  self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A, float(vf_coef), float(ent_coef), 0.0, self.out6.data_ptr(),
                                   float(lr), float(betas[0]), float(betas[1]), float(eps), float(max_norm),
                                   self.grad.data_ptr(), self.norm2.data_ptr(), st), "cda_mlp_adam")
         return chunks, tiles
@@ -414,11 +599,11 @@ class FusedUpdate:
         """obs_rows f32 [R, 168] (one row per market-step); acts = (category i32, price i32, price_offset i32, a_cont f32[.., 2]) and logp_old / adv
         / ret f32, R * A entries each, sample r * A + a belonging to row r.  adv is expected normalised.  perms: optional i64 [epochs, R]
         (tests); default a keyed permutation per epoch.  records = (rec, adv sums or None, count) replaces acts / logp_old / adv / ret (see
-        minibatch_step); with the sums given the advantages are normalised inside the loss."""
+        minibatch_step); with the sums given the advantages are normalised inside the loss.  max_norm = math.inf: no gradient clipping."""
         L, dev = _lib(), self.p.device
         assert obs_rows.shape == (self.R, OBS) and obs_rows.dtype == torch.float32 and obs_rows.is_contiguous()
         if records is not None:
-            assert records[0].dtype == torch.float32 and records[0].is_contiguous() and records[0].numel() == self.R * self.A * 8
+            assert isinstance(records[0], int) or (records[0].dtype == torch.float32 and records[0].is_contiguous() and records[0].numel() >= self.R * self.A * 8)
         else:
             for t in (*acts, logp_old, adv, ret):
                 assert t.is_contiguous()
@@ -437,4 +622,4 @@ class FusedUpdate:
                 rows = min(self.rows_mb, self.R - s)
                 self.minibatch_step(s, rows, acts, logp_old, adv, ret, clip, vf_coef, ent_coef, lr, betas, eps, max_norm, records=records,
                                     obs_rows=obs_rows if fused else None)
-        return {"pg_loss": self.out6[0], "v_loss": self.out6[1], "entropy": self.out6[2]}
+        return {"pg_loss": self.out6[0], "v_loss": self.out6[1], "entropy": self.out6[2], "kl": self.out6[6]}

@@ -101,14 +101,22 @@ def _hip_unpack(records, n_segments, seg_records, seg_row_stride, row0, num_agen
                                     torch.cuda.current_stream(obs.device).cuda_stream), "cda_handback_unpack")
 
 
+#: deadline (seconds) of a steady-state native collective call and of the device work behind it (CDA_HANDBACK_TIMEOUT_S)
 HANDBACK_TIMEOUT_S = float(os.environ.get("CDA_HANDBACK_TIMEOUT_S", "60"))
+#: deadline of the communicators' set-up, per communicator (CDA_COMM_INIT_TIMEOUT_S): a cold ncclCommInitRank over 8 GPUs can take tens of seconds, and a rank
+#: builds one communicator per chain - the set-up deadline is this times the number of communicators, and missing it falls back to torch.distributed (every rank
+#: agrees on that through an all-reduce) instead of ending the process
+COMM_INIT_TIMEOUT_S = float(os.environ.get("CDA_COMM_INIT_TIMEOUT_S", "90"))
 
 
-def _guarded(fn, what, streams=(), timeout=None):
+def _guarded(fn, what, streams=(), timeout=None, device=None, on_timeout="exit"):
     """Run `fn` (a native call that enqueues collectives) under a host watchdog: the call itself in a worker thread (RCCL sets its
     connections up lazily, inside the first collective, and that can block on the host), then every stream it enqueued on polled to
     completion - both against one deadline.  A collective that never completes makes the process EXIT non-zero with a diagnostic inside
-    `timeout` seconds instead of hanging until somebody kills the job (torch.distributed's own timeout guards only ITS collectives)."""
+    `timeout` seconds instead of hanging until somebody kills the job (torch.distributed's own timeout guards only ITS collectives);
+    on_timeout="raise": a call that does not RETURN in time raises TimeoutError instead (the set-up path: the caller falls back).
+    device: the HIP device the call must run on - the current device is a property of the host THREAD and a fresh thread starts on device 0, so the
+    worker selects it before calling `fn` (without this every rank but 0 of a multi-GPU node would build its communicators on GPU 0)."""
     import sys
     import threading
     import time
@@ -117,6 +125,8 @@ def _guarded(fn, what, streams=(), timeout=None):
 
     def run():
         try:
+            if device is not None and torch.device(device).type == "cuda":
+                torch.cuda.set_device(torch.device(device))
             box["ret"] = fn()
         except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread
             box["err"] = e
@@ -125,6 +135,8 @@ def _guarded(fn, what, streams=(), timeout=None):
     th.start()
     th.join(timeout)
     if th.is_alive():
+        if on_timeout == "raise":
+            raise TimeoutError(f"{what}: the native call did not return within {timeout:.0f} s")
         print(f"[cda watchdog] {what}: the native call did not return within {timeout:.0f} s (a collective that cannot be set up or enqueued); exiting", file=sys.stderr, flush=True)
         os._exit(3)
     if "err" in box:
@@ -168,22 +180,33 @@ class _Rccl:
             cls._inst = cls()
         return cls._inst
 
-    def new_comm(self, dist, rank, world):
-        """one communicator over all ranks: rank 0 draws the id, torch.distributed carries it to the others"""
-        uid = self.UniqueId()
-        if rank == 0:
-            rc = self.lib.ncclGetUniqueId(C.byref(uid))
-            if rc != 0:
-                raise RuntimeError(f"ncclGetUniqueId: {rc}")
-        box = [C.string_at(C.byref(uid), 128) if rank == 0 else None]        # (all 128 bytes: `.internal` would stop at the first NUL)
+    def draw_ids(self, dist, rank, world, n):
+        """n unique ids: rank 0 draws them, torch.distributed carries them to the others - on the CALLER's thread (a process-group collective)"""
+        ids = []
+        for _ in range(n):
+            uid = self.UniqueId()
+            if rank == 0:
+                rc = self.lib.ncclGetUniqueId(C.byref(uid))
+                if rc != 0:
+                    raise RuntimeError(f"ncclGetUniqueId: {rc}")
+            ids.append(C.string_at(C.byref(uid), 128) if rank == 0 else None)    # (all 128 bytes: `.internal` would stop at the first NUL)
         if world > 1:
-            dist.broadcast_object_list(box, src=0)
-        C.memmove(C.byref(uid), box[0], 128)
+            dist.broadcast_object_list(ids, src=0)
+        return ids
+
+    def init_comm(self, raw_id, rank, world):
+        """ncclCommInitRank on the CURRENT device of the calling thread (the guarded worker selects the rank's device first)"""
+        uid = self.UniqueId()
+        C.memmove(C.byref(uid), raw_id, 128)
         comm = C.c_void_p()
         rc = self.lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
         if rc != 0:
             raise RuntimeError(f"ncclCommInitRank: {rc}")
         return comm
+
+    def new_comm(self, dist, rank, world):
+        """one communicator over all ranks (id exchange + init on the calling thread's current device)"""
+        return self.init_comm(self.draw_ids(dist, rank, world, 1)[0], rank, world)
 
 
 class ShardedVecEnv:
@@ -266,7 +289,9 @@ class ShardedVecEnv:
                     comms, err = [], None
                     try:
                         rccl = _Rccl.get()
-                        comms = _guarded(lambda: [rccl.new_comm(self.dist, self.rank, self.world) for _ in range(G)], "ncclCommInitRank")
+                        ids = rccl.draw_ids(self.dist, self.rank, self.world, G)          # the process-group broadcast stays on this thread; only RCCL's own calls are guarded
+                        comms = _guarded(lambda: [rccl.init_comm(i, self.rank, self.world) for i in ids], "ncclCommInitRank", timeout=COMM_INIT_TIMEOUT_S * G,
+                                         device=dev, on_timeout="raise")
                     except Exception as e:  # noqa: BLE001 - every rank must take the same branch below
                         err = e
                     if self._all_ranks_agree(err is None, dev):
@@ -324,7 +349,7 @@ class ShardedVecEnv:
             arr = self._stream_array()
             _guarded(lambda: check(lib().cda_handback_groups(env._h, len(self.group_ranges), arr, self._comms, self.world, self._gptrs,
                                                              *[t.data_ptr() for t in a_set]), "cda_handback_groups"),
-                     "native hand-back self-check", streams=streams)
+                     "native hand-back self-check", streams=streams, device=dev)
             torch.cuda.synchronize(dev)
             for gi, (first, cnt) in enumerate(self.group_ranges):
                 buf = torch.zeros_like(self._gbuf[gi])

@@ -464,40 +464,84 @@ def _capture_rollout_step(model, env, N, A, T, seed=0, shared=True):
     return g, buf, t_dev
 
 
-def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=1e-3, seed=0, log=print, use_graph=True, chains=4, minibatch=262144,
-                gamma=0.99, lam=0.95, clip=0.2, vf_coef=0.5, ent_coef=0.01, policy=None, keep=None, sub_batches=None):
+#: the objective of this module's loops (the round-2 choice: PPO as commonly stated)
+PPO_DEFAULTS = dict(gamma=0.99, lam=0.95, clip=0.2, vf_coef=0.5, ent_coef=0.01, max_norm=0.5, kl_coef=0.0, kl_target=0.01, vf_clip=0.0, bootstrap_truncation=False,
+                    reward_scale=1e-3)
+#: the objective the REFERENCE optimises: train/train.py:519-526 sets only the batch size, the epochs and the learning rate on RLlib's PPOConfig, so everything else
+#: is RLlib's default - clip_param 0.3, lambda_ 1.0, gamma 0.99, vf_loss_coeff 1.0, entropy_coeff 0, vf_clip_param 10 (the squared value error clamped), use_kl_loss
+#: with kl_coeff 0.2 adapted towards kl_target 0.01 (x 1.5 above twice the target, x 0.5 below half of it, after every update), grad_clip None, rewards
+#: unscaled, advantages standardised per module batch, time-limit truncations bootstrapped with V(last observation).
+RLLIB_DEFAULTS = dict(gamma=0.99, lam=1.0, clip=0.3, vf_coef=1.0, ent_coef=0.0, max_norm=math.inf, kl_coef=0.2, kl_target=0.01, vf_clip=10.0, bootstrap_truncation=True,
+                      reward_scale=1.0)
+
+
+def adapt_kl_coef(kl_coef, sampled_kl, kl_target):
+    """RLlib's rule (PPOLearner._update_module_kl_coeff): the coefficient follows the KL the last minibatch step measured"""
+    if kl_coef <= 0.0 or not math.isfinite(sampled_kl):
+        return kl_coef
+    if sampled_kl > 2.0 * kl_target:
+        return kl_coef * 1.5
+    if sampled_kl < 0.5 * kl_target:
+        return kl_coef * 0.5
+    return kl_coef
+
+
+def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, seed=0, log=print, use_graph=True, chains=4, minibatch=262144,
+                gamma=None, lam=None, clip=None, vf_coef=None, ent_coef=None, policy=None, keep=None, sub_batches=None, objective=None, recorder=None, info_markets=0,
+                allreduce=None, world=1):
     """The PPO loop on the hand-written network kernels (mlp.py, include/cda_mlp.h): rollouts as `chains` independent per-chain launch
     sequences (policy forward + sampling -> env step -> auto reset, one HIP graph per chain, no cross-stream edge inside the horizon), the
     sample records completed by one GAE launch, the update as {gather + forward + loss + back-propagation, weight gradients, reduce, clip + Adam}
     per minibatch step - no autograd, no GEMM library.
+    objective: a dict over PPO_DEFAULTS' keys (RLLIB_DEFAULTS = what the reference's RLlib run optimises); the explicit keyword arguments override it.
+    recorder + info_markets = S: the last S markets run as a chain of their own with the info tensors of every step (RolloutChains.info) and the recorder
+    (episode_record.BatchedEpisodeRecorder over those markets) is fed from the rollout buffers after the horizon - no per-step host call.
+    allreduce / world: a data-parallel learner (mlp.FusedUpdate); every rank runs this loop on its own env shard.
     Needs a HIP CDAVecEnv with auto_reset and 168-float observations.  Returns (FusedPolicy, history); `keep` (a dict) receives the last
-    rollout's buffers and the RolloutChains object."""
-    from .mlp import FusedPolicy, FusedUpdate, RolloutChains
+    rollout's buffers and the RolloutChains object.  history[i]: losses, `mean_reward` (of the rollout's slice of the episodes - it depends on WHICH part of
+    the episodes the slice covers) and `episode_return` (mean return of the episodes that were COMPLETED during the iteration, None if none was)."""
+    from .mlp import EpisodeReturns, FusedPolicy, FusedUpdate, RolloutChains
+    obj = dict(PPO_DEFAULTS)
+    obj.update(objective or {})
+    for k_, v_ in (("gamma", gamma), ("lam", lam), ("clip", clip), ("vf_coef", vf_coef), ("ent_coef", ent_coef), ("reward_scale", reward_scale)):
+        if v_ is not None:
+            obj[k_] = v_
     dev = env.obs.device
     N, A, T = env.n_markets, env.num_agents, int(horizon)
     if policy is None:
         policy = FusedPolicy(dev, seed=seed)
     env.reset(seed=seed)
-    roll = RolloutChains(env, policy, T, groups=chains, seed=seed, use_graphs=use_graph)
+    use_kl = obj["kl_coef"] > 0.0
+    roll = RolloutChains(env, policy, T, groups=chains, seed=seed, use_graphs=use_graph, with_dist=use_kl, capture_ends=bool(obj["bootstrap_truncation"]),
+                         info_markets=info_markets if recorder is not None else 0)
     R = T * N
     rows_mb = max(32, min(R, (max(1, minibatch // A) // 32) * 32))
     import os
     sub_batches = int(os.environ.get("CDA_PPO_SUB_BATCHES", "1")) if sub_batches is None else int(sub_batches)
-    upd = FusedUpdate(policy, R, rows_mb, A, sub_batches=sub_batches)
+    upd = FusedUpdate(policy, R, rows_mb, A, sub_batches=sub_batches, allreduce=allreduce, world=world)
+    returns = EpisodeReturns(N, A, dev)
+    kl_coef = float(obj["kl_coef"])
     history = []
     for it in range(iters):
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         buf = roll.run()
-        records = roll.gae(gamma=gamma, lam=lam, reward_scale=reward_scale)     # advantages + returns into the sample records, one launch
+        records = roll.gae(gamma=obj["gamma"], lam=obj["lam"], reward_scale=obj["reward_scale"])     # advantages + returns into the sample records, one launch
         torch.cuda.synchronize(dev)
         t_roll = time.perf_counter()
-        stats = upd.run(buf["obs"][:T].view(R, -1), epochs=epochs, clip=clip, vf_coef=vf_coef, ent_coef=ent_coef, lr=lr, records=records)
+        upd.set_extra(kl_coef=kl_coef, vf_clip=obj["vf_clip"], dist_old=buf.get("dist"), log_std_old=roll.log_std_old if use_kl else None)
+        stats = upd.run(buf["obs"][:T].view(R, -1), epochs=epochs, clip=obj["clip"], vf_coef=obj["vf_coef"], ent_coef=obj["ent_coef"], lr=lr, max_norm=obj["max_norm"],
+                        records=records)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
+        acc = returns.update(buf, T).cpu()                                   # (outside the timed region, like everything below: logging only)
         stats = {k: float(v) for k, v in stats.items()}
-        stats.update(iter=it, mean_reward=float(buf["reward"].mean()), agent_steps=N * A * T, agent_steps_per_s=N * A * T / (t1 - t0),
-                     rollout_s=t_roll - t0, update_s=t1 - t_roll)           # (the reward mean is outside the timed region: logging only)
+        done = float(acc[1].sum())
+        stats.update(iter=it, mean_reward=float(buf["reward"].mean()), episode_return=(float(acc[0].sum()) / done) if done else None, episodes=done / A,
+                     kl_coef=kl_coef, agent_steps=N * A * T, agent_steps_per_s=N * A * T / (t1 - t0), rollout_s=t_roll - t0, update_s=t1 - t_roll)
+        kl_coef = adapt_kl_coef(kl_coef, stats["kl"], obj["kl_target"])
+        if recorder is not None and roll.info is not None:
+            recorder.record_rollout(roll, iteration=it)
         history.append(stats)
         log(json.dumps(stats))
     if keep is not None:
@@ -624,20 +668,29 @@ def main(argv=None):
     p.add_argument("--out", default=None, help="write a JSON summary (config, per-iteration stats, end-of-run env checks) to this file")
     p.add_argument("--legacy", action="store_true", help="the round-3 loop: PyTorch network (library GEMMs, autograd), one graph per rollout step")
     p.add_argument("--chains", type=int, default=4, help="fused loop: independent rollout chains (market groups on their own streams)")
+    p.add_argument("--objective", choices=("ppo", "rllib"), default="ppo", help="fused loop: PPO_DEFAULTS, or RLLIB_DEFAULTS = the objective the reference's RLlib run optimises "
+                                                                              "(clip 0.3, lambda 1, vf coeff 1, entropy 0, vf clip 10, adaptive KL penalty, no gradient clipping, truncation bootstrap)")
     args = p.parse_args(argv)
     from .vec_env import CDAVecEnv
     p_groups = max(1, min(args.groups, args.markets))
     env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False, "auto_reset": True},
                     n_markets=args.markets, device="cuda:0", with_info=False, groups=p_groups)
+    if not args.legacy and ((args.horizon * args.markets) % 32 or env.obs_dim != 168):
+        # the fused kernels step whole 32-row tiles of 168-float observations: other shapes run the PyTorch statement of the same loop
+        print(json.dumps({"note": f"fused loop needs horizon * markets % 32 == 0 and n_hist == 4 (got {args.horizon} x {args.markets}, obs {env.obs_dim}): running the legacy loop"}))
+        args.legacy = True
     if args.legacy:
         _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update, shared_obs=not args.per_sample_forward, use_graph=not args.no_graphs)
     else:
-        _, hist = train_fused(env, iters=args.iters, horizon=args.horizon, use_graph=not args.no_graphs, chains=args.chains)
+        _, hist = train_fused(env, iters=args.iters, horizon=args.horizon, use_graph=not args.no_graphs, chains=args.chains,
+                              objective=RLLIB_DEFAULTS if args.objective == "rllib" else None)
     flags = env.flags()
     _, bad = env.nav_conservation()
     summary = {"metric": "agent-steps/sec end to end (rollout + PPO update), BASELINE configs[4]",
-               "config": {"workload": f"{args.markets} markets x {args.agents} agents, PyTorch-ROCm PPO policy in the loop (256x256 tanh actor and critic, "
+               "config": {"workload": f"{args.markets} markets x {args.agents} agents, " + ("PyTorch-ROCm PPO policy (library GEMMs, autograd)" if args.legacy else
+                                      "PPO policy on the hand-written bf16 MFMA network kernels") + " in the loop (256x256 tanh actor and critic, "
                                       f"4 epochs, 262144-sample minibatches), horizon {args.horizon}, {args.iters} iterations, auto_reset on",
+                          "objective": "legacy loop's own" if args.legacy else args.objective,
                           "markets": args.markets, "agents": args.agents, "horizon": args.horizon, "iters": args.iters, "env_groups": p_groups,
                           "loop": "legacy (PyTorch network)" if args.legacy else (f"fused: hand-written bf16 MFMA network (csrc/cda_mlp.hip), {args.chains} rollout chains; GAE straight into the sample records (one launch); "
                                                                                       "a minibatch step = {gather + forward + loss + backward in one launch, weight gradients, reduce, Adam}"),

@@ -208,6 +208,17 @@ int cda_step_range(cda_env* env, int32_t first_market, int32_t n_markets,
                    const cda_info_ptrs* info_out, void* stream);
 int cda_reset_range(cda_env* env, int32_t first_market, int32_t n_markets, const uint64_t* seeds, const uint8_t* mask,
                     float* obs_out, void* stream);
+/* cda_step_range with EPISODE-END CAPTURE (auto_reset envs only; fin_index_out NULL = plain cda_step_range).  The device-side auto reset overwrites the
+ * finished episode's last observation in obs_out with the new episode's first one; the reference's consumers still need the old one - RLlib bootstraps a
+ * time-limit truncation with V(last observation) (the env's `truncateds`, continuousDoubleAuction_env.py:303), its episode record stores it with the
+ * last step (train/episode_record.py:431-470).  A market whose episode ended with this step therefore appends that observation to a compact list first:
+ * slot = atomicAdd(fin_count, 1); if slot < fin_cap: fin_obs[slot][n_hist * 42] = the observation, fin_index_out[market] = slot.  fin_index_out i32[N]
+ * is pre-set to -1 and fin_count i32[1] zeroed by the caller.  Cold paths only: the step's hot code is unchanged. */
+int cda_step_range_capture(cda_env* env, int32_t first_market, int32_t n_markets,
+                           const int32_t* category, const float* size_mean, const float* size_sigma,
+                           const int32_t* price, const int32_t* price_offset, const uint8_t* present,
+                           float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                           const cda_info_ptrs* info_out, float* fin_obs, int32_t fin_cap, int32_t* fin_count, int32_t* fin_index_out, void* stream);
 /* cda_step as n_groups (<= CDA_MAX_GROUPS) launches, group g = the markets cda_group_range() names, on streams[g].
  * One host call; each group is an independent chain of launches on its own stream, so one group's slowest market
  * overlaps the other groups' work instead of stalling the whole batch.  The outputs of group g are complete when

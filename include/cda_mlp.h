@@ -118,10 +118,22 @@ int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p, const void
  * grad f32[CDA_MLP_PARAMS] receives the gradient before clipping (its never-written entries - the heads' rows 25..31 - must be zero: allocate
  * it zeroed); scratch f64[CDA_MLP_SCRATCH]: [2] = the squared norm of this call's gradient (output), the rest is the kernels' own. */
 #define CDA_MLP_LOSS_SLOTS 64
+/* loss_out6 is f32[8] for this call and for cda_mlp_forward_backward: [0] policy loss, [1] value loss (after the clamp), [2] entropy, [3] total
+ * (policy + vf_coef value - ent_coef entropy + kl_coef KL), [4..5] d loss / d log_std, [6] mean KL(rollout policy || current policy) (0 without a KL term), [7] 0.
+ * max_norm = INFINITY: no clipping (RLlib's default). */
+#define CDA_LOSS_OUT_WORDS 8
 int cda_mlp_adam(float* theta, float* adam_m, float* adam_v, float* step_dev, void* wb,
                  const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
-                 double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float* loss_out6,
+                 double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float kl_coef, float* loss_out6,
                  float lr, float beta1, float beta2, float eps, float max_norm, float* grad, double* scratch, void* stream);
+/* The two halves of cda_mlp_adam as calls of their own, for a data-parallel learner (one process per GPU, each with its own shard of markets): between them
+ * the caller all-reduces (sums) `grad` f32[CDA_MLP_PARAMS] over the ranks (one ncclAllReduce of 0.9 MB per minibatch step - the only collective of the
+ * loop; every rank's loss was normalised with the GLOBAL minibatch size through norm_rows, so the sum IS the global gradient) and cda_mlp_apply recomputes
+ * the norm of what arrived. */
+int cda_mlp_reduce(const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
+                   double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float kl_coef, float* loss_out6, float* step_dev, float* grad, double* scratch, void* stream);
+int cda_mlp_apply(float* theta, float* adam_m, float* adam_v, const float* step_dev, void* wb, const float* grad, int32_t recompute_norm,
+                  float lr, float beta1, float beta2, float eps, float max_norm, double* scratch, void* stream);
 
 /* cda_ppo_loss (cda.h) for int32 action arrays - the env's own action tensors as the rollout kernel wrote them.  norm_rows > 0:
  * the means (and the gradient's 1/B) are over norm_rows * agents_per_row samples instead of rows * agents_per_row (a minibatch
@@ -151,6 +163,15 @@ typedef struct cda_rollout_bufs {
     uint8_t* terminated;     /* [T][N] */
     uint8_t* truncated;      /* [T][N] */
     float*   record;         /* [T][N][A][8] or NULL: the sample records below (words 0..5 written by the policy step) */
+    float*   dist;           /* [T][N][24] or NULL: the rollout policy's distribution per market-step (22 normalised log-probabilities of the categorical heads | the 2 Gaussian
+                                means) - what the update's KL term needs (cda_ppo_extra) */
+    const cda_info_ptrs* info_steps;   /* [T] (host array) or NULL: step t of this chain also writes the info tensors info_steps[t] (Info_Helper.set_info; the chain then runs
+                                the step kernel with info outputs - meant for a small chain of SAMPLED markets beside the info-less ones: train/episode_record.py:197
+                                records one episode in N).  Every pointer is indexed by GLOBAL market like all arrays here */
+    int32_t* fin_index;      /* [T][N] or NULL: episode-end capture (cda_step_range_capture): the slot in fin_obs of the last observation of an episode that ended at */
+    float*   fin_obs;        /*   (t, market), -1 = none (pre-set by the caller); fin_obs [fin_cap][168], fin_count i32[1] (zeroed by the caller before a rollout) */
+    int32_t* fin_count;
+    int32_t  fin_cap;
 } cda_rollout_bufs;
 int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
                           uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* bufs, int32_t copy_first_obs, void* stream);
@@ -170,6 +191,19 @@ int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int3
  * of rec [T][N][A][8]; stats2 f64[2] receives the sum of the advantages and of their squares. */
 int cda_gae_records(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
                     int32_t num_agents, float reward_scale, float gamma, float lam, float* rec, double* stats2, void* stream);
+/* The same with the time-limit bootstrap RLlib applies (a TRUNCATED, not terminated, step's target continues with V(last observation of the cut episode) instead of 0;
+ * the device-side auto reset overwrites that observation, so the rollout captures it: cda_rollout_bufs.fin_*): fin_index i32 [T][N], fin_value f32
+ * [max(n_trainable, 1)][fin_value_stride] = cda_mlp_values on the captured list.  n_trainable = 0: one shared policy; > 0: the league layout below. */
+int cda_gae_records_bootstrap(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
+                              int32_t num_agents, int32_t n_trainable, float reward_scale, float gamma, float lam,
+                              const int32_t* fin_index, const float* fin_value, int64_t fin_value_stride, float* rec, double* stats, void* stream);
+/* value f32 [n_rows] (net p: + p * value_stride) <- the value network of each of n_nets banked networks on obs f32 [n_rows][168] (one launch). */
+int cda_mlp_values(const void* wb_bank, const float* theta_bank, int32_t n_nets, const float* obs, int64_t n_rows, float* value, int64_t value_stride, void* stream);
+/* Returns of COMPLETED episodes out of a rollout's buffers (what a learning curve is drawn from when the horizon is shorter than an episode): running f64 [N][A]
+ * carries each (market, agent)'s return so far from rollout to rollout; a step that ends the market's episode adds the total to done_sum f64 [A] and 1 to
+ * done_count f64 [A] (both accumulate: the caller clears them) and restarts it.  per_slot: what a league needs to credit returns to the MODULE that played a slot. */
+int cda_episode_returns(const double* reward, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets, int32_t num_agents,
+                        double* running, double* done_sum, double* done_count, double* per_slot /* f64 [N][A][2] or NULL: this rollout's (sum, number) per (market, agent) */, void* stream);
 /* cda_ppo_loss32 reading sample records (rec = [all rows][A][8]; row_index as there).  adv_stats2 (may be NULL) + adv_count: the advantages are
  * normalised on the fly, (adv - mean) / (std + 1e-8) with the unbiased std over the adv_count samples the sums were taken over. */
 int cda_ppo_loss_records(const float* outputs, const float* log_std, const float* rec, const double* adv_stats2, int64_t adv_count, const int64_t* row_index,
@@ -184,10 +218,64 @@ int cda_ppo_loss_records(const float* outputs, const float* log_std, const float
  * sums; out / d_out (may be NULL): f32 [n_rows][32] copies of the outputs and their gradients.  Buffers are padded to whole 64-row tiles.
  * clear / finish / out6 / norm_rows: as cda_ppo_loss32, except that the loss sums are f64[CDA_MLP_LOSS_SLOTS][8] (a tile adds into slot `tile mod SLOTS`, words
  * 0..4: one hot cache line would stall every CU's memory pipeline behind its atomics). */
+/* extra (may be NULL): what RLlib's PPO objective has beyond clip / vf_coef / ent_coef, and the record stride of a league update.
+ *   rec_stride   floats between two rows' records; 0 = agents_per_row * 8 (a row's samples are all the row's agents).  League: a row is a market-step of A slots of which
+ *                ONE (slot p of trainable net p) feeds net p's update: rec = records + 8 p, rec_stride = 8 A, agents_per_row = 1.
+ *   kl_coef      adds kl_coef * mean KL(rollout policy || current policy) to the loss, the KL exact per row from dist_old f32 [rows of obs][24] (cda_rollout_bufs.dist)
+ *                and log_std_old f32[2] (the rollout policy's); the mean KL comes back in loss_out6[6] (the caller adapts the coefficient, RLlib: x 1.5 above
+ *                2 kl_target, x 0.5 below 0.5 kl_target).  0 = no KL term.
+ *   vf_clip      the squared value error is clamped to [0, vf_clip] (RLlib's vf_clip_param: clamped samples carry no gradient); <= 0 = off. */
+typedef struct cda_ppo_extra {
+    int32_t rec_stride;
+    float   kl_coef, vf_clip;
+    const float* dist_old;
+    const float* log_std_old;
+} cda_ppo_extra;
 int cda_mlp_forward_backward(const void* wb, const float* theta, const float* obs, const int64_t* perm, int64_t n_rows, int64_t norm_rows,
                              const float* rec, const double* adv_stats2, int64_t adv_count, int32_t agents_per_row, float clip, float vf_coef, float ent_coef,
+                             const cda_ppo_extra* extra,
                              void* x_pk, void* h1p, void* h2p, void* dz1p, void* dz2p, void* doutp, float* bias_slab,
                              double* sums5, float* out6, int32_t clear, int32_t finish, float* out, float* d_out, void* stream);
+
+/* ---- league self-play on the same kernels (SURVEY 8(f) rows 1 + 3; the reference: train/train.py:466-503, train/callbk/league_based_self_play_callback.py:1286-1344) ----
+ * The reference trains num_trained_agents SEPARATE policies (policy_0 plays slot 0, policy_1 slot 1, ...) against modules drawn per episode and slot from a pool of
+ * uniform random modules (RandomRLModule, train/model/model_handler.py:38-53) and frozen champion snapshots.  Here the networks live in BANKS - theta f32
+ * [n_nets][CDA_MLP_PARAMS], wb bf16 [n_nets][CDA_MLP_WB_ELEMS], nets 0 .. n_trainable - 1 the trainable ones, the rest frozen snapshots - and slot_net i32 [N][A]
+ * (resident in HBM, rewritten by the host between episodes from LeagueSlotMapper.assign) names the net that plays (market, slot): >= 0 a bank row,
+ * CDA_LEAGUE_RANDOM the uniform random module.  One launch per step: a (tile, net, half) job per workgroup - both halves of the trainable nets (policy +
+ * value), the policy half of a frozen net, and only where one of the tile's slots is played by it; every workgroup samples the slots of ITS net from its
+ * own logits (same key / index as cda_mlp_policy_step: a slot played by net n gets bit for bit the action a policy step with n's parameters gives it), the random
+ * slots are drawn by net 0's workgroup from include/cda_random_agents.h's stream keyed (random_seed + rollout counter, market, step, slot). */
+#define CDA_LEAGUE_RANDOM   (-1)
+#define CDA_LEAGUE_MAX_NETS 16
+typedef struct cda_league {
+    const void*    wb_bank;
+    const float*   theta_bank;
+    const int32_t* slot_net;
+    int32_t        n_nets, n_trainable;
+    uint64_t       random_seed;
+} cda_league;
+/* cda_mlp_policy_step for a league: value f32 [N] of trainable net p at value + p * value_stride; dist (may be NULL) likewise at dist + p * dist_stride; rec (may be
+ * NULL) f32 [N][A][8]: words 0..5 of every slot's record (non-network slots: the action words, zeros for the rest). */
+int cda_mlp_league_step(const cda_league* league, const float* obs, int32_t first_market, int32_t n_markets, int32_t num_agents,
+                        uint64_t seed, const int64_t* counter_dev, int64_t draw,
+                        int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset,
+                        float* a_cont, float* logp, float* value, int64_t value_stride, float* rec, float* dist, int64_t dist_stride, void* stream);
+/* cda_mlp_rollout_chain for a league: bufs as there except value f32 [n_trainable][T+1][N] and dist f32 [n_trainable][T][N][24]. */
+int cda_mlp_league_rollout_chain(cda_env* env, const cda_league* league, int32_t first_market, int32_t n_markets, int32_t n_steps,
+                                 uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* bufs, int32_t copy_first_obs, void* stream);
+/* cda_gae_records for a league: value f32 [n_trainable][T+1][N]; slot p < n_trainable gets advantage / return from net p's values, the other slots' records are left
+ * alone; stats2k f64 [n_trainable][2]: per net, the sums its update normalises the advantages with. */
+int cda_gae_records_league(const double* reward, const float* value, const uint8_t* terminated, const uint8_t* truncated, int32_t n_steps, int64_t n_markets,
+                           int32_t num_agents, int32_t n_trainable, float reward_scale, float gamma, float lam, float* rec, double* stats2k, void* stream);
+
+/* The reference's agent-to-module mapping fn (league_based_self_play_callback.py:1286-1344) for all markets at once, on the device: slot s < n_trainable -> net s;
+ * every other slot draws np.random.RandomState((episode_crc[market] + s) mod 2^32).choice(pool, p = probs) - bit for bit: one freshly seeded MT19937's first
+ * random_sample(), searchsorted(cumsum(probs) / cumsum(probs)[-1], u, side = "right") - and receives pool_net[draw] (a bank row or CDA_LEAGUE_RANDOM).
+ * episode_crc u32 [N] = zlib.crc32(str(episode id)) (host), pool_cdf f64 [pool_size] the normalised cumulative weights, slot_pool (may be NULL) i32 [N][A]: the draw
+ * itself (index into the pool; -1 for the trainable slots) - what names the module in an episode record. */
+int cda_league_assign(const uint32_t* episode_crc, int32_t n_markets, int32_t num_agents, int32_t n_trainable, const double* pool_cdf, const int32_t* pool_net,
+                      int32_t pool_size, int32_t* slot_net, int32_t* slot_pool, void* stream);
 
 /* Device self-test of the operand / accumulator conventions this file is built on: D f32[32][32] = A bf16-rounded f32[32][16] x
  * B f32[16][32] through one v_mfma_f32_32x32x16_bf16 (host pointers; synchronous). */

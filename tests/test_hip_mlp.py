@@ -134,7 +134,7 @@ def _full_backward(p, x, d_out, chunks):
                               ws["slab"].data_ptr(), st), "wgrad")
     theta0 = p.theta.clone()
     check(lib().cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), ws["slab"].data_ptr(), chunks,
-                             ws["bias_slab"].data_ptr(), tiles, None, 0, 0.0, 0.0, None, 0.0, 0.9, 0.999, 1e-8, 0.5, ws["grad"].data_ptr(), ws["norm2"].data_ptr(), st), "adam")
+                             ws["bias_slab"].data_ptr(), tiles, None, 0, 0.0, 0.0, 0.0, None, 0.0, 0.9, 0.999, 1e-8, 0.5, ws["grad"].data_ptr(), ws["norm2"].data_ptr(), st), "adam")
     torch.cuda.synchronize()
     assert torch.equal(p.theta, theta0)                  # lr = 0
     return ws
@@ -198,7 +198,7 @@ def test_clip_and_adam_equal_torch():
         torch.nn.utils.clip_grad_norm_([th], 0.5)
         opt.step()
         check(lib().cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), ws["slab"].data_ptr(), chunks,
-                                 ws["bias_slab"].data_ptr(), tiles, None, 0, 0.0, 0.0, None, 5e-5, 0.9, 0.999, 1e-8, 0.5, ws["grad"].data_ptr(), ws["norm2"].data_ptr(), st), "adam")
+                                 ws["bias_slab"].data_ptr(), tiles, None, 0, 0.0, 0.0, 0.0, None, 5e-5, 0.9, 0.999, 1e-8, 0.5, ws["grad"].data_ptr(), ws["norm2"].data_ptr(), st), "adam")
         torch.cuda.synchronize()
         # float32 update of magnitude ~lr = 5e-5: agreement to 1e-3 of a step
         assert (p.theta - th.detach()).abs().max() <= 5e-8, (step, float((p.theta - th.detach()).abs().max()))
@@ -475,7 +475,7 @@ def test_fused_forward_loss_backward_equals_the_separate_kernels(N, T, A):
     env.close()
 
 
-def test_fused_training_loop_runs_and_learns_something():
+def test_fused_training_loop_runs_end_to_end():
     from gym_continuousdoubleauction_amd import CDAVecEnv, ppo
     cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 48, "is_render": False, "auto_reset": True}
     env = CDAVecEnv(cfg, n_markets=256, with_info=False)

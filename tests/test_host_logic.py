@@ -223,3 +223,53 @@ def test_gymnasium_and_rllib_present_branch_imports_and_registers():
 @pytest.mark.gpu
 def test_gymnasium_present_branch_steps_on_the_gpu():
     _run_present(_PRESENT_GPU)
+
+
+def test_guarded_call_runs_on_the_ranks_device_and_a_slow_setup_raises(monkeypatch):
+    """The current HIP device belongs to the host THREAD: the watchdog's worker selects the rank's device before the native call (otherwise every rank of a multi-GPU
+    node would initialise its RCCL communicators on GPU 0), and the communicators' set-up deadline raises (the caller falls back to torch.distributed) instead of
+    ending the process."""
+    import threading
+    import time
+    import torch
+    from gym_continuousdoubleauction_amd import parallel
+    seen = {}
+
+    def fake_set_device(d):
+        seen["device"], seen["thread"] = torch.device(d), threading.get_ident()
+    monkeypatch.setattr(torch.cuda, "set_device", fake_set_device)
+    out = parallel._guarded(lambda: threading.get_ident(), "probe", timeout=5, device=torch.device("cuda", 3))
+    assert seen["device"] == torch.device("cuda", 3) and seen["thread"] == out != threading.get_ident()      # selected inside the worker thread, before the call
+    seen.clear()
+    parallel._guarded(lambda: None, "cpu", timeout=5, device="cpu")
+    assert not seen
+    t0 = time.monotonic()
+    try:
+        parallel._guarded(lambda: time.sleep(30), "slow communicator set-up", timeout=0.5, on_timeout="raise")
+        raise AssertionError("expected TimeoutError")
+    except TimeoutError as e:
+        assert "slow communicator set-up" in str(e) and time.monotonic() - t0 < 5
+    assert parallel.COMM_INIT_TIMEOUT_S >= parallel.HANDBACK_TIMEOUT_S
+
+
+def test_a_taken_gymnasium_id_is_left_alone_and_the_registration_switches_the_wrappers_off():
+    """real gymnasium.register only warns on a duplicate id and overrides it - the import order would then decide what gymnasium.make returns.  The
+    package checks the registry first; and its own registration asks for no passive checker / order enforcer (a multi-agent dict API is not what they wrap)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+sys.path.insert(0, {os.path.join(root, "tests", "golden", "shim")!r}); sys.path.insert(0, {root!r})
+from gymnasium.envs.registration import register, registry
+import gym_continuousdoubleauction_amd as first
+assert first.GYMNASIUM_REGISTERED and registry[first.ENV_ID]["kwargs"] == {{"disable_env_checker": True, "order_enforce": False}}
+del sys.modules["gym_continuousdoubleauction_amd"]
+registry[first.ENV_ID] = {{"id": first.ENV_ID, "entry_point": "gym_continuousDoubleAuction.envs:continuousDoubleAuctionEnv", "kwargs": {{}}}}
+import gym_continuousdoubleauction_amd as second
+assert not second.GYMNASIUM_REGISTERED and registry[second.ENV_ID]["entry_point"].startswith("gym_continuousDoubleAuction.")
+print("ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.stdout[-500:], out.stderr[-1500:])

@@ -76,7 +76,24 @@ def test_network_kernels_spill_nothing():
     """The MFMA kernels of csrc/cda_mlp.hip keep accumulators, operand rings and epilogue values in the 512-entry register file: a spill there
     is scratch traffic inside the k-loop (round 4: 137 spilled VGPRs made the training forward 1.5 x slower until its tail predicates went)."""
     ks, _ = _kernels()
-    net = {n: v for n, v in ks.items() if any(k in n for k in ("k_mlp_fwd", "k_mlp_bwd", "k_mlp_wgrad"))}
-    assert len(net) >= 10, sorted(ks)                      # forward: 3 tile sizes x 4 modes; backward: 3 tile sizes; one weight-gradient kernel
+    net = {n: v for n, v in ks.items() if any(k in n for k in ("k_mlp_fwd", "k_mlp_bwd", "k_mlp_wgrad", "k_mlp_fb", "k_grad_reduce", "k_adam", "k_gae_records", "k_grad_norm",
+                                                               "k_league_assign", "k_episode_returns"))}
+    assert len(net) >= 20, sorted(ks)                      # forward: 3 tile sizes x 5 modes; backward: 3 tile sizes; the fused update kernel; weight gradients; reduce; Adam; GAE; ...
     for n, v in net.items():
-        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (n, v)
+        assert v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (n, v)
+    # the update's dominant kernel is built for TWO workgroups per CU: 4 waves x 2 = 2 waves per SIMD = 256 registers per wave, and 160 KB / 2 of LDS
+    fb = [v for n, v in ks.items() if "k_mlp_fb" in n]
+    assert len(fb) == 1 and fb[0]["vgpr_count"] <= 256, fb
+
+
+def test_fused_update_kernel_fits_two_workgroups_per_cu():
+    """k_mlp_fb's dynamic LDS (csrc/cda_mlp.hip fb_lds: observation tile + activation tile + log-probabilities + the tile's sample records [+ the rollout policy's
+    distributions for the KL term]) must stay under half of the CU's 160 KB for every shape the loops launch: one shared policy at 4 and 8 agents per row (the
+    latter without the KL rows: DESIGN 4.2 states that cliff), a league update (one sample per row) with and without them."""
+    XS_LD, ACT_LD, LPS_LD = 176 + 8, 256 + 8, 23
+    fb_lds = lambda agents, dist: 64 * XS_LD * 2 + 64 * ACT_LD * 2 + 64 * LPS_LD * 4 + 64 * (agents * 32 + (24 * 4 if dist else 0))      # noqa: E731
+    src = open(os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_mlp.hip")).read()
+    assert "size_t fb_lds(int agents, bool with_dist) { return (size_t)64 * XS_LD * 2 + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * (agents * 32 + (with_dist ? N_LOGITS * 4 : 0)); }" in src
+    for agents, dist in ((4, False), (4, True), (8, False), (1, False), (1, True)):
+        assert fb_lds(agents, dist) <= 80 * 1024, (agents, dist, fb_lds(agents, dist))
+    assert fb_lds(8, True) > 80 * 1024                       # the stated cliff: 8 agents per row AND the KL rows -> one workgroup per CU

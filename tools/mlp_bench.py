@@ -61,12 +61,12 @@ def main():
     res["wgrad_us"] = timed(lambda: check(L.cda_mlp_wgrad(upd.x_pk.data_ptr(), upd.h1p.data_ptr(), upd.h2p.data_ptr(), upd.dz1p.data_ptr(), upd.dz2p.data_ptr(), upd.doutp.data_ptr(), R, chunks,
                                                          upd.slab.data_ptr(), st), "wgrad"), a.iters)
     res["adam_us"] = timed(lambda: check(L.cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), upd.slab.data_ptr(), chunks,
-                                                       upd.bias_slab.data_ptr(), tiles, upd.sums5.data_ptr(), R * A, 0.5, 0.01, upd.out6.data_ptr(), 0.0, 0.9, 0.999, 1e-8, 0.5, upd.grad.data_ptr(), upd.norm2.data_ptr(), st), "adam"), a.iters)
+                                                       upd.bias_slab.data_ptr(), tiles, upd.sums5.data_ptr(), R * A, 0.5, 0.01, 0.0, upd.out6.data_ptr(), 0.0, 0.9, 0.999, 1e-8, 0.5, upd.grad.data_ptr(), upd.norm2.data_ptr(), st), "adam"), a.iters)
     rec = torch.zeros(R, A, 8, device=dev)
     rec[..., 0] = acts[0].view(R, A).view(torch.float32); rec[..., 1] = acts[1].view(R, A).view(torch.float32); rec[..., 2] = acts[2].view(R, A).view(torch.float32)
     rec[..., 3:5] = acts[3].view(R, A, 2); rec[..., 5] = lp_old.view(R, A); rec[..., 6] = adv.view(R, A); rec[..., 7] = ret.view(R, A)
     res["forward_loss_backward_fused_us"] = timed(lambda: check(L.cda_mlp_forward_backward(
-        p.wb.data_ptr(), p.theta.data_ptr(), obs.data_ptr(), upd.perm.data_ptr(), R, R, rec.data_ptr(), None, 0, A, 0.2, 0.5, 0.01, upd.x_pk_mb.data_ptr(), upd.h1p.data_ptr(),
+        p.wb.data_ptr(), p.theta.data_ptr(), obs.data_ptr(), upd.perm.data_ptr(), R, R, rec.data_ptr(), None, 0, A, 0.2, 0.5, 0.01, None, upd.x_pk_mb.data_ptr(), upd.h1p.data_ptr(),
         upd.h2p.data_ptr(), upd.dz1p.data_ptr(), upd.dz2p.data_ptr(), upd.doutp.data_ptr(), upd.bias_slab.data_ptr(), upd.sums5.data_ptr(), upd.out6.data_ptr(), 1, 0, None, None, st), "fb"), a.iters)
     res["minibatch_step_fused_us"] = timed(lambda: upd.minibatch_step(0, R, None, None, None, None, 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5, records=(rec, None, 0), obs_rows=obs), a.iters)
     res["minibatch_step_us"] = timed(lambda: upd.minibatch_step(0, R, acts, lp_old, adv, ret, 0.2, 0.5, 0.01, 0.0, (0.9, 0.999), 1e-8, 0.5), a.iters)

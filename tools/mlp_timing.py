@@ -42,7 +42,7 @@ def main():
     if a.fused:
         i64, i32, f32 = C.c_int64, C.c_int32, C.c_float
         T.cda_tools_mlp_fb_dbg.argtypes = [vp, i32]; T.cda_tools_mlp_fb_dbg.restype = None
-        T.cda_mlp_forward_backward.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+        T.cda_mlp_forward_backward.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
         A = 4
         rec = torch.zeros(R, A, 8, device=dev)
         rec[..., 0:3] = torch.randint(0, 3, (R, A, 3), device=dev).int().view(torch.float32)
@@ -50,7 +50,7 @@ def main():
         perm = torch.randperm(R, device=dev)
         T.cda_tools_mlp_fb_dbg(dbg.data_ptr(), a.block)
         for rep in range(3):
-            rc = T.cda_mlp_forward_backward(p.wb.data_ptr(), p.theta.data_ptr(), obs.data_ptr(), perm.data_ptr(), R, R, rec.data_ptr(), None, 0, A, 0.2, 0.5, 0.01,
+            rc = T.cda_mlp_forward_backward(p.wb.data_ptr(), p.theta.data_ptr(), obs.data_ptr(), perm.data_ptr(), R, R, rec.data_ptr(), None, 0, A, 0.2, 0.5, 0.01, None,
                                             upd.x_pk_mb.data_ptr(), upd.h1p.data_ptr(), upd.h2p.data_ptr(), upd.dz1p.data_ptr(), upd.dz2p.data_ptr(), upd.doutp.data_ptr(),
                                             upd.bias_slab.data_ptr(), upd.sums5.data_ptr(), upd.out6.data_ptr(), 1, 0, None, None, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
