@@ -93,6 +93,10 @@ def parse():
     p.add_argument("--fused", type=int, default=0, metavar="T",
                    help="not the headline run: T steps per launch through cda_run_random (random agents sampled in the kernel, "
                         "market state resident in LDS across steps, no per-step barrier between markets)")
+    p.add_argument("--learner", choices=["none", "dp"], default="none",
+                   help="not the headline run: 'dp' = the PPO loop of BASELINE configs[4] (ppo.train_fused, hand-written network kernels) as a DATA-PARALLEL learner - every rank "
+                        "rolls out and back-propagates its own shard of markets, the ranks all-reduce the 0.9-MB gradient once per minibatch step (SURVEY 8(e): 'if the learner is "
+                        "itself data-parallel over the same shards, the all-gather can be skipped entirely'); here a step = one iteration (a 64-step rollout + its update)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline sample")
     return p.parse_args()
@@ -202,6 +206,42 @@ def pmc_entry(n, a, info, groups):
     return None
 
 
+def learner_dp(args, dist, world, rank, device, backend):
+    """--learner dp: W + K iterations of ppo.train_fused on this rank's shard, gradients summed over the ranks; K iterations timed (max over ranks of the
+    per-iteration device times, each bracketed by synchronize).  One JSON line on rank 0."""
+    import torch
+    from gym_continuousdoubleauction_amd import CDAVecEnv, ppo
+    from gym_continuousdoubleauction_amd.parallel import make_grad_allreduce
+    N, A = CONFIGS[args.config]
+    N = args.markets if args.markets is not None else N
+    A = args.agents if args.agents is not None else A
+    K, W = (args.steps if args.steps != 1000 else 8), (args.warmup if args.warmup != 64 else 2)
+    T = 64
+    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 4096, "is_render": False, "auto_reset": True}
+    env = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=False)
+    allreduce = make_grad_allreduce(dist) if world > 1 else None
+    _, hist = ppo.train_fused(env, iters=W + K, horizon=T, seed=0, log=lambda s: None, chains=args.groups or 4, allreduce=allreduce, world=world, first_market=rank * N)
+    dt = torch.tensor([sum(h["rollout_s"] + h["update_s"] for h in hist[W:])], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    flags = int((env.flags() != 0).sum().item())
+    env.close()
+    if rank == 0:
+        elapsed = float(dt.item())
+        print(json.dumps({"metric": "agent-steps/sec end to end (rollout + PPO update), data-parallel learner over the market shards", "value": world * N * A * T * K / elapsed,
+                          "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16 operands, f32 accumulation (network); int32+dec28+f64 (env)", "data": "synthetic",
+                          "config": {"workload": f"{N} markets x {A} agents per GPU (global {world * N}), PPO policy on the hand-written MFMA network kernels in the loop, horizon {T}, "
+                                                 "4 epochs, 262144-sample minibatches; a step = one iteration",
+                                     "collective": ("none (one rank)" if world == 1 else
+                                                    f"one all-reduce of the 0.9-MB gradient per minibatch step + one of the two advantage sums per rollout, torch.distributed over {backend}; "
+                                                    "no observation / reward hand-back"),
+                                     "flagged_markets": flags},
+                          "loss_last_iteration": {k: hist[-1][k] for k in ("pg_loss", "v_loss", "entropy")}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -242,6 +282,8 @@ def main():
     from gym_continuousdoubleauction_amd import CDAVecEnv
     from gym_continuousdoubleauction_amd.parallel import ShardedVecEnv, handback_stride
 
+    if args.learner == "dp":
+        return learner_dp(args, dist, world, rank, device, backend)
     N, A = CONFIGS[args.config]
     N = args.markets if args.markets is not None else N
     A = args.agents if args.agents is not None else A

@@ -132,6 +132,8 @@ class LeagueSlotMapper:
         cand = self.pool()
         if not cand:                                          # the reference's fallback for an empty pool: slot a plays policy_a (a random module here)
             bank.slot_net[:, self.num_trainable:] = LEAGUE_RANDOM
+            if slot_pool is not None:
+                slot_pool.fill_(-1)
             return bank.slot_net
         cdf = np.cumsum(self.pool_probabilities())
         cdf /= cdf[-1]

@@ -150,6 +150,20 @@ def _guarded(fn, what, streams=(), timeout=None, device=None, on_timeout="exit")
     return box.get("ret")
 
 
+def make_grad_allreduce(dist=None, group=None):
+    """The one collective of a data-parallel learner (SURVEY 8(e) "if the learner is itself data-parallel over the same shards, the all-gather can be skipped
+    entirely"): callable(tensor) -> the tensor summed in place over the ranks, on the caller's stream semantics of torch.distributed (RCCL: enqueued behind the
+    current stream's work, the current stream ordered behind it; gloo: through the host).  mlp.FusedUpdate calls it on the 0.9-MB gradient between the reduce and
+    the optimiser launches of every minibatch step; ppo.train_fused also on the two advantage sums of a rollout."""
+    import torch.distributed as tdist
+    d = dist or tdist
+
+    def allreduce(t):
+        d.all_reduce(t, op=d.ReduceOp.SUM, group=group)
+        return t
+    return allreduce
+
+
 class _Rccl:
     """RCCL through ctypes: only what the native hand-back needs - communicators the C side can call ncclAllGather on
     (cda_step_groups_handback issues the collectives itself, on the chains' own HIP streams).  The library is the copy PyTorch

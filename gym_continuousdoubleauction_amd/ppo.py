@@ -488,7 +488,7 @@ def adapt_kl_coef(kl_coef, sampled_kl, kl_target):
 
 def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, seed=0, log=print, use_graph=True, chains=4, minibatch=262144,
                 gamma=None, lam=None, clip=None, vf_coef=None, ent_coef=None, policy=None, keep=None, sub_batches=None, objective=None, recorder=None, info_markets=0,
-                allreduce=None, world=1):
+                allreduce=None, world=1, first_market=0):
     """The PPO loop on the hand-written network kernels (mlp.py, include/cda_mlp.h): rollouts as `chains` independent per-chain launch
     sequences (policy forward + sampling -> env step -> auto reset, one HIP graph per chain, no cross-stream edge inside the horizon), the
     sample records completed by one GAE launch, the update as {gather + forward + loss + back-propagation, weight gradients, reduce, clip + Adam}
@@ -496,7 +496,10 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     objective: a dict over PPO_DEFAULTS' keys (RLLIB_DEFAULTS = what the reference's RLlib run optimises); the explicit keyword arguments override it.
     recorder + info_markets = S: the last S markets run as a chain of their own with the info tensors of every step (RolloutChains.info) and the recorder
     (episode_record.BatchedEpisodeRecorder over those markets) is fed from the rollout buffers after the horizon - no per-step host call.
-    allreduce / world: a data-parallel learner (mlp.FusedUpdate); every rank runs this loop on its own env shard.
+    allreduce / world / first_market: a DATA-PARALLEL learner (one process per GPU): every rank runs this loop on its own env shard (its markets are the global
+    markets [first_market, first_market + N): seeds and sampling keys follow the global index), rolls out and back-propagates locally, and the ranks sum the
+    gradient (parallel.make_grad_allreduce: one all-reduce of 0.9 MB per minibatch step, mlp.FusedUpdate) and the two advantage sums of a rollout - no
+    observation ever crosses the fabric.  Every rank starts from the same parameters (same `seed`) and applies the same steps.
     Needs a HIP CDAVecEnv with auto_reset and 168-float observations.  Returns (FusedPolicy, history); `keep` (a dict) receives the last
     rollout's buffers and the RolloutChains object.  history[i]: losses, `mean_reward` (of the rollout's slice of the episodes - it depends on WHICH part of
     the episodes the slice covers) and `episode_return` (mean return of the episodes that were COMPLETED during the iteration, None if none was)."""
@@ -510,10 +513,10 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     N, A, T = env.n_markets, env.num_agents, int(horizon)
     if policy is None:
         policy = FusedPolicy(dev, seed=seed)
-    env.reset(seed=seed)
+    env.reset(seed=seed + int(first_market))
     use_kl = obj["kl_coef"] > 0.0
-    roll = RolloutChains(env, policy, T, groups=chains, seed=seed, use_graphs=use_graph, with_dist=use_kl, capture_ends=bool(obj["bootstrap_truncation"]),
-                         info_markets=info_markets if recorder is not None else 0)
+    roll = RolloutChains(env, policy, T, groups=chains, seed=seed + 7919 * int(first_market), use_graphs=use_graph, with_dist=use_kl,
+                         capture_ends=bool(obj["bootstrap_truncation"]), info_markets=info_markets if recorder is not None else 0)
     R = T * N
     rows_mb = max(32, min(R, (max(1, minibatch // A) // 32) * 32))
     import os
@@ -527,6 +530,9 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
         t0 = time.perf_counter()
         buf = roll.run()
         records = roll.gae(gamma=obj["gamma"], lam=obj["lam"], reward_scale=obj["reward_scale"])     # advantages + returns into the sample records, one launch
+        if allreduce is not None and world > 1:                              # the advantages are standardised over the GLOBAL batch
+            allreduce(records[1])
+            records = (records[0], records[1], records[2] * world)
         torch.cuda.synchronize(dev)
         t_roll = time.perf_counter()
         upd.set_extra(kl_coef=kl_coef, vf_clip=obj["vf_clip"], dist_old=buf.get("dist"), log_std_old=roll.log_std_old if use_kl else None)

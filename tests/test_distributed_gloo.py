@@ -193,3 +193,54 @@ def test_two_rank_shards_gather_to_the_single_process_result(tmp_path):
         assert np.array_equal(got["obs"][t].view(np.uint32), obs.numpy().view(np.uint32)), t
         assert np.array_equal(got["rew"][t].view(np.uint64), rew.numpy().view(np.uint64)), t
         assert np.array_equal(got["term"][t], term.numpy()) and np.array_equal(got["trunc"][t], trunc.numpy())
+
+
+def _dp_worker(rank, world, port, outdir):
+    """the data-parallel learner's rule with the PyTorch statement of the network: a rank's loss is normalised by the GLOBAL minibatch, the gradients are summed"""
+    import torch
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gym_continuousdoubleauction_amd import ppo
+    from gym_continuousdoubleauction_amd.parallel import make_grad_allreduce, shard_range
+    torch.manual_seed(5)                                      # every rank builds the same network
+    m = ppo.ActorCritic(168)
+    g = torch.Generator().manual_seed(11)                     # ... and knows the whole synthetic batch; it works on its own rows
+    R, A = 96, 4
+    x = torch.randn(R, 168, generator=g)
+    acts = (torch.randint(0, 9, (R * A,), generator=g), torch.randint(0, 10, (R * A,), generator=g), torch.randint(0, 3, (R * A,), generator=g), torch.randn(R * A, 2, generator=g))
+    lp_old, adv, ret = torch.randn(R * A, generator=g) * 0.1 - 7, torch.randn(R * A, generator=g), torch.randn(R * A, generator=g)
+
+    def loss_of(rows, norm_rows):
+        sel = (torch.arange(A)[None, :] + rows[:, None] * A).reshape(-1)
+        logp, ent, v = m.evaluate(x[rows], tuple(a[sel] for a in acts), agents_per_row=A)
+        ratio = (logp - lp_old[sel]).exp()
+        per = -torch.min(ratio * adv[sel], ratio.clamp(0.8, 1.2) * adv[sel]) + 0.5 * (v - ret[sel]).pow(2) - 0.01 * ent
+        return per.sum() / (norm_rows * A)
+    first, cnt = shard_range(rank, world, R)
+    loss_of(torch.arange(first, first + cnt), R).backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    allreduce = make_grad_allreduce(dist)
+    allreduce(flat)
+    for p in m.parameters():
+        p.grad = None
+    loss_of(torch.arange(R), R).backward()                     # the single-process gradient on the union batch
+    want = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert torch.allclose(flat, want, rtol=1e-4, atol=1e-7), float((flat - want).abs().max())
+    # the advantage sums of a rollout travel the same way
+    s = torch.tensor([float(adv[first * A:(first + cnt) * A].sum()), float((adv[first * A:(first + cnt) * A] ** 2).sum())], dtype=torch.float64)
+    allreduce(s)
+    assert abs(float(s[0]) - float(adv.sum())) < 1e-4 and abs(float(s[1]) - float((adv ** 2).sum())) < 1e-4
+    if rank == 0:
+        open(os.path.join(outdir, "dp_ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_learner_rule_two_ranks(tmp_path):
+    """every rank back-propagates its own shard with the loss normalised by the global minibatch; ONE all-reduce (sum) of the gradient gives the
+    single-process gradient on the union batch (here with the PyTorch statement of the network; the HIP kernels under the same rule: tests/test_hip_dp.py)."""
+    port = 29500 + (os.getpid() * 7 + 3) % 400
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "dp_ok").exists()

@@ -67,7 +67,7 @@ def test_device_assignment_equals_the_reference_mapping():
         torch.cuda.synchronize()
         sp, sn = slot_pool.cpu().numpy(), bank.slot_net.cpu().numpy()
         names = np.array(m.available_modules, dtype=object)
-        got = np.where(sp < 0, names[np.tile(np.arange(A), (N, 1))], names[np.maximum(sp, 0) + k])
+        got = np.where(sp < 0, names[np.tile(np.arange(A), (N, 1))], names[np.minimum(np.maximum(sp, 0) + k, len(names) - 1)])
         assert got.tolist() == c["assignment"]
         want_net = np.array([[net_of.get(nm, -1) if a >= k else a for a, nm in enumerate(row)] for row in c["assignment"]])
         assert np.array_equal(sn, want_net)
@@ -410,6 +410,7 @@ def test_fused_league_training_runs_the_reference_topology():
     # iterations 1, 3, 5 (episodes end every second iteration), the third one evicting champion_1
     assert [h["promoted"] for h in hist] == [None, "champion_1", None, "champion_2", None, "champion_3"]
     assert league.mapper.pool()[-2:] == ["champion_2", "champion_3"] and set(league.net_of) == {"champion_2", "champion_3"} and bank.n_frozen == 2
+    assert keep["rollout"].graphs is not None                   # the rollout stayed on its captured graphs while champions joined (the launch grid covers the bank's capacity)
     assert "module_returns" in hist[1] and "policy_0" in hist[1]["module_returns"] and "module_returns" not in hist[0]
     sn = bank.slot_net.cpu()
     assert (sn[:, 0] == 0).all() and (sn[:, 1] == 1).all() and int(sn.max()) <= 3 and bool((sn[:, 2:] >= 2).any()) and bool((sn[:, 2:] == -1).any())

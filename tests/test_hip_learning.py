@@ -25,12 +25,15 @@ def test_fused_loop_improves_the_episode_return_and_tracks_the_float32_torch_loo
     f, l = c["fused"], c["legacy"]
     assert all(x is not None and math.isfinite(x) for x in f) and all(math.isfinite(x) for x in l)
     f0, f1, l0, l1 = sum(f[:3]) / 3, sum(f[-3:]) / 3, sum(l[:3]) / 3, sum(l[-3:]) / 3
-    # an untrained policy places an order on ~8 of 9 categories every step: the order penalty alone costs ~0.1 per step; learning = fewer, better orders
-    assert f1 > f0 + 0.25 * abs(f0), (f0, f1)                  # the fused loop improves its return by at least a quarter of where it started
-    assert l1 > l0 + 0.25 * abs(l0), (l0, l1)                  # ... and so does the float32 statement of the same loop
-    assert abs(f0 - l0) <= 0.15 * abs(l0), (f0, l0)            # both start from the same place (same init law, same env seeds; other action draws)
-    assert abs(f1 - l1) <= 0.5 * abs(l1 - l0), (f1, l1)        # ... and end within half of the float32 loop's own improvement of each other
-    assert c["fused_entropy"][-1] < c["fused_entropy"][0]       # the policy has sharpened
+    # Measured (profiles/r05/learning_curve.txt): an untrained policy loses ~2000 per agent and 32-step episode (random large orders: mark-to-market losses with
+    # the 1.5 x loss multiplier, the drawdown penalty on top); after 40 iterations both loops lose ~1-2: fused -2238 -> -0.9, float32 torch -2723 -> -1.9.
+    assert f0 < -1000 and l0 < -1000, (f0, l0)                  # where an untrained policy starts (the two loops draw their initial weights differently: +-25 %)
+    assert abs(f0 - l0) <= 0.35 * abs(l0), (f0, l0)
+    assert f1 > 0.02 * f0, (f0, f1)                             # the fused loop recovers at least 98 % of that loss (measured: 99.94 %)
+    assert l1 > 0.02 * l0, (l0, l1)                             # ... and so does the float32 statement of the same loop
+    assert abs(f1 - l1) <= 0.01 * abs(l0), (f1, l1)             # ... and they end within 1 % of the starting loss of each other
+    assert min(f[20:]) > 0.02 * f0                              # no collapse on the way
+    assert c["fused_entropy"][-1] < c["fused_entropy"][0] and c["fused_v_loss"][-1] < 0.05 * c["fused_v_loss"][0]     # a sharper policy, a fitted value network
 
 
 def test_ten_optimiser_steps_follow_float32_autograd_and_torch_adam():
@@ -89,8 +92,8 @@ def test_ten_optimiser_steps_follow_float32_autograd_and_torch_adam():
     # Adam divides every coordinate's step by the root of its own second moment: a coordinate whose gradient is at the noise level of the bfloat16 operands
     # (2^-8 relative per product term) takes a full-size step in a direction the noise decides - the displacement VECTOR agrees to a few per cent, not to 1e-2;
     # the large coordinates (the ones that matter for the loss) agree far better: checked separately
-    assert cos > 0.97, cos
-    assert drift < 0.25, drift
+    assert cos > 0.998, cos                                       # measured 0.99923
+    assert drift < 0.06, drift                                    # measured 0.039
     big = d_want.abs() > 0.5 * lr * 10                           # coordinates that moved (nearly) every step the same way: a consistent, well-resolved gradient
     assert int(big.sum()) > 1000
     drift_big = float((got - want)[big].norm() / d_want[big].norm())
