@@ -837,7 +837,16 @@ struct FbArgs {
     float* out; float* d_out;        // optional f32 [rows][32] copies of the outputs and their gradients (tests, diagnostics)
     double* sums5;
     unsigned long long* dbg; int dbg_block;
+    int exper;                       // CDA_MLP_TIMING builds only (tools/fb_wgrad_fusion_probe.py): bit 0 = leave out the h1p / dz2p stores (what a fused dW2 would not need),
+                                     // bit 1 = 64 extra MFMAs per wave and tile fed from LDS after MdH2 (the arithmetic a fused dW2 = dz2^T h1 would add); results are then wrong
 };
+__device__ __forceinline__ void keep_packed(const float (&v)[16], bf16x8 (&k)[2]) {
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    f32x8 f0, f1;
+    #pragma unroll
+    for (int r = 0; r < 8; r++) { f0[r] = v[r]; f1[r] = v[8 + r]; }
+    k[0] = __builtin_convertvector(f0, bf16x8); k[1] = __builtin_convertvector(f1, bf16x8);
+}
 __device__ __forceinline__ void store_packed_keep(__bf16* __restrict__ base, long long rt, int nft, int ft, int lane, const float (&v)[16], bf16x8 (&k)[2]) {
     typedef __attribute__((ext_vector_type(8))) float f32x8;
     f32x8 f0, f1;
@@ -942,8 +951,13 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
         float v0[16], v1[16];
         #pragma unroll
         for (int r = 0; r < 16; r++) { v0[r] = tanh_biased(acc[it][0][r], b1_0); v1[r] = tanh_biased(acc[it][1][r], b1_1); }
+#ifdef CDA_MLP_TIMING
+        if (A.exper & 1) { keep_packed(v0, k1[it][0]); keep_packed(v1, k1[it][1]); } else
+#endif
+        {
         store_packed_keep(A.h1p, row0 / 32 + it, 16, ft0, lane, v0, k1[it][0]);
         store_packed_keep(A.h1p, row0 / 32 + it, 16, ft0 + 1, lane, v1, k1[it][1]);
+        }
         store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1204,12 +1218,35 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
                 v0[r] = (float)(__bf16)(acc[it][0][r] * (1.0f - h0 * h0)); v1[r] = (float)(__bf16)(acc[it][1][r] * (1.0f - h1 * h1));
                 colsum0 += v0[r]; colsum1 += v1[r];
             }
-            store_packed(A.dz2p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz2p, row0 / 32 + it, 16, ft0 + 1, lane, v1);
+#ifdef CDA_MLP_TIMING
+            if (!(A.exper & 1))
+#endif
+            { store_packed(A.dz2p, row0 / 32 + it, 16, ft0, lane, v0); store_packed(A.dz2p, row0 / 32 + it, 16, ft0 + 1, lane, v1); }
             store_lds_pair(act, ACT_LD, 32 * it, 64 * w, lane, v0, v1);         // (h2's image was last read by MH, two barriers ago)
             __builtin_amdgcn_sched_barrier(0);
         }
         colsum0 += __shfl_xor(colsum0, 32, 64); colsum1 += __shfl_xor(colsum1, 32, 64);
         if (h == 0) { bs[CDA_MLP_FEAT + f0 + 2 * j] = colsum0; bs[CDA_MLP_FEAT + f0 + 2 * j + 1] = colsum1; }
+#ifdef CDA_MLP_TIMING
+        if (A.exper & 2) {
+            // the arithmetic of a fused dW2: this wave's 64 dz2 features (A operand: the accumulators' own layout, here k2's registers stand in) against all 256
+            // features of h1 read from LDS in operand form (16 B per lane, contiguous: the xs / act bytes stand in): 2 x 8 tiles x 4 k-steps = 64 MFMAs
+            f32x16 extra[4];
+            #pragma unroll
+            for (int q = 0; q < 4; q++) extra[q] = zero16();
+            const bf16x8* lb = reinterpret_cast<const bf16x8*>(smem) + lane;
+            #pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const bf16x8 b0 = lb[64 * (2 * u)], b1 = lb[64 * (2 * u + 1)];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) extra[q] = mfma(k2[q >> 1][q & 1][u & 1], (q & 1) ? b1 : b0, extra[q]);
+            }
+            float keep = 0.0f;
+            #pragma unroll
+            for (int q = 0; q < 4; q++) keep += extra[q][0] + extra[q][15];
+            if (keep == 123.456f) bs[0] = keep;                                  // (keeps the products alive)
+        }
+#endif
     }
     MLP_MARKH(14);
     __syncthreads();
@@ -1297,10 +1334,10 @@ __device__ __forceinline__ void wgrad_store(float* __restrict__ dst, int ld, int
         }
 }
 struct WgradArgs { const bf16x8* x_pk; const bf16x8* h1p; const bf16x8* h2p; const bf16x8* dz1p; const bf16x8* dz2p; const bf16x8* doutp;
-                   long long n_rt; int n_chunks; float* slab; };
+                   long long n_rt; int n_chunks; float* slab; int first_job; };
 __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, wi = w >> 1, wj = w & 1;
-    const int job = (int)blockIdx.y, chunk = (int)blockIdx.x;
+    const int job = (int)blockIdx.y + A.first_job, chunk = (int)blockIdx.x;
     const long long rt0 = A.n_rt * chunk / A.n_chunks, rt1 = A.n_rt * (chunk + 1) / A.n_chunks;
     float* slab = A.slab + (size_t)chunk * CDA_MLP_SLAB;
     if (job < 2) {
@@ -1964,6 +2001,9 @@ extern "C" int cda_mlp_backward(const void* wb, const float* d_out, const void* 
 #ifdef CDA_MLP_TIMING
 static unsigned long long* g_fb_dbg = NULL; static int g_fb_dbg_block = 0;
 extern "C" void cda_tools_mlp_fb_dbg(void* dbg_u64x8x32, int32_t block) { g_fb_dbg = (unsigned long long*)dbg_u64x8x32; g_fb_dbg_block = block; }
+// tools/fb_wgrad_fusion_probe.py: FbArgs::exper, extra dynamic LDS for k_mlp_fb (above half of the CU's 160 KB: ONE workgroup per CU), weight-gradient jobs to leave out
+static int g_fb_exper = 0, g_fb_lds_pad = 0, g_wgrad_first_job = 0;
+extern "C" void cda_tools_mlp_experiment(int32_t fb_flags, int32_t fb_lds_pad_bytes, int32_t wgrad_first_job) { g_fb_exper = fb_flags; g_fb_lds_pad = fb_lds_pad_bytes; g_wgrad_first_job = wgrad_first_job; }
 #endif
 extern "C" int cda_mlp_forward_backward(const void* wb, const float* theta, const float* obs, const int64_t* perm, int64_t n_rows, int64_t norm_rows,
                                         const float* rec, const double* adv_stats2, int64_t adv_count, int32_t agents_per_row, float clip, float vf_coef, float ent_coef,
@@ -1983,11 +2023,11 @@ extern "C" int cda_mlp_forward_backward(const void* wb, const float* theta, cons
     A.dist_old = extra && extra->kl_coef != 0.0f ? extra->dist_old : NULL; A.log_std_old = extra ? extra->log_std_old : NULL;
     A.x_pk = (__bf16*)x_pk; A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.dz1p = (__bf16*)dz1p; A.dz2p = (__bf16*)dz2p; A.doutp = (__bf16*)doutp; A.bias_slab = bias_slab;
     A.out = out; A.d_out = d_out; A.sums5 = sums5;
+    size_t lds = fb_lds(agents_per_row, A.dist_old != NULL);
 #ifdef CDA_MLP_TIMING
-    A.dbg = g_fb_dbg; A.dbg_block = g_fb_dbg_block;
+    A.dbg = g_fb_dbg; A.dbg_block = g_fb_dbg_block; A.exper = g_fb_exper; lds += (size_t)g_fb_lds_pad;
 #endif
     if (clear && hipMemsetAsync(sums5, 0, (size_t)CDA_MLP_LOSS_SLOTS * 8 * sizeof(double), st) != hipSuccess) return CDA_ERR_HIP;
-    const size_t lds = fb_lds(agents_per_row, A.dist_old != NULL);
     int rc = allow_lds(k_mlp_fb, lds); if (rc) return rc;
     const long long tiles = (n_rows + 63) / 64;
     hipLaunchKernelGGL(k_mlp_fb, dim3((unsigned)(16 * ((tiles + 7) / 8))), dim3(256), lds, st, A);
@@ -1999,8 +2039,12 @@ extern "C" int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p,
                              int64_t n_rows, int32_t n_chunks, float* slab, void* stream) {
     if (!x_pk || !h1p || !h2p || !dz1p || !dz2p || !doutp || !slab || n_rows < 32 || (n_rows & 31) || n_chunks < 1 || n_chunks > n_rows / 32) return CDA_ERR_INVALID;
     WgradArgs A; A.x_pk = (const bf16x8*)x_pk; A.h1p = (const bf16x8*)h1p; A.h2p = (const bf16x8*)h2p; A.dz1p = (const bf16x8*)dz1p; A.dz2p = (const bf16x8*)dz2p;
-    A.doutp = (const bf16x8*)doutp; A.n_rt = n_rows / 32; A.n_chunks = n_chunks; A.slab = slab;
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)n_chunks, 5), dim3(256), 0, (hipStream_t)stream, A);
+    A.doutp = (const bf16x8*)doutp; A.n_rt = n_rows / 32; A.n_chunks = n_chunks; A.slab = slab; A.first_job = 0;
+    unsigned jobs = 5;
+#ifdef CDA_MLP_TIMING
+    A.first_job = g_wgrad_first_job; jobs = 5u - (unsigned)g_wgrad_first_job;      // (timing only: jobs 0, 1 = dW2's two blocks)
+#endif
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)n_chunks, jobs), dim3(256), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
