@@ -36,6 +36,8 @@ What the line reports (one MI355X):
                              cross-stream edge inside the K steps (mlp.RolloutChains: the rollout of the PPO loop of BASELINE configs[4], random
                              initial weights, no info tensors) - what a learner in the loop gets, where value_ordered_per_step is what it
                              would get through per-step event edges
+  value_league_self_play     the reference's training topology END TO END on the fused kernels (league_train.train_league_fused): 2048 markets x 8 agents, 2
+                             separately trained policies against random modules + champion snapshots, rollout + both PPO updates per iteration
   roofline                   HIP event pairs on the chains' own streams around the k_step launches of the headline leg;
                              `traffic` / `issue_frac` only when a committed PMC pass of exactly this shape exists
                              (profiles/pmc/<markets>x<agents>_info<0|1>_g<groups>.json)
@@ -90,6 +92,7 @@ def parse():
                    help="N>1 hand-back: 'rccl' = ncclAllGather issued natively per chain (cda_step_groups_handback), 'torch' = torch.distributed collectives per chain, "
                         "'auto' = rccl when the process group runs on RCCL and the start-up self-check passes (env: CDA_BENCH_TRANSPORT)")
     p.add_argument("--no-policy-leg", action="store_true", help="skip value_policy_in_loop")
+    p.add_argument("--no-league-leg", action="store_true", help="skip value_league_self_play")
     p.add_argument("--fused", type=int, default=0, metavar="T",
                    help="not the headline run: T steps per launch through cda_run_random (random agents sampled in the kernel, "
                         "market state resident in LDS across steps, no per-step barrier between markets)")
@@ -469,6 +472,23 @@ def main():
         except Exception as ex:  # noqa: BLE001 - an extra leg never fails the headline
             policy_leg = {"error": repr(ex)}
 
+    # the reference's own training topology, end to end (league_train.train_league_fused): 2048 markets x 8 agents, 2 separately trained policies against random
+    # modules + champion snapshots, rollout + both updates per iteration - a learner-side extra, reported in agent-steps/s like everything else on the line
+    league_leg = None
+    if world == 1 and not args.no_extra_legs and not args.no_policy_leg and not args.no_league_leg and not args.fused and not gather:
+        try:
+            from gym_continuousdoubleauction_amd.league_train import train_league_fused
+            lN, lA, lT, liters = 2048, 8, 64, 6
+            lenv = CDAVecEnv({"num_of_agents": lA, "init_cash": 1000000, "max_step": lT, "is_render": False, "auto_reset": True}, n_markets=lN, device=str(device), with_info=False)
+            _, lg, lh = train_league_fused(lenv, iters=liters, horizon=lT, num_trainable=2, log=lambda s_: None)
+            tail = lh[2:]
+            league_leg = {"value": sum(h["agent_steps"] for h in tail) / sum(h["rollout_s"] + h["update_s"] for h in tail), "iterations": liters, "timed": len(tail),
+                          "rollout_ms": statistics.median(h["rollout_s"] for h in tail) * 1e3, "update_ms": statistics.median(h["update_s"] for h in tail) * 1e3,
+                          "champions": len(lg.history), "flagged": int((lenv.flags() != 0).sum().item()), "shape": (lN, lA, lT)}
+            lenv.close()
+        except Exception as ex:  # noqa: BLE001
+            league_leg = {"error": repr(ex)}
+
     if rank == 0:
         total_agent_steps = float(world) * N * A * K
         elapsed = statistics.median(took)
@@ -537,6 +557,17 @@ def main():
                                                    f"{K} steps per HIP graph" + ("" if policy_leg["graphs"] else " (graph capture failed: direct launches)")
                                                    + f", no info tensors; min / max over the repeats: {total_agent_steps / policy_leg['max']:.4g} / {total_agent_steps / policy_leg['min']:.4g}")
                 out["config"]["flagged_markets_policy_in_loop"] = policy_leg["flagged"]
+        if league_leg is not None:
+            if "error" in league_leg:
+                out["value_league_self_play"] = None
+                out["config"]["league_self_play"] = f"failed: {league_leg['error']}"
+            else:
+                out["value_league_self_play"] = league_leg["value"]
+                lN, lA, lT = league_leg["shape"]
+                out["config"]["league_self_play"] = (f"end to end (rollout + one PPO update per trainable policy): {lN} markets x {lA} agents, 2 separately trained policies against "
+                                                     f"6 uniform random modules + champion snapshots drawn per episode and slot by the reference's mapping rule (on the device), {lT}-step "
+                                                     f"episodes; {league_leg['timed']} of {league_leg['iterations']} iterations timed: rollout {league_leg['rollout_ms']:.2f} ms + updates "
+                                                     f"{league_leg['update_ms']:.2f} ms per iteration, {league_leg['champions']} champions promoted, {league_leg['flagged']} flagged markets")
         for name, ex in extras.items():
             out[f"value_{name}"] = total_agent_steps / ex["elapsed"]
             out[f"ms_per_step_{name}"] = ex["elapsed"] / K * 1e3

@@ -2024,6 +2024,11 @@ extern "C" int cda_mlp_forward_backward(const void* wb, const float* theta, cons
     A.x_pk = (__bf16*)x_pk; A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.dz1p = (__bf16*)dz1p; A.dz2p = (__bf16*)dz2p; A.doutp = (__bf16*)doutp; A.bias_slab = bias_slab;
     A.out = out; A.d_out = d_out; A.sums5 = sums5;
     size_t lds = fb_lds(agents_per_row, A.dist_old != NULL);
+    {   // CDA_MLP_FB_ONE_WG=1 in the environment: extra dynamic LDS so that ONE workgroup fits a CU instead of two (a launch parameter, not a code path: measuring knob)
+        static int one_wg = -1;
+        if (one_wg < 0) { const char* e = getenv("CDA_MLP_FB_ONE_WG"); one_wg = e ? atoi(e) : 0; }
+        if (one_wg && lds <= 80 * 1024) lds = 81 * 1024;
+    }
 #ifdef CDA_MLP_TIMING
     A.dbg = g_fb_dbg; A.dbg_block = g_fb_dbg_block; A.exper = g_fb_exper; lds += (size_t)g_fb_lds_pad;
 #endif

@@ -14,7 +14,8 @@ for sub in ("pmc_w1", "pmc_w2", "pmc_w3"):
         acc, cnt = defaultdict(float), defaultdict(int)
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if "k_stepILb1" not in row.get("Kernel_Name", ""):
+                kn = row.get("Kernel_Name", "")
+                if "k_step" not in kn or not ("ILb1" in kn or "<true>" in kn):
                     continue
                 acc[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
         for k in acc:

@@ -15,7 +15,8 @@ so = os.path.join(ROOT, "gpurun_out", "libcda_hip_timing.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 COUNTERS = "--counters" in sys.argv      # atomics in every out-of-line decimal routine: call counts, but the cycle stamps are then meaningless
 import __graft_entry__ as G   # the product's own flags + the timing macro
-subprocess.check_call(["hipcc"] + G.HIPCC_FLAGS + ["-DCDA_PHASE_TIMING"] + (["-DCDA_DEC_COUNTERS"] if COUNTERS else []) + ["-o", so, os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_hip.hip"), os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_ppo.hip")])
+subprocess.check_call(["hipcc"] + G.HIPCC_FLAGS + ["-DCDA_PHASE_TIMING"] + (["-DCDA_DEC_COUNTERS"] if COUNTERS else []) + ["-o", so, os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_hip.hip"), os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_ppo.hip"),
+                       os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_mlp.hip")])      # (the whole library: _lib binds every symbol of both headers)
 from gym_continuousdoubleauction_amd import _lib
 _lib.LIB_PATH = so
 from gym_continuousdoubleauction_amd import CDAVecEnv
