@@ -123,8 +123,9 @@ class League:
         k, names = self.mapper.num_trainable, self.mapper.available_modules
         N, A = slot_pool.shape
         idx = torch.where(slot_pool < 0, torch.arange(A, device=slot_pool.device, dtype=torch.int32).expand(N, A), slot_pool + k).long().reshape(-1)
-        sums = torch.zeros((len(names), 2), dtype=torch.float64, device=per_slot.device).index_add_(0, idx, per_slot.reshape(-1, 2))
-        host = sums.cpu().numpy()
+        # (a one-hot product, not index_add_: a dozen bins under 16 k double-precision atomics took 1.6 ms per call - a fifth of an iteration)
+        onehot = (idx[None, :] == torch.arange(len(names), device=idx.device)[:, None]).to(torch.float64)
+        host = (onehot @ per_slot.reshape(-1, 2)).cpu().numpy()
         return {names[i]: host[i, 0] / host[i, 1] for i in range(len(names)) if host[i, 1] > 0}
 
     def maybe_promote(self, returns, iteration):
