@@ -186,6 +186,9 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
     R = T * N
     rows_mb = max(32, min(R, (max(1, minibatch) // 32) * 32))              # one sample per row: a minibatch of `minibatch` samples is that many rows
     upds = [FusedUpdate(bank.policies[p], R, rows_mb, 1) for p in range(k)]
+    # the trainable policies' updates are independent of each other: on their own streams one's kernel tails fill with the other's launches (CDA_LEAGUE_UPDATE_STREAMS=0: one stream)
+    import os
+    update_streams = list(roll.streams[:k]) if (k > 1 and len(roll.streams) >= 2 and os.environ.get("CDA_LEAGUE_UPDATE_STREAMS", "1") != "0") else []
     returns = EpisodeReturns(N, A, dev, per_slot=True)
     slot_pool = torch.full((N, A), -1, dtype=torch.int32, device=dev)
     kl_coefs = [float(obj["kl_coef"])] * k
@@ -213,11 +216,20 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
         t_roll = time.perf_counter()
         obs_rows = buf["obs"][:T].view(R, -1)
         outs = []
+        cur = torch.cuda.current_stream(dev)
+        if update_streams:
+            fork = torch.cuda.Event(); fork.record(cur)
         for p in range(k):                                                   # policy p learns from slot p's records only: rec + 8 p floats, a row every 8 A
             upds[p].set_extra(rec_stride=8 * A, kl_coef=kl_coefs[p], vf_clip=obj["vf_clip"], dist_old=buf["dist"][p] if use_kl else None,
                               log_std_old=roll.log_std_old[p] if use_kl else None)
-            outs.append(upds[p].run(obs_rows, epochs=epochs, clip=obj["clip"], vf_coef=obj["vf_coef"], ent_coef=obj["ent_coef"], lr=lr, max_norm=obj["max_norm"],
-                                    records=(rec.data_ptr() + 32 * p, stats[p], count)))
+            st = update_streams[p % len(update_streams)] if update_streams else cur
+            if update_streams:
+                st.wait_event(fork)
+            with torch.cuda.stream(st):                                      # (the policies' updates are independent chains of launches)
+                outs.append(upds[p].run(obs_rows, epochs=epochs, clip=obj["clip"], vf_coef=obj["vf_coef"], ent_coef=obj["ent_coef"], lr=lr, max_norm=obj["max_norm"],
+                                        records=(rec.data_ptr() + 32 * p, stats[p], count)))
+            if update_streams:
+                ev = torch.cuda.Event(); ev.record(st); cur.wait_event(ev)
         returns.update(buf, T)
         if (it + 1) % per_episode == 0:                                      # host work under the GPU's: the next episode's ids
             next_crcs = mapper.episode_crcs(episode_ids((it + 1) // per_episode))
