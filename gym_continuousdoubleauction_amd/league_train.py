@@ -117,7 +117,7 @@ class League:
         self.net_of = {}                                       # champion id -> bank row
         self.history = []                                      # [{"id", "iteration", "return", "source"}]
 
-    def module_returns(self, per_slot, slot_pool):
+    def module_returns(self, per_slot, slot_pool, allreduce=None):
         """{module id: mean return of the episodes it completed this iteration}: per_slot f64 [N, A, 2] (mlp.EpisodeReturns), slot_pool i32 [N, A] (the draw per slot,
         -1 = the slot's own trainable policy).  A handful of tiny device reductions + one small copy to the host."""
         k, names = self.mapper.num_trainable, self.mapper.available_modules
@@ -125,7 +125,10 @@ class League:
         idx = torch.where(slot_pool < 0, torch.arange(A, device=slot_pool.device, dtype=torch.int32).expand(N, A), slot_pool + k).long().reshape(-1)
         # (a one-hot product, not index_add_: a dozen bins under 16 k double-precision atomics took 1.6 ms per call - a fifth of an iteration)
         onehot = (idx[None, :] == torch.arange(len(names), device=idx.device)[:, None]).to(torch.float64)
-        host = (onehot @ per_slot.reshape(-1, 2)).cpu().numpy()
+        sums = onehot @ per_slot.reshape(-1, 2)
+        if allreduce is not None:                              # data parallel: the modules' returns over ALL shards (every rank then takes the same decision)
+            allreduce(sums)
+        host = sums.cpu().numpy()
         return {names[i]: host[i, 0] / host[i, 1] for i in range(len(names)) if host[i, 1] > 0}
 
     def maybe_promote(self, returns, iteration):
@@ -158,13 +161,17 @@ class League:
 
 def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epochs=4, seed=0, original_opponent_weight=1.0, champion_weight=3.0,
                        std_dev_multiplier=0.1, max_champions=8, min_iterations_between_champions=2, chains=4, minibatch=262144, objective=None, use_graph=True,
-                       recorder=None, info_markets=0, run_id="league", log=print, keep=None):
+                       recorder=None, info_markets=0, run_id="league", log=print, keep=None, allreduce=None, world=1, first_market=0):
     """League self-play on the fused kernels (include/cda_mlp.h `cda_league`): the reference's training topology - `num_trainable` SEPARATELY trained policies
     (policy_p plays slot p), every other slot drawn per episode from the pool of uniform random modules and frozen champions by the reference's mapping rule
     (computed on the device, league.LeagueSlotMapper.assign_device) - at the speed of the fused loop: ONE policy launch per step serves every module of every
     market, the rollout never leaves its HIP graphs, each trainable policy's update reads its own slot's sample records in place (record stride, no compaction).
     env: CDAVecEnv with auto_reset; an episode = env.max_step steps = max_step / horizon iterations (horizon must divide it): all markets change opponents
-    together at the episode boundary.  Returns (bank, league, history)."""
+    together at the episode boundary.  Returns (bank, league, history).
+    allreduce / world / first_market: the data-parallel learner of ppo.train_fused for the league - every rank rolls out and back-propagates its own shard of
+    markets (global indices [first_market, first_market + N): env seeds, sampling keys and EPISODE IDS follow them, so the opponents a market meets do not depend
+    on the GPU count), the ranks sum each policy's gradient (one all-reduce of 0.9 MB per policy and minibatch step) and advantage sums, and the per-module returns
+    behind the promotion rule - so every rank promotes the same champions in lockstep."""
     import numpy as np
     from . import ppo
     from .mlp import EpisodeReturns, FusedUpdate, PolicyBank, RolloutChains
@@ -176,23 +183,25 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
     if int(env.max_step) % T:
         raise ValueError("the horizon must divide the episode length (max_step)")
     per_episode = int(env.max_step) // T
-    bank = PolicyBank(dev, N, A, k, max_frozen=max_champions, seed=seed, random_seed=seed + 12345)
+    bank = PolicyBank(dev, N, A, k, max_frozen=max_champions, seed=seed, random_seed=seed + 12345 + 104729 * int(first_market))
     mapper = LeagueSlotMapper(A, k, A - k, original_opponent_weight, champion_weight)
     league = League(mapper, bank, std_dev_multiplier, max_champions, min_iterations_between_champions)
-    env.reset(seed=seed)
+    env.reset(seed=seed + int(first_market))
     use_kl = obj["kl_coef"] > 0.0
-    roll = RolloutChains(env, bank, T, groups=chains, seed=seed, use_graphs=use_graph, with_dist=use_kl, capture_ends=bool(obj["bootstrap_truncation"]),
-                         info_markets=info_markets if recorder is not None else 0)
+    roll = RolloutChains(env, bank, T, groups=chains, seed=seed + 7919 * int(first_market), use_graphs=use_graph, with_dist=use_kl,
+                         capture_ends=bool(obj["bootstrap_truncation"]), info_markets=info_markets if recorder is not None else 0)
     R = T * N
     rows_mb = max(32, min(R, (max(1, minibatch) // 32) * 32))              # one sample per row: a minibatch of `minibatch` samples is that many rows
-    upds = [FusedUpdate(bank.policies[p], R, rows_mb, 1) for p in range(k)]
+    dp = allreduce is not None and world > 1
+    upds = [FusedUpdate(bank.policies[p], R, rows_mb, 1, allreduce=allreduce if dp else None, world=world if dp else 1) for p in range(k)]
     # the trainable policies' updates are independent of each other: on their own streams one's kernel tails fill with the other's launches (CDA_LEAGUE_UPDATE_STREAMS=0: one stream)
     import os
-    update_streams = list(roll.streams[:k]) if (k > 1 and len(roll.streams) >= 2 and os.environ.get("CDA_LEAGUE_UPDATE_STREAMS", "1") != "0") else []
+    update_streams = list(roll.streams[:k]) if (k > 1 and len(roll.streams) >= 2 and not dp and os.environ.get("CDA_LEAGUE_UPDATE_STREAMS", "1") != "0") else []
+    # (data parallel: one stream - the ranks must issue their collectives in ONE order)
     returns = EpisodeReturns(N, A, dev, per_slot=True)
     slot_pool = torch.full((N, A), -1, dtype=torch.int32, device=dev)
     kl_coefs = [float(obj["kl_coef"])] * k
-    episode_ids = lambda e: [f"{run_id}-episode{e}-market{i}" for i in range(N)]     # noqa: E731
+    episode_ids = lambda e: [f"{run_id}-episode{e}-market{int(first_market) + i}" for i in range(N)]     # noqa: E731  (global market index)
     next_crcs = mapper.episode_crcs(episode_ids(0))
     if recorder is not None:
         names = lambda: np.array(mapper.available_modules, dtype=object)             # noqa: E731
@@ -212,6 +221,9 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
                     recorder._name_episodes()
         buf = roll.run()
         rec, stats, count = roll.gae(gamma=obj["gamma"], lam=obj["lam"], reward_scale=obj["reward_scale"])
+        if dp:                                                               # the advantages are standardised over the GLOBAL batch of each policy
+            allreduce(stats)
+            count = count * world
         torch.cuda.synchronize(dev)
         t_roll = time.perf_counter()
         obs_rows = buf["obs"][:T].view(R, -1)
@@ -241,7 +253,7 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
             kl_coefs[p] = ppo.adapt_kl_coef(kl_coefs[p], stats_h[f"policy_{p}"]["kl"], obj["kl_target"])
         promoted = None
         if (it + 1) % per_episode == 0:                                      # episodes just ended: credit the modules, run the reference's promotion rule
-            mr = league.module_returns(returns.per_slot, slot_pool)
+            mr = league.module_returns(returns.per_slot, slot_pool, allreduce=allreduce if dp else None)
             promoted = league.maybe_promote(mr, it)
             stats_h["module_returns"] = {m: float(v) for m, v in mr.items()}
         stats_h.update(promoted=promoted, pool=list(mapper.pool()), mean_reward_trainable=float(buf["reward"][:, :, :k].mean()))

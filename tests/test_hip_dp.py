@@ -94,3 +94,37 @@ def test_bench_learner_dp_two_ranks_on_one_gpu():
                          capture_output=True, text=True, timeout=900)
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
     assert one.returncode == 0 and d1["n_gpus"] == 1 and d1["config"]["collective"] == "none (one rank)"
+
+
+def _league_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    from gym_continuousdoubleauction_amd.league_train import train_league_fused
+    from gym_continuousdoubleauction_amd.parallel import make_grad_allreduce
+    N = 128
+    env = CDAVecEnv({"num_of_agents": 8, "init_cash": 1000000, "max_step": 16, "is_render": False, "auto_reset": True}, n_markets=N, with_info=False)
+    bank, league, hist = train_league_fused(env, iters=4, horizon=16, num_trainable=2, std_dev_multiplier=-10.0, min_iterations_between_champions=2, log=lambda s: None,
+                                            allreduce=make_grad_allreduce(dist), world=world, first_market=rank * N, chains=2)
+    torch.cuda.synchronize()
+    torch.save({"theta": bank.theta[:2].cpu(), "champions": [c["id"] for c in league.history], "returns": [h.get("module_returns") for h in hist],
+                "slot_net": bank.slot_net.cpu(), "flags": int((env.flags() != 0).sum())}, os.path.join(outdir, f"league_{rank}.pt"))
+    dist.barrier()
+    env.close()
+    dist.destroy_process_group()
+
+
+def test_league_data_parallel_ranks_stay_in_lockstep(tmp_path):
+    """The league under the data-parallel learner (two ranks, one GPU, gloo): both ranks hold the SAME two policies after four iterations (summed gradients, global
+    advantage statistics), see the same module returns (summed over the shards) and promote the same champions; their shards' opponents differ (global episode ids)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_league_worker, args=(2, 31200 + os.getpid() % 300, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / f"league_{r}.pt") for r in range(2))
+    assert torch.equal(a["theta"], b["theta"]) and not torch.equal(a["theta"][0], a["theta"][1])
+    assert a["champions"] == b["champions"] and len(a["champions"]) == 2
+    assert a["returns"] == b["returns"] and a["returns"][0] is not None
+    assert not torch.equal(a["slot_net"], b["slot_net"]) and a["flags"] == b["flags"] == 0

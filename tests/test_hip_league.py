@@ -375,7 +375,7 @@ def test_masked_and_rllib_objective_gradient_equals_float32_autograd(A, slot, kl
     for lo, hi, name in BLOCKS(mlp):
         a, b = grad[lo:hi], gm[lo:hi]
         assert (a - b).norm() <= 3e-2 * b.norm() + 1e-9, (name, float((a - b).norm() / b.norm()))
-    assert abs(float(out6[3]) - float(loss)) <= 2e-2 * abs(float(loss)) + 1e-3
+    assert abs(float(out6[3]) - float(loss.detach())) <= 2e-2 * abs(float(loss.detach())) + 1e-3
     assert abs(float(out6[1]) - float(vl)) <= 2e-2 * float(vl) + 1e-4
     if kl_coef:
         assert float(kl) > 1e-4 and abs(float(out6[6]) - float(kl)) <= 3e-2 * float(kl) + 1e-5, (float(out6[6]), float(kl))
