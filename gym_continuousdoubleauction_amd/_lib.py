@@ -29,8 +29,10 @@ MLP_SYMBOLS = [
     "cda_mlp_tile_rows", "cda_mlp_permutation", "cda_mlp_pack", "cda_mlp_policy_step", "cda_mlp_forward", "cda_mlp_prep_rows", "cda_mlp_forward_train", "cda_mlp_backward",
     "cda_mlp_wgrad", "cda_mlp_adam", "cda_ppo_loss32", "cda_gae_records", "cda_ppo_loss_records", "cda_mlp_forward_backward", "cda_mlp_rollout_chain", "cda_mlp_selftest_mfma",
     "cda_mlp_reduce", "cda_mlp_apply", "cda_gae_records_bootstrap", "cda_mlp_values", "cda_episode_returns", "cda_mlp_league_step", "cda_mlp_league_rollout_chain",
-    "cda_gae_records_league", "cda_league_assign",
+    "cda_gae_records_league", "cda_league_assign", "cda_mlp_wgrad_jobs",
 ]
+# the same entry points compiled for other history depths carry the suffix _h<H> (include/cda_mlp.h CDA_MLP_HIST_VARIANTS, csrc/cda_mlp_variant.h)
+MLP_HIST_VARIANTS = (1, 2, 8)
 
 
 class RolloutBufs(C.Structure):
@@ -117,6 +119,8 @@ def lib():
     f32 = C.c_float
     L.cda_mlp_tile_rows.argtypes = []
     L.cda_mlp_tile_rows.restype = i32
+    L.cda_mlp_wgrad_jobs.argtypes = []
+    L.cda_mlp_wgrad_jobs.restype = i32
     L.cda_mlp_pack.argtypes = [vp, vp, vp]
     L.cda_mlp_permutation.argtypes = [u64, i64, vp, vp]
     L.cda_mlp_policy_step.argtypes = [vp, vp, vp, i32, i32, i32, u64, vp, i64] + [vp] * 8 + [vp]
@@ -146,6 +150,10 @@ def lib():
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("cda_strerror", "cda_group_range"):
             fn.restype = C.c_int
+    for h in MLP_HIST_VARIANTS:                              # same signatures, other observation width
+        for name in MLP_SYMBOLS:
+            base, var = getattr(L, name), getattr(L, f"{name}_h{h}")
+            var.argtypes, var.restype = base.argtypes, base.restype
     _lib = L
     return L
 

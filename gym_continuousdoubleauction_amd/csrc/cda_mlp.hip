@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include "cda_mlp_variant.h"        // CDA_MLP_HIST != 4: every entry point of cda_mlp.h gets the suffix _h<H> (one object file per history depth)
 #include "../../include/cda_mlp.h"
 #include "../../include/cda_random_agents.h"
 
@@ -49,12 +50,34 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int OBS = CDA_MLP_OBS, KX = CDA_MLP_KX, XT = CDA_MLP_XTILES, HID = CDA_MLP_HID, NOUT = CDA_MLP_NOUT;
-constexpr int XS_LD = KX + 8;        // LDS row of the observation tile: 184 bf16 = 368 B = 16 x 23 (odd: ds_read_b128 conflict free)
+constexpr int XS_LD = KX + 8;        // LDS row of the observation tile: 184 bf16 = 368 B = 16 x 23 (odd: ds_read_b128 conflict free) at n_hist = 4; 16 x (2 k + 1) for every depth
+// An observation row is 42 H floats = 168 H bytes: 16-byte aligned for even history depths only - rows are requested VW floats at a time
+constexpr int VW = (OBS % 4 == 0) ? 4 : 2;
+typedef std::conditional<VW == 4, float4, float2>::type obsvec;
+template <typename V> __device__ __forceinline__ V vec_zero();
+template <> __device__ __forceinline__ float4 vec_zero<float4>() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+template <> __device__ __forceinline__ float2 vec_zero<float2>() { return make_float2(0.0f, 0.0f); }
+__device__ __forceinline__ obsvec obs_zero() { return vec_zero<obsvec>(); }
+// VW values -> the bf16 LDS image / an f32 LDS row (member access only: an address taken of a register vector sends it through scratch)
+__device__ __forceinline__ void obs_to_bf16(__bf16* dst, const float4& v, bool zero) {
+    bf16x4 b; b[0] = (__bf16)(zero ? 0.0f : v.x); b[1] = (__bf16)(zero ? 0.0f : v.y); b[2] = (__bf16)(zero ? 0.0f : v.z); b[3] = (__bf16)(zero ? 0.0f : v.w);
+    *reinterpret_cast<bf16x4*>(dst) = b;
+}
+__device__ __forceinline__ void obs_to_bf16(__bf16* dst, const float2& v, bool zero) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t b; b[0] = (__bf16)(zero ? 0.0f : v.x); b[1] = (__bf16)(zero ? 0.0f : v.y);
+    *reinterpret_cast<bf16x2_t*>(dst) = b;
+}
+__device__ __forceinline__ void obs_spread(float* dst, const float4& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+__device__ __forceinline__ void obs_spread(float* dst, const float2& v) { dst[0] = v.x; dst[1] = v.y; }
 constexpr int ACT_LD = HID + 8;      // LDS row of an activation tile: 264 bf16 = 528 B = 16 x 33
 constexpr int DO_LD = NOUT + 8;      // LDS row of the d_out tile: 40 bf16 = 80 B = 16 x 5
 constexpr int OUTS_LD = NOUT + 1;    // f32 row of the output tile kept in LDS for the sampling epilogue
 constexpr int N_CAT = 9, N_PRICE = 10, N_OFF = 3, N_LOGITS = 24;
 constexpr int LPS_LD = N_CAT + N_PRICE + N_OFF + 1;   // 23 floats: odd, conflict free
+// k_mlp_fb's first LDS region: the 64-row observation tile, whose bytes are reused for the output tiles (f32 [64][33] + bf16 [64][40]) once layer 1 has read it -
+// the larger of the two (the observation tile from n_hist = 3 on)
+constexpr int FB_XS_BYTES = (64 * XS_LD * 2 > 64 * OUTS_LD * 4 + 64 * DO_LD * 2) ? 64 * XS_LD * 2 : 64 * OUTS_LD * 4 + 64 * DO_LD * 2;
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 constexpr float TWO_LOG2E = 2.885390081777926814f;
@@ -86,20 +109,19 @@ __device__ __forceinline__ void load_x_bf16(const __bf16* __restrict__ x_rm, lon
 }
 template <int M>
 __device__ __forceinline__ void load_x_f32(const float* __restrict__ obs, long long row0, long long rows_end, __bf16* xs) {
-    constexpr int CH = KX / 4, N = M * CH, PER = (N + 255) / 256;                // 44 chunks of 4 values per row (42 real + 2 of zeros)
-    float4 v[PER];
+    constexpr int CH = KX / VW, N = M * CH, PER = (N + 255) / 256;               // n_hist 4: 44 chunks of 4 values per row (42 real + 2 of zeros)
+    obsvec v[PER];
     #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int c = (int)threadIdx.x + 256 * u, cc = c < N ? c : N - 1, r = cc / CH, q = cc - r * CH;
         long long gr = row0 + r; if (gr >= rows_end) gr = rows_end - 1;
-        v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (q < OBS / 4) v[u] = *reinterpret_cast<const float4*>(obs + gr * OBS + q * 4);
+        v[u] = obs_zero();
+        if (q < OBS / VW) v[u] = *reinterpret_cast<const obsvec*>(obs + gr * OBS + q * VW);
     }
     #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
-        bf16x4 b; b[0] = (__bf16)v[u].x; b[1] = (__bf16)v[u].y; b[2] = (__bf16)v[u].z; b[3] = (__bf16)v[u].w;
-        if (c < N) *reinterpret_cast<bf16x4*>(xs + r * XS_LD + q * 4) = b;
+        if (c < N) obs_to_bf16(xs + r * XS_LD + q * VW, v[u], false);
     }
 }
 
@@ -580,18 +602,19 @@ __global__ void k_make_perm(unsigned long long key, long long n, int bits, long 
 }
 
 // ---- update, step 0: gather + convert + both images of the observation rows ---------------------------------------------------
-// one workgroup per 32-row tile: the tile goes through LDS as f32 [32][193]; row-major bf16 rows out of it, and the packed image
+// one workgroup per 32-row tile: the tile goes through LDS as f32 [32][32 XT + 1]; row-major bf16 rows out of it, and the packed image
 // (lane = (feature, row half), slots = rows)
 __global__ __launch_bounds__(256) void k_prep_rows(const float* __restrict__ obs, const long long* __restrict__ perm, long long n_rows,
                                                    __bf16* __restrict__ x_rm, __bf16* __restrict__ x_pk) {
-    __shared__ float t[32][193];
+    __shared__ float t[32][32 * XT + 1];
     const long long rt = blockIdx.x;
-    for (int c = (int)threadIdx.x; c < 32 * 48; c += 256) {                     // 48 chunks of 4 floats per row: 42 real, 6 of zeros
-        const int r = c / 48, q = c - r * 48;
+    constexpr int CPR = 32 * XT / VW;                                           // chunks of VW floats per row (n_hist 4: 48 of 4: 42 real, 6 of zeros)
+    for (int c = (int)threadIdx.x; c < 32 * CPR; c += 256) {
+        const int r = c / CPR, q = c - r * CPR;
         const long long src = perm ? perm[rt * 32 + r] : rt * 32 + r;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (q < OBS / 4) v = *reinterpret_cast<const float4*>(obs + src * OBS + q * 4);
-        t[r][4 * q] = v.x; t[r][4 * q + 1] = v.y; t[r][4 * q + 2] = v.z; t[r][4 * q + 3] = v.w;
+        obsvec v = obs_zero();
+        if (q < OBS / VW) v = *reinterpret_cast<const obsvec*>(obs + src * OBS + q * VW);
+        obs_spread(&t[r][VW * q], v);
     }
     __syncthreads();
     for (int c = (int)threadIdx.x; c < 32 * (KX / 8); c += 256) {               // row-major: 22 chunks of 8 per row
@@ -874,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
     __bf16* xs = reinterpret_cast<__bf16*>(smem);                               // [M][XS_LD]; once layer 1 has read it, its bytes hold:
     float* outs = reinterpret_cast<float*>(smem);                               //   [M][OUTS_LD] f32: the outputs, then (in place) their gradients
     __bf16* dos = reinterpret_cast<__bf16*>(smem + M * OUTS_LD * 4);            //   [M][DO_LD] bf16: the gradients as MdH2's A operand
-    static_assert(M * OUTS_LD * 4 + M * DO_LD * 2 <= M * XS_LD * 2, "the output tiles fit the observation tile's bytes");
+    static_assert(M * OUTS_LD * 4 + M * DO_LD * 2 <= FB_XS_BYTES && M * XS_LD * 2 <= FB_XS_BYTES, "the region holds the observation tile, then the output tiles");
     const int lane = (int)threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     // Workgroup -> (tile, half), XCD-aware: workgroup ids go round the eight XCDs, so ids 8 apart share an L2.  The two halves of a tile gather
     // the same rows and records: id = 16 g + 8 half + k is tile 8 g + k - its sibling is dispatched 8 ids later, on the same XCD, and finds them
@@ -882,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
     const int wg = (int)blockIdx.x, half = (wg >> 3) & 1, tile_id = 8 * (wg >> 4) + (wg & 7);
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if ((long long)tile_id * M >= A.n_rows) return;                             // (the last group of eight may be short; whole workgroups leave)
-    __bf16* act = xs + M * XS_LD;                                               // [M][ACT_LD]: h1, h2, then dz2
+    __bf16* act = reinterpret_cast<__bf16*>(smem + FB_XS_BYTES);                // [M][ACT_LD]: h1, h2, then dz2
     float* lps = reinterpret_cast<float*>(act + M * ACT_LD);                    // [M][LPS_LD] f32: a row's log-probabilities, indexed by the agents' actions
     float* recs = lps + M * LPS_LD;                                             // [M][agents][8]: the tile's sample records
     const long long row0 = (long long)tile_id * M, rows_end = A.n_rows;
@@ -905,12 +928,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
         }
         R1.prime(W1b + (size_t)f0 * KX, KX, lane);
         __syncthreads();
-        constexpr int CH = KX / 4, N = M * CH, PER = (N + 255) / 256;           // 44 chunks of 4 values per row (42 real + 2 of zeros): 11 per thread
-        float4 v[PER];
+        constexpr int CH = KX / VW, N = M * CH, PER = (N + 255) / 256;          // n_hist 4: 44 chunks of 4 values per row (42 real + 2 of zeros): 11 per thread
+        obsvec v[PER];
         #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
-            v[u] = *reinterpret_cast<const float4*>(A.obs + srow[r] * OBS + (q < OBS / 4 ? q : OBS / 4 - 1) * 4);
+            const int c = (int)threadIdx.x + 256 * u, cc = c < N ? c : N - 1, r = cc / CH, q = cc - r * CH;
+            v[u] = *reinterpret_cast<const obsvec*>(A.obs + srow[r] * OBS + (q < OBS / VW ? q : OBS / VW - 1) * VW);
         }
         const int rp = 2 * A.agents, rpd = rp + (A.dist_old ? N_LOGITS / 4 : 0);    // the records: [agents][8] f32 per row = 2 16-B pieces per agent; then the row's old distribution (6 pieces)
         for (int c = (int)threadIdx.x; c < M * rpd; c += 256) {
@@ -921,9 +944,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
         #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int c = (int)threadIdx.x + 256 * u, r = c / CH, q = c - r * CH;
-            bf16x4 b; b[0] = (__bf16)v[u].x; b[1] = (__bf16)v[u].y; b[2] = (__bf16)v[u].z; b[3] = (__bf16)v[u].w;
-            if (q >= OBS / 4) { b[0] = b[1] = b[2] = b[3] = (__bf16)0.0f; }
-            *reinterpret_cast<bf16x4*>(xs + r * XS_LD + q * 4) = b;
+            if (c < N) obs_to_bf16(xs + r * XS_LD + q * VW, v[u], q >= OBS / VW);
         }
     }
     __syncthreads();                                                            // the observation tile is in LDS
@@ -1283,11 +1304,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
 // dW[i][j] = sum over rows of dz[row][i] h[row][j]: both operands come out of HBM in the packed layout, 16 B per lane, straight into
 // the MFMA (no LDS).  One workgroup = one JOB (an output panel) x one row chunk; the chunk's partial sum goes to the slab.
 //   job 0, 1: dW2[b]   256 x 256  = dz2[:, b] ^T h1[:, b]     wave (wi, wj): 128 x 128
-//   job 2, 3: dW1[256 b ..]  256 x 192 = dz1[:, b]^T x        wave (wi, wj): 128 x 96
-//   job 4:    dWo      32 x 512   = d_out^T h2                 wave w: 32 x 128
+//   then, per network half b, WG_XG jobs of dW1[256 b ..]  256 x 32 XT = dz1[:, b]^T x:  wave (wi, wj): 128 x 32 WG_TJ   (n_hist 4: jobs 2, 3: 256 x 192, 128 x 96 per wave)
+//   last job: dWo      32 x 512   = d_out^T h2                 wave w: 32 x 128
 template <int TI, int TJ>
 __device__ __forceinline__ void wgrad_wave(const bf16x8* __restrict__ Ap, int a_nft, int a_ft0, const bf16x8* __restrict__ Bp, int b_nft, int b_ft0,
                                            long long rt0, long long rt1, int lane, f32x16 (&acc)[TI][TJ]) {
+    // (a B tile past the operand's last one - the x panel's tile count need not be a multiple of a wave's share - repeats the last real tile: loaded, multiplied, never stored)
     // a step s = (row tile, k-step of 16 rows); operands of step s + D - 1 are requested before step s multiplies (ring of D register
     // sets, statically indexed; requests past the end repeat the last step and are never multiplied)
     constexpr int D = 4;
@@ -1299,7 +1321,7 @@ __device__ __forceinline__ void wgrad_wave(const bf16x8* __restrict__ Ap, int a_
         #pragma unroll
         for (int ti = 0; ti < TI; ti++) a[slot][ti] = Ap[((rt * a_nft + a_ft0 + ti) * 2 + ks) * 64 + lane];
         #pragma unroll
-        for (int tj = 0; tj < TJ; tj++) b[slot][tj] = Bp[((rt * b_nft + b_ft0 + tj) * 2 + ks) * 64 + lane];
+        for (int tj = 0; tj < TJ; tj++) { const int ft = b_ft0 + tj < b_nft ? b_ft0 + tj : b_nft - 1; b[slot][tj] = Bp[((rt * b_nft + ft) * 2 + ks) * 64 + lane]; }
     };
     request(std::integral_constant<int, 0>{}, s0); request(std::integral_constant<int, 1>{}, s0 + 1); request(std::integral_constant<int, 2>{}, s0 + 2);
     __builtin_amdgcn_sched_barrier(0);
@@ -1319,12 +1341,13 @@ __device__ __forceinline__ void wgrad_wave(const bf16x8* __restrict__ Ap, int a_
 // A_PAIRED / B_PAIRED: the operand's feature tiles are the paired ones of the hidden activations (feature_of); a_ft0 / b_ft0: first tile of
 // this wave inside the panel (i0 / j0 of the panel itself are folded into dst)
 template <int TI, int TJ, bool A_PAIRED, bool B_PAIRED>
-__device__ __forceinline__ void wgrad_store(float* __restrict__ dst, int ld, int a_ft0, int b_ft0, int lane, const f32x16 (&acc)[TI][TJ]) {
+__device__ __forceinline__ void wgrad_store(float* __restrict__ dst, int ld, int a_ft0, int b_ft0, int lane, const f32x16 (&acc)[TI][TJ], int b_nft = 1 << 30) {
     const int j = lane & 31, h = lane >> 5;
     #pragma unroll
     for (int ti = 0; ti < TI; ti++)
         #pragma unroll
         for (int tj = 0; tj < TJ; tj++) {
+            if (b_ft0 + tj >= b_nft) continue;                                   // a dummy tile (see wgrad_wave)
             const int col = B_PAIRED ? feature_of(b_ft0 + tj, j) : 32 * (b_ft0 + tj) + j;
             #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -1333,6 +1356,7 @@ __device__ __forceinline__ void wgrad_store(float* __restrict__ dst, int ld, int
             }
         }
 }
+constexpr int WG_TJ = XT <= 2 ? 1 : (XT <= 4 ? 2 : 3), WG_XG = (XT + 2 * WG_TJ - 1) / (2 * WG_TJ), WG_JOBS = 3 + 2 * WG_XG;     // x tiles per wave, groups per half, jobs (n_hist 4: 3, 1, 5)
 struct WgradArgs { const bf16x8* x_pk; const bf16x8* h1p; const bf16x8* h2p; const bf16x8* dz1p; const bf16x8* dz2p; const bf16x8* doutp;
                    long long n_rt; int n_chunks; float* slab; int first_job; };
 __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
@@ -1348,15 +1372,16 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad(WgradArgs A) {
             for (int b = 0; b < 4; b++) acc[a][b] = zero16();
         wgrad_wave<4, 4>(A.dz2p, 16, 8 * job + 4 * wi, A.h1p, 16, 8 * job + 4 * wj, rt0, rt1, lane, acc);
         wgrad_store<4, 4, true, true>(slab + CDA_MLP_SLAB_W2 + (size_t)job * HID * HID, HID, 4 * wi, 4 * wj, lane, acc);
-    } else if (job < 4) {
-        const int b = job - 2;
-        f32x16 acc[4][3];
+    } else if (job < 2 + 2 * WG_XG) {
+        // dW1: per network half, the x panel's XT tiles in WG_XG groups of 2 WG_TJ (a wave: 128 features x WG_TJ tiles; n_hist 4: one group, 128 x 96 per wave)
+        const int b = (job - 2) / WG_XG, xg = (job - 2) - b * WG_XG, x0 = 2 * WG_TJ * xg + WG_TJ * wj;
+        f32x16 acc[4][WG_TJ];
         #pragma unroll
         for (int a = 0; a < 4; a++)
             #pragma unroll
-            for (int c = 0; c < 3; c++) acc[a][c] = zero16();
-        wgrad_wave<4, 3>(A.dz1p, 16, 8 * b + 4 * wi, A.x_pk, XT, 3 * wj, rt0, rt1, lane, acc);
-        wgrad_store<4, 3, true, false>(slab + CDA_MLP_SLAB_W1 + (size_t)(256 * b) * (32 * XT), 32 * XT, 4 * wi, 3 * wj, lane, acc);
+            for (int c = 0; c < WG_TJ; c++) acc[a][c] = zero16();
+        wgrad_wave<4, WG_TJ>(A.dz1p, 16, 8 * b + 4 * wi, A.x_pk, XT, x0, rt0, rt1, lane, acc);
+        wgrad_store<4, WG_TJ, true, false>(slab + CDA_MLP_SLAB_W1 + (size_t)(256 * b) * (32 * XT), 32 * XT, 4 * wi, x0, lane, acc, XT);
     } else {
         f32x16 acc[1][4];
         #pragma unroll
@@ -1405,10 +1430,15 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
         }
         for (; c < n_chunks; c++) { const float4 v = src[(size_t)c * (CDA_MLP_SLAB / 4)]; s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w; }
         const float g[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
-        const int p = param_of_dense(d);                                          // (groups of four never straddle a row: 168, 192, 256, 512 are multiples of 4)
-        if (p >= 0) {
+        if (OBS % 4 == 0) {
+            const int p = param_of_dense(d);                                      // (groups of four never straddle a row's end: 84, 168, 336 and 192, 256, 512 are multiples of 4)
+            if (p >= 0) {
+                #pragma unroll
+                for (int e = 0; e < 4; e++) { grad[p + e] = g[e]; sq += g[e] * g[e]; }
+            }
+        } else {                                                                  // an odd history depth (42 H inputs): a group may end in W1's zero padding - entry by entry
             #pragma unroll
-            for (int e = 0; e < 4; e++) { grad[p + e] = g[e]; sq += g[e] * g[e]; }
+            for (int e = 0; e < 4; e++) { const int p = param_of_dense(d + e); if (p >= 0) { grad[p] = g[e]; sq += g[e] * g[e]; } }
         }
     } else {
         // 16 entries of the bias slab per block, the row tiles split 16 ways (a serial walk over hundreds of 4-KB strided partials by a
@@ -1817,9 +1847,9 @@ __global__ __launch_bounds__(256) void k_episode_returns(const double* __restric
     if (c > 0.0) { atomicAdd(&done_sum[a], s); atomicAdd(&done_count[a], c); }
     if (per_slot) { per_slot[2 * i] = s; per_slot[2 * i + 1] = c; }              // this rollout's completed episodes of (market, agent): sum of returns, number
 }
-__global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, long long n4) {
+__global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, long long n4) {         // n4 pieces of VW floats
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n4) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    if (i < n4) reinterpret_cast<obsvec*>(dst)[i] = reinterpret_cast<const obsvec*>(src)[i];
 }
 
 __global__ void k_selftest_mfma(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ d) {
@@ -1851,7 +1881,7 @@ int train_mt() {
 }
 size_t fwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + 2 * M * ACT_LD * 2; }
 size_t bwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * OUTS_LD * 4 + 2 * M * ACT_LD * 2; }
-size_t fb_lds(int agents, bool with_dist) { return (size_t)64 * XS_LD * 2 + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * (agents * 32 + (with_dist ? N_LOGITS * 4 : 0)); }
+size_t fb_lds(int agents, bool with_dist) { return (size_t)FB_XS_BYTES + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * (agents * 32 + (with_dist ? N_LOGITS * 4 : 0)); }
 int rollout_mt() {
     static int mt = 0;
     if (!mt) { const char* e = getenv("CDA_MLP_ROLLOUT_MT"); mt = e ? atoi(e) : 1; if (mt != 1 && mt != 2 && mt != 4) mt = 1; }
@@ -1912,6 +1942,7 @@ extern "C" int cda_tools_mlp_fwd_timing(const void* wb, const float* theta, cons
 #endif
 
 extern "C" int32_t cda_mlp_tile_rows(void) { return 32 * train_mt(); }
+extern "C" int32_t cda_mlp_wgrad_jobs(void) { return WG_JOBS; }
 
 extern "C" int cda_mlp_pack(const float* theta, void* wb, void* stream) {
     if (!theta || !wb) return CDA_ERR_INVALID;
@@ -2045,16 +2076,16 @@ extern "C" int cda_mlp_wgrad(const void* x_pk, const void* h1p, const void* h2p,
     if (!x_pk || !h1p || !h2p || !dz1p || !dz2p || !doutp || !slab || n_rows < 32 || (n_rows & 31) || n_chunks < 1 || n_chunks > n_rows / 32) return CDA_ERR_INVALID;
     WgradArgs A; A.x_pk = (const bf16x8*)x_pk; A.h1p = (const bf16x8*)h1p; A.h2p = (const bf16x8*)h2p; A.dz1p = (const bf16x8*)dz1p; A.dz2p = (const bf16x8*)dz2p;
     A.doutp = (const bf16x8*)doutp; A.n_rt = n_rows / 32; A.n_chunks = n_chunks; A.slab = slab; A.first_job = 0;
-    unsigned jobs = 5;
+    unsigned jobs = (unsigned)WG_JOBS;
 #ifdef CDA_MLP_TIMING
-    A.first_job = g_wgrad_first_job; jobs = 5u - (unsigned)g_wgrad_first_job;      // (timing only: jobs 0, 1 = dW2's two blocks)
+    A.first_job = g_wgrad_first_job; jobs = (unsigned)WG_JOBS - (unsigned)g_wgrad_first_job;      // (timing only: jobs 0, 1 = dW2's two blocks)
 #endif
     hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)n_chunks, jobs), dim3(256), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? CDA_OK : CDA_ERR_HIP;
 }
 
 // squared norm of an (all-reduced) gradient as the per-block shares k_adam sums: block b's share to scratch[NORM_PARTIALS + b], the other shares zeroed
-__global__ __launch_bounds__(256) void k_grad_norm(const float* __restrict__ grad, double* __restrict__ scratch) {
+namespace { __global__ __launch_bounds__(256) void k_grad_norm(const float* __restrict__ grad, double* __restrict__ scratch) {
     double acc = 0.0;
     for (int p = (int)(blockIdx.x * 256 + threadIdx.x); p < CDA_MLP_PARAMS; p += 256 * (RED_DENSE_BLOCKS + RED_BIAS_BLOCKS)) acc += (double)grad[p] * (double)grad[p];
     #pragma unroll
@@ -2063,7 +2094,7 @@ __global__ __launch_bounds__(256) void k_grad_norm(const float* __restrict__ gra
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) scratch[NORM_PARTIALS + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
-}
+} }
 extern "C" int cda_mlp_reduce(const float* slab, int32_t n_chunks, const float* bias_slab, int32_t n_bias_tiles,
                               double* loss_sums5, int64_t loss_samples, float vf_coef, float ent_coef, float kl_coef, float* loss_out6, float* step_dev, float* grad, double* scratch3, void* stream) {
     if (!step_dev || !slab || !bias_slab || !grad || !scratch3 || n_chunks < 1 || n_bias_tiles < 1 || (loss_sums5 && loss_samples < 1)) return CDA_ERR_INVALID;
@@ -2181,7 +2212,7 @@ extern "C" int cda_mlp_league_step(const cda_league* L, const float* obs, int32_
 // init_genrand recurrence up to word 398, the twist + tempering of outputs 0 and 1, a 53-bit double, searchsorted(cdf, u, side = "right").  A thread per
 // (market, slot): 400 dependent integer steps (the host-side numpy restatement, league.mt19937_first_double, walks the same recurrence over all seeds at
 // once: tens of milliseconds at 2048 x 6 - longer than the episode it assigns).
-__global__ __launch_bounds__(256) void k_league_assign(const unsigned int* __restrict__ episode_crc, int N, int Ag, int n_train, const double* __restrict__ cdf,
+namespace { __global__ __launch_bounds__(256) void k_league_assign(const unsigned int* __restrict__ episode_crc, int N, int Ag, int n_train, const double* __restrict__ cdf,
                                                        const int* __restrict__ pool_net, int P, int* __restrict__ slot_net, int* __restrict__ slot_pool) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= N * Ag) return;
@@ -2206,7 +2237,7 @@ __global__ __launch_bounds__(256) void k_league_assign(const unsigned int* __res
     if (idx >= P) idx = P - 1;
     slot_net[i] = pool_net[idx];
     if (slot_pool) slot_pool[i] = idx;
-}
+} }
 extern "C" int cda_league_assign(const uint32_t* episode_crc, int32_t n_markets, int32_t num_agents, int32_t n_trainable, const double* pool_cdf, const int32_t* pool_net,
                                  int32_t pool_size, int32_t* slot_net, int32_t* slot_pool, void* stream) {
     if (!episode_crc || !pool_cdf || !pool_net || !slot_net || n_markets < 1 || num_agents < 1 || num_agents > CDA_MAX_AGENTS || n_trainable < 0 || n_trainable > num_agents ||
@@ -2233,7 +2264,7 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
     const size_t NA = (size_t)N * A;
     const int n_train = L ? L->n_trainable : 0;
     if (copy_first_obs) {
-        const long long n4 = (long long)n_markets * OBS / 4;
+        const long long n4 = (long long)n_markets * OBS / VW;
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, B->obs + ((size_t)n_steps * N + first_market) * OBS,
                            B->obs + (size_t)first_market * OBS, n4);
     }

@@ -183,7 +183,7 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
     if int(env.max_step) % T:
         raise ValueError("the horizon must divide the episode length (max_step)")
     per_episode = int(env.max_step) // T
-    bank = PolicyBank(dev, N, A, k, max_frozen=max_champions, seed=seed, random_seed=seed + 12345 + 104729 * int(first_market))
+    bank = PolicyBank(dev, N, A, k, max_frozen=max_champions, seed=seed, random_seed=seed + 12345 + 104729 * int(first_market), n_hist=env.n_hist)
     mapper = LeagueSlotMapper(A, k, A - k, original_opponent_weight, champion_weight)
     league = League(mapper, bank, std_dev_multiplier, max_champions, min_iterations_between_champions)
     env.reset(seed=seed + int(first_market))

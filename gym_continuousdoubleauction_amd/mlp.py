@@ -15,14 +15,66 @@ import math
 
 import torch
 
-OBS, KX, XT, HID, FEAT, NOUT, N_LOGITS = 168, 176, 6, 256, 512, 32, 24
-OFF_W1, OFF_B1, OFF_W2, OFF_B2, OFF_WO, OFF_BO, OFF_LS, PARAMS = 0, 86016, 86528, 217600, 218112, 226304, 226336, 226338
-WB_ELEMS, SLAB, BSLAB = 385024, 245760, 1056
+HID, FEAT, NOUT, N_LOGITS, BSLAB = 256, 512, 32, 24, 1056
+#: history depths the network kernels are compiled for (include/cda_mlp.h CDA_MLP_HIST + CDA_MLP_HIST_VARIANTS): 4 = the reference's n_hist, the unsuffixed entry points
+HIST_VARIANTS = (1, 2, 4, 8)
 
 
 def _lib():
     from ._lib import lib
     return lib()
+
+
+class Layout:
+    """The constants of include/cda_mlp.h at one history depth (observation = n_hist frames of 42 floats) and the entry points compiled for it
+    (`fn("cda_mlp_policy_step")` -> the library's cda_mlp_policy_step[_h<H>])."""
+
+    def __init__(self, n_hist):
+        h = int(n_hist)
+        if h not in HIST_VARIANTS:
+            raise ValueError(f"the network kernels are compiled for n_hist in {HIST_VARIANTS} (got {n_hist}); other depths run the PyTorch loops (ppo.train)")
+        self.hist, self.OBS = h, 42 * h
+        self.KX = (self.OBS + 15) // 16 * 16
+        self.XT = (self.KX + 31) // 32
+        self.OFF_W1 = 0
+        self.OFF_B1 = FEAT * self.OBS
+        self.OFF_W2 = self.OFF_B1 + FEAT
+        self.OFF_B2 = self.OFF_W2 + 2 * HID * HID
+        self.OFF_WO = self.OFF_B2 + FEAT
+        self.OFF_BO = self.OFF_WO + NOUT * HID
+        self.OFF_LS = self.OFF_BO + NOUT
+        self.PARAMS = self.OFF_LS + 2
+        self.WB_ELEMS = FEAT * self.KX + 2 * HID * HID + 2 * NOUT * HID + 2 * HID * HID + 2 * HID * NOUT
+        self.SLAB = FEAT * 32 * self.XT + 2 * HID * HID + NOUT * FEAT
+        self.suffix = "" if h == 4 else f"_h{h}"
+
+    def fn(self, name):
+        return getattr(_lib(), name + self.suffix)
+
+
+_LAYOUTS = {}
+
+
+def layout(n_hist=4):
+    if n_hist not in _LAYOUTS:
+        _LAYOUTS[n_hist] = Layout(n_hist)
+    return _LAYOUTS[n_hist]
+
+
+def layout_of_params(n_params):
+    """the layout whose parameter vector has `n_params` entries"""
+    for h in HIST_VARIANTS:
+        if layout(h).PARAMS == int(n_params):
+            return layout(h)
+    raise ValueError(f"{n_params} parameters match no compiled history depth {HIST_VARIANTS}")
+
+
+# the reference's depth as module constants (what most callers and the tests use)
+_L4 = layout(4)
+OBS, KX, XT = _L4.OBS, _L4.KX, _L4.XT
+OFF_W1, OFF_B1, OFF_W2, OFF_B2, OFF_WO, OFF_BO, OFF_LS, PARAMS = _L4.OFF_W1, _L4.OFF_B1, _L4.OFF_W2, _L4.OFF_B2, _L4.OFF_WO, _L4.OFF_BO, _L4.OFF_LS, _L4.PARAMS
+WB_ELEMS, SLAB = _L4.WB_ELEMS, _L4.SLAB
+assert (OBS, KX, XT, OFF_B1, OFF_W2, OFF_B2, OFF_WO, OFF_BO, OFF_LS, PARAMS, WB_ELEMS, SLAB) == (168, 176, 6, 86016, 86528, 217600, 218112, 226304, 226336, 226338, 385024, 245760)
 
 
 def _check(rc, what):
@@ -35,52 +87,56 @@ def _stream(dev):
 
 
 def init_theta(obs_dim=OBS, generator=None):
-    """A fresh parameter vector with nn.Linear's default initialisation per block (uniform +-1/sqrt(fan_in)), log_std = -0.5."""
-    assert obs_dim == OBS, "the fused network is built for the reference's 4 x 42 observation"
+    """A fresh parameter vector with nn.Linear's default initialisation per block (uniform +-1/sqrt(fan_in)), log_std = -0.5; obs_dim = 42 n_hist."""
+    if obs_dim % 42:
+        raise ValueError("an observation is n_hist frames of 42 floats")
+    L = layout(obs_dim // 42)
     u = lambda n, fan_in: (torch.rand(n, generator=generator) * 2 - 1) / math.sqrt(fan_in)       # noqa: E731
-    th = torch.zeros(PARAMS)
-    th[OFF_W1:OFF_B1] = u(FEAT * OBS, OBS); th[OFF_B1:OFF_W2] = u(FEAT, OBS)
-    th[OFF_W2:OFF_B2] = u(2 * HID * HID, HID); th[OFF_B2:OFF_WO] = u(FEAT, HID)
+    th = torch.zeros(L.PARAMS)
+    th[L.OFF_W1:L.OFF_B1] = u(FEAT * L.OBS, L.OBS); th[L.OFF_B1:L.OFF_W2] = u(FEAT, L.OBS)
+    th[L.OFF_W2:L.OFF_B2] = u(2 * HID * HID, HID); th[L.OFF_B2:L.OFF_WO] = u(FEAT, HID)
     wo = u(NOUT * HID, HID).view(NOUT, HID); wo[N_LOGITS + 1:] = 0
     bo = u(NOUT, HID); bo[N_LOGITS + 1:] = 0
-    th[OFF_WO:OFF_BO] = wo.reshape(-1); th[OFF_BO:OFF_LS] = bo
-    th[OFF_LS:] = -0.5
+    th[L.OFF_WO:L.OFF_BO] = wo.reshape(-1); th[L.OFF_BO:L.OFF_LS] = bo
+    th[L.OFF_LS:] = -0.5
     return th
 
 
 def theta_from_actor_critic(model):
     """ppo.ActorCritic (block matrices with masks) -> the fused layout."""
     H = model.hidden
-    assert H == HID and model.l1.weight.shape[1] == OBS
-    th = torch.zeros(PARAMS, dtype=torch.float32)
+    L = layout(model.l1.weight.shape[1] // 42)
+    assert H == HID and model.l1.weight.shape[1] == L.OBS
+    th = torch.zeros(L.PARAMS, dtype=torch.float32)
     with torch.no_grad():
-        th[OFF_W1:OFF_B1] = model.l1.weight.detach().float().cpu().reshape(-1)
-        th[OFF_B1:OFF_W2] = model.l1.bias.detach().float().cpu()
+        th[L.OFF_W1:L.OFF_B1] = model.l1.weight.detach().float().cpu().reshape(-1)
+        th[L.OFF_B1:L.OFF_W2] = model.l1.bias.detach().float().cpu()
         w2 = model.l2.weight.detach().float().cpu()
-        th[OFF_W2:OFF_B2] = torch.stack([w2[:H, :H], w2[H:, H:]]).reshape(-1)
-        th[OFF_B2:OFF_WO] = model.l2.bias.detach().float().cpu()
+        th[L.OFF_W2:L.OFF_B2] = torch.stack([w2[:H, :H], w2[H:, H:]]).reshape(-1)
+        th[L.OFF_B2:L.OFF_WO] = model.l2.bias.detach().float().cpu()
         wo = model.out.weight.detach().float().cpu()
         blk = torch.zeros(NOUT, H)
         blk[:N_LOGITS] = wo[:N_LOGITS, :H]; blk[N_LOGITS] = wo[N_LOGITS, H:]
-        th[OFF_WO:OFF_BO] = blk.reshape(-1)
+        th[L.OFF_WO:L.OFF_BO] = blk.reshape(-1)
         bo = model.out.bias.detach().float().cpu().clone(); bo[N_LOGITS + 1:] = 0
-        th[OFF_BO:OFF_LS] = bo
-        th[OFF_LS:] = model.log_std.detach().float().cpu()
+        th[L.OFF_BO:L.OFF_LS] = bo
+        th[L.OFF_LS:] = model.log_std.detach().float().cpu()
     return th
 
 
 def actor_critic_from_theta(theta, dtype=torch.float32):
     from .ppo import ActorCritic
     th = theta.detach().float().cpu()
-    m = ActorCritic(OBS).to(dtype)
+    L = layout_of_params(th.numel())
+    m = ActorCritic(L.OBS).to(dtype)
     H = HID
     with torch.no_grad():
-        m.l1.weight.copy_(th[OFF_W1:OFF_B1].view(FEAT, OBS)); m.l1.bias.copy_(th[OFF_B1:OFF_W2])
-        w2 = th[OFF_W2:OFF_B2].view(2, H, H)
-        m.l2.weight.zero_(); m.l2.weight[:H, :H] = w2[0]; m.l2.weight[H:, H:] = w2[1]; m.l2.bias.copy_(th[OFF_B2:OFF_WO])
-        wo = th[OFF_WO:OFF_BO].view(NOUT, H)
+        m.l1.weight.copy_(th[L.OFF_W1:L.OFF_B1].view(FEAT, L.OBS)); m.l1.bias.copy_(th[L.OFF_B1:L.OFF_W2])
+        w2 = th[L.OFF_W2:L.OFF_B2].view(2, H, H)
+        m.l2.weight.zero_(); m.l2.weight[:H, :H] = w2[0]; m.l2.weight[H:, H:] = w2[1]; m.l2.bias.copy_(th[L.OFF_B2:L.OFF_WO])
+        wo = th[L.OFF_WO:L.OFF_BO].view(NOUT, H)
         m.out.weight.zero_(); m.out.weight[:N_LOGITS, :H] = wo[:N_LOGITS]; m.out.weight[N_LOGITS, H:] = wo[N_LOGITS]
-        m.out.bias.copy_(th[OFF_BO:OFF_LS]); m.log_std.copy_(th[OFF_LS:])
+        m.out.bias.copy_(th[L.OFF_BO:L.OFF_LS]); m.log_std.copy_(th[L.OFF_LS:])
     return m
 
 
@@ -94,10 +150,11 @@ def reference_outputs(theta, x, emulate_bf16=True, dtype=torch.float64, keep=Fal
     to bfloat16 as the kernels do, products and sums in `dtype`.  keep: also return (xb, h1, h2) as the kernels store them."""
     th = theta.detach().cpu().to(dtype)
     x = x.detach().cpu().to(dtype)
+    L = layout_of_params(th.numel())
     rd = _r if emulate_bf16 else (lambda t: t)
-    W1, b1 = rd(th[OFF_W1:OFF_B1].view(FEAT, OBS)), th[OFF_B1:OFF_W2]
-    W2, b2 = rd(th[OFF_W2:OFF_B2].view(2, HID, HID)), th[OFF_B2:OFF_WO]
-    Wo, bo = rd(th[OFF_WO:OFF_BO].view(NOUT, HID)), th[OFF_BO:OFF_LS]
+    W1, b1 = rd(th[L.OFF_W1:L.OFF_B1].view(FEAT, L.OBS)), th[L.OFF_B1:L.OFF_W2]
+    W2, b2 = rd(th[L.OFF_W2:L.OFF_B2].view(2, HID, HID)), th[L.OFF_B2:L.OFF_WO]
+    Wo, bo = rd(th[L.OFF_WO:L.OFF_BO].view(NOUT, HID)), th[L.OFF_BO:L.OFF_LS]
     xb = rd(x)
     h1 = rd(torch.tanh(xb @ W1.t() + b1))
     h2 = torch.cat([rd(torch.tanh(h1[:, :HID] @ W2[0].t() + b2[:HID])), rd(torch.tanh(h1[:, HID:] @ W2[1].t() + b2[HID:]))], dim=1)
@@ -111,6 +168,8 @@ def reference_gradients(theta, xb, h1, h2, d_out, dtype=torch.float64):
     """The back-propagation the kernels perform, in plain PyTorch: gradient of theta (dense vector, log_std entries zero) for given
     d_out [n, 32], with the kernels' roundings (d_out, dz2, dz1 rounded to bfloat16 where they become operands)."""
     th = theta.detach().cpu().to(dtype)
+    L = layout_of_params(th.numel())
+    OFF_W1, OFF_B1, OFF_W2, OFF_B2, OFF_WO, OFF_BO, OFF_LS, PARAMS = L.OFF_W1, L.OFF_B1, L.OFF_W2, L.OFF_B2, L.OFF_WO, L.OFF_BO, L.OFF_LS, L.PARAMS      # (this depth's, not the module's)
     W2 = _r(th[OFF_W2:OFF_B2].view(2, HID, HID)); Wo = _r(th[OFF_WO:OFF_BO].view(NOUT, HID))
     d_out = d_out.detach().cpu().to(dtype)
     dob = _r(d_out)
@@ -151,20 +210,23 @@ class FusedPolicy:
     """theta (f32 master copy), Adam state and the bf16 operand blob on one HIP device.  storage = (theta row, wb row): views into a PolicyBank's
     banks instead of tensors of its own (the league's kernels address a net as a row of the banks)."""
 
-    def __init__(self, device, theta=None, seed=0, storage=None):
+    def __init__(self, device, theta=None, seed=0, storage=None, n_hist=None):
+        """n_hist: the history depth of the observations (default: the depth `theta` was laid out for, else the reference's 4)"""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FusedPolicy needs a HIP device; the PyTorch statement of the network is ppo.ActorCritic")
         if theta is None:
             g = torch.Generator().manual_seed(int(seed))
-            theta = init_theta(generator=g)
-        assert theta.numel() == PARAMS
+            theta = init_theta(42 * int(n_hist or 4), generator=g)
+        self.L = L = layout_of_params(theta.numel())
+        if n_hist is not None and int(n_hist) != L.hist:
+            raise ValueError(f"theta is laid out for n_hist = {L.hist}, not {n_hist}")
         if storage is None:
             self.theta = theta.detach().float().to(self.device).contiguous()
-            self.wb = torch.zeros(WB_ELEMS, dtype=torch.bfloat16, device=self.device)
+            self.wb = torch.zeros(L.WB_ELEMS, dtype=torch.bfloat16, device=self.device)
         else:
             self.theta, self.wb = storage
-            assert self.theta.shape == (PARAMS,) and self.theta.is_contiguous() and self.wb.shape == (WB_ELEMS,) and self.wb.is_contiguous()
+            assert self.theta.shape == (L.PARAMS,) and self.theta.is_contiguous() and self.wb.shape == (L.WB_ELEMS,) and self.wb.is_contiguous()
             self.theta.copy_(theta.detach().float())
         self.adam_m = torch.zeros_like(self.theta)
         self.adam_v = torch.zeros_like(self.theta)
@@ -180,26 +242,27 @@ class FusedPolicy:
 
     @property
     def log_std(self):
-        return self.theta[OFF_LS:]
+        return self.theta[self.L.OFF_LS:]
 
     def pack(self):
-        _check(_lib().cda_mlp_pack(self.theta.data_ptr(), self.wb.data_ptr(), _stream(self.device)), "cda_mlp_pack")
+        _check(self.L.fn("cda_mlp_pack")(self.theta.data_ptr(), self.wb.data_ptr(), _stream(self.device)), "cda_mlp_pack")
 
     def forward(self, obs, first_row=0, n_rows=None, out=None):
         """network outputs f32 [rows, 32] (columns 0..23 policy, 24 value) for rows [first_row, first_row + n_rows) of obs f32[*, 168]"""
         obs = obs.contiguous()
-        assert obs.dtype == torch.float32 and obs.shape[-1] == OBS and obs.device == self.device
+        assert obs.dtype == torch.float32 and obs.shape[-1] == self.L.OBS and obs.device == self.device
         n_rows = obs.shape[0] - first_row if n_rows is None else n_rows
         if out is None:
             out = torch.zeros((obs.shape[0], NOUT), dtype=torch.float32, device=self.device)
-        _check(_lib().cda_mlp_forward(self.wb.data_ptr(), self.theta.data_ptr(), obs.data_ptr(), int(first_row), int(n_rows), out.data_ptr(),
-                                      _stream(self.device)), "cda_mlp_forward")
+        _check(self.L.fn("cda_mlp_forward")(self.wb.data_ptr(), self.theta.data_ptr(), obs.data_ptr(), int(first_row), int(n_rows), out.data_ptr(),
+                                            _stream(self.device)), "cda_mlp_forward")
         return out
 
     def policy_step(self, obs, num_agents, seed, counter, draw, first_market=0, n_markets=None, outs=None):
         """one launch: forward + sampling for the markets [first_market, first_market + n_markets).  Returns the dict of output tensors
         ([N, A] each; a_cont [N, A, 2]; value [N])."""
         obs = obs.contiguous()
+        assert obs.dtype == torch.float32 and obs.shape[-1] == self.L.OBS
         N = obs.shape[0]
         n_markets = N - first_market if n_markets is None else n_markets
         A, dev = int(num_agents), self.device
@@ -208,7 +271,7 @@ class FusedPolicy:
             outs = {"category": e((N, A), torch.int32), "size_mean": e((N, A), torch.float32), "size_sigma": e((N, A), torch.float32),
                     "price": e((N, A), torch.int32), "price_offset": e((N, A), torch.int32), "a_cont": e((N, A, 2), torch.float32),
                     "logp": e((N, A), torch.float32), "value": e((N,), torch.float32)}
-        _check(_lib().cda_mlp_policy_step(self.wb.data_ptr(), self.theta.data_ptr(), obs.data_ptr(), int(first_market), int(n_markets), A,
+        _check(self.L.fn("cda_mlp_policy_step")(self.wb.data_ptr(), self.theta.data_ptr(), obs.data_ptr(), int(first_market), int(n_markets), A,
                                           int(seed) & (2 ** 64 - 1), counter.data_ptr(), int(draw),
                                           *[outs[k].data_ptr() for k in ("category", "size_mean", "size_sigma", "price", "price_offset", "a_cont", "logp", "value")],
                                           _stream(dev)), "cda_mlp_policy_step")
@@ -224,16 +287,18 @@ class PolicyBank:
     rollout with no copy), the rows behind them frozen snapshots (champions: league_based_self_play_callback.py:938-1170).  slot_net i32 [N, A] names
     the row that plays each (market, slot), LEAGUE_RANDOM = the uniform random module."""
 
-    def __init__(self, device, n_markets, num_agents, n_trainable, max_frozen=8, seed=0, random_seed=0):
+    def __init__(self, device, n_markets, num_agents, n_trainable, max_frozen=8, seed=0, random_seed=0, n_hist=4):
         from ._lib import League
         self.device = torch.device(device)
+        self.L = L = layout(n_hist)
+        PARAMS, WB_ELEMS = L.PARAMS, L.WB_ELEMS
         self.n_trainable, self.max_frozen, self.n_frozen = int(n_trainable), int(max_frozen), 0
         if not 1 <= self.n_trainable <= num_agents or self.n_trainable + self.max_frozen > LEAGUE_MAX_NETS:
             raise ValueError(f"need 1 <= n_trainable <= num_agents and n_trainable + max_frozen <= {LEAGUE_MAX_NETS}")
         n_max = self.n_trainable + self.max_frozen
         self.theta = torch.zeros((n_max, PARAMS), dtype=torch.float32, device=self.device)
         self.wb = torch.zeros((n_max, WB_ELEMS), dtype=torch.bfloat16, device=self.device)
-        self.policies = [FusedPolicy(self.device, seed=seed + 7919 * p, storage=(self.theta[p], self.wb[p])) for p in range(self.n_trainable)]
+        self.policies = [FusedPolicy(self.device, seed=seed + 7919 * p, storage=(self.theta[p], self.wb[p]), n_hist=L.hist) for p in range(self.n_trainable)]
         self.slot_net = torch.full((int(n_markets), int(num_agents)), LEAGUE_RANDOM, dtype=torch.int32, device=self.device)
         self.slot_net[:, :self.n_trainable] = torch.arange(self.n_trainable, dtype=torch.int32, device=self.device)
         self.random_seed = int(random_seed) & (2 ** 64 - 1)
@@ -299,8 +364,10 @@ class RolloutChains:
         self.env, self.policy, self.T = env, policy, int(horizon)
         self.bank = policy if isinstance(policy, PolicyBank) else None
         N, A, dev, T = env.n_markets, env.num_agents, env.device, int(horizon)
-        if env.obs_dim != OBS:
-            raise ValueError("the fused network is built for n_hist = 4 (168-float observations)")
+        self.L = L = policy.L
+        if env.obs_dim != L.OBS:
+            raise ValueError(f"the policy is laid out for {L.OBS}-float observations (n_hist = {L.hist}), the env emits {env.obs_dim}")
+        OBS = L.OBS
         if not bool(env.config.get("auto_reset", False)):
             raise ValueError("RolloutChains needs an auto_reset env (episode ends are handled on the device)")
         self.N, self.A, self.device = N, A, dev
@@ -375,11 +442,11 @@ class RolloutChains:
         st = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
             if self.bank is not None:
-                _check(_lib().cda_mlp_league_rollout_chain(self.env._h, C.byref(self.bank.struct()), first, cnt, self.T, self.seed, self.counter.data_ptr(),
-                                                           C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_league_rollout_chain")
+                _check(self.L.fn("cda_mlp_league_rollout_chain")(self.env._h, C.byref(self.bank.struct()), first, cnt, self.T, self.seed, self.counter.data_ptr(),
+                                                                 C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_league_rollout_chain")
             else:
-                _check(_lib().cda_mlp_rollout_chain(self.env._h, self.policy.wb.data_ptr(), self.policy.theta.data_ptr(), first, cnt, self.T, self.seed,
-                                                    self.counter.data_ptr(), C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_rollout_chain")
+                _check(self.L.fn("cda_mlp_rollout_chain")(self.env._h, self.policy.wb.data_ptr(), self.policy.theta.data_ptr(), first, cnt, self.T, self.seed,
+                                                          self.counter.data_ptr(), C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_rollout_chain")
 
     def _capture(self):
         graphs = []
@@ -402,7 +469,7 @@ class RolloutChains:
         if self.capture_ends:
             self.buf["fin_count"].zero_(); self.buf["fin_index"].fill_(-1)
         if self.with_dist:                                        # the log_std the rollout samples with (a row per trainable net)
-            src = self.bank.theta[:self.bank.n_trainable, OFF_LS:] if self.bank else self.policy.theta[OFF_LS:].view(1, 2)
+            src = self.bank.theta[:self.bank.n_trainable, self.L.OFF_LS:] if self.bank else self.policy.theta[self.L.OFF_LS:].view(1, 2)
             self.log_std_old.copy_(src)
         if self.use_graphs and self.graphs is None and len(self.streams) >= 1:
             torch.cuda.synchronize(dev)
@@ -441,7 +508,7 @@ class RolloutChains:
         fin_index = fin_value = None
         if self.capture_ends:
             wb, th = (self.bank.wb, self.bank.theta) if self.bank else (self.policy.wb, self.policy.theta)
-            _check(L.cda_mlp_values(wb.data_ptr(), th.data_ptr(), max(k, 1), self.buf["fin_obs"].data_ptr(), self.fin_cap, self.fin_value.data_ptr(), self.fin_cap, st), "cda_mlp_values")
+            _check(self.L.fn("cda_mlp_values")(wb.data_ptr(), th.data_ptr(), max(k, 1), self.buf["fin_obs"].data_ptr(), self.fin_cap, self.fin_value.data_ptr(), self.fin_cap, st), "cda_mlp_values")
             fin_index, fin_value = self.buf["fin_index"].data_ptr(), self.fin_value.data_ptr()
         _check(L.cda_gae_records_bootstrap(self.buf["reward"].data_ptr(), self.buf["value"].data_ptr(), self.buf["terminated"].data_ptr(), self.buf["truncated"].data_ptr(),
                                            self.T, self.N, self.A, k, float(reward_scale), float(gamma), float(lam), fin_index, fin_value, self.fin_cap if self.capture_ends else 0,
@@ -470,6 +537,16 @@ class EpisodeReturns:
         return self.acc                                                                   # (device tensor: read it with the iteration's other statistics)
 
 
+class _Fns:
+    """attribute access -> the entry point compiled for a layout's history depth (`_Fns(L).cda_mlp_wgrad` = the library's cda_mlp_wgrad[_h<H>])"""
+
+    def __init__(self, L):
+        self._L = L
+
+    def __getattr__(self, name):
+        return self._L.fn(name)
+
+
 class FusedUpdate:
     """The PPO update on the kernels of include/cda_mlp.h: per epoch a keyed permutation of the R unique observation rows, per minibatch
     {gather + forward + loss + back-propagation (one launch), weight gradients, reduce, clip + Adam}: four launches, no autograd, no GEMM
@@ -492,11 +569,14 @@ class FusedUpdate:
         if self.R % 32 or self.rows_mb % 32 or self.rows_mb > self.R:
             raise ValueError("rows and minibatch rows must be multiples of 32")
         dev = policy.device
-        self.tile_rows = int(_lib().cda_mlp_tile_rows())
+        self.L = Lo = policy.L
+        KX, XT, SLAB, PARAMS = Lo.KX, Lo.XT, Lo.SLAB, Lo.PARAMS          # (this policy's history depth)
+        self.tile_rows = int(Lo.fn("cda_mlp_tile_rows")())
         self.n_tiles = (self.rows_mb + self.tile_rows - 1) // self.tile_rows
         pad = self.n_tiles * self.tile_rows                            # the kernels write whole workgroup tiles
         pad = ((pad + 63) // 64) * 64                                  # (the fused kernel's are 64 rows whatever CDA_MLP_MT says)
-        self.chunks = int(chunks) if chunks else max(1, min(51, self.rows_mb // 512))      # 5 jobs x 51 chunks = 255 workgroups: one wave of the 256 CUs
+        jobs = int(Lo.fn("cda_mlp_wgrad_jobs")())
+        self.chunks = int(chunks) if chunks else max(1, min(255 // jobs, self.rows_mb // 512))      # n_hist 4: 5 jobs x 51 chunks = 255 workgroups: one wave of the 256 CUs
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)                      # noqa: E731
         self.x_rm, self.x_pk = e(self.R * KX, bf), e(self.R * 32 * XT, bf)         # (the separate kernels' per-epoch images of the shuffled rows)
@@ -529,7 +609,8 @@ class FusedUpdate:
         """rows [s, s + rows) of the prepared (shuffled) observations: one optimiser step.  obs_rows (with records, fused=True): the unshuffled f32
         observation rows - the fused kernel gathers rows perm[s .. s + rows) itself, no prepared images needed.  records = (rec f32 [R, A, 8] or its
         address, adv sums f64[2] or None, their count): the loss reads sample records (RolloutChains.gae) instead of the seven per-sample arrays."""
-        L, p, dev = _lib(), self.p, self.p.device
+        p, dev = self.p, self.p.device
+        L = _Fns(self.L)
         st = _stream(dev)
         ptr = lambda x: x if isinstance(x, int) else x.data_ptr()           # noqa: E731
         if obs_rows is not None and records is not None and self.fused:
@@ -563,18 +644,18 @@ class FusedUpdate:
         chunks = max(1, min(self.chunks, rs // 32))
         for k in range(sub):
             o = s + k * rs
-            x_rm = self.x_rm.data_ptr() + o * KX * 2
-            x_pk = self.x_pk.data_ptr() + o * 32 * XT * 2
+            x_rm = self.x_rm.data_ptr() + o * self.L.KX * 2
+            x_pk = self.x_pk.data_ptr() + o * 32 * self.L.XT * 2
             _check(L.cda_mlp_forward_train(p.wb.data_ptr(), p.theta.data_ptr(), x_rm, rs, self.h1p.data_ptr(), self.h2p.data_ptr(), self.out.data_ptr(), st), "cda_mlp_forward_train")
             last = k == sub - 1
             if records is not None:
                 rec, stats, count = records
-                _check(L.cda_ppo_loss_records(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, ptr(rec), stats.data_ptr() if stats is not None else None, int(count),
+                _check(L.cda_ppo_loss_records(self.out.data_ptr(), p.theta.data_ptr() + self.L.OFF_LS * 4, ptr(rec), stats.data_ptr() if stats is not None else None, int(count),
                                               self.perm.data_ptr() + o * 8, rs, self.A, NOUT, float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(),
                                               self.sums5.data_ptr(), self.out6.data_ptr(), rows, 0 if (apply or k) else 1, 0 if (apply or not last) else 1, st),
                        "cda_ppo_loss_records")
             else:
-              _check(L.cda_ppo_loss32(self.out.data_ptr(), p.theta.data_ptr() + OFF_LS * 4, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(), acts[3].data_ptr(),
+              _check(L.cda_ppo_loss32(self.out.data_ptr(), p.theta.data_ptr() + self.L.OFF_LS * 4, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(), acts[3].data_ptr(),
                                     logp_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), self.perm.data_ptr() + o * 8, rs, self.A, NOUT,
                                     float(clip), float(vf_coef), float(ent_coef), self.d_out.data_ptr(), self.sums5.data_ptr(), self.out6.data_ptr(), rows,
                                     0 if (apply or k) else 1, 0 if (apply or not last) else 1, st),
@@ -582,7 +663,7 @@ class FusedUpdate:
             _check(L.cda_mlp_backward(p.wb.data_ptr(), self.d_out.data_ptr(), self.h1p.data_ptr(), self.h2p.data_ptr(), rs, self.dz1p.data_ptr(), self.dz2p.data_ptr(),
                                       self.doutp.data_ptr(), self.bias_slab.data_ptr() + k * tiles_sub * BSLAB * 4, st), "cda_mlp_backward")
             _check(L.cda_mlp_wgrad(x_pk, self.h1p.data_ptr(), self.h2p.data_ptr(), self.dz1p.data_ptr(), self.dz2p.data_ptr(), self.doutp.data_ptr(), rs, chunks,
-                                   self.slab.data_ptr() + k * chunks * SLAB * 4, st), "cda_mlp_wgrad")
+                                   self.slab.data_ptr() + k * chunks * self.L.SLAB * 4, st), "cda_mlp_wgrad")
         chunks, tiles = chunks * sub, tiles_sub * sub
         if apply:
             _check(L.cda_mlp_adam(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), self.slab.data_ptr(), chunks,
@@ -597,8 +678,8 @@ class FusedUpdate:
         / ret f32, R * A entries each, sample r * A + a belonging to row r.  adv is expected normalised.  perms: optional i64 [epochs, R]
         (tests); default a keyed permutation per epoch.  records = (rec, adv sums or None, count) replaces acts / logp_old / adv / ret (see
         minibatch_step); with the sums given the advantages are normalised inside the loss.  max_norm = math.inf: no gradient clipping."""
-        L, dev = _lib(), self.p.device
-        assert obs_rows.shape == (self.R, OBS) and obs_rows.dtype == torch.float32 and obs_rows.is_contiguous()
+        L, dev = _Fns(self.L), self.p.device
+        assert obs_rows.shape == (self.R, self.L.OBS) and obs_rows.dtype == torch.float32 and obs_rows.is_contiguous()
         if records is not None:
             assert isinstance(records[0], int) or (records[0].dtype == torch.float32 and records[0].is_contiguous() and records[0].numel() >= self.R * self.A * 8)
         else:

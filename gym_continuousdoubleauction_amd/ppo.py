@@ -512,7 +512,7 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     dev = env.obs.device
     N, A, T = env.n_markets, env.num_agents, int(horizon)
     if policy is None:
-        policy = FusedPolicy(dev, seed=seed)
+        policy = FusedPolicy(dev, seed=seed, n_hist=env.n_hist)
     env.reset(seed=seed + int(first_market))
     use_kl = obj["kl_coef"] > 0.0
     roll = RolloutChains(env, policy, T, groups=chains, seed=seed + 7919 * int(first_market), use_graphs=use_graph, with_dist=use_kl,
@@ -667,6 +667,7 @@ def main(argv=None):
     p.add_argument("--horizon", type=int, default=64)
     p.add_argument("--iters", type=int, default=4)
     p.add_argument("--max-step", type=int, default=4096)
+    p.add_argument("--n-hist", type=int, default=4, help="history depth of the observation (the reference trains with 4; the fused kernels are compiled for 1, 2, 4, 8)")
     p.add_argument("--fp32-update", action="store_true", help="PPO update in float32 instead of bfloat16 autocast")
     p.add_argument("--groups", type=int, default=1, help="market groups of the env step (independent launch chains, vec_env.CDAVecEnv)")
     p.add_argument("--no-graphs", action="store_true", help="eager rollout and update (no HIP graphs)")
@@ -679,11 +680,12 @@ def main(argv=None):
     args = p.parse_args(argv)
     from .vec_env import CDAVecEnv
     p_groups = max(1, min(args.groups, args.markets))
-    env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False, "auto_reset": True},
+    env = CDAVecEnv({"num_of_agents": args.agents, "init_cash": 1000000, "max_step": args.max_step, "is_render": False, "auto_reset": True, "n_hist": args.n_hist},
                     n_markets=args.markets, device="cuda:0", with_info=False, groups=p_groups)
-    if not args.legacy and ((args.horizon * args.markets) % 32 or env.obs_dim != 168):
-        # the fused kernels step whole 32-row tiles of 168-float observations: other shapes run the PyTorch statement of the same loop
-        print(json.dumps({"note": f"fused loop needs horizon * markets % 32 == 0 and n_hist == 4 (got {args.horizon} x {args.markets}, obs {env.obs_dim}): running the legacy loop"}))
+    from .mlp import HIST_VARIANTS
+    if not args.legacy and ((args.horizon * args.markets) % 32 or env.n_hist not in HIST_VARIANTS):
+        # the fused kernels step whole 32-row tiles and are compiled per history depth: other shapes run the PyTorch statement of the same loop
+        print(json.dumps({"note": f"fused loop needs horizon * markets % 32 == 0 and n_hist in {HIST_VARIANTS} (got {args.horizon} x {args.markets}, n_hist {env.n_hist}): running the legacy loop"}))
         args.legacy = True
     if args.legacy:
         _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update, shared_obs=not args.per_sample_forward, use_graph=not args.no_graphs)

@@ -39,31 +39,38 @@
 extern "C" {
 #endif
 
-#define CDA_MLP_OBS       168
-#define CDA_MLP_KX        176                    /* observation padded to 11 MFMA k-steps of 16 */
-#define CDA_MLP_XTILES    6                      /* ... and to 6 feature tiles of 32 in the packed layout */
+/* History depth the entry points are compiled for.  The unsuffixed names are the reference's n_hist = 4 (config/train_config.json:17: 168-float observations);
+ * the library also holds the SAME entry points for the depths listed in CDA_MLP_HIST_VARIANTS under the names <name>_h<H> (cda_mlp_policy_step_h8, ...: same
+ * signatures, the constants below evaluated at that depth - one object file per depth, csrc/cda_mlp_variant.h).  Python: mlp.layout(n_hist). */
+#ifndef CDA_MLP_HIST
+#define CDA_MLP_HIST 4
+#endif
+#define CDA_MLP_HIST_VARIANTS "1 2 8"
+#define CDA_MLP_OBS       (42 * CDA_MLP_HIST)                       /* 168 */
+#define CDA_MLP_KX        ((CDA_MLP_OBS + 15) / 16 * 16)             /* 176: the observation padded to MFMA k-steps of 16 */
+#define CDA_MLP_XTILES    ((CDA_MLP_KX + 31) / 32)                   /* 6: ... and to feature tiles of 32 in the packed layout */
 #define CDA_MLP_HID       256
 #define CDA_MLP_FEAT      512
 #define CDA_MLP_NOUT      32
 #define CDA_MLP_OFF_W1    0
-#define CDA_MLP_OFF_B1    86016
-#define CDA_MLP_OFF_W2    86528
-#define CDA_MLP_OFF_B2    217600
-#define CDA_MLP_OFF_WO    218112
-#define CDA_MLP_OFF_BO    226304
-#define CDA_MLP_OFF_LS    226336
-#define CDA_MLP_PARAMS    226338
-#define CDA_MLP_WB_W1     0                      /* offsets (bf16 elements) inside the operand blob */
-#define CDA_MLP_WB_W2     90112
-#define CDA_MLP_WB_WO     221184
-#define CDA_MLP_WB_W2T    237568
-#define CDA_MLP_WB_WOT    368640
-#define CDA_MLP_WB_ELEMS  385024
-/* dense gradient slab of one row chunk: dW1 [512][192] | dW2 [2][256][256] | dWo [32][512]  (f32) */
+#define CDA_MLP_OFF_B1    (CDA_MLP_FEAT * CDA_MLP_OBS)              /* 86016 */
+#define CDA_MLP_OFF_W2    (CDA_MLP_OFF_B1 + CDA_MLP_FEAT)            /* 86528 */
+#define CDA_MLP_OFF_B2    (CDA_MLP_OFF_W2 + 2 * CDA_MLP_HID * CDA_MLP_HID)   /* 217600 */
+#define CDA_MLP_OFF_WO    (CDA_MLP_OFF_B2 + CDA_MLP_FEAT)            /* 218112 */
+#define CDA_MLP_OFF_BO    (CDA_MLP_OFF_WO + CDA_MLP_NOUT * CDA_MLP_HID)      /* 226304 */
+#define CDA_MLP_OFF_LS    (CDA_MLP_OFF_BO + CDA_MLP_NOUT)            /* 226336 */
+#define CDA_MLP_PARAMS    (CDA_MLP_OFF_LS + 2)                       /* 226338 */
+#define CDA_MLP_WB_W1     0                                          /* offsets (bf16 elements) inside the operand blob */
+#define CDA_MLP_WB_W2     (CDA_MLP_FEAT * CDA_MLP_KX)                /* 90112 */
+#define CDA_MLP_WB_WO     (CDA_MLP_WB_W2 + 2 * CDA_MLP_HID * CDA_MLP_HID)    /* 221184 */
+#define CDA_MLP_WB_W2T    (CDA_MLP_WB_WO + 2 * CDA_MLP_NOUT * CDA_MLP_HID)   /* 237568 */
+#define CDA_MLP_WB_WOT    (CDA_MLP_WB_W2T + 2 * CDA_MLP_HID * CDA_MLP_HID)   /* 368640 */
+#define CDA_MLP_WB_ELEMS  (CDA_MLP_WB_WOT + 2 * CDA_MLP_HID * CDA_MLP_NOUT)   /* 385024 */
+/* dense gradient slab of one row chunk: dW1 [512][32 XTILES] | dW2 [2][256][256] | dWo [32][512]  (f32) */
 #define CDA_MLP_SLAB_W1   0
-#define CDA_MLP_SLAB_W2   98304
-#define CDA_MLP_SLAB_WO   229376
-#define CDA_MLP_SLAB      245760
+#define CDA_MLP_SLAB_W2   (CDA_MLP_FEAT * 32 * CDA_MLP_XTILES)       /* 98304 */
+#define CDA_MLP_SLAB_WO   (CDA_MLP_SLAB_W2 + 2 * CDA_MLP_HID * CDA_MLP_HID)  /* 229376 */
+#define CDA_MLP_SLAB      (CDA_MLP_SLAB_WO + CDA_MLP_NOUT * CDA_MLP_FEAT)    /* 245760 */
 /* bias partial sums of one row tile of the backward kernel: db1 [512] | db2 [512] | dbo [32]  (f32) */
 #define CDA_MLP_BSLAB     1056
 #define CDA_MLP_SCRATCH   512                    /* f64 words of cda_mlp_adam's scratch */
@@ -71,6 +78,8 @@ extern "C" {
 /* rows per workgroup of the update's forward / backward kernels (32, 64 or 128: CDA_MLP_MT in the environment, default 128) = rows per
  * bias partial of cda_mlp_backward */
 int32_t cda_mlp_tile_rows(void);
+/* output panels ("jobs") of cda_mlp_wgrad: 2 (dW2) + 2 x groups of the x panel (dW1) + 1 (dWo) = 5 at n_hist 4; a caller sizes n_chunks so that jobs x chunks fills the 256 CUs */
+int32_t cda_mlp_wgrad_jobs(void);
 
 /* theta -> wb (one launch).  Called after every optimiser step (cda_mlp_adam does it itself). */
 int cda_mlp_pack(const float* theta, void* wb, void* stream);

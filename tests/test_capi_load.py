@@ -127,3 +127,26 @@ def test_learner_side_entry_points_refuse_bad_arguments_before_touching_the_devi
     src, dst, nb = (C.c_void_p * 1)(16), (C.c_void_p * 1)(16), (C.c_int64 * 1)(64)
     assert L.cda_store_slots(0, src, dst, nb, one, 0, None) == INVALID and L.cda_store_slots(13, src, dst, nb, one, 0, None) == INVALID
     assert L.cda_store_slots(1, src, dst, (C.c_int64 * 1)(0), one, 0, None) == INVALID and L.cda_store_slots(1, src, dst, nb, None, 0, None) == INVALID
+
+
+def test_every_network_entry_point_exists_for_every_compiled_history_depth():
+    """include/cda_mlp.h: the unsuffixed entry points are n_hist = 4; CDA_MLP_HIST_VARIANTS names the other depths the library holds them for, as <name>_h<H>.  The
+    rename list (csrc/cda_mlp_variant.h) must cover every function the header declares, and the built library must export every one of them."""
+    import ctypes as C
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "cda_mlp.h")).read()
+    variants = [int(x) for x in re.search(r'#define CDA_MLP_HIST_VARIANTS "([0-9 ]+)"', hdr).group(1).split()]
+    declared = set(re.findall(r"^(?:int|int32_t)\s+(cda_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 25 and variants == [1, 2, 8]
+    renames = set(re.findall(r"#define (cda_[a-z0-9_]+) CDA_MLP_SFX\(\1\)", open(os.path.join(root, "gym_continuousdoubleauction_amd", "csrc", "cda_mlp_variant.h")).read()))
+    assert renames == declared, (sorted(declared - renames), sorted(renames - declared))
+    from gym_continuousdoubleauction_amd import _lib
+    assert set(_lib.MLP_SYMBOLS) == declared and tuple(variants) == tuple(_lib.MLP_HIST_VARIANTS)
+    so = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        for h in variants:
+            getattr(so, f"{name}_h{h}")
+    import __graft_entry__ as G
+    assert tuple(G.MLP_HIST_VARIANTS) == tuple(variants)
