@@ -1318,10 +1318,17 @@ __device__ __forceinline__ void wgrad_wave(const bf16x8* __restrict__ Ap, int a_
     auto request = [&](auto slot_c, long long s) {
         constexpr int slot = decltype(slot_c)::value;
         const long long sc = s < s1 ? s : s1 - 1, rt = sc >> 1; const int ks = (int)(sc & 1);
+#ifdef CDA_WGRAD_NT              /* experiment (tools/wgrad_nt_probe.sh): the operands are read once - non-temporal requests */
+        #pragma unroll
+        for (int ti = 0; ti < TI; ti++) a[slot][ti] = __builtin_nontemporal_load(&Ap[((rt * a_nft + a_ft0 + ti) * 2 + ks) * 64 + lane]);
+        #pragma unroll
+        for (int tj = 0; tj < TJ; tj++) { const int ft = b_ft0 + tj < b_nft ? b_ft0 + tj : b_nft - 1; b[slot][tj] = __builtin_nontemporal_load(&Bp[((rt * b_nft + ft) * 2 + ks) * 64 + lane]); }
+#else
         #pragma unroll
         for (int ti = 0; ti < TI; ti++) a[slot][ti] = Ap[((rt * a_nft + a_ft0 + ti) * 2 + ks) * 64 + lane];
         #pragma unroll
         for (int tj = 0; tj < TJ; tj++) { const int ft = b_ft0 + tj < b_nft ? b_ft0 + tj : b_nft - 1; b[slot][tj] = Bp[((rt * b_nft + ft) * 2 + ks) * 64 + lane]; }
+#endif
     };
     request(std::integral_constant<int, 0>{}, s0); request(std::integral_constant<int, 1>{}, s0 + 1); request(std::integral_constant<int, 2>{}, s0 + 2);
     __builtin_amdgcn_sched_barrier(0);

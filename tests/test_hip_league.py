@@ -479,3 +479,29 @@ def test_record_from_a_fused_rollout_equals_the_oracle_replayed_record(tmp_path)
     # the rows of an unfinished episode are flagged
     assert got.to_pandas().groupby("episode_id")["episode_complete"].first().tolist().count(False) == S
     ora.close(); env.close()
+
+
+def test_league_training_records_sampled_episodes_with_module_ids(tmp_path):
+    """train_league_fused(recorder=..., info_markets=S): the sampled chain's episodes land in the reference's Parquet schema with the module that played each slot
+    (the league's draw), one file per flush, the callback's NAV check at every episode end."""
+    import pyarrow.parquet as pq
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    from gym_continuousdoubleauction_amd.episode_record import BatchedEpisodeRecorder, schema
+    from gym_continuousdoubleauction_amd.league_train import train_league_fused
+    N, A, S, T = 128, 8, 2, 16
+    env = CDAVecEnv({"num_of_agents": A, "init_cash": 1000000, "max_step": T, "is_render": False, "auto_reset": True}, n_markets=N, with_info=False)
+    rec = BatchedEpisodeRecorder(str(tmp_path), num_agents=A, markets=range(N - S, N), run_id="lg")
+    bank, league, hist = train_league_fused(env, iters=3, horizon=T, num_trainable=2, std_dev_multiplier=-10.0, log=lambda s: None, recorder=rec, info_markets=S, run_id="lg")
+    path = rec.close()
+    t = pq.read_table(path)
+    assert t.schema.equals(schema()) and t.num_rows == 3 * S * T * A
+    df = t.to_pandas()
+    assert set(df["episode_id"]) == {f"lg-episode{e}-market{m}" for e in range(3) for m in (N - 2, N - 1)}
+    assert (df[df.agent_id == "agent_0"]["module_id"] == "policy_0").all() and (df[df.agent_id == "agent_1"]["module_id"] == "policy_1").all()
+    pool = df[~df.agent_id.isin(["agent_0", "agent_1"])]["module_id"]
+    assert pool.str.match(r"^(policy_[2-7]|champion_\d+)$").all() and df["episode_complete"].all()
+    assert rec.nav_checked == 3 * S and rec.nav_violations == 0
+    # a module id is constant over an episode's rows of one agent, and the champions that were promoted can appear from the episode after their promotion only
+    assert (df.groupby(["episode_id", "agent_id"])["module_id"].nunique() == 1).all()
+    assert not df[df.episode_id.str.contains("episode0")]["module_id"].str.startswith("champion").any()
+    env.close()

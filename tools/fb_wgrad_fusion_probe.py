@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--agents", type=int, default=4)
     a = ap.parse_args()
-    T = C.CDLL(os.path.join(ROOT, "tools", "libcda_tools.so"))
+    T = C.CDLL(os.environ.get("CDA_TOOLS_LIB") or os.path.join(ROOT, "tools", "libcda_tools.so"))
     vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
     T.cda_tools_mlp_experiment.argtypes = [i32, i32, i32]; T.cda_tools_mlp_experiment.restype = None
     T.cda_mlp_forward_backward.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]

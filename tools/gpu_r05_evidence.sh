@@ -10,7 +10,8 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> $O/gpu_suite.t
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench_driver_command.err; echo "bench rc=$?"
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --learner dp > $O/bench_learner_dp_one_rank.json 2> /dev/null
-timeout 600 python -m gym_continuousdoubleauction_amd.ppo --iters 8 --out $O/bench_ppo.json > /dev/null 2>&1
+timeout 600 python -m gym_continuousdoubleauction_amd.ppo --iters 10 --out $O/bench_ppo.json > /dev/null 2>&1
+for h in 1 2 8; do timeout 300 python -m gym_continuousdoubleauction_amd.ppo --iters 10 --n-hist $h --out $O/bench_ppo_n_hist$h.json > /dev/null 2>&1; done
 timeout 600 python -m gym_continuousdoubleauction_amd.league_train --fused --markets 2048 --agents 8 --trainable 2 --episode 64 --iters 12 --out $O/bench_league.json > /dev/null 2>&1
 timeout 600 python tools/record_cost_probe.py > $O/record_cost.txt 2>&1; grep -v amdgpu $O/record_cost.txt
 export TMPDIR=/tmp PYTHONPATH=$R; cd /tmp
