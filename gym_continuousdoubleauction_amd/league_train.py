@@ -123,9 +123,12 @@ class League:
         k, names = self.mapper.num_trainable, self.mapper.available_modules
         N, A = slot_pool.shape
         idx = torch.where(slot_pool < 0, torch.arange(A, device=slot_pool.device, dtype=torch.int32).expand(N, A), slot_pool + k).long().reshape(-1)
-        # (a one-hot product, not index_add_: a dozen bins under 16 k double-precision atomics took 1.6 ms per call - a fifth of an iteration)
-        onehot = (idx[None, :] == torch.arange(len(names), device=idx.device)[:, None]).to(torch.float64)
-        sums = onehot @ per_slot.reshape(-1, 2)
+        # (masked sums - not index_add_: a dozen bins under 16 k double-precision atomics took 1.6 ms per call, a fifth of an iteration; not a one-hot matrix product
+        # either: a float64 GEMM with two columns is 1.9 ms in the library)
+        mask = idx[None, :] == torch.arange(len(names), device=idx.device)[:, None]                    # [modules, N * A]
+        flat = per_slot.reshape(-1, 2)
+        zero = torch.zeros((), dtype=torch.float64, device=flat.device)
+        sums = torch.stack([torch.where(mask, flat[:, 0][None, :], zero).sum(1), torch.where(mask, flat[:, 1][None, :], zero).sum(1)], dim=1)
         if allreduce is not None:                              # data parallel: the modules' returns over ALL shards (every rank then takes the same decision)
             allreduce(sums)
         host = sums.cpu().numpy()
@@ -293,7 +296,7 @@ def main(argv=None):
                                          objective=ppo.RLLIB_DEFAULTS if args.objective == "rllib" else None)
     flags = env.flags()
     _, bad = env.nav_conservation()
-    tail = hist[1:] or hist
+    tail = hist[2:] if len(hist) >= 4 else (hist[1:] or hist)          # (two warm-up iterations: graph capture, first replays)
     summary = {"metric": "agent-steps/sec end to end (league rollout + one PPO update per trainable policy)",
                "config": {"workload": f"{args.markets} markets x {args.agents} agents, {k} separately trained policies (policy_p plays slot p) against modules drawn per episode "
                                       f"and slot from {args.agents - k} uniform random modules + up to 8 champion snapshots (the reference's mapping rule, on the device); episode "
@@ -301,7 +304,7 @@ def main(argv=None):
                                       "for every module, 4 epochs per policy per iteration",
                           "markets": args.markets, "agents": args.agents, "trainable": k, "episode": args.episode, "horizon": args.horizon or args.episode, "chains": args.chains,
                           "objective": args.objective},
-               "iterations": hist,
+               "iterations": hist, "timed_iterations": len(tail),
                "value": sum(h["agent_steps"] for h in tail) / sum(h["rollout_s"] + h["update_s"] for h in tail), "unit": "agent-steps/s",
                "rollout_agent_steps_per_s": sum(h["agent_steps"] for h in tail) / sum(h["rollout_s"] for h in tail),
                "champions": league.history, "flagged_markets": int((flags != 0).sum().item()), "nav_conservation_violations": int(bad.sum().item()),
