@@ -67,7 +67,10 @@ class BatchedEpisodeRecorder:
         rec.close()
     """
 
-    def __init__(self, output_dir, num_agents, markets=(0,), run_id="", iteration=None, rows_per_file=65536, tag=None):
+    def __init__(self, output_dir, num_agents, markets=(0,), run_id="", iteration=None, rows_per_file=65536, tag=None, sample_every=1):
+        """sample_every (record_rollout): keep one episode in N, chosen by `zlib.crc32(str(episode id)) % N == 0` - the reference recorder's rule
+        (train/episode_record.py:284-291; config/train_config.json episode_sample_every 10); 1 keeps everything."""
+        self.sample_every = max(1, int(sample_every))
         self.output_dir = output_dir
         self.num_agents = int(num_agents)
         self.markets = np.asarray(list(markets), dtype=np.int64)
@@ -171,11 +174,23 @@ class BatchedEpisodeRecorder:
         mods = getattr(self, "module_namer", None)
         self.begin_episodes([namer(int(m), self._ordinal) for m in self.markets], module_ids=None if mods is None else [mods(int(m)) for m in self.markets])
 
+    def sampled(self, episode_id):
+        """the reference's sampling decision (train/episode_record.py:284-291): a pure function of the episode id"""
+        import zlib
+        return self.sample_every == 1 or zlib.crc32(str(episode_id).encode("utf-8")) % self.sample_every == 0
+
     def finish(self, complete=True):
         """The recorded markets' episodes ended (complete=False: sampling stopped before they did)."""
         if self._steps:
-            self._pending.append(self._table(complete))
-            self._pending_rows += self._pending[-1].num_rows
+            table = self._table(complete)
+            if self.sample_every > 1:                      # keep the rows of the sampled episodes only
+                import pyarrow as pa
+                import pyarrow.compute as pc
+                keep = [e for e in self._episode_ids if self.sampled(e)]
+                table = table.filter(pc.is_in(table.column("episode_id"), value_set=pa.array(keep, pa.string()))) if keep else table.slice(0, 0)
+            if table.num_rows:
+                self._pending.append(table)
+                self._pending_rows += table.num_rows
             self._steps = []
         if self._pending_rows >= self.rows_per_file:
             self.flush()

@@ -66,3 +66,32 @@ def test_record_from_hip_env_equals_reference_file(tmp_path):
 
     path = R.replay_and_record(TensorStepper, str(tmp_path))
     R.assert_same_as_reference(path)
+
+
+def test_sample_every_keeps_the_episodes_the_reference_rule_names(tmp_path):
+    """One episode in N by crc32 of the episode id (train/episode_record.py:284-291): the same subset on every worker, no coordination."""
+    import zlib
+    import pyarrow.parquet as pq
+    from gym_continuousdoubleauction_amd.episode_record import BatchedEpisodeRecorder
+    import oracle_lib as O
+    cfg = {"num_of_agents": 4, "init_cash": 1000000, "max_step": 64, "is_render": False}
+    env = O.OracleEnv(cfg, n_markets=6)
+    env.reset(np.arange(6, dtype=np.uint64))
+    rec = BatchedEpisodeRecorder(str(tmp_path), num_agents=4, markets=range(6), sample_every=3)
+    rng = np.random.default_rng(0)
+    ids = []
+    for ep in range(4):
+        names = [f"run-episode{ep}-market{m}" for m in range(6)]
+        ids += names
+        rec.begin_episodes(names)
+        for t in range(3):
+            acts = (rng.integers(0, 9, (6, 4)).astype(np.int32), rng.uniform(-1, 1, (6, 4)).astype(np.float32), rng.uniform(0, 1, (6, 4)).astype(np.float32),
+                    rng.integers(0, 10, (6, 4)).astype(np.int32), rng.integers(0, 3, (6, 4)).astype(np.int32))
+            obs, rew, term, trunc, info = env.step(*acts)
+            rec.record_step(obs, rew, info, acts)
+        rec.finish(complete=True)
+    path = rec.close()
+    want = {e for e in ids if zlib.crc32(e.encode()) % 3 == 0}
+    assert 0 < len(want) < len(ids)
+    t = pq.read_table(path).to_pandas()
+    assert set(t["episode_id"]) == want and len(t) == len(want) * 3 * 4
