@@ -91,6 +91,8 @@ def parse():
     p.add_argument("--transport", choices=["auto", "rccl", "torch"], default=os.environ.get("CDA_BENCH_TRANSPORT", "auto"),
                    help="N>1 hand-back: 'rccl' = ncclAllGather issued natively per chain (cda_step_groups_handback), 'torch' = torch.distributed collectives per chain, "
                         "'auto' = rccl when the process group runs on RCCL and the start-up self-check passes (env: CDA_BENCH_TRANSPORT)")
+    p.add_argument("--probe-native", action="store_true", help="internal: a sacrificial child of an N > 1 run - steps a tiny env through the native RCCL hand-back and exits 0 only if "
+                                                               "that transport carried it (see probe_native_transport)")
     p.add_argument("--no-policy-leg", action="store_true", help="skip value_policy_in_loop")
     p.add_argument("--no-league-leg", action="store_true", help="skip value_league_self_play")
     p.add_argument("--fused", type=int, default=0, metavar="T",
@@ -209,6 +211,39 @@ def pmc_entry(n, a, info, groups):
     return None
 
 
+def probe_native_transport(dist, world, rank, local_rank, device, timeout_s=150.0):
+    """The native hand-back (ncclAllGather issued by the library itself, one communicator per chain) has never run with more than one real RCCL rank: no multi-GPU node was
+    available while it was built.  A collective that hangs cannot be recovered from inside the process that issued it (its kernels spin on the device), so before an
+    N > 1 run trusts it, every rank sends a SACRIFICIAL CHILD process through it: `bench.py --probe-native` on this rank's GPU, a rendezvous of its own (MASTER_PORT + 23),
+    64 markets, a few steps, transport forced to rccl.  The child exits 0 only if the native transport carried the records and the learner-side arrays agreed with
+    torch.distributed's (ShardedVecEnv's start-up self-check); a child that hangs is killed after `timeout_s` - with it its device work - and costs the parent nothing.
+    The ranks then agree (all-reduce MIN): native for all, or torch.distributed for all.  Returns (use_native, note)."""
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 23)
+    env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
+    env["CDA_HANDBACK_TIMEOUT_S"] = str(min(60.0, timeout_s / 2))
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe-native", "--gpus", str(world), "--markets", "64", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+           "--no-extra-legs", "--transport", "rccl"] + (["--force-gather"] if world == 1 else [])     # (one rank: a one-rank communicator, so that one GPU runs the real call)
+    if world > 1:
+        dist.barrier()                                               # the children rendezvous with each other: start them together
+    ok, note = 0.0, ""
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        ok = 1.0 if out.returncode == 0 else 0.0
+        if not ok:
+            note = f"rank {rank}: the probe exited {out.returncode}: {(out.stderr or out.stdout).strip().splitlines()[-1][:200] if (out.stderr or out.stdout).strip() else ''}"
+    except subprocess.TimeoutExpired:
+        note = f"rank {rank}: the probe did not finish within {timeout_s:.0f} s (killed)"
+    t = torch.tensor([ok], device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    use = float(t.item()) >= 1.0
+    return use, ("the native RCCL hand-back passed a sacrificial-child probe on every rank" if use else
+                 f"the native RCCL hand-back failed its sacrificial-child probe ({note or 'on another rank'}): torch.distributed carries the records")
+
+
 def learner_dp(args, dist, world, rank, device, backend):
     """--learner dp: W + K iterations of ppo.train_fused on this rank's shard, gradients summed over the ranks; K iterations timed (max over ranks of the
     per-iteration device times, each bracketed by synchronize).  One JSON line on rank 0."""
@@ -287,6 +322,11 @@ def main():
 
     if args.learner == "dp":
         return learner_dp(args, dist, world, rank, device, backend)
+    probe_note = None
+    if world > 1 and backend == "nccl" and args.transport == "auto" and not args.no_gather and not args.fused and not args.probe_native \
+            and os.environ.get("CDA_BENCH_PROBE_NATIVE", "1") != "0":
+        use_native, probe_note = probe_native_transport(dist, world, rank, local_rank, device)
+        args.transport = "rccl" if use_native else "torch"
     N, A = CONFIGS[args.config]
     N = args.markets if args.markets is not None else N
     A = args.agents if args.agents is not None else A
@@ -431,6 +471,14 @@ def main():
     head_groups, head_ranges = env.groups, list(env.group_ranges)
     head_transport = None if head.sh is None else ("ncclAllGather issued by cda_step_groups_handback" if head.sh.transport == "rccl" else "torch.distributed")
     head_transport_note = None if head.sh is None else getattr(head.sh, "transport_note", None)
+    if probe_note:
+        head_transport_note = f"{probe_note}; {head_transport_note}" if head_transport_note else probe_note
+    if args.probe_native:                                            # the sacrificial child: its exit code is the verdict (the legs above went through the transport)
+        ok = head.sh is not None and head.sh.transport == "rccl" and n_flagged == 0
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier(); dist.destroy_process_group()
+        sys.exit(0 if ok else 4)
     head.close()
 
     extras = {}

@@ -208,3 +208,23 @@ def test_uneven_shards_hand_back_on_the_hip_env_two_ranks_one_gpu(tmp_path):
             assert np.array_equal(got[r]["obs"][t].view(np.uint32), oo.view(np.uint32)), (r, t)
             assert np.array_equal(got[r]["rew"][t].view(np.uint64), orw.view(np.uint64)), (r, t)
     ora.close()
+
+
+@pytest.mark.gpu
+def test_native_transport_probe_runs_in_a_sacrificial_child():
+    """bench.py, N > 1: before the native RCCL hand-back (never run with more than one real rank) is trusted, every rank sends a child process through it and the ranks
+    agree on the verdict; a hang costs the child, not the run.  One GPU: the child runs the real ncclAllGather on a one-rank communicator (passes); a child that is
+    not given the time is killed and the verdict is torch.distributed."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    env_keep = {k: os.environ.pop(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") if k in os.environ}
+    try:
+        ok, note = bench.probe_native_transport(None, 1, 0, 0, torch.device("cuda:0"), timeout_s=300.0)
+        assert ok and "passed a sacrificial-child probe" in note, note
+        ok, note = bench.probe_native_transport(None, 1, 0, 0, torch.device("cuda:0"), timeout_s=0.05)
+        assert not ok and "did not finish" in note and "torch.distributed carries the records" in note, note
+    finally:
+        os.environ.update(env_keep)
