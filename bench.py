@@ -220,7 +220,8 @@ def probe_native_transport(dist, world, rank, local_rank, device, timeout_s=150.
     The ranks then agree (all-reduce MIN): native for all, or torch.distributed for all.  Returns (use_native, note)."""
     import subprocess
     import torch
-    env = dict(os.environ)
+    # (TORCHELASTIC_*: under torch.distributed.run the agent hosts the rendezvous store and ranks only connect to it - the children have no agent: rank 0's must host its own)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 23)
     env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
     env["CDA_HANDBACK_TIMEOUT_S"] = str(min(60.0, timeout_s / 2))
