@@ -1846,9 +1846,16 @@ __global__ __launch_bounds__(256) void k_episode_returns(const double* __restric
     if (i >= B) return;
     const long long n = i / Ag; const int a = (int)(i - n * Ag);
     double run = running[i], s = 0.0, c = 0.0;
-    for (int t = 0; t < T; t++) {
-        run += reward[(long long)t * B + i];
-        if (term[(long long)t * N + n] | trunc[(long long)t * N + n]) { s += run; c += 1.0; run = 0.0; }
+    for (int t0 = 0; t0 < T; t0 += 8) {                                         // eight steps' operands requested together (one step at a time: a round trip per step, 72 us for 64)
+        double rw[8]; bool dn[8];
+        #pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = t0 + u < T ? t0 + u : T - 1;
+            rw[u] = reward[(long long)t * B + i]; dn[u] = (term[(long long)t * N + n] | trunc[(long long)t * N + n]) != 0;
+        }
+        #pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (t0 + u < T) { run += rw[u]; if (dn[u]) { s += run; c += 1.0; run = 0.0; } }
     }
     running[i] = run;
     if (c > 0.0) { atomicAdd(&done_sum[a], s); atomicAdd(&done_count[a], c); }
