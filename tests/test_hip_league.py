@@ -505,3 +505,19 @@ def test_league_training_records_sampled_episodes_with_module_ids(tmp_path):
     assert (df.groupby(["episode_id", "agent_id"])["module_id"].nunique() == 1).all()
     assert not df[df.episode_id.str.contains("episode0")]["module_id"].str.startswith("champion").any()
     env.close()
+
+
+def test_every_slot_trainable_is_independent_learners():
+    """num_trainable == num_agents: no pool, no draws - four separately trained policies, one per slot, each updated from its own slot's records"""
+    from gym_continuousdoubleauction_amd import CDAVecEnv
+    from gym_continuousdoubleauction_amd.league_train import train_league_fused
+    N, A = 128, 4
+    env = CDAVecEnv({"num_of_agents": A, "init_cash": 1000000, "max_step": 16, "is_render": False, "auto_reset": True}, n_markets=N, with_info=False)
+    bank, league, hist = train_league_fused(env, iters=2, horizon=16, num_trainable=A, max_champions=4, min_iterations_between_champions=1, std_dev_multiplier=-10.0, log=lambda s: None)
+    assert bank.n_trainable == A and all(float(p.adam_step.item()) == 2 * 4 for p in bank.policies)
+    th = [p.theta.cpu() for p in bank.policies]
+    assert all(torch.isfinite(t).all() for t in th) and all(not torch.equal(th[0], t) for t in th[1:])
+    assert set(hist[-1]["module_returns"]) == {f"policy_{a}" for a in range(A)}
+    assert (bank.slot_net.cpu() == torch.arange(A, dtype=torch.int32)).all()          # champions exist (the rule promoted one per iteration) but no slot ever draws one
+    assert len(league.history) == 2 and (env.flags() == 0).all()
+    env.close()
