@@ -119,7 +119,6 @@ class LeagueSlotMapper:
         net_of: {module id: bank row} for the pool's network modules (champions); modules not named there play the uniform random law
         (the reference's fixed opponents are RandomRLModules, train/model/model_handler.py:38-53).  slot_pool (optional i32 [N, A] device tensor)
         receives the draw itself: available_modules[num_trainable + slot_pool] is the module's id (-1: the slot's own trainable policy)."""
-        import ctypes as C
         import torch
         from ._lib import check, lib
         from .mlp import LEAGUE_RANDOM

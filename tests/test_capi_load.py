@@ -150,3 +150,50 @@ def test_every_network_entry_point_exists_for_every_compiled_history_depth():
             getattr(so, f"{name}_h{h}")
     import __graft_entry__ as G
     assert tuple(G.MLP_HIST_VARIANTS) == tuple(variants)
+
+
+def test_network_entry_points_refuse_bad_arguments_before_touching_the_device(hip_lib):
+    """include/cda_mlp.h: every entry point of the network / league / learner side, in every compiled history depth, validates first - all-NULL arguments and
+    out-of-range sizes return CDA_ERR_INVALID with no launch (this test runs without a GPU), so a binding bug on the consumer's side is an error code, not a fault."""
+    from gym_continuousdoubleauction_amd import _lib
+    L, _ = hip_lib
+    INVALID = -1
+
+    def zero(t):
+        if t is C.c_void_p or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return None
+        return 0.0 if t in (C.c_float, C.c_double) else 0
+    for name in _lib.MLP_SYMBOLS:
+        for sfx in [""] + [f"_h{h}" for h in _lib.MLP_HIST_VARIANTS]:
+            fn = getattr(L, name + sfx)
+            if not fn.argtypes:
+                assert fn() > 0                                    # (cda_mlp_tile_rows, cda_mlp_wgrad_jobs: constants of the build)
+                continue
+            assert fn(*[zero(t) for t in fn.argtypes]) == INVALID, name + sfx
+    one = C.c_void_p(64)                                          # non-NULL, never dereferenced: the size checks fail first
+    for sfx in ("", "_h8"):
+        fb = getattr(L, "cda_mlp_forward_backward" + sfx)
+        call_fb = lambda rows, agents, extra=None, adv=None, adv_n=0, finish=0, out6=one: fb(   # noqa: E731
+            one, one, one, one, rows, 0, one, adv, adv_n, agents, 0.2, 0.5, 0.01, extra, one, one, one, one, one, one, one, one, out6, 1, finish, None, None, None)
+        assert call_fb(0, 4) == INVALID and call_fb(48, 4) == INVALID and call_fb(64, 0) == INVALID and call_fb(64, 17) == INVALID
+        assert call_fb(64, 4, adv=one, adv_n=1) == INVALID and call_fb(64, 4, finish=1, out6=None) == INVALID
+        x = _lib.PpoExtra()
+        x.rec_stride, x.kl_coef, x.vf_clip = 24, 0.0, 0.0          # a league record stride below agents * 8
+        assert call_fb(64, 4, extra=C.pointer(x)) == INVALID
+        x.rec_stride = 34                                          # not a multiple of 4 floats (the records are read as 16-byte pieces)
+        assert call_fb(64, 4, extra=C.pointer(x)) == INVALID
+        x.rec_stride, x.kl_coef = 0, 0.2                           # a KL penalty without the rollout's stored distributions
+        assert call_fb(64, 4, extra=C.pointer(x)) == INVALID
+        wg = getattr(L, "cda_mlp_wgrad" + sfx)
+        assert wg(one, one, one, one, one, one, 64, 3, one, None) == INVALID and wg(one, one, one, one, one, one, 40, 1, one, None) == INVALID
+        vals = getattr(L, "cda_mlp_values" + sfx)
+        assert vals(one, one, 0, one, 64, one, 64, None) == INVALID and vals(one, one, 17, one, 64, one, 64, None) == INVALID and vals(one, one, 2, one, 0, one, 64, None) == INVALID
+        assign = getattr(L, "cda_league_assign" + sfx)
+        assert assign(one, 8, 4, 2, one, one, 0, one, None, None) == INVALID and assign(one, 0, 4, 2, one, one, 3, one, None, None) == INVALID
+        assert assign(one, 8, 17, 2, one, one, 3, one, None, None) == INVALID and assign(one, 8, 4, 5, one, one, 3, one, None, None) == INVALID
+        gl = getattr(L, "cda_gae_records_league" + sfx)
+        assert gl(one, one, one, one, 8, 8, 4, 0, 1.0, 0.99, 0.95, one, one, None) == INVALID and gl(one, one, one, one, 8, 8, 4, 5, 1.0, 0.99, 0.95, one, one, None) == INVALID
+        er = getattr(L, "cda_episode_returns" + sfx)
+        assert er(one, one, one, 0, 8, 4, one, one, one, None, None) == INVALID and er(one, one, one, 8, 8, 17, one, one, one, None, None) == INVALID
+        red = getattr(L, "cda_mlp_reduce" + sfx)
+        assert red(one, 0, one, 1, None, 0, 0.5, 0.01, 0.0, None, one, one, one, None) == INVALID and red(one, 1, one, 1, one, 0, 0.5, 0.01, 0.0, None, one, one, one, None) == INVALID
