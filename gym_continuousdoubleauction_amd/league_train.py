@@ -1,17 +1,21 @@
 """League self-play on the batched env (SURVEY §8(f)-1 + 3 together): the trainable slots learn with PPO against a pool of
 fixed random opponents and frozen champion snapshots, assigned per episode by the reference's mapping rule.
 
-What the reference does with RLlib (train/train.py:453-541 + train/callbk/league_based_self_play_callback.py: opponent
-sampling :1286-1344, champion snapshots :938-1170) and what this module keeps of it:
-  * slots below `num_trainable` are played by the learning policy, every other slot by a module drawn from the pool
-    (`LeagueSlotMapper`, weights original_opponent_weight / champion_weight, keyed by the episode id);
-  * only the trainable slots' transitions feed the PPO update;
-  * a champion is a frozen copy of the learning policy, added to the pool when the iteration's mean return of the
-    trainable slots beats the best so far by `promote_margin` (a plain statement of the idea, not the reference's full
-    trigger logic with its win-rate windows and checkpoint handling).
-One iteration = one whole episode of every market (`horizon == max_step`), so all markets change opponents together and the
-rollout needs no host sync.
+Two loops:
+  * `train_league_fused` - the reference's training topology (train/train.py:466-503: `num_trained_agents` SEPARATELY trained policies, policy_p plays slot p; every
+    other slot drawn per episode from uniform random modules and champions, callbk/league_based_self_play_callback.py:1286-1344; promotion by the reference's
+    rule, :780-880) on the hand-written network kernels (include/cda_mlp.h `cda_league`): one policy launch per step for every module of every market, rollouts
+    replayed from HIP graphs, each policy's update reading its own slot's records in place.  This is the one `bench.py` and `profiles/r05/bench_league.json` measure.
+  * `train_league` - the same idea on the float32 torch network (ppo.ActorCritic), one shared learning policy, step by step from the host: the statement the
+    fused loop's tests compare against, 30-50 x slower.  What it keeps of the reference:
+      - slots below `num_trainable` are played by the learning policy, every other slot by a module drawn from the pool
+        (`LeagueSlotMapper`, weights original_opponent_weight / champion_weight, keyed by the episode id);
+      - only the trainable slots' transitions feed the PPO update;
+      - a champion is a frozen copy of the learning policy, added to the pool when the iteration's mean return of the trainable slots beats the
+        best so far by `promote_margin` (a plain statement of the idea; the reference's trigger is `League.maybe_promote` below);
+      - one iteration = one whole episode of every market (`horizon == max_step`).
 
+    python -m gym_continuousdoubleauction_amd.league_train --fused --markets 2048 --agents 8 --episode 64 --iters 10
     python -m gym_continuousdoubleauction_amd.league_train --markets 1024 --agents 4 --iters 6
 """
 import argparse
