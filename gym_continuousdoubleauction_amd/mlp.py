@@ -433,7 +433,7 @@ class RolloutChains:
         self._fork = torch.cuda.Event()
         self._joins = [torch.cuda.Event() for _ in range(G)]
         self.graphs = None
-        self._have_obs = False
+        self._have_obs, self._env_epoch = False, 0
         self.use_graphs = bool(use_graphs)
         self.join_mode = "events"
 
@@ -461,10 +461,12 @@ class RolloutChains:
         """one rollout of `horizon` steps; returns the buffer dict (views stay valid; the next run() overwrites them)"""
         dev = self.device
         cur = torch.cuda.current_stream(dev)
-        if not self._have_obs:                                   # the very first rollout starts from the env's current observation
+        if not self._have_obs or self._env_epoch != getattr(self.env, "host_epoch", 0):
+            # the very first rollout - and the first one after the markets were reset / stepped from the HOST (env.host_epoch) - starts from the env's own
+            # observation tensor; every other rollout continues from its predecessor's last observation (the chains do not write env.obs)
             self.env.join()
             self.buf["obs"][self.T].copy_(self.env.obs)
-            self._have_obs = True
+            self._have_obs, self._env_epoch = True, getattr(self.env, "host_epoch", 0)
         self.counter.add_(1)                                     # fresh draws for this rollout (on the caller's stream, before the fork)
         if self.capture_ends:
             self.buf["fin_count"].zero_(); self.buf["fin_index"].fill_(-1)

@@ -26,6 +26,8 @@ class CDAVecEnv:
     def __init__(self, config=None, n_markets=1, device="cuda:0", with_info=True, out_buffers=1, groups=1, handback=False, group_streams=None):
         self.cfg_struct, self.config = K.make_config(config)
         self.n_markets = int(n_markets)
+        self.host_epoch = 0                 # bumped by every host-side call that changes the markets (reset / step / run_random / place_order / set_state): consumers that keep
+                                            # their own copy of the observations across calls (mlp.RolloutChains) compare it to know when theirs is stale
         self.num_agents = self.cfg_struct.num_agents
         self.n_hist = self.cfg_struct.n_hist
         self.obs_dim = self.n_hist * K.SNAPSHOT_DIM
@@ -176,6 +178,7 @@ class CDAVecEnv:
             mask_t = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
             if mask_t.shape != (self.n_markets,):
                 raise ValueError("mask must have shape [n_markets]")
+        self.host_epoch += 1
         self.join()                         # (groups > 1: the reset is issued on the caller's stream, after every group's last step)
         with torch.cuda.device(self.device):
             check(lib().cda_reset(self._h, seeds_t.data_ptr() if seeds_t is not None else None,
@@ -237,6 +240,7 @@ class CDAVecEnv:
             d = category
             present = d.get("present", present)
             category, size_mean, size_sigma, price, price_offset = (d[k] for k in ACTION_KEYS)
+        self.host_epoch += 1
         cat = self._prep(category, torch.int32)
         sm = self._prep(size_mean, torch.float32)
         ss = self._prep(size_sigma, torch.float32)
@@ -277,6 +281,7 @@ class CDAVecEnv:
         counter-based sampler of include/cda_random_agents.h) play up to `n_steps` steps, each market stopping at its own
         episode end.  Returns (obs f32[N,obs_dim], episode_return f64[N,A], terminated, truncated, steps_taken i32[N]);
         bit-identical to `n_steps` calls of step() on `random_actions(t)`."""
+        self.host_epoch += 1
         N, A, dev = self.n_markets, self.num_agents, self.device
         self.join()
         if not hasattr(self, "_rr_steps"):
@@ -311,6 +316,7 @@ class CDAVecEnv:
 
     # ------------------------------------------------------------------ diagnostics
     def place_order(self, market, trader, type_, side, size, price=1):
+        self.host_epoch += 1
         check(lib().cda_place_order(self._h, market, trader, type_, side, size, price), "cda_place_order")
 
     def mark_to_mkt(self, market=0):
@@ -336,6 +342,7 @@ class CDAVecEnv:
         return np.ctypeslib.as_array(buf).view(np.int32).reshape(-1, 5)[: n.value].copy()
 
     def set_state(self, market, state):
+        self.host_epoch += 1
         torch.cuda.synchronize(self.device)
         check(lib().cda_set_state(self._h, market, C.byref(state)), "cda_set_state")
 

@@ -521,3 +521,26 @@ def test_every_slot_trainable_is_independent_learners():
     assert (bank.slot_net.cpu() == torch.arange(A, dtype=torch.int32)).all()          # champions exist (the rule promoted one per iteration) but no slot ever draws one
     assert len(league.history) == 2 and (env.flags() == 0).all()
     env.close()
+
+
+@pytest.mark.parametrize("league", [False, True])
+def test_a_host_side_reset_between_rollouts_is_where_the_next_rollout_starts(league):
+    """RolloutChains carries the last observation from rollout to rollout (the chains never write env.obs); when the markets are reset or stepped from the HOST in
+    between (env.host_epoch), the next rollout starts from the env's own observation tensor - and replays through the oracle from that reset."""
+    from gym_continuousdoubleauction_amd import CDAVecEnv, mlp
+    N, A, T = 64, 4, 9
+    cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 4096, "is_render": False, "auto_reset": True}
+    env = CDAVecEnv(cfg, n_markets=N, with_info=False)
+    actor = _bank(N, A, 2, 1, seed=5, scale=1.0) if league else mlp.FusedPolicy(DEV, seed=3)
+    env.reset(seed=700)
+    roll = mlp.RolloutChains(env, actor, T, groups=2, seed=17)
+    b0 = {key: v.cpu().clone() for key, v in roll.run().items() if torch.is_tensor(v)}
+    _replay(cfg, N, 700, b0, T)
+    b1 = {key: v.cpu().clone() for key, v in roll.run().items() if torch.is_tensor(v)}          # no host call in between: continues where the first one ended
+    assert torch.equal(b1["obs"][0], b0["obs"][T])
+    first = env.reset(seed=9000).clone()
+    b2 = {key: v.cpu().clone() for key, v in roll.run().items() if torch.is_tensor(v)}
+    assert torch.equal(b2["obs"][0], first.cpu()) and not torch.equal(b2["obs"][0], b1["obs"][T])
+    _replay(cfg, N, 9000, b2, T)
+    assert (env.flags() == 0).all() and (env.check_invariants() == 0).all()
+    env.close()
