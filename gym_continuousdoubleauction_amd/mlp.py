@@ -429,7 +429,8 @@ class RolloutChains:
             from .streams import concurrent_streams
             self.streams = list(concurrent_streams(dev, G))
         else:
-            self.streams = [torch.cuda.current_stream(dev)]
+            cur = torch.cuda.current_stream(dev)                   # one chain: the caller's stream - unless that is the default stream and graphs are wanted
+            self.streams = [torch.cuda.Stream(dev) if (use_graphs and cur == torch.cuda.default_stream(dev)) else cur]     # (no capture on the default stream)
         self._fork = torch.cuda.Event()
         self._joins = [torch.cuda.Event() for _ in range(G)]
         self.graphs = None

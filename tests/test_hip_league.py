@@ -197,7 +197,7 @@ def _replay(cfg, N, seed, b, T, with_fin=None):
     return finals
 
 
-@pytest.mark.parametrize("groups,use_graphs", [(1, False), (3, True)])
+@pytest.mark.parametrize("groups,use_graphs", [(1, False), (1, True), (3, True)])
 def test_league_rollout_replays_through_the_oracle(groups, use_graphs):
     """A league rollout as independent chains: the recorded actions of ALL slots (trainable, frozen, random) replayed through the CPU oracle reproduce the recorded
     observations and rewards bit for bit; every step's record is what a single league step on that step's observation gives; episode ends are captured."""
@@ -234,6 +234,7 @@ def test_league_rollout_replays_through_the_oracle(groups, use_graphs):
         for p in range(k):
             assert torch.equal(bank.policies[p].forward(buf["obs"][T])[:, 24].cpu(), b["value"][p, T])
         assert torch.equal(roll.log_std_old.cpu(), bank.theta[:k, mlp.OFF_LS:].cpu())
+    assert (roll.graphs is not None) == use_graphs                # (one chain on the default stream: captured on a side stream, not a silent fall-back to direct launches)
     assert (env.flags() == 0).all() and (env.check_invariants() == 0).all()
     env.close()
 

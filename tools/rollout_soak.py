@@ -47,11 +47,19 @@ def replay(cfg, N, seed, b, T):
     return finals, steps
 
 
+QUIET = False
+
+
+def say(*a, **k):
+    if not QUIET:
+        print(*a, **k)
+
+
 def one(rng, index):
     from gym_continuousdoubleauction_amd import CDAVecEnv, mlp
     H = int(rng.choice([1, 2, 4, 8]))
     A = int(rng.choice([2, 3, 4, 5, 8, 12, 16]))
-    N = int(rng.choice([33, 64, 96, 160, 257]))
+    N = int(rng.choice([33, 64, 96, 160, 257, 1024]))
     T = int(rng.integers(5, 25))
     max_step = int(rng.choice([T // 2 + 1, T, 3 * T, 4096]))
     league = bool(rng.integers(0, 2))
@@ -61,7 +69,7 @@ def one(rng, index):
     cash = int(rng.choice([1000000, 20000, 3000]))                      # small accounts: bankruptcies (terminations) inside the rollout
     seed = int(rng.integers(1, 1 << 30))
     cfg = {"num_of_agents": A, "init_cash": cash, "max_step": max_step, "is_render": False, "auto_reset": True, "n_hist": H}
-    print(f"  {index:3d}: {N:3d} markets x {A:2d} agents, n_hist {H}, max_step {max_step:4d}, init_cash {cash:7d}, horizon {T:2d}, {groups} chain(s), "
+    say(f"  {index:3d}: {N:3d} markets x {A:2d} agents, n_hist {H}, max_step {max_step:4d}, init_cash {cash:7d}, horizon {T:2d}, {groups} chain(s), "
           f"{'graphs' if graphs else 'direct'}, {'league' if league else 'one shared policy'}, dist {int(with_dist)}, capture {int(capture)}, seed {seed}", flush=True)
     env = CDAVecEnv(cfg, n_markets=N, with_info=False)
     gen = torch.Generator().manual_seed(seed)
@@ -105,22 +113,35 @@ def one(rng, index):
                 assert np.array_equal(b["fin_obs"][fi[t, j]].numpy().view(np.uint32), want.view(np.uint32)), ("captured observation", t, j)
     assert (env.flags() == 0).all() and (env.check_invariants() == 0).all()
     env.close()
-    print(f"       {what}: {steps} market-steps, {ended} episode ends - ok", flush=True)
-    return steps, ended
+    say(f"       {what}: {steps} market-steps, {ended} episode ends - ok", flush=True)
+    return steps, ended, (H, A, league, graphs, capture, with_dist)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--quiet", action="store_true", help="only the summary (and the configuration that fails)")
     a = ap.parse_args()
+    global QUIET
+    QUIET = a.quiet
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     steps = ended = 0
+    from collections import Counter
+    cover = Counter()
     print(f"fused rollouts against the CPU oracle, {a.configs} random configurations (seed {a.seed}):")
     for i in range(a.configs):
-        s, e = one(rng, i)
+        state = rng.bit_generator.state
+        try:
+            s, e, (H, A, league, graphs, capture, dist) = one(rng, i)
+        except BaseException:
+            print(f"configuration {i} FAILED (generator state before it: {state})", flush=True)
+            raise
         steps += s; ended += e
+        cover[f"n_hist {H}"] += 1; cover[f"{A} agents"] += 1; cover["league" if league else "one shared policy"] += 1
+        cover["graphs" if graphs else "direct launches"] += 1; cover["episode-end capture"] += int(capture); cover["stored distributions"] += int(dist)
+    print("configurations per dimension: " + ", ".join(f"{k}: {v}" for k, v in sorted(cover.items())))
     print(f"{a.configs} configurations, {steps} market-steps, {ended} episode ends replayed bit for bit in {time.time() - t0:.0f} s: no difference")
 
 
