@@ -333,9 +333,49 @@ BLOCKS = lambda mlp: ((mlp.OFF_W1, mlp.OFF_B1, "W1"), (mlp.OFF_B1, mlp.OFF_W2, "
 def test_masked_and_rllib_objective_gradient_equals_float32_autograd(A, slot, kl_coef, vf_clip):
     """The fused update's gradient - record stride selecting ONE slot per row (league), KL(old || new) exact per row, clamped value error - against loss.backward()
     through ppo.ActorCritic in float32 on the selected samples only."""
+    check_gradient(A, slot, kl_coef, vf_clip)
+
+
+def _loss_gradient_on_outputs(out, log_std, sel, dist_old, ls_old, clip, vf_coef, ent_coef, kl_coef, vf_clip):
+    """d loss / d outputs and d loss / d log_std by float64 autograd, starting from the kernel's OWN float32 outputs [R, 32] (so the clip / clamp decisions are taken
+    on the same numbers): sel [R, agents, 8] the rows' sample records, dist_old [R, 24] - all in minibatch order"""
+    R, agents = sel.shape[0], sel.shape[1]
+    o = out.double().clone().requires_grad_()
+    ls = log_std.double().clone().requires_grad_()
+    O = o.repeat_interleave(agents, 0)
+    flat = sel.reshape(R * agents, 8)
+    acts = [flat[:, c].contiguous().view(torch.int32).long() for c in range(3)]
+    a_cont, lp_old, adv, ret = flat[:, 3:5].double(), flat[:, 5].double(), flat[:, 6].double(), flat[:, 7].double()
+    logp = ent = 0.0
+    for (lo, hi), a in zip(((0, 9), (9, 19), (19, 22)), acts):
+        l = torch.log_softmax(O[:, lo:hi], -1)
+        logp = logp + l.gather(1, a.view(-1, 1)).squeeze(1)
+        ent = ent - (l.exp() * l).sum(-1)
+    z = (a_cont - O[:, 22:24]) * torch.exp(-ls)
+    logp = logp + (-0.5 * z * z - ls - 0.5 * math.log(2 * math.pi)).sum(-1)
+    ent = ent + (0.5 + 0.5 * math.log(2 * math.pi) + ls).sum()
+    ratio = (logp - lp_old).exp()
+    pg = -torch.min(ratio * adv, ratio.clamp(1 - clip, 1 + clip) * adv).mean()
+    sq = (O[:, 24] - ret).pow(2)
+    vl = (sq.clamp(max=vf_clip) if vf_clip > 0 else sq).mean()
+    loss = pg + vf_coef * vl - ent_coef * ent.mean()
+    if kl_coef:
+        d, lo_ = dist_old.double(), ls_old.double()
+        kl = 0.0
+        for lo, hi in ((0, 9), (9, 19), (19, 22)):
+            kl = kl + (d[:, lo:hi].exp() * (d[:, lo:hi] - torch.log_softmax(o[:, lo:hi], -1))).sum(-1)
+        kl = kl + ((ls - lo_) + (torch.exp(2 * lo_) + (d[:, 22:24] - o[:, 22:24]) ** 2) / (2 * torch.exp(2 * ls)) - 0.5).sum(-1)
+        loss = loss + kl_coef * kl.mean()
+    loss.backward()
+    return o.grad, ls.grad
+
+
+def check_gradient(A, slot, kl_coef, vf_clip, R=512, seed=6, chunks=4, check_clip_share=True, soak=False):
+    """(also driven over random shapes by tools/gradient_soak.py, soak=True: there the TIGHT check is the loss gradient on the kernel's own outputs; the whole
+    gradient against float32 autograd is held to wider bands - a sample whose ratio / value error sits within bfloat16 noise of a clip / clamp boundary takes the
+    other branch in float32, a discrete change of that sample's whole contribution, and random shapes with few samples per minibatch meet that)"""
     from gym_continuousdoubleauction_amd import mlp
-    R = 512
-    g = torch.Generator().manual_seed(6)
+    g = torch.Generator().manual_seed(seed)
     th = mlp.init_theta(generator=torch.Generator().manual_seed(13))
     p = mlp.FusedPolicy(DEV, theta=th)
     th_old = th.clone(); th_old[:mlp.OFF_LS] += 0.02 * torch.randn(mlp.OFF_LS, generator=g); th_old[mlp.OFF_LS:] = torch.tensor([-0.4, -0.65])
@@ -352,7 +392,7 @@ def test_masked_and_rllib_objective_gradient_equals_float32_autograd(A, slot, kl
     dist_old = torch.cat([torch.log_softmax(old_out[:, :9], -1), torch.log_softmax(old_out[:, 9:19], -1), torch.log_softmax(old_out[:, 19:22], -1), old_out[:, 22:24]], dim=1).contiguous()
     ls_old = th_old[mlp.OFF_LS:].clone()
     agents = 1 if slot is not None else A
-    upd = mlp.FusedUpdate(p, R, R, agents, chunks=4)
+    upd = mlp.FusedUpdate(p, R, R, agents, chunks=chunks)
     upd.perm.copy_(torch.randperm(R, generator=g))
     recd, xd, dd, lsd = rec.to(DEV), x.to(DEV), dist_old.to(DEV), ls_old.to(DEV)
     upd.set_extra(rec_stride=8 * A if slot is not None else 0, kl_coef=kl_coef, vf_clip=vf_clip, dist_old=dd, log_std_old=lsd)
@@ -371,21 +411,33 @@ def test_masked_and_rllib_objective_gradient_equals_float32_autograd(A, slot, kl
                                         0.3, 1.0, 0.01, kl_coef, vf_clip, agents)
     loss.backward()
     gm = _grad_vector(m)
+    # (1) tight: the loss gradient the kernel fed its backward pass, against float64 autograd on the kernel's own outputs (same decisions at the clip / clamp
+    #     boundaries): every shape-dependent piece - record stride, agents per row, the KL rows, the clamp - is in this step
+    pm = perm[:R]
+    g_out, g_ls = _loss_gradient_on_outputs(upd.out[:R].cpu(), p.theta[mlp.OFF_LS:].cpu(), sel[pm], dist_old[pm], ls_old, 0.3, 1.0, 0.01, kl_coef, vf_clip)
+    d_out = upd.d_out[:R].cpu().double()
+    scale = float(g_out.abs().max())
+    err = float((d_out[:, :25] - g_out[:, :25]).abs().max())
+    assert err <= 1e-4 * scale, ("d loss / d outputs", err, scale)
+    assert float(d_out[:, 25:].abs().max()) == 0.0
+    assert float((grad[mlp.OFF_LS:] - g_ls).abs().max()) <= 1e-4 * float(g_ls.abs().max()) + 1e-9, ("d loss / d log_std", grad[mlp.OFF_LS:], g_ls)
+    # (2) the whole gradient against float32 autograd through the PyTorch network
     cos = float((grad * gm).sum() / (grad.norm() * gm.norm()))
-    assert cos > 0.999, cos                                       # bfloat16 operands against float32: direction within 1e-3, every block's magnitude within 3 %
+    assert cos > (0.98 if soak else 0.999), cos                   # bfloat16 operands against float32: direction within 1e-3, every block's magnitude within 3 %
     for lo, hi, name in BLOCKS(mlp):
         a, b = grad[lo:hi], gm[lo:hi]
-        assert (a - b).norm() <= 3e-2 * b.norm() + 1e-9, (name, float((a - b).norm() / b.norm()))
+        assert (a - b).norm() <= (0.15 if soak else 3e-2) * b.norm() + 1e-9, (name, float((a - b).norm() / b.norm()))
     assert abs(float(out6[3]) - float(loss.detach())) <= 2e-2 * abs(float(loss.detach())) + 1e-3
-    assert abs(float(out6[1]) - float(vl)) <= 2e-2 * float(vl) + 1e-4
+    assert abs(float(out6[1]) - float(vl.detach())) <= 2e-2 * float(vl.detach()) + 1e-4
     if kl_coef:
         assert float(kl) > 1e-4 and abs(float(out6[6]) - float(kl)) <= 3e-2 * float(kl) + 1e-5, (float(out6[6]), float(kl))
     else:
         assert float(out6[6]) == 0.0
-    if vf_clip:                                                    # the clamp is active on a real share of the samples
+    if vf_clip and check_clip_share:                               # the clamp is active on a real share of the samples
         frac = float(((m.evaluate(x, acts, agents_per_row=agents)[2] - sel[..., 7].reshape(-1)).pow(2) > vf_clip).float().mean())
         assert 0.2 < frac < 0.95, frac
     del perm
+    return cos
 
 
 def test_fused_league_training_runs_the_reference_topology():

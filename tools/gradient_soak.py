@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Soak of the fused update's gradient (k_mlp_fb + k_mlp_wgrad + k_grad_reduce: bf16 MFMA operands, f32 accumulation) against float32 autograd through the PyTorch
+statement of the network and of the objective, over random shapes: rows per minibatch (whole and ragged 64-row tiles), agents per row, a league's record stride
+selecting one slot, KL penalty, value-error clamp, weight-gradient chunk counts.  tests/test_hip_league.py check_gradient(soak=True): TIGHT (1e-4 of the largest entry)
+for the loss gradient the kernel feeds its backward pass, against float64 autograd on the kernel's own outputs - where every shape-dependent piece lives; the whole
+gradient against float32 autograd through the PyTorch network within cos > 0.98 / 15 % per block (random shapes with few samples meet clip / clamp decisions that flip
+under bfloat16 noise; the pinned seeds of the test hold 0.999 / 3 %).
+
+    python tools/gradient_soak.py --configs 60 --seed 1 > profiles/r05/gradient_soak.txt
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    from test_hip_league import check_gradient
+    rng = np.random.default_rng(a.seed)
+    t0, worst, failed = time.time(), 1.0, 0
+    print(f"fused update gradient against float32 autograd, {a.configs} random shapes (seed {a.seed}):")
+    for i in range(a.configs):
+        R = int(rng.choice([64, 96, 160, 512, 1056, 2048, 4128]))
+        A = int(rng.integers(1, 17))
+        slot = int(rng.integers(0, A)) if rng.integers(0, 2) else None
+        kl = float(rng.choice([0.0, 0.2, 1.0]))
+        vf_clip = float(rng.choice([0.0, 0.5, 10.0]))
+        chunks = int(rng.integers(1, min(8, R // 32) + 1))
+        seed = int(rng.integers(1, 1 << 30))
+        what = f"  {i:3d}: {R:4d} rows x {A:2d} agents, slot {slot}, kl_coef {kl}, vf_clip {vf_clip}, {chunks} chunk(s), seed {seed}"
+        try:
+            cos = check_gradient(A, slot, kl, vf_clip, R=R, seed=seed, chunks=chunks, check_clip_share=False, soak=True)
+        except AssertionError as ex:
+            print(f"{what}: FAILED {ex}", flush=True)
+            failed += 1
+            continue
+        worst = min(worst, cos)
+        print(f"{what}: cos {cos:.6f} - ok", flush=True)
+    print(f"{a.configs} shapes in {time.time() - t0:.0f} s: {failed} outside the tolerances; smallest cosine of the others {worst:.6f}")
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()
