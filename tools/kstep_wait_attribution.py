@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """VERDICT r4 #4, part one: where does k_step's 40 % wait share come from?  Condenses three rocprofv3 --pmc passes over `bench.py --steps 200 --repeats 1`
-(run by tools/gpu_r05_b.sh) into one table: cycles of a market-wave by what the SQ says it was doing.  Usage: kstep_wait_attribution.py <dir with pmc_w1..3>"""
+(run by tools/r5_kstep_wait_attribution.sh) into one table: cycles of a market-wave by what the SQ says it was doing.  Usage: kstep_wait_attribution.py <dir with pmc_w1..3>"""
 import csv
 import glob
 import os

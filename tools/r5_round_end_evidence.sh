@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: the evidence kept under profiles/r05/ - GPU suite + smoke, the driver's bench command, rocprofv3 kernel stats of it and of the league loop,
-# the record-cost probe, the data-parallel learner's one-rank line.   Usage (through gpurun): bash tools/gpu_r05_evidence.sh
+# the record-cost probe, the data-parallel learner's one-rank line.   Usage (through gpurun): bash tools/r5_round_end_evidence.sh
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 O=$R/gpurun_out/r05/evidence; mkdir -p $O
