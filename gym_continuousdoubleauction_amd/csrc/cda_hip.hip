@@ -29,6 +29,12 @@
 #include "../../include/cda_random_agents.h"
 #include "cda_dec.hpp"
 #include "cda_market.hpp"
+#include <type_traits>
+#include "../../include/cda_mlp.h"          // the network's layout constants (n_hist = 4): k_policy_step evaluates the policy inside the step kernel
+namespace cda { namespace mlpdev {
+#include "cda_mlp_dev.inc"
+} }
+#pragma clang fp contract(off)              // (the include above switched contraction on for the network's arithmetic; everything below is the env's)
 
 using namespace cda;
 
@@ -591,6 +597,48 @@ int cda_step_range_capture(cda_env* e, int32_t first_market, int32_t n_markets,
     }
     HIPCHK(hipSetDevice(e->device));
     return launch_step(e, first_market, n_markets, S, (hipStream_t)stream);
+}
+
+// The policy inside the step kernel (k_policy_step, cda_kernels.inc): what include/cda_mlp.h's rollout chains launch per step when the env qualifies.
+int cda_policy_step_supported(const cda_env* e) {
+    if (!e) return 0;
+    const cda_config& c = e->P.cfg;
+    return e->cap == 256 && c.n_hist == 4 && c.num_agents <= 8 && !e->handback &&
+           cda::cap256::policy_step_lds_bytes(c.num_agents, c.n_hist) <= 160 * 1024;
+}
+int cda_policy_step_range(cda_env* e, int32_t first_market, int32_t n_markets, const void* wb, const float* theta, const float* obs_in,
+                          uint64_t seed, const int64_t* counter_dev, int64_t draw,
+                          int32_t* category, float* size_mean, float* size_sigma, int32_t* price, int32_t* price_offset,
+                          float* a_cont, float* logp, float* value, float* rec, float* dist,
+                          float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                          float* fin_obs, int32_t fin_cap, int32_t* fin_count, int32_t* fin_index_out, void* stream) {
+    if (!e || !wb || !theta || !obs_in || !counter_dev || !a_cont || !logp || !value) return CDA_ERR_INVALID;
+    if (!cda_policy_step_supported(e)) return CDA_ERR_UNSUPPORTED;
+    StepArgs S;
+    int rc = fill_step_args(e, S, category, size_mean, size_sigma, price, price_offset, NULL, obs_out, reward_out, terminated_out, truncated_out, NULL);
+    if (rc) return rc;
+    if (!range_ok(e, first_market, n_markets)) return CDA_ERR_INVALID;
+    if (fin_index_out) {
+        if (!e->P.cfg.auto_reset || !fin_obs || !fin_count || fin_cap < 1) return CDA_ERR_INVALID;
+        S.fin_obs = fin_obs; S.fin_count = fin_count; S.fin_index_out = fin_index_out; S.fin_cap = fin_cap;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    const size_t smem = (size_t)cda::cap256::policy_step_lds_bytes(e->P.cfg.num_agents, e->P.cfg.n_hist);
+    {   // more than 64 KB of dynamic LDS: granted once per device
+        static unsigned long long granted = 0;
+        if (!(granted >> (e->device & 63) & 1ull)) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cda::cap256::k_policy_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            granted |= 1ull << (e->device & 63);
+        }
+    }
+    cda::cap256::PolicyStepKernArgs KA;
+    KA.K.arena = e->arena; KA.K.P = e->P; KA.K.S = S; KA.K.S.first_market = first_market; KA.K.S.end_market = first_market + n_markets;
+    KA.F.obs_in = obs_in; KA.F.wb = wb; KA.F.theta = theta; KA.F.seed = seed; KA.F.counter = (const long long*)counter_dev; KA.F.draw = draw;
+    KA.F.category = category; KA.F.size_mean = size_mean; KA.F.size_sigma = size_sigma; KA.F.price = price; KA.F.price_offset = price_offset;
+    KA.F.a_cont = a_cont; KA.F.logp = logp; KA.F.value = value; KA.F.rec = rec; KA.F.dist = dist;
+    hipLaunchKernelGGL(cda::cap256::k_policy_step, dim3((unsigned)((n_markets + cda::cap256::PS_WPB - 1) / cda::cap256::PS_WPB)), dim3(64 * cda::cap256::PS_WPB), smem, (hipStream_t)stream, KA);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
 }
 
 int cda_step(cda_env* e, const int32_t* category, const float* size_mean, const float* size_sigma,

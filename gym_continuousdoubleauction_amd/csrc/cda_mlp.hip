@@ -45,50 +45,11 @@
 #endif
 
 namespace {
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-constexpr int OBS = CDA_MLP_OBS, KX = CDA_MLP_KX, XT = CDA_MLP_XTILES, HID = CDA_MLP_HID, NOUT = CDA_MLP_NOUT;
-constexpr int XS_LD = KX + 8;        // LDS row of the observation tile: 184 bf16 = 368 B = 16 x 23 (odd: ds_read_b128 conflict free) at n_hist = 4; 16 x (2 k + 1) for every depth
-// An observation row is 42 H floats = 168 H bytes: 16-byte aligned for even history depths only - rows are requested VW floats at a time
-constexpr int VW = (OBS % 4 == 0) ? 4 : 2;
-typedef std::conditional<VW == 4, float4, float2>::type obsvec;
-template <typename V> __device__ __forceinline__ V vec_zero();
-template <> __device__ __forceinline__ float4 vec_zero<float4>() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
-template <> __device__ __forceinline__ float2 vec_zero<float2>() { return make_float2(0.0f, 0.0f); }
-__device__ __forceinline__ obsvec obs_zero() { return vec_zero<obsvec>(); }
-// VW values -> the bf16 LDS image / an f32 LDS row (member access only: an address taken of a register vector sends it through scratch)
-__device__ __forceinline__ void obs_to_bf16(__bf16* dst, const float4& v, bool zero) {
-    bf16x4 b; b[0] = (__bf16)(zero ? 0.0f : v.x); b[1] = (__bf16)(zero ? 0.0f : v.y); b[2] = (__bf16)(zero ? 0.0f : v.z); b[3] = (__bf16)(zero ? 0.0f : v.w);
-    *reinterpret_cast<bf16x4*>(dst) = b;
-}
-__device__ __forceinline__ void obs_to_bf16(__bf16* dst, const float2& v, bool zero) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    bf16x2_t b; b[0] = (__bf16)(zero ? 0.0f : v.x); b[1] = (__bf16)(zero ? 0.0f : v.y);
-    *reinterpret_cast<bf16x2_t*>(dst) = b;
-}
-__device__ __forceinline__ void obs_spread(float* dst, const float4& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
-__device__ __forceinline__ void obs_spread(float* dst, const float2& v) { dst[0] = v.x; dst[1] = v.y; }
-constexpr int ACT_LD = HID + 8;      // LDS row of an activation tile: 264 bf16 = 528 B = 16 x 33
-constexpr int DO_LD = NOUT + 8;      // LDS row of the d_out tile: 40 bf16 = 80 B = 16 x 5
-constexpr int OUTS_LD = NOUT + 1;    // f32 row of the output tile kept in LDS for the sampling epilogue
-constexpr int N_CAT = 9, N_PRICE = 10, N_OFF = 3, N_LOGITS = 24;
-constexpr int LPS_LD = N_CAT + N_PRICE + N_OFF + 1;   // 23 floats: odd, conflict free
+#include "cda_mlp_dev.inc"      // types, tile constants, tanh / MFMA / weight-ring helpers, the sampling arithmetic: shared with csrc/cda_hip.hip (k_policy_step)
 // k_mlp_fb's first LDS region: the 64-row observation tile, whose bytes are reused for the output tiles (f32 [64][33] + bf16 [64][40]) once layer 1 has read it -
 // the larger of the two (the observation tile from n_hist = 3 on)
 constexpr int FB_XS_BYTES = (64 * XS_LD * 2 > 64 * OUTS_LD * 4 + 64 * DO_LD * 2) ? 64 * XS_LD * 2 : 64 * OUTS_LD * 4 + 64 * DO_LD * 2;
 
-__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-constexpr float TWO_LOG2E = 2.885390081777926814f;
-__device__ __forceinline__ float tanh_biased(float a, float bias_scaled) {
-    // tanh(a + b) = 1 - 2 / (2^((a + b) 2 log2 e) + 1), b 2 log2 e folded by the caller: fma, v_exp_f32, add, v_rcp_f32, fma.  2^t overflows to
-    // +inf for large t (-> 1) and underflows to 0 (-> -1): no clamp needed
-    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(a, TWO_LOG2E, bias_scaled));
-    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-}
-__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int r = 0; r < 16; r++) z[r] = 0.0f; return z; }
 
 // ---- the observation tile: M rows -> LDS image [row][XS_LD] bf16, columns 168 .. 175 zero --------------------------------------
 template <int M, int NT = 256>
@@ -125,31 +86,6 @@ __device__ __forceinline__ void load_x_f32(const float* __restrict__ obs, long l
     }
 }
 
-// The B operand (weights) of a layer goes through a register ring of RING k-steps, statically indexed (the loops are unrolled): a layer is
-// PRIMED - its first RING steps requested - before the previous layer's epilogue and barrier, and while step ks multiplies, step ks + RING
-// is requested.  hipcc on its own looks ONE step ahead and sinks every other request to just before its use, which leaves a wave with
-// 2 .. 8 MFMAs per step waiting ~600 cycles for L2 each time: hence the sched_barriers.
-// The weights live in HBM in OPERAND ORDER (cda_mlp_pack / k_adam write them so): for a wave's group of 32 JT output features, column tile jt and
-// k-step ks, the 64 lanes' 16-byte pieces are 1 KB of CONTIGUOUS memory - a wave request is eight whole cache lines.  (Read from nn.Linear's
-// row-major [out][in] instead, a request touched 32 rows 512 B apart and used 32 B of every 128-B line; four waves' working set does not fit
-// the 32-KB L1, so every k-step re-fetched four times its bytes from L2: ~400 cycles per k-step however many MFMAs it held.)
-// PAIRED (two column tiles): tile jt, lane j holds weight row 2 j + jt of the group - a lane then holds two NEIGHBOURING output features of the
-// same rows, which is one dword of the row-major LDS image of the activations (no cross-lane exchange) - see feature_of() and pack_one().
-template <int JT, int KSTEPS, int PF, bool PAIRED = false>
-struct WRing {
-    static constexpr int RING = PF < KSTEPS ? PF : KSTEPS;
-    bf16x8 b[RING][JT];
-    const __bf16* base;                                                          // the group's image + this lane's 16 bytes
-    __device__ __forceinline__ const bf16x8* piece(int jt, int ks) const { return reinterpret_cast<const bf16x8*>(base + (size_t)(jt * KSTEPS + ks) * 512); }
-    __device__ __forceinline__ void prime(const __bf16* __restrict__ group, int /*ld*/, int lane) {
-        base = group + lane * 8;
-        #pragma unroll
-        for (int ks = 0; ks < RING; ks++)
-            #pragma unroll
-            for (int jt = 0; jt < JT; jt++) b[ks][jt] = *piece(jt, ks);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-};
 // Feature tiles of the hidden activations come in pairs (one wave's 64 features): position q of tile ft is feature
 // 64 (ft / 2) + 2 q + (ft & 1) - in the packed HBM images of h1 / h2 / dz1 / dz2 and wherever they are consumed.
 __host__ __device__ __forceinline__ constexpr int feature_of(int ft, int q) { return 64 * (ft >> 1) + 2 * q + (ft & 1); }
@@ -249,48 +185,6 @@ struct FwdArgs {
 #define MLP_MARK8(i) do {} while (0)
 #endif
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
-    z += 0x9e3779b97f4a7c15ull;
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ float u01(unsigned long long w, int half) {               // (0, 1): 24 bits of one 32-bit half
-    const unsigned int x = half ? (unsigned int)(w >> 32) : (unsigned int)w;
-    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
-}
-template <int N>
-__device__ __forceinline__ int sample_head(const float* l, float u, float& logp) {
-    float mx = l[0];
-    #pragma unroll
-    for (int j = 1; j < N; j++) mx = fmaxf(mx, l[j]);
-    float e[N], s = 0.0f;
-    #pragma unroll
-    for (int j = 0; j < N; j++) { e[j] = __expf(l[j] - mx); s += e[j]; }
-    const float t = u * s;
-    float c = 0.0f, la = l[N - 1];
-    int a = N - 1;
-    bool found = false;
-    #pragma unroll
-    for (int j = 0; j < N; j++) { c += e[j]; if (!found && t < c) { a = j; la = l[j]; found = true; } }
-    logp += la - mx - __logf(s);
-    return a;
-}
-
-// softmax of one head: p[q], c = max + log(sum) (log p[q] = l[q] - c), entropy
-template <int N> __device__ __forceinline__ void head_probs_c(const float* l, float* p, float& c, float& ent) {
-    float mx = l[0];
-    #pragma unroll
-    for (int q = 1; q < N; q++) mx = fmaxf(mx, l[q]);
-    float s = 0.0f;
-    #pragma unroll
-    for (int q = 0; q < N; q++) { p[q] = __expf(l[q] - mx); s += p[q]; }
-    const float ls = __logf(s), inv = 1.0f / s;
-    float hh = 0.0f;
-    #pragma unroll
-    for (int q = 0; q < N; q++) { p[q] *= inv; hh -= p[q] * (l[q] - mx - ls); }
-    c = mx + ls; ent = hh;
-}
 
 template <int MT, int MODE>
 __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
@@ -419,9 +313,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
         // log-probability, and the env's five action words (size_mean = tanh, size_sigma = sigmoid: the Box bounds of
         // action_helper.py:126-138)
         const int ag = A.agents;
-        const unsigned long long key = mix64(A.seed + (unsigned long long)A.counter[0] * 0xd1342543de82ef95ull + (unsigned long long)A.draw * 0x2545f4914f6cdd1dull);
+        const unsigned long long key = rollout_key(A.seed, A.counter[0], A.draw);
         const float ls0 = theta[CDA_MLP_OFF_LS], ls1 = theta[CDA_MLP_OFF_LS + 1];
-        const float HALF_LOG_2PI = 0.918938533204672742f;
         for (int s = (int)threadIdx.x; s < M * ag; s += 256) {
             const int row = s / ag, a = s - row * ag;
             const long long grow = row0 + row;
@@ -451,18 +344,12 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             #pragma unroll
             for (int q = 0; q < N_LOGITS; q++) l[q] = outs[row * OUTS_LD + q];
             if (MODE == MODE_SAMPLE && a == 0 && !A.split_halves) A.value[grow] = outs[row * OUTS_LD + N_LOGITS];
-            const unsigned long long w0 = mix64(key + (unsigned long long)i), w1 = mix64(w0), w2 = mix64(w1);
-            float lp = 0.0f;
-            const int c = sample_head<N_CAT>(l, u01(w0, 0), lp);
-            const int p = sample_head<N_PRICE>(l + N_CAT, u01(w0, 1), lp);
-            const int o = sample_head<N_OFF>(l + N_CAT + N_PRICE, u01(w1, 0), lp);
-            const float rr = sqrtf(-2.0f * __logf(u01(w1, 1))), th = 6.283185307179586f * u01(w2, 0);
-            const float n0 = rr * __cosf(th), n1 = rr * __sinf(th);
-            const float x0 = l[22] + __expf(ls0) * n0, x1 = l[23] + __expf(ls1) * n1;
-            lp += -0.5f * n0 * n0 - ls0 - HALF_LOG_2PI - 0.5f * n1 * n1 - ls1 - HALF_LOG_2PI;
+            const SampledAction sa = sample_action(l, key, i, ls0, ls1);         // (cda_mlp_dev.inc: the arithmetic k_policy_step shares)
+            const int c = sa.cat, p = sa.price, o = sa.off;
+            const float x0 = sa.x0, x1 = sa.x1, lp = sa.logp;
             A.env_cat[i] = c; A.env_price[i] = p; A.env_off[i] = o;
-            A.env_mean[i] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x0) + 1.0f), 1.0f);      // tanh(x0): 1 - 2 / (e^(2 x0) + 1); libm's tanhf is a call of ~100 instructions
-            A.env_sigma[i] = 1.0f / (1.0f + __expf(-x1));
+            A.env_mean[i] = sa.size_mean;
+            A.env_sigma[i] = sa.size_sigma;
             A.a_cont[2 * i] = x0; A.a_cont[2 * i + 1] = x1;
             A.logp[i] = lp;
             if (A.rec) {
@@ -477,14 +364,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             for (int row = (int)threadIdx.x; row < M; row += 256) {
                 const long long grow = row0 + row;
                 if (grow >= rows_end) continue;
-                float l[N_LOGITS], p[N_CAT + N_PRICE + N_OFF], c0, c1, c2, e0;
+                float l[N_LOGITS], o24[N_LOGITS];
                 #pragma unroll
                 for (int q = 0; q < N_LOGITS; q++) l[q] = outs[row * OUTS_LD + q];
-                head_probs_c<N_CAT>(l, p, c0, e0); head_probs_c<N_PRICE>(l + N_CAT, p + N_CAT, c1, e0); head_probs_c<N_OFF>(l + N_CAT + N_PRICE, p + N_CAT + N_PRICE, c2, e0);
+                dist_row(l, o24);
                 float4* dp = reinterpret_cast<float4*>(dist + grow * N_LOGITS);
-                float o24[N_LOGITS];
-                #pragma unroll
-                for (int q = 0; q < N_LOGITS; q++) o24[q] = q < N_CAT ? l[q] - c0 : (q < N_CAT + N_PRICE ? l[q] - c1 : (q < N_CAT + N_PRICE + N_OFF ? l[q] - c2 : l[q]));
                 #pragma unroll
                 for (int q = 0; q < N_LOGITS / 4; q++) dp[q] = make_float4(o24[4 * q], o24[4 * q + 1], o24[4 * q + 2], o24[4 * q + 3]);
             }
@@ -2282,8 +2166,28 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, B->obs + ((size_t)n_steps * N + first_market) * OBS,
                            B->obs + (size_t)first_market * OBS, n4);
     }
+    // One launch per step where the env qualifies (include/cda.h cda_policy_step_range: the policy evaluated inside the step kernel) - one shared policy, this
+    // history depth's default build, no info chain; CDA_POLICY_STEP=0 in the environment keeps the two launches (A / B runs, tests of both paths).
+    bool one_launch = false;
+#if CDA_MLP_HIST == 4
+    {
+        static int want = -1;
+        if (want < 0) { const char* ev = getenv("CDA_POLICY_STEP"); want = ev ? atoi(ev) : 1; }
+        one_launch = want != 0 && !L && !B->info_steps && cda_policy_step_supported(env);
+    }
+#endif
     for (int32_t t = 0; t < n_steps; t++) {
         const size_t o = (size_t)t * NA;
+        if (one_launch) {
+            const int rc1 = cda_policy_step_range(env, first_market, n_markets, wb, theta, B->obs + (size_t)t * N * OBS, seed, counter_dev, t,
+                                                  B->category + o, B->size_mean + o, B->size_sigma + o, B->price + o, B->price_offset + o,
+                                                  B->a_cont + 2 * o, B->logp + o, B->value + (size_t)t * N, B->record ? B->record + 8 * o : NULL,
+                                                  B->dist ? B->dist + (size_t)t * N * N_LOGITS : NULL,
+                                                  B->obs + (size_t)(t + 1) * N * OBS, B->reward + o, B->terminated + (size_t)t * N, B->truncated + (size_t)t * N,
+                                                  B->fin_obs, B->fin_cap, B->fin_count, B->fin_index ? B->fin_index + (size_t)t * N : NULL, stream);
+            if (rc1) return rc1;
+            continue;
+        }
         FwdArgs P; memset(&P, 0, sizeof P);
         P.obs = B->obs + (size_t)t * N * OBS; P.first_row = first_market; P.n_rows = n_markets;
         P.wb = (const __bf16*)(L ? L->wb_bank : wb); P.theta = L ? L->theta_bank : theta;
