@@ -11,6 +11,7 @@ timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_com
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --learner dp > $O/bench_learner_dp_one_rank.json 2> /dev/null
 timeout 600 python -m gym_continuousdoubleauction_amd.ppo --iters 10 --out $O/bench_ppo.json > /dev/null 2>&1
+CDA_POLICY_STEP=0 timeout 600 python -m gym_continuousdoubleauction_amd.ppo --iters 10 --out $O/bench_ppo_two_launches_per_step.json > /dev/null 2>&1
 for h in 1 2 8; do timeout 300 python -m gym_continuousdoubleauction_amd.ppo --iters 10 --n-hist $h --out $O/bench_ppo_n_hist$h.json > /dev/null 2>&1; done
 timeout 600 python -m gym_continuousdoubleauction_amd.league_train --fused --markets 2048 --agents 8 --trainable 2 --episode 64 --iters 12 --out $O/bench_league.json > /dev/null 2>&1
 timeout 600 python tools/record_cost_probe.py > $O/record_cost.txt 2>&1; grep -v amdgpu $O/record_cost.txt
@@ -25,7 +26,7 @@ python - <<'PY'
 import json
 d = json.loads([l for l in open("gpurun_out/r05/evidence/bench_driver_command.json") if l.startswith("{")][0])
 print("driver command: value", round(d["value"] / 1e6, 1), "M; policy in loop", round((d.get("value_policy_in_loop") or 0) / 1e6, 1), "league", round((d.get("value_league_self_play") or 0) / 1e6, 1), "roofline frac", round(d["roofline"]["frac"], 4), "cpu", d.get("cpu_baseline", {}).get("value"))
-for n in ("bench_ppo", "bench_league"):
+for n in ("bench_ppo", "bench_ppo_two_launches_per_step", "bench_league"):
     x = json.load(open(f"gpurun_out/r05/evidence/{n}.json")); print(n, round(x["value"] / 1e6, 1), "M")
 x = json.loads([l for l in open("gpurun_out/r05/evidence/bench_learner_dp_one_rank.json") if l.startswith("{")][0]); print("learner dp one rank", round(x["value"] / 1e6, 1), "M")
 PY
