@@ -31,8 +31,9 @@ What the line reports (one MI355X):
   value_one_launch           info on, the whole batch as ONE launch per step (--groups 1)
   value_ordered_per_step     info on, group chains, every step ordered after the caller's stream and the caller's stream
                              after it (CDAVecEnv.step's default: what a policy-in-the-loop consumer pays)
-  value_policy_in_loop       a CONSUMER between the steps: every chain runs {policy network forward + action sampling (one hand-written MFMA launch,
-                             csrc/cda_mlp.hip) -> env step -> auto reset} for its own markets on its own stream, K steps per HIP graph, no
+  value_policy_in_loop       a CONSUMER between the steps: every chain runs {policy network forward + action sampling -> env step -> auto reset} for its own
+                             markets on its own stream - ONE launch per step where the env qualifies (k_policy_step: the policy evaluated inside the step
+                             kernel, include/cda.h cda_policy_step_range), else a hand-written MFMA launch + the step launch -, K steps per HIP graph, no
                              cross-stream edge inside the K steps (mlp.RolloutChains: the rollout of the PPO loop of BASELINE configs[4], random
                              initial weights, no info tensors) - what a learner in the loop gets, where value_ordered_per_step is what it
                              would get through per-step event edges
