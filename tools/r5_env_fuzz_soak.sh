@@ -3,9 +3,9 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export PYTHONPATH=$PWD; O=gpurun_out/r05; mkdir -p $O
 {
-echo "Final build of round 5 (episode-end capture in the two cold reset paths of k_step; the hot code unchanged): HIP vs oracle on random configurations, six fresh seeds x 250 configurations"
+echo "Final build of round 5 (episode-end capture in the cold reset paths of k_step; k_policy_step beside it in the same translation unit): HIP vs oracle on random configurations, six fresh seeds x 250 configurations"
 echo "(tests/test_hip_vs_oracle_batch.py -k random_configurations: random agent counts, balances, laws incl. trend, shuffled dict orders, prefilled 0-512-order books per side)"
-for s in 52001 52002 52003 52004 52005 52006; do
+for s in 53001 53002 53003 53004 53005 53006; do
   echo "CDA_FUZZ_CASES=250 CDA_FUZZ_SEED=$s"
   CDA_FUZZ_CASES=250 CDA_FUZZ_SEED=$s timeout 600 python -m pytest tests/test_hip_vs_oracle_batch.py -q -m gpu -k "random_configurations" 2>&1 | tail -1
 done
