@@ -127,6 +127,9 @@ def test_learner_side_entry_points_refuse_bad_arguments_before_touching_the_devi
     src, dst, nb = (C.c_void_p * 1)(16), (C.c_void_p * 1)(16), (C.c_int64 * 1)(64)
     assert L.cda_store_slots(0, src, dst, nb, one, 0, None) == INVALID and L.cda_store_slots(13, src, dst, nb, one, 0, None) == INVALID
     assert L.cda_store_slots(1, src, dst, (C.c_int64 * 1)(0), one, 0, None) == INVALID and L.cda_store_slots(1, src, dst, nb, None, 0, None) == INVALID
+    # the policy inside the step kernel (include/cda.h): no env / missing arrays are refused before anything is launched
+    assert L.cda_policy_step_supported(None) == 0
+    assert L.cda_policy_step_range(None, 0, 8, one, one, one, 1, one, 0, *([one] * 5), *([one] * 5), *([one] * 4), None, 0, None, None, None) == INVALID
 
 
 def test_every_network_entry_point_exists_for_every_compiled_history_depth():
