@@ -2185,8 +2185,10 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
                                                   B->dist ? B->dist + (size_t)t * N * N_LOGITS : NULL,
                                                   B->obs + (size_t)(t + 1) * N * OBS, B->reward + o, B->terminated + (size_t)t * N, B->truncated + (size_t)t * N,
                                                   B->fin_obs, B->fin_cap, B->fin_count, B->fin_index ? B->fin_index + (size_t)t * N : NULL, stream);
-            if (rc1) return rc1;
-            continue;
+            if (rc1 == CDA_OK) continue;
+            if (t != 0) return rc1;
+            one_launch = false;                                  // refused at the first step (nothing has run yet): the two launches take over
+            (void)hipGetLastError();
         }
         FwdArgs P; memset(&P, 0, sizeof P);
         P.obs = B->obs + (size_t)t * N * OBS; P.first_row = first_market; P.n_rows = n_markets;
