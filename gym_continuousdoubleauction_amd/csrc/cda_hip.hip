@@ -34,7 +34,25 @@
 namespace cda { namespace mlpdev {
 #include "cda_mlp_dev.inc"
 } }
-#pragma clang fp contract(off)              // (the include above switched contraction on for the network's arithmetic; everything below is the env's)
+// ... and for the other compiled history depths (CDA_MLP_HIST_VARIANTS): the header's layout macros follow CDA_MLP_HIST
+#undef CDA_MLP_HIST
+#define CDA_MLP_HIST 1
+namespace cda { namespace mlpdev_h1 {
+#include "cda_mlp_dev.inc"
+} }
+#undef CDA_MLP_HIST
+#define CDA_MLP_HIST 2
+namespace cda { namespace mlpdev_h2 {
+#include "cda_mlp_dev.inc"
+} }
+#undef CDA_MLP_HIST
+#define CDA_MLP_HIST 8
+namespace cda { namespace mlpdev_h8 {
+#include "cda_mlp_dev.inc"
+} }
+#undef CDA_MLP_HIST
+#define CDA_MLP_HIST 4
+#pragma clang fp contract(off)              // (the includes above switched contraction on for the network's arithmetic; everything below is the env's)
 
 using namespace cda;
 
@@ -600,11 +618,20 @@ int cda_step_range_capture(cda_env* e, int32_t first_market, int32_t n_markets,
 }
 
 // The policy inside the step kernel (k_policy_step, cda_kernels.inc): what include/cda_mlp.h's rollout chains launch per step when the env qualifies.
+static int policy_step_lds(const cda_env* e) {            // dynamic LDS of k_policy_step at this env's shape; 0 = no instance for its history depth
+    const cda_config& c = e->P.cfg;
+    switch (c.n_hist) {
+        case 4: return cda::cap256::policy_step_lds_bytes(c.num_agents, c.n_hist);
+        case 1: return cda::cap256::policy_step_lds_bytes_h1(c.num_agents, c.n_hist);
+        case 2: return cda::cap256::policy_step_lds_bytes_h2(c.num_agents, c.n_hist);
+        case 8: return cda::cap256::policy_step_lds_bytes_h8(c.num_agents, c.n_hist);
+        default: return 0;
+    }
+}
 int cda_policy_step_supported(const cda_env* e) {
     if (!e) return 0;
-    const cda_config& c = e->P.cfg;
-    return e->cap == 256 && c.n_hist == 4 && c.num_agents <= 8 && !e->handback &&
-           cda::cap256::policy_step_lds_bytes(c.num_agents, c.n_hist) <= 160 * 1024;
+    const int lds = e->cap == 256 ? policy_step_lds(e) : 0;
+    return lds > 0 && lds <= 160 * 1024 && e->P.cfg.num_agents <= 8 && !e->handback;
 }
 int cda_policy_step_range(cda_env* e, int32_t first_market, int32_t n_markets, const void* wb, const float* theta, const float* obs_in,
                           uint64_t seed, const int64_t* counter_dev, int64_t draw,
@@ -623,12 +650,15 @@ int cda_policy_step_range(cda_env* e, int32_t first_market, int32_t n_markets, c
         S.fin_obs = fin_obs; S.fin_count = fin_count; S.fin_index_out = fin_index_out; S.fin_cap = fin_cap;
     }
     HIPCHK(hipSetDevice(e->device));
-    const size_t smem = (size_t)cda::cap256::policy_step_lds_bytes(e->P.cfg.num_agents, e->P.cfg.n_hist);
-    {   // more than 64 KB of dynamic LDS: granted once per device
-        static unsigned long long granted = 0;
-        if (!(granted >> (e->device & 63) & 1ull)) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cda::cap256::k_policy_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            granted |= 1ull << (e->device & 63);
+    const size_t smem = (size_t)policy_step_lds(e);
+    typedef void (*kern_t)(cda::cap256::PolicyStepKernArgs);
+    const int hist = e->P.cfg.n_hist, slot = hist == 4 ? 0 : (hist == 1 ? 1 : (hist == 2 ? 2 : 3));
+    const kern_t kern = hist == 4 ? cda::cap256::k_policy_step : (hist == 1 ? cda::cap256::k_policy_step_h1 : (hist == 2 ? cda::cap256::k_policy_step_h2 : cda::cap256::k_policy_step_h8));
+    {   // more than 64 KB of dynamic LDS: granted once per device and instance
+        static unsigned long long granted[4] = {0, 0, 0, 0};
+        if (!(granted[slot] >> (e->device & 63) & 1ull)) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            granted[slot] |= 1ull << (e->device & 63);
         }
     }
     cda::cap256::PolicyStepKernArgs KA;
@@ -636,7 +666,7 @@ int cda_policy_step_range(cda_env* e, int32_t first_market, int32_t n_markets, c
     KA.F.obs_in = obs_in; KA.F.wb = wb; KA.F.theta = theta; KA.F.seed = seed; KA.F.counter = (const long long*)counter_dev; KA.F.draw = draw;
     KA.F.category = category; KA.F.size_mean = size_mean; KA.F.size_sigma = size_sigma; KA.F.price = price; KA.F.price_offset = price_offset;
     KA.F.a_cont = a_cont; KA.F.logp = logp; KA.F.value = value; KA.F.rec = rec; KA.F.dist = dist;
-    hipLaunchKernelGGL(cda::cap256::k_policy_step, dim3((unsigned)((n_markets + cda::cap256::PS_WPB - 1) / cda::cap256::PS_WPB)), dim3(64 * cda::cap256::PS_WPB), smem, (hipStream_t)stream, KA);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_markets + cda::cap256::PS_WPB - 1) / cda::cap256::PS_WPB)), dim3(64 * cda::cap256::PS_WPB), smem, (hipStream_t)stream, KA);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }

@@ -2166,16 +2166,14 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, B->obs + ((size_t)n_steps * N + first_market) * OBS,
                            B->obs + (size_t)first_market * OBS, n4);
     }
-    // One launch per step where the env qualifies (include/cda.h cda_policy_step_range: the policy evaluated inside the step kernel) - one shared policy, this
-    // history depth's default build, no info chain; CDA_POLICY_STEP=0 in the environment keeps the two launches (A / B runs, tests of both paths).
+    // One launch per step where the env qualifies (include/cda.h cda_policy_step_range: the policy evaluated inside the step kernel) - one shared policy,
+    // no info chain; CDA_POLICY_STEP=0 in the environment keeps the two launches (A / B runs, tests of both paths).
     bool one_launch = false;
-#if CDA_MLP_HIST == 4
     {
         static int want = -1;
         if (want < 0) { const char* ev = getenv("CDA_POLICY_STEP"); want = ev ? atoi(ev) : 1; }
-        one_launch = want != 0 && !L && !B->info_steps && cda_policy_step_supported(env);
+        one_launch = want != 0 && !L && !B->info_steps && cda_policy_step_supported(env);      // (the env's history depth is this build's: checked above)
     }
-#endif
     for (int32_t t = 0; t < n_steps; t++) {
         const size_t o = (size_t)t * NA;
         if (one_launch) {

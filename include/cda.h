@@ -220,12 +220,13 @@ int cda_step_range_capture(cda_env* env, int32_t first_market, int32_t n_markets
                            float* obs_out, double* reward_out, uint8_t* terminated_out, uint8_t* truncated_out,
                            const cda_info_ptrs* info_out, float* fin_obs, int32_t fin_cap, int32_t* fin_count, int32_t* fin_index_out, void* stream);
 /* The rollout's POLICY INSIDE THE STEP KERNEL (one launch per chain and step instead of a policy launch and a step launch): for the markets of the range, the
- * policy / value network of include/cda_mlp.h (wb, theta: cda_mlp_pack's images, n_hist = 4) is evaluated on obs_in f32 [N][168] by the step kernel's own
+ * policy / value network of include/cda_mlp.h (wb, theta: cda_mlp_pack's images for the env's history depth) is evaluated on obs_in f32 [N][42 n_hist] by the step kernel's own
  * workgroups (sixteen market-waves each: bf16 MFMA on their sixteen rows), every agent's action is sampled exactly as cda_mlp_policy_step samples it (same key:
  * seed, *counter_dev, draw = the step's number; bit for bit the same actions, log-probabilities, values, records), WRITTEN to the five action arrays / a_cont /
  * logp / value / rec (may be NULL) / dist (may be NULL), and the markets are stepped with them exactly as cda_step_range_capture steps them (same outputs, same
  * auto reset and episode-end capture).  What the reference does between two env.step calls - RLlib's policy forward + action sampling, train/train.py:453-541 -
- * moved into the step itself.  cda_policy_step_supported: 1 when this env qualifies (256-order book tile, n_hist 4, <= 8 agents, no hand-back records);
+ * moved into the step itself.  cda_policy_step_supported: 1 when this env qualifies (256-order book tile, n_hist 1 / 2 / 4 / 8 - the depths the network is
+ * compiled for -, <= 8 agents, no hand-back records);
  * otherwise cda_policy_step_range returns CDA_ERR_UNSUPPORTED and the caller launches the two kernels (cda_mlp_rollout_chain does). */
 int cda_policy_step_supported(const cda_env* env);
 int cda_policy_step_range(cda_env* env, int32_t first_market, int32_t n_markets, const void* wb, const float* theta, const float* obs_in,

@@ -16,26 +16,28 @@ DEV = "cuda:0"
 KEYS = ("category", "size_mean", "size_sigma", "price", "price_offset")
 
 
-def _bufs(N, A, cap):
+def _bufs(N, A, cap, obs_dim=168):
     e = lambda shape, dt: torch.zeros(shape, dtype=dt, device=DEV)          # noqa: E731
     return {"category": e((N, A), torch.int32), "size_mean": e((N, A), torch.float32), "size_sigma": e((N, A), torch.float32), "price": e((N, A), torch.int32),
             "price_offset": e((N, A), torch.int32), "a_cont": e((N, A, 2), torch.float32), "logp": e((N, A), torch.float32), "value": e((N,), torch.float32),
-            "rec": e((N, A, 8), torch.float32), "dist": e((N, 24), torch.float32), "obs": e((N, 168), torch.float32), "reward": e((N, A), torch.float64),
-            "term": e((N,), torch.uint8), "trunc": e((N,), torch.uint8), "fin_obs": e((cap, 168), torch.float32), "fin_count": e((1,), torch.int32),
+            "rec": e((N, A, 8), torch.float32), "dist": e((N, 24), torch.float32), "obs": e((N, obs_dim), torch.float32), "reward": e((N, A), torch.float64),
+            "term": e((N,), torch.uint8), "trunc": e((N,), torch.uint8), "fin_obs": e((cap, obs_dim), torch.float32), "fin_count": e((1,), torch.int32),
             "fin_index": torch.full((N,), -1, dtype=torch.int32, device=DEV)}
 
 
-@pytest.mark.parametrize("A,N,max_step,cash,deep", [(4, 150, 7, 1000000, False), (8, 70, 5, 20000, False), (2, 33, 40, 1000000, False), (4, 40, 4096, 1000000, True)])
-def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_step_launch(A, N, max_step, cash, deep):
+@pytest.mark.parametrize("A,N,max_step,cash,deep,H", [(4, 150, 7, 1000000, False, 4), (8, 70, 5, 20000, False, 4), (2, 33, 40, 1000000, False, 4), (4, 40, 4096, 1000000, True, 4),
+                                                       (4, 70, 6, 1000000, False, 1), (8, 50, 9, 20000, False, 2), (3, 45, 5, 1000000, False, 8), (4, 40, 4096, 1000000, True, 8)])
+def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_step_launch(A, N, max_step, cash, deep, H):
     from gym_continuousdoubleauction_amd import CDAVecEnv, mlp
     from gym_continuousdoubleauction_amd._lib import check, lib
     L = lib()
     T, seed = 14, 77
-    cfg = {"num_of_agents": A, "init_cash": cash, "max_step": max_step, "is_render": False, "auto_reset": True}
+    cfg = {"num_of_agents": A, "init_cash": cash, "max_step": max_step, "is_render": False, "auto_reset": True, "n_hist": H}
     envs = [CDAVecEnv(cfg, n_markets=N, with_info=False) for _ in range(2)]
+    OBSD = 42 * H
     assert L.cda_policy_step_supported(envs[1]._h) == 1
-    th = mlp.init_theta(generator=torch.Generator().manual_seed(5)); th[:mlp.OFF_LS] *= 1.5
-    p = mlp.FusedPolicy(DEV, theta=th)
+    th = mlp.init_theta(OBSD, generator=torch.Generator().manual_seed(5)); th[:mlp.layout(H).OFF_LS] *= 1.5
+    p = mlp.FusedPolicy(DEV, theta=th, n_hist=H)
     obs = [e.reset(seed=900).clone() for e in envs]
     if deep:                                                      # four markets far beyond the LDS tile: the general build (HBM tier) steps them, inside both kernels
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -45,7 +47,7 @@ def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_
                 prefill_book(e, i, np.random.default_rng(50 + i), A, 400, 400)
     counter = torch.full((1,), 3, dtype=torch.int64, device=DEV)
     cap = N * (T // max_step + 2)
-    b1, b2 = _bufs(N, A, cap), _bufs(N, A, cap)
+    b1, b2 = _bufs(N, A, cap, OBSD), _bufs(N, A, cap, OBSD)
     st = torch.cuda.current_stream().cuda_stream
     ends = 0
     for t in range(T):
@@ -95,12 +97,12 @@ def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_
 
 
 def test_unsupported_envs_say_so_and_the_rollout_chain_falls_back():
-    """512-order tiles, other history depths and more than 8 agents are not built into the one-launch kernel: cda_policy_step_range returns CDA_ERR_UNSUPPORTED
+    """512-order tiles, history depths the network is not compiled for and more than 8 agents are not built into the one-launch kernel: cda_policy_step_range returns CDA_ERR_UNSUPPORTED
     and the rollout chain launches the two kernels (the rollout still replays: tests/test_hip_hist.py, tools/rollout_soak.py at 12 / 16 agents)."""
     from gym_continuousdoubleauction_amd import CDAVecEnv
     from gym_continuousdoubleauction_amd._lib import lib
     L = lib()
-    for cfg, want in (({"num_of_agents": 4}, 1), ({"num_of_agents": 12}, 0), ({"num_of_agents": 4, "n_hist": 2}, 0), ({"num_of_agents": 4, "book_capacity": 512}, 0)):
+    for cfg, want in (({"num_of_agents": 4}, 1), ({"num_of_agents": 4, "n_hist": 8}, 1), ({"num_of_agents": 12}, 0), ({"num_of_agents": 4, "n_hist": 3}, 0), ({"num_of_agents": 4, "book_capacity": 512}, 0)):
         env = CDAVecEnv(dict(cfg, init_cash=1000000, max_step=64, is_render=False, auto_reset=True), n_markets=32, with_info=False)
         assert L.cda_policy_step_supported(env._h) == want, cfg
         if not want:

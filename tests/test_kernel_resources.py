@@ -71,15 +71,16 @@ def test_step_kernels_keep_four_waves_per_simd_and_spill_no_vgpr():
         if "k_run_random" in n or "k_reset" in n:                 # (the episode kernel keeps more state live and spills a few VGPRs)
             assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 16, (n, v)
     # the policy inside the step kernel: sixteen market-waves per workgroup = the same four waves per SIMD, and the same hot body as k_step<false> behind the forward pass
-    pol = [n for n in ks if "k_policy_step" in n]
-    assert len(pol) == 1, pol                                    # (256-order tile only)
-    v = ks[pol[0]]
-    assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] == 0, (pol[0], v)
-    body = bodies[pol[0]]
-    assert sum("v_mfma_f32_32x32x16_bf16" in l for l in body) == 11 + 16 + 16      # one tile per wave: layer 1 (176 / 16 k-steps), layer 2, heads
-    scratch = [i for i, l in enumerate(body) if "scratch_" in l]
-    calls = [i for i, l in enumerate(body) if "s_swappc" in l]
-    assert len(scratch) <= 2 and all(min(abs(i - c) for c in calls) <= 4 for i in scratch), (len(scratch),)
+    pol = {n: v for n, v in ks.items() if "k_policy_step" in n}
+    assert len(pol) == 4, sorted(pol)                            # one per compiled history depth (256-order tile only)
+    for n, v in pol.items():
+        assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] == 0, (n, v)
+        body = bodies[n]
+        k1 = {"k_policy_stepE": 11, "k_policy_step_h1E": 3, "k_policy_step_h2E": 6, "k_policy_step_h8E": 21}[[k for k in ("k_policy_step_h1E", "k_policy_step_h2E", "k_policy_step_h8E", "k_policy_stepE") if k in n][0]]
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in body) == k1 + 16 + 16, n      # one tile per wave: layer 1 (KX / 16 k-steps), layer 2, heads
+        scratch = [i for i, l in enumerate(body) if "scratch_" in l]
+        calls = [i for i, l in enumerate(body) if "s_swappc" in l]
+        assert len(scratch) <= 2 and all(min(abs(i - c) for c in calls) <= 4 for i in scratch), (n, len(scratch))
 
 
 @pytest.mark.skipif(not (os.path.exists(READELF) and os.path.exists(OBJDUMP) and shutil.which(os.environ.get("HIPCC", "hipcc"))),
