@@ -37,6 +37,8 @@ What the line reports (one MI355X):
                              cross-stream edge inside the K steps (mlp.RolloutChains: the rollout of the PPO loop of BASELINE configs[4], random
                              initial weights, no info tensors) - what a learner in the loop gets, where value_ordered_per_step is what it
                              would get through per-step event edges
+  value_run_random_one_launch  row H (CDA_rand.run_random): 256 steps of uniform random agents for every market in ONE launch (cda_run_random) - what the batch does when
+                             no market-wave ever waits for the batch's slowest one (a per-step launch lasts as long as its slowest wave)
   value_league_self_play     the reference's training topology END TO END on the fused kernels (league_train.train_league_fused): 2048 markets x 8 agents, 2
                              separately trained policies against random modules + champion snapshots, rollout + both PPO updates per iteration
   roofline                   HIP event pairs on the chains' own streams around the k_step launches of the headline leg;
@@ -522,6 +524,25 @@ def main():
         except Exception as ex:  # noqa: BLE001 - an extra leg never fails the headline
             policy_leg = {"error": repr(ex)}
 
+    # row H (the reference's CDA_rand.run_random): whole random-agent episodes in ONE launch per batch - a market-wave never waits for the batch's slowest wave
+    rr_leg = None
+    if world == 1 and not args.no_extra_legs and not args.fused and not gather:
+        try:
+            renv = CDAVecEnv(dict(cfg, max_step=1 << 20), n_markets=N, device=str(device), with_info=False)
+            renv.reset(seed=seeds)
+            rsteps = 256
+            renv.run_random(rsteps, action_seed=ACTION_SEED)                   # warm-up launch
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            _, _, _, _, taken = renv.run_random(rsteps, action_seed=ACTION_SEED + 1)
+            ev1.record()
+            torch.cuda.synchronize()
+            rr_leg = {"value": float(taken.sum().item()) * A / (ev0.elapsed_time(ev1) * 1e-3), "steps": rsteps, "ms": ev0.elapsed_time(ev1), "flagged": int((renv.flags() != 0).sum().item())}
+            renv.close()
+        except Exception as ex:  # noqa: BLE001
+            rr_leg = {"error": repr(ex)}
+
     # the reference's own training topology, end to end (league_train.train_league_fused): 2048 markets x 8 agents, 2 separately trained policies against random
     # modules + champion snapshots, rollout + both updates per iteration - a learner-side extra, reported in agent-steps/s like everything else on the line
     league_leg = None
@@ -618,6 +639,11 @@ def main():
                                                      f"6 uniform random modules + champion snapshots drawn per episode and slot by the reference's mapping rule (on the device), {lT}-step "
                                                      f"episodes; {league_leg['timed']} of {league_leg['iterations']} iterations timed: rollout {league_leg['rollout_ms']:.2f} ms + updates "
                                                      f"{league_leg['update_ms']:.2f} ms per iteration, {league_leg['champions']} champions promoted, {league_leg['flagged']} flagged markets")
+        if rr_leg is not None:
+            out["value_run_random_one_launch"] = rr_leg.get("value")
+            out["config"]["run_random_one_launch"] = (f"failed: {rr_leg['error']}" if "error" in rr_leg else
+                                                      f"cda_run_random: {rr_leg['steps']} steps of uniform random agents for every market in one launch ({rr_leg['ms']:.2f} ms; in-kernel "
+                                                      f"counter-based sampler, no info tensors, {rr_leg['flagged']} flagged markets) - the reference's CDA_rand.run_random, SURVEY 8 row H")
         for name, ex in extras.items():
             out[f"value_{name}"] = total_agent_steps / ex["elapsed"]
             out[f"ms_per_step_{name}"] = ex["elapsed"] / K * 1e3
