@@ -633,6 +633,15 @@ int cda_policy_step_supported(const cda_env* e) {
     const int lds = e->cap == 256 ? policy_step_lds(e) : 0;
     return lds > 0 && lds <= 160 * 1024 && e->P.cfg.num_agents <= 8 && !e->handback;
 }
+// ... and whether it pays: every workgroup of k_policy_step streams the whole network for its sixteen rows, so the one launch wins while all of the env's
+// workgroups are resident at once (N <= 16 x CUs: 4096 markets on an MI355X - policy in the loop 278 -> 301-308 M at 4096 x 4) and loses to the batched policy
+// kernel beyond (16 384 x 4: 433 -> 408 M); below a quarter of that it is a wash (profiles/r05/policy_in_the_step_kernel.txt, C)
+int cda_policy_step_advised(const cda_env* e) {
+    if (!cda_policy_step_supported(e)) return 0;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus < 1) return 0;
+    return (long long)e->P.n_markets <= 16LL * cus;
+}
 int cda_policy_step_range(cda_env* e, int32_t first_market, int32_t n_markets, const void* wb, const float* theta, const float* obs_in,
                           uint64_t seed, const int64_t* counter_dev, int64_t draw,
                           int32_t* category, float* size_mean, float* size_sigma, int32_t* price, int32_t* price_offset,

@@ -2172,7 +2172,8 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
     {
         static int want = -1;
         if (want < 0) { const char* ev = getenv("CDA_POLICY_STEP"); want = ev ? atoi(ev) : 1; }
-        one_launch = want != 0 && !L && !B->info_steps && cda_policy_step_supported(env);      // (the env's history depth is this build's: checked above)
+        // (the env's history depth is this build's: checked above.  CDA_POLICY_STEP=2: wherever supported, also where the batched policy kernel is the faster one)
+        one_launch = want != 0 && !L && !B->info_steps && (want == 2 ? cda_policy_step_supported(env) : cda_policy_step_advised(env));
     }
     for (int32_t t = 0; t < n_steps; t++) {
         const size_t o = (size_t)t * NA;

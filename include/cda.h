@@ -229,6 +229,7 @@ int cda_step_range_capture(cda_env* env, int32_t first_market, int32_t n_markets
  * compiled for -, <= 8 agents, no hand-back records);
  * otherwise cda_policy_step_range returns CDA_ERR_UNSUPPORTED and the caller launches the two kernels (cda_mlp_rollout_chain does). */
 int cda_policy_step_supported(const cda_env* env);
+int cda_policy_step_advised(const cda_env* env);      /* supported AND the env's markets fit the device in one round of sixteen-market workgroups (N <= 16 x CUs): where the one launch wins */
 int cda_policy_step_range(cda_env* env, int32_t first_market, int32_t n_markets, const void* wb, const float* theta, const float* obs_in,
                           uint64_t seed, const int64_t* counter_dev, int64_t draw,
                           int32_t* category, float* size_mean, float* size_sigma, int32_t* price, int32_t* price_offset,

@@ -109,3 +109,11 @@ def test_unsupported_envs_say_so_and_the_rollout_chain_falls_back():
             one = C.c_void_p(64)
             assert L.cda_policy_step_range(env._h, 0, 32, one, one, one, 1, one, 0, *([one] * 5), *([one] * 5), *([one] * 4), None, 0, None, None, None) == -4
         env.close()
+    # supported is not advised: every workgroup streams the whole network for its sixteen rows - beyond one resident round of workgroups (N > 16 x CUs) the batched
+    # policy kernel is the faster one and the rollout chain keeps the two launches
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    small = CDAVecEnv(dict(num_of_agents=4, init_cash=1000000, max_step=64, is_render=False, auto_reset=True), n_markets=16 * cus, with_info=False)
+    big = CDAVecEnv(dict(num_of_agents=4, init_cash=1000000, max_step=64, is_render=False, auto_reset=True), n_markets=16 * cus + 16, with_info=False)
+    assert (L.cda_policy_step_supported(small._h), L.cda_policy_step_advised(small._h)) == (1, 1)
+    assert (L.cda_policy_step_supported(big._h), L.cda_policy_step_advised(big._h)) == (1, 0)
+    small.close(); big.close()
