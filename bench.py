@@ -520,7 +520,31 @@ def main():
             policy_leg = {"elapsed": statistics.median(ptook), "min": min(ptook), "max": max(ptook), "chains": chains, "graphs": roll.graphs is not None,
                           "flagged": int((penv.flags() != 0).sum().item())}
             penv.close()
-            del roll, pol
+            del roll
+            # ... and the same loop with EVERY EPISODE CHECKED AND SUMMARISED ON THE DEVICE (cda_episode_metrics_enable): per-step tallies of what the reference's callback
+            # tallies, sum-of-NAV conservation + the episode summary in the in-kernel auto reset; short episodes (64 steps) so that ends happen inside the timed rollouts
+            menv = CDAVecEnv(dict(pcfg, max_step=64), n_markets=N, device=str(device), with_info=False)
+            menv.reset(seed=seeds)
+            legs = {}
+            for on in (False, True):
+                menv.enable_episode_metrics(on)
+                mroll = RolloutChains(menv, pol, K, groups=chains, seed=ACTION_SEED, use_graphs=True)
+                for _ in range(3):
+                    mroll.run()
+                mtook = []
+                for _ in range(max(R, 5)):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    mroll.run()
+                    if on:
+                        mtab = menv.collect_episode_metrics()
+                    torch.cuda.synchronize()
+                    mtook.append(time.perf_counter() - t0)
+                legs[on] = statistics.median(mtook)
+                del mroll
+            policy_leg.update(metrics_on=legs[True], metrics_off=legs[False], metrics_episodes=float(mtab[1][0].item()), metrics_violations=float(mtab[1][1].item()))
+            menv.close()
+            del pol
         except Exception as ex:  # noqa: BLE001 - an extra leg never fails the headline
             policy_leg = {"error": repr(ex)}
 
@@ -628,6 +652,13 @@ def main():
                                                    f"{K} steps per HIP graph" + ("" if policy_leg["graphs"] else " (graph capture failed: direct launches)")
                                                    + f", no info tensors; min / max over the repeats: {total_agent_steps / policy_leg['max']:.4g} / {total_agent_steps / policy_leg['min']:.4g}")
                 out["config"]["flagged_markets_policy_in_loop"] = policy_leg["flagged"]
+                if "metrics_on" in policy_leg:
+                    out["value_policy_in_loop_episode_metrics"] = total_agent_steps / policy_leg["metrics_on"]
+                    out["config"]["policy_in_loop_episode_metrics"] = (
+                        "the same loop over 64-step episodes with every episode checked (exact sum of NAV) and summarised on the device in the in-kernel auto reset, the step "
+                        f"tallying the callback's counters and reward terms, + one collection per rollout: {total_agent_steps / policy_leg['metrics_on']:.4g} against "
+                        f"{total_agent_steps / policy_leg['metrics_off']:.4g} agent-steps/s with the metrics off on the same env ({(policy_leg['metrics_on'] / policy_leg['metrics_off'] - 1) * 100:+.2f} % time); "
+                        f"last collection: {policy_leg['metrics_episodes']:.0f} episodes, {policy_leg['metrics_violations']:.0f} violations")
         if league_leg is not None:
             if "error" in league_leg:
                 out["value_league_self_play"] = None

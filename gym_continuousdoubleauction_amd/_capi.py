@@ -19,7 +19,14 @@ NUM_REWARD_TERMS = 5
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = -1, -2, -3, -4, -5
 
-FLAG_BOOK_OVERFLOW, FLAG_INT_OVERFLOW, FLAG_DEC_DOMAIN = 1, 2, 4
+FLAG_BOOK_OVERFLOW, FLAG_INT_OVERFLOW, FLAG_DEC_DOMAIN, FLAG_NAV_CONSERVATION = 1, 2, 4, 8
+
+# episode metrics (include/cda.h CDA_EM_*): columns of the per-module table / of the per-env row cda_episode_metrics_collect returns
+EM_AGENT_FIELDS, EM_ENV_FIELDS, EM_MAX_MODULES = 32, 8, 32
+EM_EPISODES, EM_AGENT_STEPS, EM_PASSES, EM_REJECTIONS, EM_PLACED, EM_TRADES, EM_PASSIVE, EM_TERM_SUM, EM_TERM_SQ = 0, 1, 2, 3, 4, 5, 6, 7, 12
+EM_RETURN_SUM, EM_RETURN_SQ, EM_NAV_SUM, EM_NAV_MIN, EM_NAV_MAX, EM_DRAWDOWN_SUM, EM_ABS_POSITION_SUM, EM_NUM_TRADES_SUM = 17, 18, 19, 20, 21, 22, 23, 24
+EM_MAKER_RATIO_SUM, EM_MAKER_RATIO_N, EM_MAKER_RATIO_MAX, EM_BANKRUPT = 25, 26, 27, 28
+EM_ENV_EPISODES, EM_ENV_NAV_VIOLATIONS, EM_ENV_NAV_ERROR_SUM, EM_ENV_NAV_ERROR_MAX, EM_ENV_MAKER_MAX_SUM, EM_ENV_MAKER_MAX_N, EM_ENV_STEPS, EM_ENV_TERMINATED = range(8)
 
 T_MARKET, T_LIMIT, T_MODIFY, T_CANCEL = 0, 1, 2, 3
 S_BID, S_ASK = 0, 1

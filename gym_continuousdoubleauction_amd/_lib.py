@@ -21,6 +21,7 @@ SYMBOLS = [
     "cda_step_range", "cda_reset_range", "cda_step_groups", "cda_group_range", "cda_random_actions", "cda_book_peak", "cda_check_invariants", "cda_selftest_libm", "cda_selftest_libm_host", "cda_book_capacity",
     "cda_get_book", "cda_book_spill", "cda_book_spill_wanted", "cda_num_agents", "cda_handback_stride", "cda_set_handback", "cda_set_handback_geometry", "cda_handback_unpack", "cda_ppo_loss", "cda_policy_sample", "cda_gae", "cda_store_slots", "cda_step_groups_handback", "cda_handback_groups",
     "cda_step_range_capture", "cda_policy_step_supported", "cda_policy_step_advised", "cda_policy_step_range",
+    "cda_episode_metrics_enable", "cda_episode_metrics_collect",
 ]
 
 
@@ -143,6 +144,8 @@ def lib():
     L.cda_policy_step_supported.argtypes = [vp]
     L.cda_policy_step_advised.argtypes = [vp]
     L.cda_policy_step_range.argtypes = [vp, i32, i32, vp, vp, vp, u64, vp, i64] + [vp] * 5 + [vp] * 5 + [vp] * 4 + [vp, i32, vp, vp, vp]
+    L.cda_episode_metrics_enable.argtypes = [vp, i32, C.c_double]
+    L.cda_episode_metrics_collect.argtypes = [vp, vp, i32, vp, vp, i32, vp]
     L.cda_ppo_loss32.argtypes = [vp] * 10 + [i64, i32, i32, f32, f32, f32, vp, vp, vp, i64, i32, i32, vp]
     L.cda_gae_records.argtypes = [vp, vp, vp, vp, i32, i64, i32, f32, f32, f32, vp, vp, vp]
     L.cda_ppo_loss_records.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, f32, f32, f32, vp, vp, vp, i64, i32, i32, vp]

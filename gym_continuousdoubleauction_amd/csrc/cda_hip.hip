@@ -73,9 +73,11 @@ struct MarketPtrs {
     uint32_t* hdr; uint32_t* acc; float* hist; int32_t* book;
     int32_t* spill;          // the market's HBM tier (cda_book.inc): int32 hdr[16], then the two sides' rings
 };
-// arena = [N market records][done_buf: N bytes, padded to 256][N spill regions]
+// arena = [N market records][done_buf: N bytes, padded to 256][episode metrics: f64 [N][A][CDA_EM_AGENT_FIELDS], f64 [N][CDA_EM_ENV_FIELDS]][N spill regions]
 __host__ __device__ static inline size_t spill_region_bytes(int32_t spill_cap) { return spill_cap > 0 ? 64 + (size_t)spill_cap * 2 * BOOK_FIELDS * 4 : 0; }
-__host__ __device__ static inline size_t spill_arena_off(const Params& P) { return (size_t)P.n_markets * (size_t)P.lay.stride + (((size_t)P.n_markets + 255) & ~(size_t)255); }
+__host__ __device__ static inline size_t em_agent_off(const Params& P) { return (size_t)P.n_markets * (size_t)P.lay.stride + (((size_t)P.n_markets + 255) & ~(size_t)255); }
+__host__ __device__ static inline size_t em_env_off(const Params& P) { return em_agent_off(P) + (size_t)P.n_markets * (size_t)P.cfg.num_agents * CDA_EM_AGENT_FIELDS * 8; }
+__host__ __device__ static inline size_t spill_arena_off(const Params& P) { return em_env_off(P) + (size_t)P.n_markets * CDA_EM_ENV_FIELDS * 8; }
 __device__ __forceinline__ MarketPtrs market_ptrs(uint8_t* arena, const Params& P, int mi) {
     uint8_t* rec = arena + (size_t)mi * (size_t)P.lay.stride;
     MarketPtrs r;
@@ -181,6 +183,118 @@ __device__ __forceinline__ void clear_step_counters(Acc& a) {          // exchg_
 }
 
 // ------------------------------------------------------------------------------------------
+// episode metrics (include/cda.h cda_episode_metrics_*): the reference callback's per-episode tallies and its end-of-episode check, on the device
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ EpStats* ep_stats(const MarketPtrs& mp, const Params& P) { return reinterpret_cast<EpStats*>(reinterpret_cast<uint8_t*>(mp.hdr) + P.lay.ep_off); }
+// fire-and-forget: a hardware atomic whose result nobody reads is a store-like request (no return value, no wait).  Only the market's own wave ever touches its tallies,
+// so the order of the additions to one address is the program's: the f64 sums are the sums in step order, bit for bit.
+__device__ __forceinline__ void ep_add(double* p, double v) {
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)p, v);
+}
+__device__ __forceinline__ void ep_add(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// on_episode_step (league_based_self_play_callback.py:541-600) for agent `lane` of this market: the step's counters are read BEFORE they are zeroed (exchg_helper.py:116-120)
+__device__ __forceinline__ void ep_tally(EpStats* es, const StepReward& rw, const Acc& a, bool passed) {
+    ep_add(&es->term_sum[0], rw.t0); ep_add(&es->term_sum[1], rw.t1); ep_add(&es->term_sum[2], rw.t2); ep_add(&es->term_sum[3], rw.t3); ep_add(&es->term_sum[4], rw.t4);
+    ep_add(&es->term_sq[0], rw.t0 * rw.t0); ep_add(&es->term_sq[1], rw.t1 * rw.t1); ep_add(&es->term_sq[2], rw.t2 * rw.t2); ep_add(&es->term_sq[3], rw.t3 * rw.t3);
+    ep_add(&es->term_sq[4], rw.t4 * rw.t4);
+    ep_add(&es->ret, rw.r);
+    ep_add(&es->passes, passed ? 1 : 0); ep_add(&es->rejections, a.num_rejected_step); ep_add(&es->placed, a.order_step_placed);
+    ep_add(&es->trades, a.num_trades_step); ep_add(&es->passive, a.num_passive_fills_step);
+}
+__device__ __forceinline__ double ep_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t ep_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ep_clear(EpStats* es) {                  // lane a: discard agent a's running tallies
+    uint4* q = reinterpret_cast<uint4*>(es);
+    #pragma unroll
+    for (int i = 0; i < (int)(sizeof(EpStats) / 16); i++) q[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+// on_episode_end (league_based_self_play_callback.py:627-755) for ONE market whose episode is over, called by every lane of its wave with the decimal tables staged and
+// the market's HEADER in memory as the episode's last step left it (done mask, step count).  `acc`: the accounts of that step - the wave's LDS image where the step ran in
+// this launch (what this wave has just stored need not be what its L1 returns), NULL = the record in memory.  Cold by construction: once per market and episode; called
+// from the kernels' own level, never from inside another out-of-line routine (a kernel's scratch is the deepest call chain's).
+//   - sum of NAV in agent order, exactly (Decimal arithmetic, prec 28: the code of k_nav_conservation), against num_agents x init_cash;
+//   - agent a's tallies and last-step account figures (_log_episode_account :418-470) -> accumulators of (market, a); the episode's -> accumulators of the market;
+//   - the running tallies are cleared, the header in memory is marked ST_EP_SUMMARISED (+ CDA_FLAG_NAV_CONSERVATION on a violation).
+// Returns whether conservation was violated (for a caller that holds the header in registers and is about to store it).
+__attribute__((noinline, cold)) __device__ bool episode_summarise(uint8_t* arena, const Params* Pp, int mi, const Acc* acc) {
+    const Params& P = *Pp;
+    const int lane = lane_id(), A = P.cfg.num_agents;
+    uint8_t* rec = arena + (size_t)mi * (size_t)P.lay.stride;
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(rec);
+    if (!acc) acc = reinterpret_cast<const Acc*>(rec + P.lay.acc_off);
+    EpStats* s = reinterpret_cast<EpStats*>(rec + P.lay.ep_off) + (lane < A ? lane : 0);
+    double* f = reinterpret_cast<double*>(arena + em_agent_off(P)) + ((size_t)mi * (size_t)A + (size_t)(lane < A ? lane : 0)) * CDA_EM_AGENT_FIELDS;
+    double* M = reinterpret_cast<double*>(arena + em_env_off(P)) + (size_t)mi * CDA_EM_ENV_FIELDS;
+    // EVERY load first - the header words, the tallies (written by atomics: read where they live), the accumulator rows - and unconditionally (a lane beyond the agents
+    // reads agent 0's): the seventy-odd requests are ONE round trip under the decimal arithmetic below.  Read and updated field by field, each store would fence the
+    // next load behind it (and every lock-step episode end of a batch is N of these at once).
+    const uint32_t done_mask = hdr[H_DONE_MASK], status = hdr[H_STATUS], flags = hdr[H_FLAGS];
+    const int t_step = (int)hdr[H_T_STEP];
+    double ts[CDA_NUM_REWARD_TERMS], tq[CDA_NUM_REWARD_TERMS], fv[CDA_EM_BANKRUPT + 1], mv[CDA_EM_ENV_FIELDS];
+    #pragma unroll
+    for (int j = 0; j < CDA_NUM_REWARD_TERMS; j++) { ts[j] = ep_load(&s->term_sum[j]); tq[j] = ep_load(&s->term_sq[j]); }
+    const double ret = ep_load(&s->ret);
+    const int passes = ep_load(&s->passes), rejections = ep_load(&s->rejections), placed = ep_load(&s->placed), trades = ep_load(&s->trades), passive = ep_load(&s->passive);
+    #pragma unroll
+    for (int j = 0; j <= CDA_EM_BANKRUPT; j++) fv[j] = f[j];
+    #pragma unroll
+    for (int j = 0; j < CDA_EM_ENV_FIELDS; j++) mv[j] = M[j];
+    __builtin_amdgcn_sched_barrier(0);
+    D total = d_zero();
+    for (int a = 0; a < A; a++) total = d_add(total, ld_dec(acc[a].nav));
+    D err = d_sub(total, d_mul_int(d_from_i64(P.cfg.init_cash), (uint32_t)A));
+    err.sign = 0;
+    uint32_t ferr = 0;
+    const double e = d_to_double(err, &ferr);
+    const bool viol = e > P.ep_tol || ferr != 0;
+    double ratio = -1.0;                                                 // lane a: agent a's passive share of its own fills, if it has enough of them
+    if (lane < A) {
+        const Acc& ac = acc[lane];
+        uint32_t f2 = 0;
+        const D navd = ld_dec(ac.nav);
+        const double nav = d_to_double(navd, &f2);
+        const D ddd = d_sub(ld_dec(ac.max_nav), navd);
+        const double dd = d_sgn(ddd) > 0 ? d_to_double(ddd, &f2) : 0.0;      // float(max(0, max_nav - nav)), reward_helper.py:60-62
+        if (trades >= 5) ratio = (double)passive / (double)trades;
+        const bool first = fv[CDA_EM_EPISODES] == 0.0;
+        fv[CDA_EM_EPISODES] += 1.0;
+        fv[CDA_EM_AGENT_STEPS] += (double)t_step;
+        fv[CDA_EM_PASSES] += (double)passes; fv[CDA_EM_REJECTIONS] += (double)rejections; fv[CDA_EM_PLACED] += (double)placed;
+        fv[CDA_EM_TRADES] += (double)trades; fv[CDA_EM_PASSIVE] += (double)passive;
+        #pragma unroll
+        for (int j = 0; j < CDA_NUM_REWARD_TERMS; j++) { fv[CDA_EM_TERM_SUM + j] += ts[j]; fv[CDA_EM_TERM_SQ + j] += tq[j]; }
+        fv[CDA_EM_RETURN_SUM] += ret; fv[CDA_EM_RETURN_SQ] += ret * ret;
+        fv[CDA_EM_NAV_SUM] += nav;
+        fv[CDA_EM_NAV_MIN] = first ? nav : fmin(fv[CDA_EM_NAV_MIN], nav);
+        fv[CDA_EM_NAV_MAX] = first ? nav : fmax(fv[CDA_EM_NAV_MAX], nav);
+        fv[CDA_EM_DRAWDOWN_SUM] += dd;
+        fv[CDA_EM_ABS_POSITION_SUM] += fabs((double)ac.net_position);
+        fv[CDA_EM_NUM_TRADES_SUM] += (double)ac.num_trades;
+        if (ratio >= 0.0) { fv[CDA_EM_MAKER_RATIO_SUM] += ratio; fv[CDA_EM_MAKER_RATIO_N] += 1.0; fv[CDA_EM_MAKER_RATIO_MAX] = fmax(fv[CDA_EM_MAKER_RATIO_MAX], ratio); }
+        fv[CDA_EM_BANKRUPT] += (double)((done_mask >> lane) & 1u);
+        #pragma unroll
+        for (int j = 0; j <= CDA_EM_BANKRUPT; j++) f[j] = fv[j];
+        ep_clear(s);
+    }
+    double best = -1.0;                                                  // maker_fill_ratio_max (:344-372): the episode's most maker-like agent
+    for (int a = 0; a < A; a++) best = fmax(best, __shfl(ratio, a, WAVE));
+    if (lane == 0) {
+        mv[CDA_EM_ENV_EPISODES] += 1.0;
+        mv[CDA_EM_ENV_NAV_VIOLATIONS] += viol ? 1.0 : 0.0;
+        mv[CDA_EM_ENV_NAV_ERROR_SUM] += e;
+        mv[CDA_EM_ENV_NAV_ERROR_MAX] = fmax(mv[CDA_EM_ENV_NAV_ERROR_MAX], e);
+        if (best >= 0.0) { mv[CDA_EM_ENV_MAKER_MAX_SUM] += best; mv[CDA_EM_ENV_MAKER_MAX_N] += 1.0; }
+        mv[CDA_EM_ENV_STEPS] += (double)t_step;
+        mv[CDA_EM_ENV_TERMINATED] += __popc(done_mask) == A ? 1.0 : 0.0;
+        #pragma unroll
+        for (int j = 0; j < CDA_EM_ENV_FIELDS; j++) M[j] = mv[j];
+        hdr[H_STATUS] = status | (uint32_t)ST_EP_SUMMARISED;
+        if (viol) hdr[H_FLAGS] = flags | CDA_FLAG_NAV_CONSERVATION;
+    }
+    return viol;
+}
+
+// ------------------------------------------------------------------------------------------
 // run_random - a whole random-agent episode per launch (CDA_rand.py:40-85)
 // ------------------------------------------------------------------------------------------
 struct RunArgs {
@@ -281,6 +395,96 @@ __global__ void k_check_invariants(const uint8_t* arena, Params P, int CAP, uint
     }
     if (net != 0) v |= CDA_INV_NET_POSITION;
     out[i] = v;
+}
+// cda_episode_metrics_collect, stage 1: block b reduces its share of the (market, agent) accumulators by module - thread (group g of 8, field f of 32) walks the
+// pairs g + 8 (b + EM_BLOCKS k) and keeps one accumulator per module in registers - and of the per-market accumulators; the groups of a block are combined in LDS
+// in a fixed order.  Stage 2 adds the blocks' partials in block order: the result does not depend on timing.
+constexpr int EM_BLOCKS = 256;
+__device__ __forceinline__ double em_combine(int field, double x, double y) {
+    return field == CDA_EM_NAV_MIN ? fmin(x, y) : ((field == CDA_EM_NAV_MAX || field == CDA_EM_MAKER_RATIO_MAX) ? fmax(x, y) : x + y);
+}
+__device__ __forceinline__ double em_identity(int field) {
+    return field == CDA_EM_NAV_MIN ? __longlong_as_double(0x7ff0000000000000LL) : ((field == CDA_EM_NAV_MAX || field == CDA_EM_MAKER_RATIO_MAX) ? __longlong_as_double(0xfff0000000000000LL) : 0.0);
+}
+__global__ __launch_bounds__(256) void k_em_partial(uint8_t* arena, Params P, const int32_t* module_of, int n_modules, int clear, double* partials) {
+    __shared__ double red[8][CDA_EM_AGENT_FIELDS];
+    const int tid = (int)threadIdx.x, g = tid >> 5, f = tid & 31, b = (int)blockIdx.x;
+    double* F = reinterpret_cast<double*>(arena + em_agent_off(P));
+    double* M = reinterpret_cast<double*>(arena + em_env_off(P));
+    const long long pairs = (long long)P.n_markets * P.cfg.num_agents;
+    double acc[CDA_EM_MAX_MODULES];
+    #pragma unroll
+    for (int k = 0; k < CDA_EM_MAX_MODULES; k++) acc[k] = em_identity(f);
+    for (long long p = (long long)b * 8 + g; p < pairs; p += (long long)EM_BLOCKS * 8) {
+        double* row = F + p * CDA_EM_AGENT_FIELDS;
+        const double n = row[CDA_EM_EPISODES], v = row[f];
+        const int m = module_of ? module_of[p] : 0;
+        if (n != 0.0 && m >= 0 && m < n_modules) {
+            #pragma unroll
+            for (int k = 0; k < CDA_EM_MAX_MODULES; k++) acc[k] = k == m ? em_combine(f, acc[k], v) : acc[k];
+        }
+        if (clear) { __syncwarp(); row[f] = 0.0; }            // (every lane of the 32 has read row[0] before anyone clears it)
+    }
+    double* out = partials + (size_t)b * (CDA_EM_MAX_MODULES * CDA_EM_AGENT_FIELDS + CDA_EM_ENV_FIELDS);
+    #pragma unroll
+    for (int k = 0; k < CDA_EM_MAX_MODULES; k++) {             // (unrolled: acc[] stays in registers)
+        if (k < n_modules) {
+            __syncthreads();
+            red[g][f] = acc[k];
+            __syncthreads();
+            if (g == 0) { double r = red[0][f]; for (int q = 1; q < 8; q++) r = em_combine(f, r, red[q][f]); out[k * CDA_EM_AGENT_FIELDS + f] = r; }
+        }
+    }
+    // the per-market accumulators: thread (group of 32, field of 8)
+    __syncthreads();
+    const int g2 = tid >> 3, f2 = tid & 7;
+    double a2 = 0.0;
+    for (int i = b * 32 + g2; i < P.n_markets; i += EM_BLOCKS * 32) {
+        double* row = M + (size_t)i * CDA_EM_ENV_FIELDS;
+        const double v = row[f2];
+        a2 = f2 == CDA_EM_ENV_NAV_ERROR_MAX ? fmax(a2, v) : a2 + v;
+        if (clear) row[f2] = 0.0;
+    }
+    double* red2 = &red[0][0];                                 // 256 doubles
+    red2[tid] = a2;
+    __syncthreads();
+    if (tid < CDA_EM_ENV_FIELDS) {
+        double r = red2[tid];
+        for (int q = 1; q < 32; q++) { const double v = red2[q * 8 + tid]; r = tid == CDA_EM_ENV_NAV_ERROR_MAX ? fmax(r, v) : r + v; }
+        out[CDA_EM_MAX_MODULES * CDA_EM_AGENT_FIELDS + tid] = r;
+    }
+}
+// stage 2: one wave per output word; lane l adds the partials of blocks l, l + 64, ... in that order, the lanes are combined by a butterfly - a fixed order again
+__global__ __launch_bounds__(64) void k_em_final(const double* partials, int n_modules, double* agent_out, double* env_out) {
+    const int t = (int)blockIdx.x, lane = (int)threadIdx.x;
+    const size_t per = CDA_EM_MAX_MODULES * CDA_EM_AGENT_FIELDS + CDA_EM_ENV_FIELDS;
+    const bool agent = t < n_modules * CDA_EM_AGENT_FIELDS;
+    const int f = agent ? t % CDA_EM_AGENT_FIELDS : -1 - (t - n_modules * CDA_EM_AGENT_FIELDS);        // env words: negative
+    const size_t col = agent ? (size_t)t : (size_t)(CDA_EM_MAX_MODULES * CDA_EM_AGENT_FIELDS + (t - n_modules * CDA_EM_AGENT_FIELDS));
+    const size_t ncol = agent ? (size_t)(t / CDA_EM_AGENT_FIELDS) * CDA_EM_AGENT_FIELDS + CDA_EM_EPISODES : col;
+    auto comb = [f](double x, double y) { return f >= 0 ? em_combine(f, x, y) : (-1 - f == CDA_EM_ENV_NAV_ERROR_MAX ? fmax(x, y) : x + y); };
+    double v[EM_BLOCKS / 64], nn[EM_BLOCKS / 64];
+    #pragma unroll
+    for (int k = 0; k < EM_BLOCKS / 64; k++) { v[k] = partials[(size_t)(lane + 64 * k) * per + col]; nn[k] = partials[(size_t)(lane + 64 * k) * per + ncol]; }
+    double r = v[0], n = nn[0];
+    #pragma unroll
+    for (int k = 1; k < EM_BLOCKS / 64; k++) { r = comb(r, v[k]); n += nn[k]; }
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { r = comb(r, __shfl_xor(r, d, 64)); n += __shfl_xor(n, d, 64); }
+    if (lane == 0) {
+        if (agent) agent_out[t] = n == 0.0 ? 0.0 : r;           // a module that played nothing reports zeros, not infinities
+        else env_out[t - n_modules * CDA_EM_AGENT_FIELDS] = r;
+    }
+}
+// cda_episode_metrics_enable: the switch lives in every market's header (ST_EP_ON); the running tallies start from zero
+__global__ void k_ep_enable(uint8_t* arena, Params P, int on) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= P.n_markets) return;
+    uint8_t* rec = arena + (size_t)i * (size_t)P.lay.stride;
+    uint32_t* h = (uint32_t*)rec;
+    h[H_STATUS] = on ? (h[H_STATUS] | (uint32_t)ST_EP_ON) : (h[H_STATUS] & ~(uint32_t)(ST_EP_ON | ST_EP_SUMMARISED));
+    uint32_t* t = (uint32_t*)(rec + P.lay.ep_off);
+    for (int k = 0; k < P.cfg.num_agents * (int)(sizeof(EpStats) / 4); k++) t[k] = 0;
 }
 __global__ void k_flags(uint8_t* arena, Params P, uint32_t* out) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -401,6 +605,7 @@ struct cda_env {
     uint8_t* handback;       // cda_set_handback: caller-owned [N, handback_stride(A)] bytes, or NULL
     int64_t hb_row_stride, hb_rows_total;   // cda_set_handback_geometry: rows between two ranks' first markets / global row count (0, 0 = equal shards of N)
     int32_t spill_wanted;    // orders per side the spill ring was asked to hold (automatic: num_agents * max_step rounded up); P.lay.spill_cap is what it got
+    double* em_partials;     // cda_episode_metrics_collect: the blocks' partial sums (EM_BLOCKS rows)
 };
 static inline int32_t handback_stride_of(int32_t num_agents) { return (CDA_SNAPSHOT_DIM * 4 + num_agents * 8 + 3 + 7) & ~7; }
 
@@ -516,9 +721,12 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     hipError_t he = hipMalloc((void**)&e->arena, e->arena_bytes);
     if (he != hipSuccess) { free(e); return he == hipErrorOutOfMemory ? CDA_ERR_NOMEM : hip_fail(he, "hipMalloc"); }
     e->done_buf = e->arena + records;
+    P.ep_tol = 1e-6;
     hipLaunchKernelGGL(k_init_arena, dim3((unsigned)((n_markets + 255) / 256)), dim3(256), 0, 0, e->arena, P);
-    he = hipDeviceSynchronize();
-    if (he != hipSuccess) { (void)hipFree(e->arena); free(e); return hip_fail(he, "k_init_arena"); }
+    he = hipMemsetAsync(e->arena + em_agent_off(P), 0, spill_arena_off(P) - em_agent_off(P), 0);          // the episode-metric accumulators
+    if (he == hipSuccess) he = hipMalloc((void**)&e->em_partials, (size_t)EM_BLOCKS * (CDA_EM_MAX_MODULES * CDA_EM_AGENT_FIELDS + CDA_EM_ENV_FIELDS) * sizeof(double));
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    if (he != hipSuccess) { (void)hipFree(e->arena); if (e->em_partials) (void)hipFree(e->em_partials); free(e); return hip_fail(he, "k_init_arena"); }
     *out = e;
     return CDA_OK;
 }
@@ -527,6 +735,7 @@ int cda_destroy(cda_env* e) {
     if (!e) return CDA_OK;
     (void)hipSetDevice(e->device);
     (void)hipFree(e->arena);
+    if (e->em_partials) (void)hipFree(e->em_partials);
     free(e);
     return CDA_OK;
 }
@@ -549,15 +758,15 @@ int cda_reset(cda_env* e, const uint64_t* seeds, const uint8_t* mask, float* obs
 // one launch of k_step (+ the auto-reset pass) over [first, first + n) on `stream`; arguments validated by the callers
 static int launch_step(cda_env* e, int32_t first, int32_t n, const StepArgs& S0, hipStream_t stream) {
     const size_t smem = smem_for(e, CDA_WPB) + ZIG_LDS_BYTES;
-    if (e->cap == 512) {
-        cda::cap512::StepKernArgs K; K.arena = e->arena; K.P = e->P; K.S = S0; K.S.first_market = first; K.S.end_market = first + n;
-        if (K.S.has_info) hipLaunchKernelGGL(cda::cap512::k_step<true>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
-        else hipLaunchKernelGGL(cda::cap512::k_step<false>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
-    } else {
-        cda::cap256::StepKernArgs K; K.arena = e->arena; K.P = e->P; K.S = S0; K.S.first_market = first; K.S.end_market = first + n;
-        if (K.S.has_info) hipLaunchKernelGGL(cda::cap256::k_step<true>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
-        else hipLaunchKernelGGL(cda::cap256::k_step<false>, grid_for(n), dim3(64 * CDA_WPB), smem, stream, K);
-    }
+    const bool tally = e->P.lay.ep_on != 0;               // episode metrics on: the instances that tally (their code is not even in the others)
+#define CDA_LAUNCH_STEP(ns) do { \
+        cda::ns::StepKernArgs K; K.arena = e->arena; K.P = e->P; K.S = S0; K.S.first_market = first; K.S.end_market = first + n; \
+        if (K.S.has_info) { if (tally) hipLaunchKernelGGL((cda::ns::k_step<true, true>), grid_for(n), dim3(64 * CDA_WPB), smem, stream, K); \
+                            else hipLaunchKernelGGL((cda::ns::k_step<true, false>), grid_for(n), dim3(64 * CDA_WPB), smem, stream, K); } \
+        else { if (tally) hipLaunchKernelGGL((cda::ns::k_step<false, true>), grid_for(n), dim3(64 * CDA_WPB), smem, stream, K); \
+               else hipLaunchKernelGGL((cda::ns::k_step<false, false>), grid_for(n), dim3(64 * CDA_WPB), smem, stream, K); } } while (0)
+    if (e->cap == 512) CDA_LAUNCH_STEP(cap512); else CDA_LAUNCH_STEP(cap256);
+#undef CDA_LAUNCH_STEP
     HIPCHK(hipGetLastError());
     // auto_reset: in the info-less kernel a market whose episode ended resets itself as the kernel's last act (reset_after_step in
     // cda_kernels.inc); with info tensors the pass is a launch of its own behind the step (every market-wave of it exits at once unless its
@@ -662,12 +871,15 @@ int cda_policy_step_range(cda_env* e, int32_t first_market, int32_t n_markets, c
     const size_t smem = (size_t)policy_step_lds(e);
     typedef void (*kern_t)(cda::cap256::PolicyStepKernArgs);
     const int hist = e->P.cfg.n_hist, slot = hist == 4 ? 0 : (hist == 1 ? 1 : (hist == 2 ? 2 : 3));
-    const kern_t kern = hist == 4 ? cda::cap256::k_policy_step : (hist == 1 ? cda::cap256::k_policy_step_h1 : (hist == 2 ? cda::cap256::k_policy_step_h2 : cda::cap256::k_policy_step_h8));
+    const bool tally = e->P.lay.ep_on != 0;
+    const kern_t kern = tally ? (hist == 4 ? cda::cap256::k_policy_step<true> : (hist == 1 ? cda::cap256::k_policy_step_h1<true> : (hist == 2 ? cda::cap256::k_policy_step_h2<true> : cda::cap256::k_policy_step_h8<true>)))
+                              : (hist == 4 ? cda::cap256::k_policy_step<false> : (hist == 1 ? cda::cap256::k_policy_step_h1<false> : (hist == 2 ? cda::cap256::k_policy_step_h2<false> : cda::cap256::k_policy_step_h8<false>)));
     {   // more than 64 KB of dynamic LDS: granted once per device and instance
-        static unsigned long long granted[4] = {0, 0, 0, 0};
-        if (!(granted[slot] >> (e->device & 63) & 1ull)) {
+        static unsigned long long granted[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int gslot = slot + (tally ? 4 : 0);
+        if (!(granted[gslot] >> (e->device & 63) & 1ull)) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            granted[slot] |= 1ull << (e->device & 63);
+            granted[gslot] |= 1ull << (e->device & 63);
         }
     }
     cda::cap256::PolicyStepKernArgs KA;
@@ -789,8 +1001,11 @@ int cda_run_random(cda_env* e, int32_t n_steps, uint64_t action_seed, uint64_t m
     R.n_steps = n_steps; R.seed = action_seed; R.market_base = market_index_base;
     R.obs_out = obs_out; R.return_out = episode_return_out; R.terminated_out = terminated_out; R.truncated_out = truncated_out;
     R.steps_out = steps_taken_out;
-    if (e->cap == 512) { cda::cap512::RunKernArgs K; K.arena = e->arena; K.P = e->P; K.R = R; hipLaunchKernelGGL(cda::cap512::k_run_random, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, K); }
-    else { cda::cap256::RunKernArgs K; K.arena = e->arena; K.P = e->P; K.R = R; hipLaunchKernelGGL(cda::cap256::k_run_random, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, K); }
+#define CDA_LAUNCH_RUN(ns) do { cda::ns::RunKernArgs K; K.arena = e->arena; K.P = e->P; K.R = R; \
+        if (e->P.lay.ep_on) hipLaunchKernelGGL(cda::ns::k_run_random<true>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, K); \
+        else hipLaunchKernelGGL(cda::ns::k_run_random<false>, grid_for(e->P.n_markets), dim3(64 * CDA_WPB), smem_for(e, CDA_WPB) + ZIG_LDS_BYTES, (hipStream_t)stream, K); } while (0)
+    if (e->cap == 512) CDA_LAUNCH_RUN(cap512); else CDA_LAUNCH_RUN(cap256);
+#undef CDA_LAUNCH_RUN
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -867,6 +1082,27 @@ int cda_nav_conservation(cda_env* e, double tolerance, double* abs_error_out, ui
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_nav_conservation, dim3((unsigned)((e->P.n_markets + 63) / 64)), dim3(64), DEC_TABLE_BYTES, (hipStream_t)stream,
                        (const uint8_t*)e->arena, e->P, tolerance, abs_error_out, violated_out);
+    HIPCHK(hipGetLastError());
+    return CDA_OK;
+}
+
+int cda_episode_metrics_enable(cda_env* e, int32_t on, double nav_tolerance) {
+    if (!e || (on != 0 && on != 1) || !(nav_tolerance >= 0.0)) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    e->P.lay.ep_on = on;
+    e->P.ep_tol = nav_tolerance;
+    hipLaunchKernelGGL(k_ep_enable, dim3((unsigned)((e->P.n_markets + 255) / 256)), dim3(256), 0, 0, e->arena, e->P, (int)on);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return CDA_OK;
+}
+int cda_episode_metrics_collect(cda_env* e, const int32_t* module_of, int32_t n_modules, double* agent_out, double* env_out, int32_t clear, void* stream) {
+    if (!e || !agent_out || !env_out || n_modules < 1 || n_modules > CDA_EM_MAX_MODULES) return CDA_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_em_partial, dim3(EM_BLOCKS), dim3(256), 0, (hipStream_t)stream, e->arena, e->P, module_of, (int)n_modules, (int)(clear != 0), e->em_partials);
+    const int n_out = n_modules * CDA_EM_AGENT_FIELDS + CDA_EM_ENV_FIELDS;
+    hipLaunchKernelGGL(k_em_final, dim3((unsigned)n_out), dim3(64), 0, (hipStream_t)stream, (const double*)e->em_partials, (int)n_modules, agent_out, env_out);
     HIPCHK(hipGetLastError());
     return CDA_OK;
 }
@@ -1022,7 +1258,7 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
         const int tail_n[2] = {s->n_bids - tb, s->n_asks - ta}, tile_n[2] = {tb, ta};
         if (tail_n[0] > P.lay.spill_cap || tail_n[1] > P.lay.spill_cap) { free(rec); return CDA_ERR_INVALID; }
         h[H_N_BIDS] = (uint32_t)tb; h[H_N_ASKS] = (uint32_t)ta;
-        h[H_STATUS] = (tail_n[0] > 0 ? ST_TAIL_BID : 0) | (tail_n[1] > 0 ? ST_TAIL_ASK : 0);
+        h[H_STATUS] = (tail_n[0] > 0 ? ST_TAIL_BID : 0) | (tail_n[1] > 0 ? ST_TAIL_ASK : 0) | (P.lay.ep_on ? ST_EP_ON : 0);
         int32_t* ring = NULL;
         const size_t side_bytes = (size_t)BOOK_FIELDS * (size_t)P.lay.spill_cap * 4;
         if (tail_n[0] > 0 || tail_n[1] > 0) { ring = (int32_t*)calloc(1, 2 * side_bytes); if (!ring) { free(rec); return CDA_ERR_NOMEM; } }
@@ -1066,7 +1302,9 @@ int cda_set_state(cda_env* e, int32_t market, const cda_market_state* s) {
         ap[a].order_step_placed = o->order_step_placed; ap[a].num_rejected_step = o->num_rejected_step;
     }
     memcpy(rec + P.lay.hist_off, s->hist, sizeof(float) * (size_t)P.cfg.n_hist * CDA_SNAPSHOT_DIM);
-    hipError_t he = hipMemcpy(dev_rec, rec, (size_t)P.lay.stride, hipMemcpyHostToDevice);
+    // (the running episode tallies behind the book tile are not part of the dump: they stay as they are)
+    hipError_t he = hipMemcpy(rec + P.lay.ep_off, dev_rec + P.lay.ep_off, (size_t)P.cfg.num_agents * sizeof(EpStats), hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipMemcpy(dev_rec, rec, (size_t)P.lay.stride, hipMemcpyHostToDevice);
     free(rec);
     if (he != hipSuccess) return hip_fail(he, "hipMemcpy H2D");
     return CDA_OK;

@@ -57,7 +57,10 @@ constexpr int HEADER_BYTES = H_WORDS * 4;   // 256: one coalesced load per wave
 // H_STATUS bits.  H_N_BIDS / H_N_ASKS count the orders of a side that live in the record's book TILE (the LDS-staged top of
 // the book); a side whose ST_TAIL bit is set continues in the market's HBM spill ring (cda_book.inc), otherwise the tile is
 // the whole side - the only case the hot path ever sees.
-enum { ST_LEVELS_VALID = 1, ST_TAIL_BID = 2, ST_TAIL_ASK = 4, ST_TAIL_ANY = 6 };
+enum { ST_LEVELS_VALID = 1, ST_TAIL_BID = 2, ST_TAIL_ASK = 4, ST_TAIL_ANY = 6,
+       ST_EP_SUMMARISED = 8,     // episode metrics: this market's finished episode has been checked and credited (a later reset must not do it again)
+       ST_EP_ON = 16 };          // episode metrics are on (cda_episode_metrics_enable sets it in every market's header): the step learns it from the record it loads
+                                 // anyway - as a kernel argument it would be one more scalar the hot kernel carries through every phase
 
 struct Acc {                     // 144 B, 16-byte aligned; lane a owns account a
     cda_dec cash, hold, posval, vwap, nav, prev_nav, max_nav;     // 7 x 16 B
@@ -67,6 +70,16 @@ struct Acc {                     // 144 B, 16-byte aligned; lane a owns account 
 };
 static_assert(sizeof(Acc) == 144, "Acc layout");
 
+// Episode metrics (include/cda.h cda_episode_metrics_*): the RUNNING episode's tallies of agent a - what the reference's callback keeps per episode
+// (train/callbk/league_based_self_play_callback.py:55-90 _new_tally, :541-600 on_episode_step) - live in the market record behind the book tile.  The
+// step adds to them with fire-and-forget atomics (nothing is loaded, no register is held across the step); the cold episode-end path reads and clears them.
+struct EpStats {                 // 112 B
+    double term_sum[CDA_NUM_REWARD_TERMS], term_sq[CDA_NUM_REWARD_TERMS];   // sum / sum of squares of each reward term over the episode's steps
+    double ret;                  // the episode's return so far
+    int32_t passes, rejections, placed, trades, passive, pad;
+};
+static_assert(sizeof(EpStats) == 112, "EpStats layout");
+
 constexpr int BOOK_FIELDS = 4;
 __device__ __forceinline__ int oo_owner(int32_t oo) { return oo & 15; }
 __device__ __forceinline__ int oo_pack(int32_t oid, int owner) { return (int32_t)(((uint32_t)oid << 4) | (uint32_t)owner); }
@@ -74,6 +87,8 @@ __device__ __forceinline__ int oo_pack(int32_t oid, int owner) { return (int32_t
 struct Layout {                  // byte offsets inside a market record
     int32_t acc_off, hist_off, book_off, stride;
     int32_t spill_cap;           // orders per side the market's HBM spill ring holds (a power of two; 0 = no HBM tier)
+    int32_t ep_off;              // EpStats[num_agents] (always laid out; touched only while ep_on)
+    int32_t ep_on;               // cda_episode_metrics_enable (host copy of the headers' ST_EP_ON: k_reset stages the decimal tables for the episode-end check)
 };
 
 // the record layout of an env with `num_agents` agents, `n_hist` frames and a book tile of `cap` orders
@@ -83,8 +98,10 @@ __host__ __device__ constexpr Layout record_layout(int num_agents, int n_hist, i
     l.acc_off = off; off += num_agents * (int)sizeof(Acc);
     l.hist_off = off; off += n_hist * CDA_SNAPSHOT_DIM * 4; off = (off + 15) & ~15;
     l.book_off = off; off += cap * BOOK_FIELDS * 4;
+    l.ep_off = off; off += num_agents * (int)sizeof(EpStats);
     l.stride = (off + 255) & ~255;
     l.spill_cap = 0;
+    l.ep_on = 0;
     return l;
 }
 
@@ -93,6 +110,7 @@ struct Params {
     Layout lay;
     int32_t n_markets;
     float mkt_mul, lim_mul;
+    double ep_tol;               // episode metrics: the callback's nav_tolerance (1e-6)
 };
 
 // ---- uniform (per-wave) market scalars kept in registers -----------------------------------

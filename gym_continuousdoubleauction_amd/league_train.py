@@ -168,13 +168,17 @@ class League:
 
 def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epochs=4, seed=0, original_opponent_weight=1.0, champion_weight=3.0,
                        std_dev_multiplier=0.1, max_champions=8, min_iterations_between_champions=2, chains=4, minibatch=262144, objective=None, use_graph=True,
-                       recorder=None, info_markets=0, run_id="league", log=print, keep=None, allreduce=None, world=1, first_market=0):
+                       recorder=None, info_markets=0, run_id="league", log=print, keep=None, allreduce=None, world=1, first_market=0, episode_metrics=True,
+                       strict_nav_check=True):
     """League self-play on the fused kernels (include/cda_mlp.h `cda_league`): the reference's training topology - `num_trainable` SEPARATELY trained policies
     (policy_p plays slot p), every other slot drawn per episode from the pool of uniform random modules and frozen champions by the reference's mapping rule
     (computed on the device, league.LeagueSlotMapper.assign_device) - at the speed of the fused loop: ONE policy launch per step serves every module of every
     market, the rollout never leaves its HIP graphs, each trainable policy's update reads its own slot's sample records in place (record stride, no compaction).
     env: CDAVecEnv with auto_reset; an episode = env.max_step steps = max_step / horizon iterations (horizon must divide it): all markets change opponents
     together at the episode boundary.  Returns (bank, league, history).
+    episode_metrics (default on): every episode end is checked and tallied on the device (ppo.train_fused), here PER MODULE - keyed by the draw of the mapping fn, so
+    a champion's or a random module's figures are its own whatever slot it played (the reference's `module_episode_returns_mean` keying, callbk:780-800);
+    history[i]["episode_metrics"] = {"episodes", "nav_conservation_violations", ..., "modules": {module id: {...}}}; a violation raises (strict_nav_check).
     allreduce / world / first_market: the data-parallel learner of ppo.train_fused for the league - every rank rolls out and back-propagates its own shard of
     markets (global indices [first_market, first_market + N): env seeds, sampling keys and EPISODE IDS follow them, so the opponents a market meets do not depend
     on the GPU count), the ranks sum each policy's gradient (one all-reduce of 0.9 MB per policy and minibatch step) and advantage sums, and the per-module returns
@@ -194,6 +198,9 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
     mapper = LeagueSlotMapper(A, k, A - k, original_opponent_weight, champion_weight)
     league = League(mapper, bank, std_dev_multiplier, max_champions, min_iterations_between_champions)
     env.reset(seed=seed + int(first_market))
+    if episode_metrics:
+        env.enable_episode_metrics(True)
+    module_of, module_names = torch.zeros((N, A), dtype=torch.int32, device=dev), list(mapper.available_modules)
     use_kl = obj["kl_coef"] > 0.0
     roll = RolloutChains(env, bank, T, groups=chains, seed=seed + 7919 * int(first_market), use_graphs=use_graph, with_dist=use_kl,
                          capture_ends=bool(obj["bootstrap_truncation"]), info_markets=info_markets if recorder is not None else 0)
@@ -220,6 +227,9 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
         t0 = time.perf_counter()
         if it % per_episode == 0:                                            # a new episode everywhere: new opponents (one launch; the crcs were computed while the GPU worked)
             mapper.assign_device(bank, crcs=next_crcs, net_of=league.net_of, slot_pool=slot_pool)
+            if episode_metrics:                                              # who plays what during the coming episodes: index into the pool AS IT STANDS NOW
+                torch.where(slot_pool < 0, torch.arange(A, device=dev, dtype=torch.int32).expand(N, A), slot_pool + k, out=module_of)
+                module_names = list(mapper.available_modules)
             if recorder is not None:
                 sp = slot_pool[N - roll.info_markets:].cpu().numpy() if roll.info_markets else None
                 mods = names()
@@ -250,6 +260,7 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
             if update_streams:
                 ev = torch.cuda.Event(); ev.record(st); cur.wait_event(ev)
         returns.update(buf, T)
+        em = env.collect_episode_metrics(module_of=module_of, n_modules=len(module_names)) if episode_metrics else None     # (before the pool changes)
         if (it + 1) % per_episode == 0:                                      # host work under the GPU's: the next episode's ids
             next_crcs = mapper.episode_crcs(episode_ids((it + 1) // per_episode))
         torch.cuda.synchronize(dev)
@@ -266,8 +277,16 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
         stats_h.update(promoted=promoted, pool=list(mapper.pool()), mean_reward_trainable=float(buf["reward"][:, :, :k].mean()))
         if recorder is not None and roll.info is not None:
             recorder.record_rollout(roll, iteration=it)
+        if em is not None:
+            from . import episode_metrics as EM
+            if dp:                                                           # the additive columns over all shards (min / max columns stay this rank's)
+                allreduce(em[0]); allreduce(em[1])
+            summ = EM.summarise(*em, module_names=module_names)
+            stats_h["episode_metrics"] = summ
         history.append(stats_h)
         log(json.dumps(stats_h))
+        if em is not None:
+            EM.check_nav_conservation(it, summ, strict=strict_nav_check, log=log)
     if keep is not None:
         keep.update(buffers=roll.buf, rollout=roll, updates=upds, slot_pool=slot_pool, returns=returns)
     return bank, league, history

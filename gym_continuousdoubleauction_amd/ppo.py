@@ -488,7 +488,7 @@ def adapt_kl_coef(kl_coef, sampled_kl, kl_target):
 
 def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, seed=0, log=print, use_graph=True, chains=4, minibatch=262144,
                 gamma=None, lam=None, clip=None, vf_coef=None, ent_coef=None, policy=None, keep=None, sub_batches=None, objective=None, recorder=None, info_markets=0,
-                allreduce=None, world=1, first_market=0):
+                allreduce=None, world=1, first_market=0, episode_metrics=True, strict_nav_check=True):
     """The PPO loop on the hand-written network kernels (mlp.py, include/cda_mlp.h): rollouts as `chains` independent per-chain launch
     sequences (policy forward + sampling -> env step -> auto reset, one HIP graph per chain, no cross-stream edge inside the horizon), the
     sample records completed by one GAE launch, the update as {gather + forward + loss + back-propagation, weight gradients, reduce, clip + Adam}
@@ -500,6 +500,10 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     markets [first_market, first_market + N): seeds and sampling keys follow the global index), rolls out and back-propagates locally, and the ranks sum the
     gradient (parallel.make_grad_allreduce: one all-reduce of 0.9 MB per minibatch step, mlp.FusedUpdate) and the two advantage sums of a rollout - no
     observation ever crosses the fabric.  Every rank starts from the same parameters (same `seed`) and applies the same steps.
+    episode_metrics (default on): every episode that ends anywhere inside a rollout is checked (exact sum of NAV) and tallied ON THE DEVICE, in the cold path of the
+    in-kernel auto reset (CDAVecEnv.enable_episode_metrics); history[i]["episode_metrics"] holds what the reference's callback logs per episode
+    (episode_metrics.summarise: pass / rejection fractions, reward-term means and variance shares, NAV / drawdown / inventory at the episode's end, the most maker-like
+    agent's passive share) and a violation raises NavConservationError like the reference's strict_nav_check run (train/train.py:1125-1164); strict_nav_check=False logs it.
     Needs a HIP CDAVecEnv with auto_reset and 168-float observations.  Returns (FusedPolicy, history); `keep` (a dict) receives the last
     rollout's buffers and the RolloutChains object.  history[i]: losses, `mean_reward` (of the rollout's slice of the episodes - it depends on WHICH part of
     the episodes the slice covers) and `episode_return` (mean return of the episodes that were COMPLETED during the iteration, None if none was)."""
@@ -514,6 +518,8 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     if policy is None:
         policy = FusedPolicy(dev, seed=seed, n_hist=env.n_hist)
     env.reset(seed=seed + int(first_market))
+    if episode_metrics:
+        env.enable_episode_metrics(True)
     use_kl = obj["kl_coef"] > 0.0
     roll = RolloutChains(env, policy, T, groups=chains, seed=seed + 7919 * int(first_market), use_graphs=use_graph, with_dist=use_kl,
                          capture_ends=bool(obj["bootstrap_truncation"]), info_markets=info_markets if recorder is not None else 0)
@@ -538,6 +544,7 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
         upd.set_extra(kl_coef=kl_coef, vf_clip=obj["vf_clip"], dist_old=buf.get("dist"), log_std_old=roll.log_std_old if use_kl else None)
         stats = upd.run(buf["obs"][:T].view(R, -1), epochs=epochs, clip=obj["clip"], vf_coef=obj["vf_coef"], ent_coef=obj["ent_coef"], lr=lr, max_norm=obj["max_norm"],
                         records=records)
+        em = env.collect_episode_metrics() if episode_metrics else None      # (two small launches, inside the timed region: the episodes that ended during this rollout)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         acc = returns.update(buf, T).cpu()                                   # (outside the timed region, like everything below: logging only)
@@ -548,8 +555,16 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
         kl_coef = adapt_kl_coef(kl_coef, stats["kl"], obj["kl_target"])
         if recorder is not None and roll.info is not None:
             recorder.record_rollout(roll, iteration=it)
+        if em is not None:
+            from . import episode_metrics as EM
+            summ = EM.summarise(*em, module_names=["policy_0"])
+            stats["episode_metrics"] = dict(summ.get("all", {}), episodes=summ["episodes"], nav_conservation_violations=summ["nav_conservation_violations"],
+                                            nav_conservation_error=summ["nav_conservation_error"], maker_fill_ratio_max=summ.get("maker_fill_ratio_max"),
+                                            episode_len_mean=summ.get("episode_len_mean"))
         history.append(stats)
         log(json.dumps(stats))
+        if em is not None:
+            EM.check_nav_conservation(it, summ, strict=strict_nav_check, log=log)
     if keep is not None:
         keep.update(buffers=roll.buf, rollout=roll, update=upd)
     return policy, history

@@ -388,6 +388,28 @@ class CDAVecEnv:
             check(lib().cda_nav_conservation(self._h, float(tolerance), err.data_ptr(), bad.data_ptr(), self._stream()), "cda_nav_conservation")
         return err, bad.view(torch.bool)
 
+    # ------------------------------------------------------------------ every episode checked and summarised on the device
+    def enable_episode_metrics(self, on=True, nav_tolerance=1e-6):
+        """From now on every step tallies what the reference's callback tallies per episode, and every episode END is checked (exact sum of NAV against
+        num_agents x init_cash, `nav_tolerance` = the callback's) and credited on the device, in the cold paths that handle it - the in-kernel auto reset
+        included (include/cda.h cda_episode_metrics_enable; train/callbk/league_based_self_play_callback.py:541-755)."""
+        check(lib().cda_episode_metrics_enable(self._h, 1 if on else 0, float(nav_tolerance)), "cda_episode_metrics_enable")
+        self.episode_metrics_on = bool(on)
+
+    def collect_episode_metrics(self, module_of=None, n_modules=1, clear=True, out=None):
+        """The episodes that ended since the last collection, reduced on the device (two launches, a fixed order): (f64 [n_modules, EM_AGENT_FIELDS] per-module
+        sums over the (episode, agent) pairs module m played - module_of i32 [N, A], None = one module -, f64 [EM_ENV_FIELDS] per-env sums); device tensors,
+        columns = _capi.EM_*.  episode_metrics.summarise() turns them into the callback's metrics."""
+        self.join()
+        if out is None:                                     # (both are written whole by the second launch)
+            out = (torch.empty((int(n_modules), K.EM_AGENT_FIELDS), dtype=torch.float64, device=self.device), torch.empty(K.EM_ENV_FIELDS, dtype=torch.float64, device=self.device))
+        if module_of is not None:
+            assert module_of.dtype == torch.int32 and module_of.is_contiguous() and module_of.numel() == self.n_markets * self.num_agents and module_of.device == self.device
+        with torch.cuda.device(self.device):
+            check(lib().cda_episode_metrics_collect(self._h, module_of.data_ptr() if module_of is not None else None, int(n_modules), out[0].data_ptr(), out[1].data_ptr(),
+                                                    1 if clear else 0, self._stream()), "cda_episode_metrics_collect")
+        return out
+
     def state_bytes_per_market(self):
         return int(lib().cda_state_bytes_per_market(self._h))
 

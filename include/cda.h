@@ -55,6 +55,8 @@ typedef enum cda_status {
 #define CDA_FLAG_BOOK_OVERFLOW   0x1u   /* a rest was dropped: the market's book (LDS tile + HBM spill ring) was full */
 #define CDA_FLAG_INT_OVERFLOW    0x2u   /* a size/position/price left the int32 / 2^24 domain */
 #define CDA_FLAG_DEC_DOMAIN      0x4u   /* a ledger value left the 28-digit / exponent domain */
+#define CDA_FLAG_NAV_CONSERVATION 0x8u  /* episode metrics (cda_episode_metrics_enable): an episode of this market ended with sum(NAV) != num_agents * init_cash
+                                           beyond the tolerance; unlike the others it survives the device-side auto reset */
 
 /*
  * Env config: the 17 keys of continuousDoubleAuction_env.py:27-55 with the defaults of
@@ -322,6 +324,67 @@ int cda_random_actions(uint64_t action_seed, uint64_t market_index_base, int32_t
  * arithmetic); error = total - Decimal(init_cash) * A.  abs_error_out f64[N] (device) receives float(abs(error)),
  * violated_out u8[N] (device, nullable) whether it exceeds `tolerance` (the reference's nav_tolerance, 1e-6). */
 int cda_nav_conservation(cda_env* env, double tolerance, double* abs_error_out, uint8_t* violated_out, void* stream);
+
+/* ---- every episode checked and summarised on the device --------------------------------------------------------------------
+ * What the reference's callback does around an episode (train/callbk/league_based_self_play_callback.py):
+ *   on_episode_step (:541-600)   tallies per episode: passes, rejections, per-agent trades / passive fills, sum and sum of squares of the five reward terms;
+ *   on_episode_end  (:627-755)   sum of the agents' NAV == num_agents x init_cash in Decimal (nav_tolerance 1e-6), `nav_conservation_violations` += 1 otherwise;
+ *                                per-agent NAV / drawdown / |net_position| / num_trades of the last step (_log_episode_account :418-470); pass and rejection
+ *                                fractions, reward-term means and variance shares, the most maker-like agent's passive share (_log_activity :295-416);
+ *   train.py:1109-1164           the driver stops the run on a violation (strict_nav_check).
+ * With auto_reset the finished episode's ledger is wiped by the in-kernel reset before any host code could look at it, so all of it happens on the
+ * device.  cda_episode_metrics_enable(env, 1, tolerance): from now on
+ *   - every step adds agent a's step counters and reward terms to the running tallies of (market, a) in the market record (fire-and-forget atomics:
+ *     nothing is loaded and no register is held across the step);
+ *   - a market whose episode ended (all agents done, or max_step reached) is CHECKED AND CREDITED exactly once, in the cold paths that handle an episode
+ *     end - the in-kernel auto reset of cda_step / cda_policy_step_range, the auto-reset pass behind a step with info tensors, cda_reset of a market
+ *     whose episode is over, the end of cda_run_random: the exact decimal sum of NAV (the arithmetic of cda_nav_conservation) sets the sticky
+ *     CDA_FLAG_NAV_CONSERVATION bit (it survives the auto reset) and counts a violation; the tallies and the last step's account figures are added
+ *     to per-(market, agent) and per-market accumulators;  a reset of a market whose episode is NOT over discards its running tallies (an episode
+ *     the reference's callback never sees end either).
+ * cda_episode_metrics_collect reduces the accumulators over the markets, by module: module_of i32[N,A] (device; NULL = every slot is module 0) names
+ * the module that played slot a of market i during the episodes collected (league self-play: the draw of cda_league_assign; values outside
+ * [0, n_modules) are skipped) -> agent_out f64[n_modules, CDA_EM_AGENT_FIELDS], env_out f64[CDA_EM_ENV_FIELDS] (device), in a FIXED order (two launches;
+ * the same inputs give the same bits).  clear != 0 zeroes the accumulators behind the read.  Call it before slot assignments change.
+ * Sums of integers are exact in f64 (< 2^53). */
+#define CDA_EM_AGENT_FIELDS 32
+enum {                                   /* per module: sums over the (episode, agent) pairs the module played */
+    CDA_EM_EPISODES = 0,                 /* (episode, agent) pairs credited */
+    CDA_EM_AGENT_STEPS = 1,              /* tally["agent_steps"] */
+    CDA_EM_PASSES = 2,                   /* is_pass_action */
+    CDA_EM_REJECTIONS = 3,               /* num_rejected_step */
+    CDA_EM_PLACED = 4,                   /* order_step_placed */
+    CDA_EM_TRADES = 5,                   /* num_trades_step */
+    CDA_EM_PASSIVE = 6,                  /* num_passive_fills_step */
+    CDA_EM_TERM_SUM = 7,                 /* 7..11: sum of reward term j over the agent-steps */
+    CDA_EM_TERM_SQ = 12,                 /* 12..16: sum of its square */
+    CDA_EM_RETURN_SUM = 17,              /* sum of episode returns (f64 sum of the step rewards, in step order) */
+    CDA_EM_RETURN_SQ = 18,
+    CDA_EM_NAV_SUM = 19,                 /* float(NAV) at the episode's last step */
+    CDA_EM_NAV_MIN = 20,
+    CDA_EM_NAV_MAX = 21,
+    CDA_EM_DRAWDOWN_SUM = 22,            /* float(max(0, max_nav - nav)) */
+    CDA_EM_ABS_POSITION_SUM = 23,
+    CDA_EM_NUM_TRADES_SUM = 24,          /* acc.num_trades (the episode total) */
+    CDA_EM_MAKER_RATIO_SUM = 25,         /* passive / trades of the pairs with trades >= 5 (_MIN_TRADES_FOR_MAKER_RATIO) */
+    CDA_EM_MAKER_RATIO_N = 26,
+    CDA_EM_MAKER_RATIO_MAX = 27,
+    CDA_EM_BANKRUPT = 28                 /* pairs that ended in done_set (nav <= 0) */
+};
+#define CDA_EM_ENV_FIELDS 8
+enum {                                   /* per env: sums over the episodes that ended */
+    CDA_EM_ENV_EPISODES = 0,
+    CDA_EM_ENV_NAV_VIOLATIONS = 1,       /* nav_conservation_violations */
+    CDA_EM_ENV_NAV_ERROR_SUM = 2,        /* float(abs(sum(NAV) - A * init_cash)) */
+    CDA_EM_ENV_NAV_ERROR_MAX = 3,
+    CDA_EM_ENV_MAKER_MAX_SUM = 4,        /* maker_fill_ratio_max: the episode's max over its qualifying agents */
+    CDA_EM_ENV_MAKER_MAX_N = 5,          /* episodes with a qualifying agent */
+    CDA_EM_ENV_STEPS = 6,                /* env steps of the episodes */
+    CDA_EM_ENV_TERMINATED = 7            /* episodes that ended with every agent done (the others were truncated at max_step) */
+};
+int cda_episode_metrics_enable(cda_env* env, int32_t on, double nav_tolerance);
+int cda_episode_metrics_collect(cda_env* env, const int32_t* module_of, int32_t n_modules, double* agent_out, double* env_out, int32_t clear, void* stream);
+#define CDA_EM_MAX_MODULES 32
 
 /* Test/diagnostic hook: Trader.place_order (agent/trader.py:49-106) for ONE decoded order on one
  * market, bypassing decode and the RNG. type: 0 market, 1 limit, 2 modify, 3 cancel; side: 0 bid,

@@ -52,35 +52,41 @@ def _kernels():
 def test_step_kernels_keep_four_waves_per_simd_and_spill_no_vgpr():
     ks, bodies = _kernels()
     steps = {n: v for n, v in ks.items() if "k_stepILb" in n}
-    assert len(steps) == 4, sorted(ks)                     # two book tiles x with / without info tensors
+    assert len(steps) == 8, sorted(ks)                     # two book tiles x with / without info tensors x with / without the episode-metric tallies
     for n, v in steps.items():
         # the metadata is the maximum over the call graph: it includes the out-of-line general step (slow_step), which is free to
         # spill - what must hold is the occupancy (128 VGPRs = four waves per SIMD) and a HOT body without scratch traffic: at most
         # the one save / restore pair the compiler puts around the call of slow_step, on the branch a BASELINE market never takes
         assert v["vgpr_count"] <= 128, (n, v)
         body = bodies[n]
+        # ... around the calls in the kernel's cold tail (slow_step hands "the episode ended" back; the kernel then calls the episode-end routines from its own level)
         scratch = [i for i, l in enumerate(body) if "scratch_" in l]
-        assert len(scratch) <= 2, (n, len(scratch))
+        assert len(scratch) <= 6, (n, len(scratch))
         calls = [i for i, l in enumerate(body) if "s_swappc" in l]
         for i in scratch:
-            assert min(abs(i - c) for c in calls) <= 4, (n, body[i])
+            assert min(abs(i - c) for c in calls) <= 24 and i > len(body) - 200, (n, i, len(body), body[i])
+        # the instances launched while the metrics are off carry no tally: not one atomic in them
+        if "k_stepILb0ELb0" in n or "k_stepILb1ELb0" in n:
+            assert not any("atomic_add_f64" in l for l in body), n
+        else:
+            assert sum("atomic_add_f64" in l for l in body) == 11, n
     for cap in ("cap256", "cap512"):
         slow = [n for n in bodies if cap in n and "slow_step" in n]
         assert len(slow) == 2, slow                          # the general build exists once per info variant, out of line
     for n, v in ks.items():
-        if "k_run_random" in n or "k_reset" in n:                 # (the episode kernel keeps more state live and spills a few VGPRs)
-            assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 16, (n, v)
+        if "k_run_random" in n or "k_reset" in n:                 # (the episode kernel keeps more state live and spills a few VGPRs; more in the instance that tallies)
+            assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= (32 if "k_run_randomILb1" in n else 16), (n, v)
     # the policy inside the step kernel: sixteen market-waves per workgroup = the same four waves per SIMD, and the same hot body as k_step<false> behind the forward pass
     pol = {n: v for n, v in ks.items() if "k_policy_step" in n}
-    assert len(pol) == 4, sorted(pol)                            # one per compiled history depth (256-order tile only)
+    assert len(pol) == 8, sorted(pol)                            # one per compiled history depth (256-order tile only) x with / without the tallies
     for n, v in pol.items():
-        assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] == 0, (n, v)
+        assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 2, (n, v)          # (the save / restore around the cold tail's calls)
         body = bodies[n]
-        k1 = {"k_policy_stepE": 11, "k_policy_step_h1E": 3, "k_policy_step_h2E": 6, "k_policy_step_h8E": 21}[[k for k in ("k_policy_step_h1E", "k_policy_step_h2E", "k_policy_step_h8E", "k_policy_stepE") if k in n][0]]
+        k1 = {"k_policy_stepI": 11, "k_policy_step_h1I": 3, "k_policy_step_h2I": 6, "k_policy_step_h8I": 21}[[k for k in ("k_policy_step_h1I", "k_policy_step_h2I", "k_policy_step_h8I", "k_policy_stepI") if k in n][0]]
         assert sum("v_mfma_f32_32x32x16_bf16" in l for l in body) == k1 + 16 + 16, n      # one tile per wave: layer 1 (KX / 16 k-steps), layer 2, heads
         scratch = [i for i, l in enumerate(body) if "scratch_" in l]
         calls = [i for i, l in enumerate(body) if "s_swappc" in l]
-        assert len(scratch) <= 2 and all(min(abs(i - c) for c in calls) <= 4 for i in scratch), (n, len(scratch))
+        assert len(scratch) <= 6 and all(min(abs(i - c) for c in calls) <= 24 and i > len(body) - 200 for i in scratch), (n, len(scratch))
 
 
 @pytest.mark.skipif(not (os.path.exists(READELF) and os.path.exists(OBJDUMP) and shutil.which(os.environ.get("HIPCC", "hipcc"))),

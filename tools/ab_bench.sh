@@ -1,11 +1,12 @@
-#!/bin/bash
-# Run ON THE GPU BOX: A/B of library builds on the headline workload.  Usage: tools/ab_bench.sh lib1.so lib2.so ...   (two rounds each)
-# prints agent-steps/s (M): info on / info off, 1000 timed steps, four chains
-R=${GRAFT_REPO_ROOT:-$PWD}
-for round in 1 2; do
-  for lib in "$@"; do
-    a=$(CDA_HIP_LIB=$R/$lib python $R/bench.py --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']/1e6,1), round(d['roofline']['kernel_ms']*1e3,2))")
-    b=$(CDA_HIP_LIB=$R/$lib python $R/bench.py --no-cpu-baseline --no-extra-legs --no-info 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']/1e6,1), round(d['roofline']['kernel_ms']*1e3,2))")
-    echo "$lib  info-on: $a   info-off: $b"
-  done
+# same-box A/B: HEAD's tree (a git worktree built under _ab_head/: `git worktree add -f _ab_head HEAD && (cd _ab_head && python __graft_entry__.py)`) against this tree,
+# alternating; tools/ab_report.py prints the means.  Experimental builds of this tree's library: tools/build_variant.sh + CDA_HIP_LIB.
+cd $GRAFT_REPO_ROOT
+for i in 1 2 3; do
+python _ab_head/bench.py --no-cpu-baseline --no-league-leg > gpurun_out/ab_head_1000_$i.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-league-leg > gpurun_out/ab_new_1000_$i.json 2>/dev/null
 done
+for i in 1 2 3; do
+python _ab_head/bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/ab_head_20_$i.json 2>/dev/null
+python bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/ab_new_20_$i.json 2>/dev/null
+done
+python tools/episode_metrics_probe.py > gpurun_out/em_probe.json
