@@ -506,7 +506,10 @@ def main():
             penv = CDAVecEnv(pcfg, n_markets=N, device=str(device), with_info=False)
             penv.reset(seed=seeds)
             pol = FusedPolicy(device, seed=0)
-            chains = max(1, min(4, N))
+            # chains: 4 market groups on 4 streams for long rollouts (their launches overlap each other's tails: +3 % at 256 steps), ONE chain on the caller's stream below
+            # 200 steps - every further chain starts ~35 us after its predecessor (one hipGraphLaunch each) and the fork / join edges cost 30-50 us, which a 1-ms
+            # rollout does not earn back (tools/policy_leg_probe.py, profiles/r06/policy_leg_probe_*.jsonl; the headline leg makes the same choice with --groups)
+            chains = max(1, min(4, N)) if K >= 200 else 1
             roll = RolloutChains(penv, pol, K, groups=chains, seed=ACTION_SEED, use_graphs=True)
             for _ in range(max(2, min(4, W // max(K, 1) + 2))):        # warm-up rollouts (the first one captures the chains' graphs)
                 roll.run()

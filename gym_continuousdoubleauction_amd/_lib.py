@@ -39,7 +39,7 @@ MLP_HIST_VARIANTS = (1, 2, 8)
 class RolloutBufs(C.Structure):
     """cda_rollout_bufs (include/cda_mlp.h)"""
     _fields_ = [(n, C.c_void_p) for n in ("obs", "category", "size_mean", "size_sigma", "price", "price_offset", "a_cont", "logp", "value", "reward",
-                                          "terminated", "truncated", "record", "dist", "info_steps", "fin_index", "fin_obs", "fin_count")] + [("fin_cap", C.c_int32)]
+                                          "terminated", "truncated", "record", "dist", "info_steps", "fin_index", "fin_obs", "fin_count")] + [("fin_cap", C.c_int32), ("counter_bump", C.c_void_p)]
 
 
 class League(C.Structure):

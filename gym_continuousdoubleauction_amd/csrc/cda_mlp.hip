@@ -1750,6 +1750,8 @@ __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ d
     if (i < n4) reinterpret_cast<obsvec*>(dst)[i] = reinterpret_cast<const obsvec*>(src)[i];
 }
 
+__global__ void k_bump_counter(long long* counter) { if (threadIdx.x == 0) counter[0] += 1; }       // a chain's own rollout counter, behind its last launch
+
 __global__ void k_selftest_mfma(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ d) {
     const int lane = (int)threadIdx.x, j = lane & 31, h = lane >> 5;
     bf16x8 av, bv;
@@ -2218,7 +2220,13 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
     V.value = B->value + (size_t)n_steps * N;
     V.n_train = n_train; V.value_stride = (long long)(n_steps + 1) * N;
     V.split_halves = 2;                                  // the value network alone
-    return launch_fwd<MODE_VALUE>(V, rollout_mt(), st, L ? (unsigned)n_train : 0u);
+    const int rcv = launch_fwd<MODE_VALUE>(V, rollout_mt(), st, L ? (unsigned)n_train : 0u);
+    if (rcv) return rcv;
+    if (B->counter_bump) {                               // fresh draws for this chain's next rollout: no launch ahead of a rollout, none on anybody's critical path
+        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(64), 0, st, (long long*)B->counter_bump);
+        if (hipGetLastError() != hipSuccess) return CDA_ERR_HIP;
+    }
+    return CDA_OK;
 }
 extern "C" int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
                                      uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* B, int32_t copy_first_obs, void* stream) {

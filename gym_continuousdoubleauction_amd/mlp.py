@@ -395,7 +395,6 @@ class RolloutChains:
             ptrs.update(fin_index=self.buf["fin_index"].data_ptr(), fin_obs=self.buf["fin_obs"].data_ptr(), fin_count=self.buf["fin_count"].data_ptr(), fin_cap=cap)
         self.adv_stats = torch.zeros((kn, 2), dtype=torch.float64, device=dev)
         self.seed = int(seed) & (2 ** 64 - 1)
-        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         # the chains: G groups over the info-less markets (+ one chain of the sampled markets with info tensors)
         S = max(0, min(int(info_markets), N - 1))
         self.info_markets, n_plain = S, N - S
@@ -425,12 +424,20 @@ class RolloutChains:
             cb.info_steps = C.cast(self._info_steps, C.c_void_p)
             self._cbufs.append(cb)
         G = len(self.ranges)
+        # the rollout counter (fresh draws per rollout): ONE PER CHAIN, all equal, each bumped by its own chain as the chain's last launch (cda_rollout_bufs.counter_bump) -
+        # a shared counter had to be incremented by a launch AHEAD of the fork: 20-30 us on the critical path of every rollout (tools/policy_leg_probe.py)
+        self._counters = torch.ones(G, dtype=torch.int64, device=dev)
+        for g in range(G):
+            self._cbufs[g].counter_bump = self._counters[g:].data_ptr()
         if G > 1:
             from .streams import concurrent_streams
             self.streams = list(concurrent_streams(dev, G))
+            self._capture_stream = None
         else:
-            cur = torch.cuda.current_stream(dev)                   # one chain: the caller's stream - unless that is the default stream and graphs are wanted
-            self.streams = [torch.cuda.Stream(dev) if (use_graphs and cur == torch.cuda.default_stream(dev)) else cur]     # (no capture on the default stream)
+            # one chain: it runs on the CALLER's stream, whatever that is at run() - no fork, no join, one graph launch per rollout; the capture needs a
+            # stream of its own (nothing is captured on the default stream)
+            self.streams = [None]
+            self._capture_stream = torch.cuda.Stream(dev) if use_graphs else None
         self._fork = torch.cuda.Event()
         self._joins = [torch.cuda.Event() for _ in range(G)]
         self.graphs = None
@@ -438,22 +445,28 @@ class RolloutChains:
         self.use_graphs = bool(use_graphs)
         self.join_mode = "events"
 
+    @property
+    def counter(self):
+        """the rollout counter the LAST run() sampled with (i64 [1], a fresh device tensor): what cda_mlp_policy_step needs to reproduce its draws"""
+        return self._counters[:1] - 1
+
     def _enqueue(self, g, copy_first_obs):
         first, cnt = self.ranges[g]
         st = torch.cuda.current_stream(self.device).cuda_stream
+        ctr = self._counters[g:].data_ptr()
         with torch.cuda.device(self.device):
             if self.bank is not None:
-                _check(self.L.fn("cda_mlp_league_rollout_chain")(self.env._h, C.byref(self.bank.struct()), first, cnt, self.T, self.seed, self.counter.data_ptr(),
+                _check(self.L.fn("cda_mlp_league_rollout_chain")(self.env._h, C.byref(self.bank.struct()), first, cnt, self.T, self.seed, ctr,
                                                                  C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_league_rollout_chain")
             else:
                 _check(self.L.fn("cda_mlp_rollout_chain")(self.env._h, self.policy.wb.data_ptr(), self.policy.theta.data_ptr(), first, cnt, self.T, self.seed,
-                                                          self.counter.data_ptr(), C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_rollout_chain")
+                                                          ctr, C.byref(self._cbufs[g]), int(copy_first_obs), st), "cda_mlp_rollout_chain")
 
     def _capture(self):
         graphs = []
         for g, s in enumerate(self.streams):
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=s):
+            with torch.cuda.graph(gr, stream=s if s is not None else self._capture_stream):
                 self._enqueue(g, True)
             graphs.append(gr)
         self.graphs = graphs
@@ -468,7 +481,6 @@ class RolloutChains:
             self.env.join()
             self.buf["obs"][self.T].copy_(self.env.obs)
             self._have_obs, self._env_epoch = True, getattr(self.env, "host_epoch", 0)
-        self.counter.add_(1)                                     # fresh draws for this rollout (on the caller's stream, before the fork)
         if self.capture_ends:
             self.buf["fin_count"].zero_(); self.buf["fin_index"].fill_(-1)
         if self.with_dist:                                        # the log_std the rollout samples with (a row per trainable net)
@@ -482,9 +494,19 @@ class RolloutChains:
                 import warnings
                 warnings.warn(f"HIP graph capture of the rollout chains failed ({ex}); using direct launches")
                 self.graphs, self.use_graphs = None, False
-        self._fork.record(cur)
+        if len(self.streams) == 1 and self.streams[0] is None:    # one chain: on the caller's stream, in order with everything around it
+            if self.graphs is not None:
+                self.graphs[0].replay()
+            else:
+                self._enqueue(0, True)
+            return self.buf
+        # the fork: the chains start behind everything the caller's stream holds - nothing to wait for when that stream is idle (every earlier launch of the
+        # caller has then completed; the host-side query costs a microsecond, an event edge per chain ~10)
+        fork = not cur.query()
+        if fork:
+            self._fork.record(cur)
         for g, s in enumerate(self.streams):
-            if s.cuda_stream != cur.cuda_stream:
+            if fork and s.cuda_stream != cur.cuda_stream:
                 s.wait_event(self._fork)
             with torch.cuda.stream(s):
                 if self.graphs is not None:

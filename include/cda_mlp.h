@@ -181,6 +181,8 @@ typedef struct cda_rollout_bufs {
     float*   fin_obs;        /*   (t, market), -1 = none (pre-set by the caller); fin_obs [fin_cap][168], fin_count i32[1] (zeroed by the caller before a rollout) */
     int32_t* fin_count;
     int32_t  fin_cap;
+    int64_t* counter_bump;   /* NULL, or the chain's OWN rollout counter (normally == counter_dev): incremented by one as the chain's last launch - a caller with one
+                                counter per chain then never launches anything ahead of a rollout (a shared counter may only be bumped when no chain is in flight) */
 } cda_rollout_bufs;
 int cda_mlp_rollout_chain(cda_env* env, const void* wb, const float* theta, int32_t first_market, int32_t n_markets, int32_t n_steps,
                           uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* bufs, int32_t copy_first_obs, void* stream);

@@ -9,4 +9,4 @@ for i in 1 2 3; do
 python _ab_head/bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/ab_head_20_$i.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/ab_new_20_$i.json 2>/dev/null
 done
-python tools/episode_metrics_probe.py > gpurun_out/em_probe.json
+
