@@ -39,7 +39,7 @@ What the line reports (one MI355X):
                              would get through per-step event edges
   value_run_random_one_launch  row H (CDA_rand.run_random): 256 steps of uniform random agents for every market in ONE launch (cda_run_random) - what the batch does when
                              no market-wave ever waits for the batch's slowest one (a per-step launch lasts as long as its slowest wave)
-  value_league_self_play     the reference's training topology END TO END on the fused kernels (league_train.train_league_fused): 2048 markets x 8 agents, 2
+  value_league_self_play     the reference's training topology END TO END on the fused kernels (league_train.train_league_fused): 8192 markets x 8 agents, 2
                              separately trained policies against random modules + champion snapshots, rollout + both PPO updates per iteration
   roofline                   HIP event pairs on the chains' own streams around the k_step launches of the headline leg;
                              `traffic` / `issue_frac` only when a committed PMC pass of exactly this shape exists
@@ -576,7 +576,9 @@ def main():
     if world == 1 and not args.no_extra_legs and not args.no_policy_leg and not args.no_league_leg and not args.fused and not gather:
         try:
             from gym_continuousdoubleauction_amd.league_train import train_league_fused
-            lN, lA, lT, liters = 2048, 8, 64, 6
+            # the reference fixes 8 agents / 2 trainable policies / the pool's weights, not the number of parallel games: 8192 markets fill the machine (two rounds of
+            # market-waves per launch; profiles/r06/bench_league_by_markets.json: 2048 x 8 136 M, 4096 x 8 184 M, 8192 x 8 202 M end to end, same hyper-parameters)
+            lN, lA, lT, liters = int(os.environ.get("CDA_BENCH_LEAGUE_MARKETS", 8192)), 8, 64, 6
             lenv = CDAVecEnv({"num_of_agents": lA, "init_cash": 1000000, "max_step": lT, "is_render": False, "auto_reset": True}, n_markets=lN, device=str(device), with_info=False)
             _, lg, lh = train_league_fused(lenv, iters=liters, horizon=lT, num_trainable=2, log=lambda s_: None)
             tail = lh[2:]

@@ -29,7 +29,7 @@ SYMBOLS = [
 MLP_SYMBOLS = [
     "cda_mlp_tile_rows", "cda_mlp_permutation", "cda_mlp_pack", "cda_mlp_policy_step", "cda_mlp_forward", "cda_mlp_prep_rows", "cda_mlp_forward_train", "cda_mlp_backward",
     "cda_mlp_wgrad", "cda_mlp_adam", "cda_ppo_loss32", "cda_gae_records", "cda_ppo_loss_records", "cda_mlp_forward_backward", "cda_mlp_rollout_chain", "cda_mlp_selftest_mfma",
-    "cda_mlp_reduce", "cda_mlp_apply", "cda_gae_records_bootstrap", "cda_mlp_values", "cda_episode_returns", "cda_mlp_league_step", "cda_mlp_league_rollout_chain",
+    "cda_mlp_reduce", "cda_mlp_apply", "cda_gae_records_bootstrap", "cda_mlp_values", "cda_mlp_values_counted", "cda_episode_returns", "cda_mlp_league_step", "cda_mlp_league_rollout_chain",
     "cda_gae_records_league", "cda_league_assign", "cda_mlp_wgrad_jobs",
 ]
 # the same entry points compiled for other history depths carry the suffix _h<H> (include/cda_mlp.h CDA_MLP_HIST_VARIANTS, csrc/cda_mlp_variant.h)
@@ -136,6 +136,7 @@ def lib():
     L.cda_gae_records_bootstrap.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, f32, f32, f32, vp, vp, i64, vp, vp, vp]
     L.cda_gae_records_league.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, f32, f32, f32, vp, vp, vp]
     L.cda_mlp_values.argtypes = [vp, vp, i32, vp, i64, vp, i64, vp]
+    L.cda_mlp_values_counted.argtypes = [vp, vp, i32, vp, i64, vp, vp, i64, vp]
     L.cda_episode_returns.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp]
     L.cda_mlp_league_step.argtypes = [C.POINTER(League), vp, i32, i32, i32, u64, vp, i64] + [vp] * 8 + [i64, vp, vp, i64, vp]
     L.cda_mlp_league_rollout_chain.argtypes = [vp, C.POINTER(League), i32, i32, i32, u64, vp, C.POINTER(RolloutBufs), i32, vp]

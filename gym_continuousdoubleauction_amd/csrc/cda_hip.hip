@@ -30,6 +30,7 @@
 #include "cda_dec.hpp"
 #include "cda_market.hpp"
 #include <type_traits>
+#include <mutex>
 #include "../../include/cda_mlp.h"          // the network's layout constants (n_hist = 4): k_policy_step evaluates the policy inside the step kernel
 namespace cda { namespace mlpdev {
 #include "cda_mlp_dev.inc"
@@ -671,6 +672,7 @@ static size_t smem_for(const cda_env* e, int waves) {
     return (size_t)DEC_TABLE_BYTES + (size_t)waves * (size_t)per;
 }
 
+static int grant_policy_step_lds(const cda_env* e);
 int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env** out) {
     if (!cfg || !out || n_markets < 1) return CDA_ERR_INVALID;
     int rc = cfg_ok(cfg); if (rc) return rc;
@@ -727,6 +729,7 @@ int cda_create(const cda_config* cfg, int32_t n_markets, int32_t device, cda_env
     if (he == hipSuccess) he = hipMalloc((void**)&e->em_partials, (size_t)EM_BLOCKS * (CDA_EM_MAX_MODULES * CDA_EM_AGENT_FIELDS + CDA_EM_ENV_FIELDS) * sizeof(double));
     if (he == hipSuccess) he = hipDeviceSynchronize();
     if (he != hipSuccess) { (void)hipFree(e->arena); if (e->em_partials) (void)hipFree(e->em_partials); free(e); return hip_fail(he, "k_init_arena"); }
+    if (cda_policy_step_supported(e)) (void)grant_policy_step_lds(e);          // (a refusal resurfaces as CDA_ERR_HIP at the first cda_policy_step_range)
     *out = e;
     return CDA_OK;
 }
@@ -837,6 +840,22 @@ static int policy_step_lds(const cda_env* e) {            // dynamic LDS of k_po
         default: return 0;
     }
 }
+// More than 64 KB of dynamic LDS has to be granted per device and kernel instance: once, under a lock (envs are created and stepped from several host threads - one per
+// GPU in the guarded collectives of parallel.py), at cda_create - not lazily inside the launch path, whose first call sits inside a stream capture (round-5 ADVICE).
+static int grant_policy_step_lds(const cda_env* e) {
+    static std::mutex mu;
+    static unsigned long long granted[4] = {0, 0, 0, 0};      // per history-depth instance: a bit per device (both tally variants together)
+    const int hist = e->P.cfg.n_hist, slot = hist == 4 ? 0 : (hist == 1 ? 1 : (hist == 2 ? 2 : 3));
+    std::lock_guard<std::mutex> lock(mu);
+    if (granted[slot] >> (e->device & 63) & 1ull) return 0;
+    typedef void (*kern_t)(cda::cap256::PolicyStepKernArgs);
+    const kern_t ks[2] = {hist == 4 ? cda::cap256::k_policy_step<false> : (hist == 1 ? cda::cap256::k_policy_step_h1<false> : (hist == 2 ? cda::cap256::k_policy_step_h2<false> : cda::cap256::k_policy_step_h8<false>)),
+                          hist == 4 ? cda::cap256::k_policy_step<true> : (hist == 1 ? cda::cap256::k_policy_step_h1<true> : (hist == 2 ? cda::cap256::k_policy_step_h2<true> : cda::cap256::k_policy_step_h8<true>))};
+    for (int k = 0; k < 2; k++)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ks[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 1;
+    granted[slot] |= 1ull << (e->device & 63);
+    return 0;
+}
 int cda_policy_step_supported(const cda_env* e) {
     if (!e) return 0;
     const int lds = e->cap == 256 ? policy_step_lds(e) : 0;
@@ -874,14 +893,8 @@ int cda_policy_step_range(cda_env* e, int32_t first_market, int32_t n_markets, c
     const bool tally = e->P.lay.ep_on != 0;
     const kern_t kern = tally ? (hist == 4 ? cda::cap256::k_policy_step<true> : (hist == 1 ? cda::cap256::k_policy_step_h1<true> : (hist == 2 ? cda::cap256::k_policy_step_h2<true> : cda::cap256::k_policy_step_h8<true>)))
                               : (hist == 4 ? cda::cap256::k_policy_step<false> : (hist == 1 ? cda::cap256::k_policy_step_h1<false> : (hist == 2 ? cda::cap256::k_policy_step_h2<false> : cda::cap256::k_policy_step_h8<false>)));
-    {   // more than 64 KB of dynamic LDS: granted once per device and instance
-        static unsigned long long granted[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int gslot = slot + (tally ? 4 : 0);
-        if (!(granted[gslot] >> (e->device & 63) & 1ull)) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            granted[gslot] |= 1ull << (e->device & 63);
-        }
-    }
+    (void)slot;
+    if (grant_policy_step_lds(e)) return CDA_ERR_HIP;     // (normally a no-op: cda_create granted it - outside any stream capture)
     cda::cap256::PolicyStepKernArgs KA;
     KA.K.arena = e->arena; KA.K.P = e->P; KA.K.S = S; KA.K.S.first_market = first_market; KA.K.S.end_market = first_market + n_markets;
     KA.F.obs_in = obs_in; KA.F.wb = wb; KA.F.theta = theta; KA.F.seed = seed; KA.F.counter = (const long long*)counter_dev; KA.F.draw = draw;

@@ -175,6 +175,7 @@ struct FwdArgs {
     // (net, half) jobs: y < 2 n_train: net y / 2, half y & 1; above: the policy half of net n_train + (y - 2 n_train).  slot_net i32 [*, A]: the net that
     // plays (market, slot), < 0 = the uniform random module (drawn by net 0's policy workgroup).  value / dist of net p live p * value_stride / p * dist_stride further on.
     int n_train; const int* slot_net; long long value_stride, dist_stride; unsigned long long random_seed;
+    const int* rows_limit;       // MODE_VALUE, optional (device): only rows [first_row, first_row + min(n_rows, *rows_limit)) are evaluated - whole tiles beyond leave at entry
     unsigned long long* dbg; int dbg_block;       // CDA_MLP_TIMING builds (tools/libcda_tools.so) only: cycle stamps of one workgroup, [4 waves][32]
 };
 #ifdef CDA_MLP_TIMING
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
     float* outs = reinterpret_cast<float*>(act + M * ACT_LD);                   // MODE_SAMPLE: [M][OUTS_LD]
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const long long row0 = A.first_row + (long long)blockIdx.x * M, rows_end = A.first_row + A.n_rows;
+    if (MODE == MODE_VALUE && A.rows_limit != nullptr && (long long)blockIdx.x * M >= (long long)A.rows_limit[0]) return;     // (uniform: before any barrier)
     MLP_MARK(0);
     // A league launch (MODE_LEAGUE; the bootstrap values of its trainable nets: MODE_VALUE with n_train > 0): blockIdx.y names the (net, half) job
     // and the net's parameters are its row of the banks.  Uniform per workgroup: scalar registers.
@@ -2172,8 +2174,8 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
     // no info chain; CDA_POLICY_STEP=0 in the environment keeps the two launches (A / B runs, tests of both paths).
     bool one_launch = false;
     {
-        static int want = -1;
-        if (want < 0) { const char* ev = getenv("CDA_POLICY_STEP"); want = ev ? atoi(ev) : 1; }
+        const char* ev = getenv("CDA_POLICY_STEP");              // read per call: an A / B run toggles it between two rollouts of one process
+        const int want = ev ? atoi(ev) : 1;
         // (the env's history depth is this build's: checked above.  CDA_POLICY_STEP=2: wherever supported, also where the batched policy kernel is the faster one)
         one_launch = want != 0 && !L && !B->info_steps && (want == 2 ? cda_policy_step_supported(env) : cda_policy_step_advised(env));
     }
@@ -2241,12 +2243,16 @@ extern "C" int cda_mlp_league_rollout_chain(cda_env* env, const cda_league* L, i
 
 // The values of captured last observations (cda_step_range_capture's list): value f32 [n_nets_trainable][cap] <- the value network(s) on fin_obs [cap][168].  Every
 // row of the list is evaluated (the count lives on the device; rows never written hold finite garbage nobody reads).
-extern "C" int cda_mlp_values(const void* wb_bank, const float* theta_bank, int32_t n_nets, const float* obs, int64_t n_rows, float* value, int64_t value_stride, void* stream) {
+extern "C" int cda_mlp_values_counted(const void* wb_bank, const float* theta_bank, int32_t n_nets, const float* obs, int64_t n_rows, const int32_t* n_rows_dev,
+                                      float* value, int64_t value_stride, void* stream) {
     if (!wb_bank || !theta_bank || n_nets < 1 || n_nets > CDA_LEAGUE_MAX_NETS || !obs || !value || n_rows < 1) return CDA_ERR_INVALID;
     FwdArgs V; memset(&V, 0, sizeof V);
     V.obs = obs; V.first_row = 0; V.n_rows = n_rows; V.wb = (const __bf16*)wb_bank; V.theta = theta_bank; V.value = value;
-    V.n_train = n_nets; V.value_stride = value_stride; V.split_halves = 2;
+    V.n_train = n_nets; V.value_stride = value_stride; V.split_halves = 2; V.rows_limit = (const int*)n_rows_dev;
     return launch_fwd<MODE_VALUE>(V, n_rows >= 32768 ? 4 : rollout_mt(), (hipStream_t)stream, (unsigned)n_nets);
+}
+extern "C" int cda_mlp_values(const void* wb_bank, const float* theta_bank, int32_t n_nets, const float* obs, int64_t n_rows, float* value, int64_t value_stride, void* stream) {
+    return cda_mlp_values_counted(wb_bank, theta_bank, n_nets, obs, n_rows, NULL, value, value_stride, stream);
 }
 
 extern "C" int cda_mlp_selftest_mfma(int32_t device, const float* a_host, const float* b_host, float* d_host) {

@@ -29,6 +29,7 @@
 #define cda_gae_records CDA_MLP_SFX(cda_gae_records)
 #define cda_gae_records_bootstrap CDA_MLP_SFX(cda_gae_records_bootstrap)
 #define cda_mlp_values CDA_MLP_SFX(cda_mlp_values)
+#define cda_mlp_values_counted CDA_MLP_SFX(cda_mlp_values_counted)
 #define cda_episode_returns CDA_MLP_SFX(cda_episode_returns)
 #define cda_ppo_loss_records CDA_MLP_SFX(cda_ppo_loss_records)
 #define cda_mlp_forward_backward CDA_MLP_SFX(cda_mlp_forward_backward)

@@ -138,41 +138,77 @@ class BatchedEpisodeRecorder:
         if roll.capture_ends:
             fin_idx, fin_obs = host(b["fin_index"]), b["fin_obs"].detach().cpu().numpy()
         if not hasattr(self, "_ordinal"):
-            self._ordinal, self._t_in_episode = 0, 0
-            self.nav_checked = self.nav_violations = 0
-            self._name_episodes()
+            self._init_market_state()
         wall = time.time()
+        keys = sorted({src for _, _, src in INFO_COLUMNS if src} | {"nav", "reward_terms"})
         for t in range(T):
             o = obs_next[t].copy()
             done = (term[t] | trunc[t]).astype(bool)
             if fin_idx is not None:
                 for j in np.nonzero(fin_idx[t] >= 0)[0]:
                     o[j] = fin_obs[fin_idx[t][j]]
-            step = {"t": self._t_in_episode, "wall": wall, "obs": o.astype(np.float32, copy=False), "reward": rew[t].astype(np.float64, copy=False),
-                    "actions": [a[t] for a in acts]}
-            for name in {src for _, _, src in INFO_COLUMNS if src} | {"nav", "reward_terms"}:
-                step[name] = info[name][t]
-            self._steps.append(step)
-            self._t_in_episode += 1
-            if done.any():
-                if getattr(self, "init_cash", None) is not None:
-                    nav = np.ascontiguousarray(info["nav"][t]).view(K.DEC_DTYPE).reshape(S, A)
-                    for j in range(S):
+            # every recorded market keeps its OWN episode: step counter, ordinal, rows - an env may end a market's episode early (all agents done,
+            # done_helper.py:36-52) and the device-side auto reset then desynchronises the sampled markets; only the market whose `done` fired is closed, checked and renamed
+            for j in range(S):
+                step = {"t": int(self._mk_t[j]), "wall": wall, "obs": o[j:j + 1].astype(np.float32, copy=False), "reward": rew[t][j:j + 1].astype(np.float64, copy=False),
+                        "actions": [a[t][j:j + 1] for a in acts]}
+                for name in keys:
+                    step[name] = info[name][t][j:j + 1]
+                self._mk_steps[j].append(step)
+                self._mk_t[j] += 1
+                if done[j]:
+                    if getattr(self, "init_cash", None) is not None:
+                        nav = np.ascontiguousarray(info["nav"][t][j]).view(K.DEC_DTYPE).reshape(A)
                         with decimal.localcontext() as ctx:
                             ctx.prec = 28
-                            total = sum((K.dec_to_decimal(nav[j, a]) for a in range(A)), decimal.Decimal(0))
+                            total = sum((K.dec_to_decimal(nav[a]) for a in range(A)), decimal.Decimal(0))
                         self.nav_checked += 1
                         if abs(total - decimal.Decimal(A) * decimal.Decimal(int(self.init_cash))) > decimal.Decimal(str(getattr(self, "nav_tolerance", 1e-6))):
                             self.nav_violations += 1
-                self.finish(complete=bool(done.all()))
-                self._ordinal += 1
-                self._t_in_episode = 0
-                self._name_episodes()
+                    self._finish_market(j, complete=True)
+                    self._mk_ordinal[j] += 1
+                    self._mk_t[j] = 0
+                    self._name_market(j)
+        self._ordinal = int(self._mk_ordinal.min())
 
-    def _name_episodes(self):
+    def _init_market_state(self):
+        S = len(self.markets)
+        self._ordinal = 0
+        self._mk_ordinal, self._mk_t = np.zeros(S, np.int64), np.zeros(S, np.int64)
+        self._mk_steps = [[] for _ in range(S)]
+        self._mk_episode, self._mk_modules = [None] * S, [None] * S
+        self.nav_checked = self.nav_violations = 0
+        self._name_episodes()
+
+    def _name_market(self, j):
         namer = getattr(self, "episode_namer", None) or (lambda m, k: f"market{m}-episode{k}")
         mods = getattr(self, "module_namer", None)
-        self.begin_episodes([namer(int(m), self._ordinal) for m in self.markets], module_ids=None if mods is None else [mods(int(m)) for m in self.markets])
+        m = int(self.markets[j])
+        self._mk_episode[j] = str(namer(m, int(self._mk_ordinal[j])))
+        self._mk_modules[j] = None if mods is None else [None if x is None else str(x) for x in mods(m)]
+
+    def _name_episodes(self):
+        """(re)name the episodes that have not recorded a step yet - the league calls this after it has drawn new opponents at an episode boundary"""
+        if not hasattr(self, "_mk_t"):
+            self._init_market_state()
+            return
+        for j in range(len(self.markets)):
+            if self._mk_t[j] == 0:
+                self._name_market(j)
+
+    def _finish_market(self, j, complete):
+        """close recorded market j's running episode: its rows become a table of their own (the column assembly of finish() on a one-market view)"""
+        if not self._mk_steps[j]:
+            return
+        saved = (self._steps, self.markets, self._episode_ids, self._module_ids)
+        try:
+            self._steps, self.markets = self._mk_steps[j], self.markets[j:j + 1]
+            self._episode_ids = [self._mk_episode[j]]
+            self._module_ids = None if self._mk_modules[j] is None else [self._mk_modules[j]]
+            self.finish(complete=complete)
+        finally:
+            self._steps, self.markets, self._episode_ids, self._module_ids = saved
+            self._mk_steps[j] = []
 
     def sampled(self, episode_id):
         """the reference's sampling decision (train/episode_record.py:284-291): a pure function of the episode id"""
@@ -193,13 +229,19 @@ class BatchedEpisodeRecorder:
                 self._pending_rows += table.num_rows
             self._steps = []
         if self._pending_rows >= self.rows_per_file:
-            self.flush()
+            self._write()
 
     def flush(self):
-        import pyarrow as pa
-        import pyarrow.parquet as pq
+        """close what is still running as incomplete (sampling stopped before the episodes did) and write the pending rows"""
+        for j in range(len(getattr(self, "_mk_steps", []))):
+            self._finish_market(j, complete=False)
         if self._steps:
             self.finish(complete=False)
+        return self._write()
+
+    def _write(self):
+        import pyarrow as pa
+        import pyarrow.parquet as pq
         if not self._pending:
             return None
         os.makedirs(self.output_dir, exist_ok=True)

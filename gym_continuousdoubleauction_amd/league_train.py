@@ -213,6 +213,10 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
     update_streams = list(roll.streams[:k]) if (k > 1 and len(roll.streams) >= 2 and not dp and os.environ.get("CDA_LEAGUE_UPDATE_STREAMS", "1") != "0") else []
     # (data parallel: one stream - the ranks must issue their collectives in ONE order)
     returns = EpisodeReturns(N, A, dev, per_slot=True)
+    # Opponents change for ALL markets at the `it % per_episode == 0` boundary (lock-step by construction: a market that terminates early - every agent done - auto-resets
+    # and plays its next episode against the SAME draw until the boundary; its early end is credited to that draw).  EpisodeReturns.per_slot holds one rollout's completed
+    # episodes, so over a window of several rollouts they are summed here.
+    window_per_slot = torch.zeros_like(returns.per_slot) if per_episode > 1 else None
     slot_pool = torch.full((N, A), -1, dtype=torch.int32, device=dev)
     kl_coefs = [float(obj["kl_coef"])] * k
     episode_ids = lambda e: [f"{run_id}-episode{e}-market{int(first_market) + i}" for i in range(N)]     # noqa: E731  (global market index)
@@ -260,6 +264,8 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
             if update_streams:
                 ev = torch.cuda.Event(); ev.record(st); cur.wait_event(ev)
         returns.update(buf, T)
+        if window_per_slot is not None:                                      # an episode window of several rollouts: an early end in an EARLIER rollout of the window counts too
+            window_per_slot.add_(returns.per_slot)
         em = env.collect_episode_metrics(module_of=module_of, n_modules=len(module_names)) if episode_metrics else None     # (before the pool changes)
         if (it + 1) % per_episode == 0:                                      # host work under the GPU's: the next episode's ids
             next_crcs = mapper.episode_crcs(episode_ids((it + 1) // per_episode))
@@ -271,10 +277,13 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
             kl_coefs[p] = ppo.adapt_kl_coef(kl_coefs[p], stats_h[f"policy_{p}"]["kl"], obj["kl_target"])
         promoted = None
         if (it + 1) % per_episode == 0:                                      # episodes just ended: credit the modules, run the reference's promotion rule
-            mr = league.module_returns(returns.per_slot, slot_pool, allreduce=allreduce if dp else None)
+            mr = league.module_returns(returns.per_slot if window_per_slot is None else window_per_slot, slot_pool, allreduce=allreduce if dp else None)
+            if window_per_slot is not None:
+                window_per_slot.zero_()
             promoted = league.maybe_promote(mr, it)
             stats_h["module_returns"] = {m: float(v) for m, v in mr.items()}
         stats_h.update(promoted=promoted, pool=list(mapper.pool()), mean_reward_trainable=float(buf["reward"][:, :, :k].mean()))
+        roll.check_capture_overflow()                                       # (outside the timed region; warns)
         if recorder is not None and roll.info is not None:
             recorder.record_rollout(roll, iteration=it)
         if em is not None:

@@ -533,7 +533,9 @@ class RolloutChains:
         fin_index = fin_value = None
         if self.capture_ends:
             wb, th = (self.bank.wb, self.bank.theta) if self.bank else (self.policy.wb, self.policy.theta)
-            _check(self.L.fn("cda_mlp_values")(wb.data_ptr(), th.data_ptr(), max(k, 1), self.buf["fin_obs"].data_ptr(), self.fin_cap, self.fin_value.data_ptr(), self.fin_cap, st), "cda_mlp_values")
+            # (bounded by the device-side count: an iteration in which no episode ended costs an empty launch, not a forward pass over the list's capacity)
+            _check(self.L.fn("cda_mlp_values_counted")(wb.data_ptr(), th.data_ptr(), max(k, 1), self.buf["fin_obs"].data_ptr(), self.fin_cap, self.buf["fin_count"].data_ptr(),
+                                                       self.fin_value.data_ptr(), self.fin_cap, st), "cda_mlp_values_counted")
             fin_index, fin_value = self.buf["fin_index"].data_ptr(), self.fin_value.data_ptr()
         _check(L.cda_gae_records_bootstrap(self.buf["reward"].data_ptr(), self.buf["value"].data_ptr(), self.buf["terminated"].data_ptr(), self.buf["truncated"].data_ptr(),
                                            self.T, self.N, self.A, k, float(reward_scale), float(gamma), float(lam), fin_index, fin_value, self.fin_cap if self.capture_ends else 0,
@@ -541,6 +543,18 @@ class RolloutChains:
         if self.bank:
             return self.buf["record"].view(self.T * self.N, self.A, 8), self.adv_stats, self.T * self.N
         return self.buf["record"].view(self.T * self.N, self.A, 8), self.adv_stats[0], self.T * self.N * self.A
+
+
+    def check_capture_overflow(self):
+        """after a rollout (synchronising read): did more episodes end than the capture list holds?  The consumer then bootstrapped the overflowed truncations with 0;
+        warn - silently it would bias the value targets.  Returns the number of ends that found no slot."""
+        if not self.capture_ends:
+            return 0
+        lost = int(self.buf["fin_count"].item()) - self.fin_cap
+        if lost > 0:
+            import warnings
+            warnings.warn(f"episode-end capture overflowed: {lost} of {lost + self.fin_cap} episode ends of this rollout found no slot (their time-limit bootstrap fell back to 0)")
+        return max(0, lost)
 
 
 class EpisodeReturns:
@@ -609,8 +623,13 @@ class FusedUpdate:
         self.doutp = e(pad * NOUT, bf)
         self.out, self.d_out = e(pad * NOUT, f32).view(-1, NOUT), e(pad * NOUT, f32).view(-1, NOUT)
         self.slab, self.bias_slab = e(self.sub * self.chunks * SLAB, f32), e((max(self.n_tiles, pad // 64) + self.sub) * BSLAB, f32)
-        self.grad, self.norm2 = e(PARAMS, f32), e(512, torch.float64)        # (norm2[2] = the squared gradient norm of the last step)
-        self.sums5, self.out6 = e(64 * 8, torch.float64), e(8, f32)       # CDA_MLP_LOSS_SLOTS x 8: the loss sums (slot 0, words 0..4 for the separate loss kernels); out6: CDA_LOSS_OUT_WORDS
+        # the gradient and, right behind it, the step's loss statistics (out6: CDA_LOSS_OUT_WORDS): ONE buffer, so that a data-parallel learner's all-reduce sums both - every
+        # rank's out6 holds its share of the GLOBAL means (its sums over loss_samples = the global minibatch), their sum is the global mean: pg / value loss, entropy and
+        # the KL that ppo.adapt_kl_coef steers kl_coef with are then the same numbers on every rank (round-5 ADVICE: per-rank partials made the ranks' objectives diverge)
+        self._grad_stats = e(PARAMS + 8, f32)
+        self.grad, self.out6 = self._grad_stats[:PARAMS], self._grad_stats[PARAMS:]
+        self.norm2 = e(512, torch.float64)                                  # (norm2[2] = the squared gradient norm of the last step)
+        self.sums5 = e(64 * 8, torch.float64)                               # CDA_MLP_LOSS_SLOTS x 8: the loss sums (slot 0, words 0..4 for the separate loss kernels)
         self.perm = torch.zeros(self.R, dtype=torch.int64, device=dev)
         pad64 = ((self.rows_mb + 63) // 64) * 64
         self.x_pk_mb = e(pad64 * 32 * XT, bf) if self.fused else None         # the fused kernel's packed image of the minibatch's observations
@@ -659,7 +678,7 @@ class FusedUpdate:
                 # data parallel: this rank's share of the gradient (its loss normalised by the global minibatch), summed over the ranks, then the same step everywhere
                 _check(L.cda_mlp_reduce(self.slab.data_ptr(), chunks, self.bias_slab.data_ptr(), tiles, self.sums5.data_ptr(), rows * self.A * self.world, float(vf_coef), float(ent_coef), kl,
                                         self.out6.data_ptr(), p.adam_step.data_ptr(), self.grad.data_ptr(), self.norm2.data_ptr(), st), "cda_mlp_reduce")
-                self.allreduce(self.grad)
+                self.allreduce(self._grad_stats)                                  # gradient | loss statistics: one collective
                 _check(L.cda_mlp_apply(p.theta.data_ptr(), p.adam_m.data_ptr(), p.adam_v.data_ptr(), p.adam_step.data_ptr(), p.wb.data_ptr(), self.grad.data_ptr(), 1,
                                        float(lr), float(betas[0]), float(betas[1]), float(eps), float(max_norm), self.norm2.data_ptr(), st), "cda_mlp_apply")
             return chunks, tiles

@@ -553,6 +553,7 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
         stats.update(iter=it, mean_reward=float(buf["reward"].mean()), episode_return=(float(acc[0].sum()) / done) if done else None, episodes=done / A,
                      kl_coef=kl_coef, agent_steps=N * A * T, agent_steps_per_s=N * A * T / (t1 - t0), rollout_s=t_roll - t0, update_s=t1 - t_roll)
         kl_coef = adapt_kl_coef(kl_coef, stats["kl"], obj["kl_target"])
+        roll.check_capture_overflow()                                       # (outside the timed region; warns)
         if recorder is not None and roll.info is not None:
             recorder.record_rollout(roll, iteration=it)
         if em is not None:

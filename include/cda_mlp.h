@@ -210,6 +210,11 @@ int cda_gae_records_bootstrap(const double* reward, const float* value, const ui
                               const int32_t* fin_index, const float* fin_value, int64_t fin_value_stride, float* rec, double* stats, void* stream);
 /* value f32 [n_rows] (net p: + p * value_stride) <- the value network of each of n_nets banked networks on obs f32 [n_rows][168] (one launch). */
 int cda_mlp_values(const void* wb_bank, const float* theta_bank, int32_t n_nets, const float* obs, int64_t n_rows, float* value, int64_t value_stride, void* stream);
+/* ... of the first min(n_rows, *n_rows_dev) rows only (n_rows_dev i32[1] on the device, NULL = all): the captured list's length lives on the device (fin_count) -
+ * the grid covers the list's capacity, whole row tiles beyond the count leave at entry (an iteration in which no episode ended costs an empty launch, not a
+ * forward pass over `capacity` rows). */
+int cda_mlp_values_counted(const void* wb_bank, const float* theta_bank, int32_t n_nets, const float* obs, int64_t n_rows, const int32_t* n_rows_dev,
+                           float* value, int64_t value_stride, void* stream);
 /* Returns of COMPLETED episodes out of a rollout's buffers (what a learning curve is drawn from when the horizon is shorter than an episode): running f64 [N][A]
  * carries each (market, agent)'s return so far from rollout to rollout; a step that ends the market's episode adds the total to done_sum f64 [A] and 1 to
  * done_count f64 [A] (both accumulate: the caller clears them) and restarts it.  per_slot: what a league needs to credit returns to the MODULE that played a slot. */

@@ -55,7 +55,7 @@ def _worker(rank, world, port, outdir):
     th, x, rec = _batch()
     first, cnt = shard_range(rank, world, R)
     p, upd = _steps(th, x, rec, slice(first, first + cnt), world, make_grad_allreduce(dist))
-    torch.save({"theta": p.theta.cpu(), "grad": upd.grad.cpu(), "norm2": upd.norm2[2].cpu(), "step": p.adam_step.cpu()}, os.path.join(outdir, f"dp_{rank}.pt"))
+    torch.save({"theta": p.theta.cpu(), "grad": upd.grad.cpu(), "norm2": upd.norm2[2].cpu(), "step": p.adam_step.cpu(), "out6": upd.out6.cpu()}, os.path.join(outdir, f"dp_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,6 +72,10 @@ def test_two_ranks_one_gpu_take_the_single_process_steps(tmp_path):
     g, gw = got[0]["grad"].double(), upd.grad.cpu().double()
     assert (g - gw).norm() <= 2e-4 * gw.norm(), float((g - gw).norm() / gw.norm())
     assert abs(float(got[0]["norm2"]) - float(upd.norm2[2])) <= 1e-3 * float(upd.norm2[2])
+    # the loss statistics travel with the gradient: every rank holds the GLOBAL means (what adapt_kl_coef and the logs read), not its share of them
+    o, ow = got[0]["out6"].double(), upd.out6.cpu().double()
+    assert torch.equal(got[0]["out6"], got[1]["out6"]) and float(ow[:4].abs().min()) > 0
+    assert ((o[:4] - ow[:4]).abs() <= 2e-3 * ow[:4].abs() + 1e-5).all(), (o, ow)
     moved = (want - th).double().norm()                          # (Adam normalises every coordinate's step: a coordinate whose gradient is at rounding level may step the other way - norms, not maxima)
     assert float((want - th).abs().max()) > 0.5 * LR and (got[0]["theta"] - want).double().norm() <= 0.02 * moved, (float(moved), float((got[0]["theta"] - want).double().norm()))
 
