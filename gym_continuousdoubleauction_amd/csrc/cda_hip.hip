@@ -66,6 +66,10 @@ using namespace cda;
 #ifndef CDA_MIN_WAVES
 #define CDA_MIN_WAVES 4
 #endif
+// (experiments: -DCDA_MIN_WAVES=5 budgets the step kernels for FIVE waves per SIMD - 96 VGPRs -, CDA_VGPR_CAP_ATTR takes any other attribute; profiles/r06/five_waves_per_simd.txt)
+#ifndef CDA_VGPR_CAP_ATTR
+#define CDA_VGPR_CAP_ATTR
+#endif
 
 // ------------------------------------------------------------------------------------------
 // device helpers shared by the kernels
