@@ -254,11 +254,7 @@ def learner_dp(args, dist, world, rank, device, backend):
     import torch
     from gym_continuousdoubleauction_amd import CDAVecEnv, ppo
     from gym_continuousdoubleauction_amd.parallel import make_grad_allreduce
-    N, A = CONFIGS[args.config]
-    N = args.markets if args.markets is not None else N
-    A = args.agents if args.agents is not None else A
-    K, W = (args.steps if args.steps != 1000 else 8), (args.warmup if args.warmup != 64 else 2)
-    T = 64
+    N, A, K, W, T = learner_shape(args)
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": 4096, "is_render": False, "auto_reset": True}
     env = CDAVecEnv(cfg, n_markets=N, device=str(device), with_info=False)
     allreduce = make_grad_allreduce(dist) if world > 1 else None
@@ -270,18 +266,241 @@ def learner_dp(args, dist, world, rank, device, backend):
     env.close()
     if rank == 0:
         elapsed = float(dt.item())
-        print(json.dumps({"metric": "agent-steps/sec end to end (rollout + PPO update), data-parallel learner over the market shards", "value": world * N * A * T * K / elapsed,
-                          "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "bf16 operands, f32 accumulation (network); int32+dec28+f64 (env)", "data": "synthetic",
-                          "config": {"workload": f"{N} markets x {A} agents per GPU (global {world * N}), PPO policy on the hand-written MFMA network kernels in the loop, horizon {T}, "
-                                                 "4 epochs, 262144-sample minibatches; a step = one iteration",
-                                     "collective": ("none (one rank)" if world == 1 else
-                                                    f"one all-reduce of the 0.9-MB gradient per minibatch step + one of the two advantage sums per rollout, torch.distributed over {backend}; "
-                                                    "no observation / reward hand-back"),
-                                     "flagged_markets": flags},
-                          "loss_last_iteration": {k: hist[-1][k] for k in ("pg_loss", "v_loss", "entropy")}}))
+        print(json.dumps(learner_line(world, N, A, T, K, W, elapsed, backend, flags, {k: hist[-1][k] for k in ("pg_loss", "v_loss", "entropy")})))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_shape(args, use_dist):
+    """Shape of the headline run from the command line: (N markets per GPU, A agents, K timed steps, W warm-up steps, R timed legs, hand-back?, chains, event lanes,
+    total steps, max_step)."""
+    N, A = CONFIGS[args.config]
+    N = args.markets if args.markets is not None else N
+    A = args.agents if args.agents is not None else A
+    K, W = args.steps, args.warmup
+    if args.fused and (args.steps % args.fused or args.warmup % args.fused):
+        raise SystemExit("--fused T needs --steps and --warmup to be multiples of T")
+    gather = use_dist and not args.no_gather and not args.fused
+    R = max(1, args.repeats if args.repeats is not None else (5 if K < 200 and not args.fused else 1))
+    total_steps = W + R * K
+    max_step = max(4096, total_steps + 1)                          # no truncation inside the run
+    # default number of group chains: 4 pays once the chains are long, 2 when the whole timed region is a few dozen steps and the
+    # staggered start / drain of four chains is a visible share of it (profiles/r02)
+    event_lanes = args.event_lanes or ("all" if K >= 200 else "one")
+    # with the hand-back two chains: every chain adds a collective and a rebuild launch per step to the host's work, and at four chains
+    # the host, not the GPU, bounds the step (tools/handback_rccl_probe.py: 47 us per step at four chains, 41.6 us at two)
+    groups = args.groups if args.groups is not None else (1 if args.fused else (2 if gather else (4 if K >= 200 else 2)))
+    groups = max(1, min(groups, N))
+    return N, A, K, W, R, gather, groups, event_lanes, total_steps, max_step
+
+
+def learner_shape(args):
+    """--learner dp: (N, A, K timed iterations, W warm-up iterations, T steps per rollout)."""
+    N, A = CONFIGS[args.config]
+    N = args.markets if args.markets is not None else N
+    A = args.agents if args.agents is not None else A
+    return N, A, (args.steps if args.steps != 1000 else 8), (args.warmup if args.warmup != 64 else 2), 64
+
+
+def learner_line(world, N, A, T, K, W, elapsed, backend, flags, losses):
+    """The ONE JSON line of `--learner dp` (no device work in here; see headline_line)."""
+    return {"metric": "agent-steps/sec end to end (rollout + PPO update), data-parallel learner over the market shards", "value": world * N * A * T * K / elapsed,
+            "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16 operands, f32 accumulation (network); int32+dec28+f64 (env)", "data": "synthetic",
+            "config": {"workload": f"{N} markets x {A} agents per GPU (global {world * N}), PPO policy on the hand-written MFMA network kernels in the loop, horizon {T}, "
+                                   "4 epochs, 262144-sample minibatches; a step = one iteration",
+                       "collective": ("none (one rank)" if world == 1 else
+                                      f"one all-reduce of the 0.9-MB gradient per minibatch step + one of the two advantage sums per rollout, torch.distributed over {backend}; "
+                                      "no observation / reward hand-back"),
+                       "flagged_markets": flags},
+            "loss_last_iteration": losses}
+
+
+def group_ranges(n, groups):
+    """[(first market, count)] of the contiguous market groups: the library's own rule (cda_group_range, a host function)."""
+    import ctypes as C
+    from gym_continuousdoubleauction_amd._lib import lib
+    out = []
+    for g in range(groups):
+        first, cnt = C.c_int32(), C.c_int32()
+        lib().cda_group_range(n, groups, g, C.byref(first), C.byref(cnt))
+        out.append((first.value, cnt.value))
+    return out
+
+
+def dry_run(args):
+    """CDA_BENCH_DRY_RUN=1 (tests/test_bench_dry_contract.py; no GPU, no library): everything of an N-rank run that is NOT device work - the rendezvous from the
+    launcher's environment (gloo), the barriers, the MAX-over-ranks reduction of the elapsed time, the shape logic of the command line and the line's schema -
+    with FABRICATED measurements (rank r 'measures' 40 us x (1 + r / 100) per step), so that the first real multi-GPU run cannot fail on bookkeeping.
+    The line says `"data": "dry run"`; nothing in it is a measurement."""
+    import types
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    use_dist = world > 1 or args.force_gather
+    backend = "gloo"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=PG_TIMEOUT)
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        if use_dist:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.learner == "dp":
+        N, A, K, W, T = learner_shape(args)
+        elapsed = max_over_ranks(K * 7e-3 * (1 + rank / 100))
+        out = learner_line(world, N, A, T, K, W, elapsed, backend, 0, {"pg_loss": 0.0, "v_loss": 0.0, "entropy": 0.0})
+    else:
+        N, A, K, W, R, gather, groups, event_lanes, total_steps, max_step = run_shape(args, use_dist)
+        took = [max_over_ranks(K * 40e-6 * (1 + rank / 100)) for _ in range(R)]
+        transport = "torch" if args.transport == "auto" else args.transport
+        out = headline_line(args, types.SimpleNamespace(
+            world=world, n_gpus=world, N=N, A=A, K=K, W=W, R=R, took=took, kms=[[0.036]] * R, head_ranges=group_ranges(N, groups), head_groups=groups,
+            headline_info=not args.no_info, gather=gather, tile=0, spill=0, spill_wanted=0, peak_orders=0, primer_steps=0,
+            head_transport=None if not gather else ("ncclAllGather issued by cda_step_groups_handback" if transport == "rccl" else "torch.distributed"),
+            head_transport_note="dry run" if gather else None, n_flagged=0, total_steps=total_steps, MAX_RESIDENT=4096, policy_leg=None, league_leg=None, rr_leg=None, extras={}))
+    out["data"] = "dry run (fabricated timings: CDA_BENCH_DRY_RUN=1)"
+    if "roofline" in out:
+        out["roofline"].update(traffic=None, traffic_source=None, issue_frac=None, valu_busy_frac=None)
+    if rank == 0:
+        print(json.dumps(out))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def headline_line(args, m):
+    """The ONE JSON line of the headline run from its measurements `m` (a namespace: the timed legs' wall times, the HIP-event kernel times, the shape, the extra legs).
+    No device work in here: tests/test_bench_dry_contract.py builds the same line from fabricated measurements under a world-2 gloo group."""
+    import statistics
+    from gym_continuousdoubleauction_amd.parallel import handback_stride
+    world = m.world
+    n_gpus = m.n_gpus
+    N = m.N
+    A = m.A
+    K = m.K
+    W = m.W
+    R = m.R
+    took = m.took
+    kms = m.kms
+    head_ranges = m.head_ranges
+    head_groups = m.head_groups
+    headline_info = m.headline_info
+    gather = m.gather
+    tile = m.tile
+    spill = m.spill
+    spill_wanted = m.spill_wanted
+    peak_orders = m.peak_orders
+    primer_steps = m.primer_steps
+    head_transport = m.head_transport
+    head_transport_note = m.head_transport_note
+    n_flagged = m.n_flagged
+    total_steps = m.total_steps
+    MAX_RESIDENT = m.MAX_RESIDENT
+    policy_leg = m.policy_leg
+    league_leg = m.league_leg
+    rr_leg = m.rr_leg
+    extras = m.extras
+    total_agent_steps = float(world) * N * A * K
+    elapsed = statistics.median(took)
+    value = total_agent_steps / elapsed
+    B = ALG_BYTES_CONST + ALG_BYTES_PER_AGENT * A                         # algorithmic bytes per market-step
+    markets_per_launch = [c for _, c in head_ranges] if head_groups > 1 else [N]
+    lanes_ms = [statistics.mean(x) for x in zip(*kms)] if kms else []     # per timed stream, averaged over the repeats
+    if len(lanes_ms) == 1 and len(markets_per_launch) > 1:                 # one chain timed: the others run the same launches
+        lanes_ms = lanes_ms * len(markets_per_launch)
+    n_lanes = max(1, len(lanes_ms))
+    # `achieved`: algorithmic bytes of one launch / that launch's duration.  With G concurrent group chains G launches are
+    # in flight at any time; the aggregate rate of the device is the sum over the concurrent launches.
+    per_launch_gbps = [B * m / (ms * 1e-3) / 1e9 for m, ms in zip(markets_per_launch, lanes_ms)]
+    achieved = sum(per_launch_gbps)
+    kernel_ms = sum(lanes_ms) / n_lanes if lanes_ms else None
+    # HBM bytes and issued wave-instructions per market-step from committed PMC passes of EXACTLY this shape (markets, agents,
+    # info, chains) - rocprofv3 --pmc, each counter group in its own run, FETCH_SIZE / WRITE_SIZE calibrated on known byte
+    # counts (tools/profile_gpu.sh); null otherwise.
+    traffic = traffic_src = issue_frac = valu_busy = None
+    pmc = None if (args.fused or gather) else pmc_entry(N, A, headline_info, head_groups)
+    if pmc:
+        traffic = pmc["hbm_bytes_per_market_step"] * markets_per_launch[0]
+        traffic_src = f"profiles/pmc/{N}x{A}_info{int(headline_info)}_g{head_groups}.json (rocprofv3 --pmc, calibrated; this build, this shape)"
+        cycles = elapsed / K * GPU_CLOCK_GHZ * 1e9                         # device cycles per step of the whole batch
+        issue_frac = pmc["wave_insts_per_market_step"] * N / (N_SIMD * cycles)
+        valu_busy = VALU_CYCLES * pmc["valu_insts_per_market_step"] * N / (N_SIMD * cycles)
+    shape = ("BASELINE configs[2]" if (N, A) == CONFIGS["c3"] else "per-GPU share of BASELINE configs[3]" if (N, A) == CONFIGS["c4"] else "custom shape")
+    how = "FUSED episodes (cda_run_random)" if args.fused else (
+        f"step() {'with every info tensor (row a14)' if headline_info else 'without info tensors'}, {head_groups} free-running group chain(s)"
+        + (", per-chain hand-back of the new frame | reward | flags to every rank" if gather else ""))
+    out = {
+        "metric": f"agent-steps/sec (whole node), 4 agents x N parallel markets; {how}",
+        "value": value, "unit": "agent-steps/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32+dec28+f64",
+        "data": "synthetic" + ("" if total_steps <= MAX_RESIDENT or args.fused else f" (action stream cycles with period {MAX_RESIDENT} steps)"),
+        "timed_repeats": {"n": R, "ms_per_step": [x / K * 1e3 for x in took], "min": min(took) / K * 1e3, "median": elapsed / K * 1e3,
+                          "max": max(took) / K * 1e3, "value_is": "the median leg" if R > 1 else "the one leg"},
+        "config": {"workload": f"{N} markets x {A} random agents per GPU ({shape}); unbounded book: LDS tile of {tile} resting orders per market "
+                               f"(the top of the book, both sides) + HBM spill ring of {spill} per side (the reference's OrderTree is unbounded; "
+                               f"most held by any market in this run: {peak_orders}); global {world * N} markets"
+                               + (f"; FUSED: {args.fused} steps per launch (cda_run_random)" if args.fused else ""),
+                   "markets_per_gpu": N, "agents": A, "info_outputs": bool(headline_info), "groups": head_groups,
+                   "book_tile": tile, "book_spill": spill, "book_spill_wanted": spill_wanted, "spill_halved": bool(spill < spill_wanted),
+                   "actions": f"cda_random_actions(seed {ACTION_SEED}, step, global market, agent), resident in HBM",
+                   "clock_primer": f"{primer_steps} untimed steps on a scratch env before the measured envs' resets",
+                   "collective": (f"{head_groups} all-gathers per step (one per chain, own stream + communicator; transport: {head_transport}"
+                                  + (f" [{head_transport_note}]" if head_transport_note else "") + f"; asked: {args.transport}) of {handback_stride(A)}-B records "
+                                  f"(newest frame | reward | flags), rebuilt into [global markets, ...] arrays by cda_handback_unpack") if gather else "none",
+                   "flagged_markets": n_flagged, "peak_resting_orders": peak_orders},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "k_run_random (per step)" if args.fused else "k_step", "kernel_ms": kernel_ms,
+                     "concurrent_launches": n_lanes, "markets_per_launch": markets_per_launch[0],
+                     "algorithmic_bytes_per_launch": B * markets_per_launch[0], "achieved_per_launch": per_launch_gbps[0] if per_launch_gbps else None,
+                     "issue_frac": issue_frac, "valu_busy_frac": valu_busy},
+    }
+    if policy_leg is not None:
+        if "error" in policy_leg:
+            out["value_policy_in_loop"] = None
+            out["config"]["policy_in_loop"] = f"failed: {policy_leg['error']}"
+        else:
+            out["value_policy_in_loop"] = total_agent_steps / policy_leg["elapsed"]
+            out["ms_per_step_policy_in_loop"] = policy_leg["elapsed"] / K * 1e3
+            out["config"]["policy_in_loop"] = (f"{policy_leg['chains']} chains x {{168-512-512-32 bf16 MFMA policy/value forward + sampling -> k_step -> auto reset}}, "
+                                               f"{K} steps per HIP graph" + ("" if policy_leg["graphs"] else " (graph capture failed: direct launches)")
+                                               + f", no info tensors; min / max over the repeats: {total_agent_steps / policy_leg['max']:.4g} / {total_agent_steps / policy_leg['min']:.4g}")
+            out["config"]["flagged_markets_policy_in_loop"] = policy_leg["flagged"]
+            if "metrics_on" in policy_leg:
+                out["value_policy_in_loop_episode_metrics"] = total_agent_steps / policy_leg["metrics_on"]
+                out["config"]["policy_in_loop_episode_metrics"] = (
+                    "the same loop over 64-step episodes with every episode checked (exact sum of NAV) and summarised on the device in the in-kernel auto reset, the step "
+                    f"tallying the callback's counters and reward terms, + one collection per rollout: {total_agent_steps / policy_leg['metrics_on']:.4g} against "
+                    f"{total_agent_steps / policy_leg['metrics_off']:.4g} agent-steps/s with the metrics off on the same env ({(policy_leg['metrics_on'] / policy_leg['metrics_off'] - 1) * 100:+.2f} % time); "
+                    f"last collection: {policy_leg['metrics_episodes']:.0f} episodes, {policy_leg['metrics_violations']:.0f} violations")
+    if league_leg is not None:
+        if "error" in league_leg:
+            out["value_league_self_play"] = None
+            out["config"]["league_self_play"] = f"failed: {league_leg['error']}"
+        else:
+            out["value_league_self_play"] = league_leg["value"]
+            lN, lA, lT = league_leg["shape"]
+            out["config"]["league_self_play"] = (f"end to end (rollout + one PPO update per trainable policy): {lN} markets x {lA} agents, 2 separately trained policies against "
+                                                 f"6 uniform random modules + champion snapshots drawn per episode and slot by the reference's mapping rule (on the device), {lT}-step "
+                                                 f"episodes; {league_leg['timed']} of {league_leg['iterations']} iterations timed: rollout {league_leg['rollout_ms']:.2f} ms + updates "
+                                                 f"{league_leg['update_ms']:.2f} ms per iteration, {league_leg['champions']} champions promoted, {league_leg['flagged']} flagged markets")
+    if rr_leg is not None:
+        out["value_run_random_one_launch"] = rr_leg.get("value")
+        out["config"]["run_random_one_launch"] = (f"failed: {rr_leg['error']}" if "error" in rr_leg else
+                                                  f"cda_run_random: {rr_leg['steps']} steps of uniform random agents for every market in one launch ({rr_leg['ms']:.2f} ms; in-kernel "
+                                                  f"counter-based sampler, no info tensors, {rr_leg['flagged']} flagged markets) - the reference's CDA_rand.run_random, SURVEY 8 row H")
+    for name, ex in extras.items():
+        out[f"value_{name}"] = total_agent_steps / ex["elapsed"]
+        out[f"ms_per_step_{name}"] = ex["elapsed"] / K * 1e3
+        out["config"][f"flagged_markets_{name}"] = ex["flagged"]
+    return out
 
 
 def main():
@@ -294,6 +513,8 @@ def main():
             port = sk.getsockname()[1]
         os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if os.environ.get("CDA_BENCH_DRY_RUN") == "1":
+        return dry_run(args)
     import statistics
 
     import torch
@@ -331,24 +552,8 @@ def main():
             and os.environ.get("CDA_BENCH_PROBE_NATIVE", "1") != "0":
         use_native, probe_note = probe_native_transport(dist, world, rank, local_rank, device)
         args.transport = "rccl" if use_native else "torch"
-    N, A = CONFIGS[args.config]
-    N = args.markets if args.markets is not None else N
-    A = args.agents if args.agents is not None else A
-    K, W = args.steps, args.warmup
-    if args.fused and (args.steps % args.fused or args.warmup % args.fused):
-        raise SystemExit("--fused T needs --steps and --warmup to be multiples of T")
-    gather = use_dist and not args.no_gather and not args.fused
-    R = max(1, args.repeats if args.repeats is not None else (5 if K < 200 and not args.fused else 1))
-    total_steps = W + R * K
-    max_step = max(4096, total_steps + 1)                          # no truncation inside the run
+    N, A, K, W, R, gather, groups, event_lanes, total_steps, max_step = run_shape(args, use_dist)
     cfg = {"num_of_agents": A, "init_cash": 1000000, "max_step": max_step, "is_render": False}
-    # default number of group chains: 4 pays once the chains are long, 2 when the whole timed region is a few dozen steps and the
-    # staggered start / drain of four chains is a visible share of it (profiles/r02)
-    event_lanes = args.event_lanes or ("all" if K >= 200 else "one")
-    # with the hand-back two chains: every chain adds a collective and a rebuild launch per step to the host's work, and at four chains
-    # the host, not the GPU, bounds the step (tools/handback_rccl_probe.py: 47 us per step at four chains, 41.6 us at two)
-    groups = args.groups if args.groups is not None else (1 if args.fused else (2 if gather else (4 if K >= 200 else 2)))
-    groups = max(1, min(groups, N))
     first_market = rank * N                           # global market index -> seed and action key, independent of the GPU count
     seeds = (SEED_BASE + first_market + torch.arange(N, dtype=torch.int64)).numpy().astype("uint64")
     headline_info = not args.no_info
@@ -590,100 +795,8 @@ def main():
             league_leg = {"error": repr(ex)}
 
     if rank == 0:
-        total_agent_steps = float(world) * N * A * K
-        elapsed = statistics.median(took)
-        value = total_agent_steps / elapsed
-        B = ALG_BYTES_CONST + ALG_BYTES_PER_AGENT * A                         # algorithmic bytes per market-step
-        markets_per_launch = [c for _, c in head_ranges] if head_groups > 1 else [N]
-        lanes_ms = [statistics.mean(x) for x in zip(*kms)] if kms else []     # per timed stream, averaged over the repeats
-        if len(lanes_ms) == 1 and len(markets_per_launch) > 1:                 # one chain timed: the others run the same launches
-            lanes_ms = lanes_ms * len(markets_per_launch)
-        n_lanes = max(1, len(lanes_ms))
-        # `achieved`: algorithmic bytes of one launch / that launch's duration.  With G concurrent group chains G launches are
-        # in flight at any time; the aggregate rate of the device is the sum over the concurrent launches.
-        per_launch_gbps = [B * m / (ms * 1e-3) / 1e9 for m, ms in zip(markets_per_launch, lanes_ms)]
-        achieved = sum(per_launch_gbps)
-        kernel_ms = sum(lanes_ms) / n_lanes if lanes_ms else None
-        # HBM bytes and issued wave-instructions per market-step from committed PMC passes of EXACTLY this shape (markets, agents,
-        # info, chains) - rocprofv3 --pmc, each counter group in its own run, FETCH_SIZE / WRITE_SIZE calibrated on known byte
-        # counts (tools/profile_gpu.sh); null otherwise.
-        traffic = traffic_src = issue_frac = valu_busy = None
-        pmc = None if (args.fused or gather) else pmc_entry(N, A, headline_info, head_groups)
-        if pmc:
-            traffic = pmc["hbm_bytes_per_market_step"] * markets_per_launch[0]
-            traffic_src = f"profiles/pmc/{N}x{A}_info{int(headline_info)}_g{head_groups}.json (rocprofv3 --pmc, calibrated; this build, this shape)"
-            cycles = elapsed / K * GPU_CLOCK_GHZ * 1e9                         # device cycles per step of the whole batch
-            issue_frac = pmc["wave_insts_per_market_step"] * N / (N_SIMD * cycles)
-            valu_busy = VALU_CYCLES * pmc["valu_insts_per_market_step"] * N / (N_SIMD * cycles)
-        shape = ("BASELINE configs[2]" if (N, A) == CONFIGS["c3"] else "per-GPU share of BASELINE configs[3]" if (N, A) == CONFIGS["c4"] else "custom shape")
-        how = "FUSED episodes (cda_run_random)" if args.fused else (
-            f"step() {'with every info tensor (row a14)' if headline_info else 'without info tensors'}, {head_groups} free-running group chain(s)"
-            + (", per-chain hand-back of the new frame | reward | flags to every rank" if gather else ""))
-        out = {
-            "metric": f"agent-steps/sec (whole node), 4 agents x N parallel markets; {how}",
-            "value": value, "unit": "agent-steps/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32+dec28+f64",
-            "data": "synthetic" + ("" if total_steps <= MAX_RESIDENT or args.fused else f" (action stream cycles with period {MAX_RESIDENT} steps)"),
-            "timed_repeats": {"n": R, "ms_per_step": [x / K * 1e3 for x in took], "min": min(took) / K * 1e3, "median": elapsed / K * 1e3,
-                              "max": max(took) / K * 1e3, "value_is": "the median leg" if R > 1 else "the one leg"},
-            "config": {"workload": f"{N} markets x {A} random agents per GPU ({shape}); unbounded book: LDS tile of {tile} resting orders per market "
-                                   f"(the top of the book, both sides) + HBM spill ring of {spill} per side (the reference's OrderTree is unbounded; "
-                                   f"most held by any market in this run: {peak_orders}); global {world * N} markets"
-                                   + (f"; FUSED: {args.fused} steps per launch (cda_run_random)" if args.fused else ""),
-                       "markets_per_gpu": N, "agents": A, "info_outputs": bool(headline_info), "groups": head_groups,
-                       "book_tile": tile, "book_spill": spill, "book_spill_wanted": spill_wanted, "spill_halved": bool(spill < spill_wanted),
-                       "actions": f"cda_random_actions(seed {ACTION_SEED}, step, global market, agent), resident in HBM",
-                       "clock_primer": f"{primer_steps} untimed steps on a scratch env before the measured envs' resets",
-                       "collective": (f"{head_groups} all-gathers per step (one per chain, own stream + communicator; transport: {head_transport}"
-                                      + (f" [{head_transport_note}]" if head_transport_note else "") + f"; asked: {args.transport}) of {handback_stride(A)}-B records "
-                                      f"(newest frame | reward | flags), rebuilt into [global markets, ...] arrays by cda_handback_unpack") if gather else "none",
-                       "flagged_markets": n_flagged, "peak_resting_orders": peak_orders},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_run_random (per step)" if args.fused else "k_step", "kernel_ms": kernel_ms,
-                         "concurrent_launches": n_lanes, "markets_per_launch": markets_per_launch[0],
-                         "algorithmic_bytes_per_launch": B * markets_per_launch[0], "achieved_per_launch": per_launch_gbps[0] if per_launch_gbps else None,
-                         "issue_frac": issue_frac, "valu_busy_frac": valu_busy},
-        }
-        if policy_leg is not None:
-            if "error" in policy_leg:
-                out["value_policy_in_loop"] = None
-                out["config"]["policy_in_loop"] = f"failed: {policy_leg['error']}"
-            else:
-                out["value_policy_in_loop"] = total_agent_steps / policy_leg["elapsed"]
-                out["ms_per_step_policy_in_loop"] = policy_leg["elapsed"] / K * 1e3
-                out["config"]["policy_in_loop"] = (f"{policy_leg['chains']} chains x {{168-512-512-32 bf16 MFMA policy/value forward + sampling -> k_step -> auto reset}}, "
-                                                   f"{K} steps per HIP graph" + ("" if policy_leg["graphs"] else " (graph capture failed: direct launches)")
-                                                   + f", no info tensors; min / max over the repeats: {total_agent_steps / policy_leg['max']:.4g} / {total_agent_steps / policy_leg['min']:.4g}")
-                out["config"]["flagged_markets_policy_in_loop"] = policy_leg["flagged"]
-                if "metrics_on" in policy_leg:
-                    out["value_policy_in_loop_episode_metrics"] = total_agent_steps / policy_leg["metrics_on"]
-                    out["config"]["policy_in_loop_episode_metrics"] = (
-                        "the same loop over 64-step episodes with every episode checked (exact sum of NAV) and summarised on the device in the in-kernel auto reset, the step "
-                        f"tallying the callback's counters and reward terms, + one collection per rollout: {total_agent_steps / policy_leg['metrics_on']:.4g} against "
-                        f"{total_agent_steps / policy_leg['metrics_off']:.4g} agent-steps/s with the metrics off on the same env ({(policy_leg['metrics_on'] / policy_leg['metrics_off'] - 1) * 100:+.2f} % time); "
-                        f"last collection: {policy_leg['metrics_episodes']:.0f} episodes, {policy_leg['metrics_violations']:.0f} violations")
-        if league_leg is not None:
-            if "error" in league_leg:
-                out["value_league_self_play"] = None
-                out["config"]["league_self_play"] = f"failed: {league_leg['error']}"
-            else:
-                out["value_league_self_play"] = league_leg["value"]
-                lN, lA, lT = league_leg["shape"]
-                out["config"]["league_self_play"] = (f"end to end (rollout + one PPO update per trainable policy): {lN} markets x {lA} agents, 2 separately trained policies against "
-                                                     f"6 uniform random modules + champion snapshots drawn per episode and slot by the reference's mapping rule (on the device), {lT}-step "
-                                                     f"episodes; {league_leg['timed']} of {league_leg['iterations']} iterations timed: rollout {league_leg['rollout_ms']:.2f} ms + updates "
-                                                     f"{league_leg['update_ms']:.2f} ms per iteration, {league_leg['champions']} champions promoted, {league_leg['flagged']} flagged markets")
-        if rr_leg is not None:
-            out["value_run_random_one_launch"] = rr_leg.get("value")
-            out["config"]["run_random_one_launch"] = (f"failed: {rr_leg['error']}" if "error" in rr_leg else
-                                                      f"cda_run_random: {rr_leg['steps']} steps of uniform random agents for every market in one launch ({rr_leg['ms']:.2f} ms; in-kernel "
-                                                      f"counter-based sampler, no info tensors, {rr_leg['flagged']} flagged markets) - the reference's CDA_rand.run_random, SURVEY 8 row H")
-        for name, ex in extras.items():
-            out[f"value_{name}"] = total_agent_steps / ex["elapsed"]
-            out[f"ms_per_step_{name}"] = ex["elapsed"] / K * 1e3
-            out["config"][f"flagged_markets_{name}"] = ex["flagged"]
+        import types
+        out = headline_line(args, types.SimpleNamespace(world=world, n_gpus=n_gpus, N=N, A=A, K=K, W=W, R=R, took=took, kms=kms, head_ranges=head_ranges, head_groups=head_groups, headline_info=headline_info, gather=gather, tile=tile, spill=spill, spill_wanted=spill_wanted, peak_orders=peak_orders, primer_steps=primer_steps, head_transport=head_transport, head_transport_note=head_transport_note, n_flagged=n_flagged, total_steps=total_steps, MAX_RESIDENT=MAX_RESIDENT, policy_leg=policy_leg, league_leg=league_leg, rr_leg=rr_leg, extras=extras))
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, A, args.cpu_seconds, max_step, first_market)
