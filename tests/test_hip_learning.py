@@ -106,19 +106,38 @@ def test_ten_optimiser_steps_follow_float32_autograd_and_torch_adam():
 
 def test_fused_league_loop_improves_both_trained_policies_and_promotes_champions():
     """The reference's topology on the fused kernels (8 agents, 2 separately trained policies against uniform random modules + champion snapshots, league_train.
-    train_league_fused) with whole 32-step episodes per iteration: BOTH trained policies' mean episode return recovers most of an untrained policy's loss within 40
-    iterations at lr 3e-4, the random modules' does not, champions are promoted by the reference's rule on the way (measured: profiles/r05/league_learning_curve.txt)."""
-    from gym_continuousdoubleauction_amd import CDAVecEnv
-    from gym_continuousdoubleauction_amd.league_train import train_league_fused
-    env = CDAVecEnv({"num_of_agents": 8, "init_cash": 1000000, "max_step": 32, "is_render": False, "auto_reset": True}, n_markets=512, with_info=False)
-    _, league, hist = train_league_fused(env, iters=40, horizon=32, num_trainable=2, lr=3e-4, log=lambda s: None)
-    mr = [h["module_returns"] for h in hist]
+    train_league_fused) with whole 32-step episodes per iteration: BOTH trained policies' mean episode return recovers an untrained policy's loss within 40
+    iterations at lr 3e-4, the random modules' does not, champions are promoted by the reference's rule on the way - and both end inside a stated band of the LEGACY
+    float32 torch league loop (league_train.train_league: library GEMMs, autograd, torch.optim.Adam, one float32 network on both trainable slots) on the same env
+    shape, seed, learning rate and episode length (measured: profiles/r06/league_vs_float32.txt, tools/league_curve.py --against-float32)."""
+    from league_curve import curves
+    c = curves(markets=512, agents=8, episode=32, iters=40, lr=3e-4, seed=0)
+    m3 = lambda x, sl: sum(x[sl]) / 3                                # noqa: E731
+    l0, l1 = m3(c["legacy"], slice(0, 3)), m3(c["legacy"], slice(-3, None))
+    assert l0 < -1500 and l1 > 0.05 * l0, (l0, l1)                   # the float32 loop: -3580 -> -59 (98.4 % recovered); its own bar 95 %
     for p in ("policy_0", "policy_1"):
-        first, last = sum(m[p] for m in mr[:3]) / 3, sum(m[p] for m in mr[-3:]) / 3
+        first, last = m3(c[p], slice(0, 3)), m3(c[p], slice(-3, None))
         assert first < -1500 and math.isfinite(last), (p, first, last)
-        assert last > 0.15 * first, (p, first, last)                 # measured at 1024 markets: -3072 -> -110 after 40 iterations (96 %); the bar is 85 %
-    rnd = [v for k, v in mr[-1].items() if not k.startswith("champion_") and k not in ("policy_0", "policy_1")]
-    assert rnd and sum(rnd) / len(rnd) < 5 * max(mr[-1]["policy_0"], mr[-1]["policy_1"]) < 0      # the fixed random opponents stay far below the learners
-    assert len(league.history) >= 8                                 # a promotion every second iteration through the rolling window
-    assert (env.flags() == 0).all() and (env.check_invariants() == 0).all()
-    env.close()
+        assert abs(first - l0) <= 0.35 * abs(l0), (p, first, l0)     # same starting point (the loops draw their initial weights differently)
+        assert last > 0.07 * first, (p, first, last)                 # measured at 512 markets: -3261 -> -83 (97.4 %), -3284 -> -159 (95.2 %); the bar is 93 %
+        assert abs(last - l1) <= 0.05 * abs(l0), (p, last, l1)       # ... and within 5 % of the starting loss of where the float32 loop ends (measured 0.7 % / 2.8 %)
+        assert min(c[p][20:]) > 0.25 * first                         # no collapse on the way
+    rnd = c["random"][-1]
+    assert rnd and sum(rnd) / len(rnd) < 5 * max(c["policy_0"][-1], c["policy_1"][-1]) < 0      # the fixed random opponents stay far below the learners
+    assert c["champions"] >= 8 and c["clean"]                        # a promotion every second iteration through the rolling window; no flag, no invariant violation
+
+
+def test_fused_league_loop_under_the_rllib_objective_recovers_like_the_float32_loop():
+    """The same league run optimising ppo.RLLIB_DEFAULTS (what the reference's RLlib run optimises: clip 0.3, lambda 1, vf coeff 1 / clip 10, adaptive KL penalty per
+    policy, truncation bootstrap, unscaled rewards): both trained policies recover >= 98 % of the starting loss (measured 99.7 %: profiles/r06/league_vs_float32_rllib.txt)
+    and end at or above the float32 PPO loop's final return."""
+    from gym_continuousdoubleauction_amd import ppo
+    from league_curve import curves
+    c = curves(markets=512, agents=8, episode=32, iters=40, lr=3e-4, seed=0, objective=dict(ppo.RLLIB_DEFAULTS))
+    m3 = lambda x, sl: sum(x[sl]) / 3                                # noqa: E731
+    l0, l1 = m3(c["legacy"], slice(0, 3)), m3(c["legacy"], slice(-3, None))
+    for p in ("policy_0", "policy_1"):
+        first, last = m3(c[p], slice(0, 3)), m3(c[p], slice(-3, None))
+        assert first < -1500 and last > 0.02 * first, (p, first, last)
+        assert last > l1 - 0.02 * abs(l0), (p, last, l1)
+    assert c["champions"] >= 8 and c["clean"]
