@@ -18,6 +18,9 @@ action dict (exchg/action_helper.py:164-170).  So do these facades: the order tr
 array (0 = not in the dict, else 1 + position in it), and `LOB_actions` lists the decoded orders in that order too.
 """
 import numbers
+import os
+from itertools import chain
+from operator import itemgetter
 
 import numpy as np
 import torch
@@ -39,6 +42,15 @@ except Exception:  # noqa: BLE001
         class _Base:  # minimal stand-in so the class still constructs without either
             def __init__(self):
                 pass
+
+_G_CAT, _G_MEAN, _G_SIGMA = itemgetter("category"), itemgetter("size_mean"), itemgetter("size_sigma")
+_SIDES, _TYPES = ("bid", "ask"), ("market", "limit", "modify", "cancel")
+
+
+def _host_io_default():
+    """CDA_FACADE_HOST_IO=0: the staged path (one pinned H2D copy of the actions, one D2H copy of `packed` per step) instead of kernel I/O on pinned host memory"""
+    return os.environ.get("CDA_FACADE_HOST_IO", "1") != "0"
+
 
 _TERM_NAMES = ("nav_term", "order_penalty", "trade_penalty", "drawdown_penalty", "passive_bonus")
 _DEC_FIELDS = ("cash", "cash_on_hold", "position_val", "vwap", "nav", "prev_nav", "max_nav")
@@ -107,10 +119,15 @@ class _ActionStage:
             self.t[k] = self.dev[j * 4 * words:(j + 1) * 4 * words].view(torch.int32 if dt is np.int32 else torch.float32).view(n, a)
         self.np["present"] = hn[20 * words:21 * words].reshape(n, a)
         self.t["present"] = self.dev[20 * words:21 * words].view(n, a)
+        # the SAME arrays as the kernel sees them when it reads the pinned block in place (CDAVecEnv.step_host_io): pinned host memory is device-addressable at its own address
+        base = self.host.data_ptr()
+        self.host_ptrs = tuple(base + j * 4 * words for j in range(5)) + (base + 20 * words,)
+        self._hn = hn
+        self.flat = {k: v.reshape(-1) for k, v in self.np.items()}
 
     def clear(self):
-        self.host.zero_()
-        self.np["price_offset"][:] = 1                    # neutral 'join' (action_helper.py:256-258)
+        self._hn.fill(0)
+        self.np["price_offset"].fill(1)                   # neutral 'join' (action_helper.py:256-258)
 
     def upload(self):
         self.dev.copy_(self.host, non_blocking=True)
@@ -133,25 +150,76 @@ def _nan_none(x):
     return None if x != x else float(x)
 
 
+_DEC_CTX = None
+
+
+def _nav_words(a):
+    """uint8[..., 16] decimals -> nested lists of their four 32-bit words"""
+    return np.ascontiguousarray(a).view(np.uint32).reshape(a.shape[:-1] + (4,)).tolist()
+
+
+def _dec_str(row):
+    """str(Decimal) of one 16-byte decimal as its four little-endian 32-bit words (w0, w1, w2, exp:int16 | sign << 16): the exact sign / coefficient / exponent triple
+    (K.dec_to_decimal builds the same object digit by digit; this is the per-step path of the info dicts)."""
+    global _DEC_CTX
+    import decimal
+    if _DEC_CTX is None:
+        _DEC_CTX = decimal.Context(prec=60)                       # a 96-bit coefficient has at most 29 digits: scaleb never rounds
+    w0, w1, w2, w3 = row
+    exp = (w3 & 0xFFFF) - ((w3 & 0x8000) << 1)
+    d = decimal.Decimal(w0 | (w1 << 32) | (w2 << 64))
+    if w3 & 0xFF0000:
+        d = d.copy_negate()
+    return str(d.scaleb(exp, _DEC_CTX))
+
+
 def _info_dict(info, i, k, reward, model_action):
-    """info[agent k of market i] as the reference builds it (exchg/info_helper.py:30-116) from the host copy of the SoA info tensors"""
-    nav = info["nav"][i].view(DEC_DTYPE).reshape(-1)[k]
+    """info[agent k of market i] as the reference builds it (exchg/info_helper.py:30-116) from the host copy of the SoA info tensors (`info`: a _Snap, or a dict of
+    numpy arrays).  Every field goes through ONE .tolist() of its array per step (cached in the _Snap): indexing a numpy array element by element and converting
+    each scalar costs five times as much."""
+    rows = info.rows if isinstance(info, _Snap) else (lambda name: _nav_words(info[name]) if name == "nav" else info[name].tolist())
+    terms = rows("reward_terms")[i][k]
     d = {
-        "reward": reward, "NAV": str(K.dec_to_decimal(nav)), "num_trades": int(info["num_trades"][i, k]),
-        "net_position": int(info["net_position"][i, k]), "VWAP": float(info["vwap"][i, k]), "cash": float(info["cash"][i, k]),
-        "cash_on_hold": float(info["cash_on_hold"][i, k]), "position_val": float(info["position_val"][i, k]),
-        "drawdown": float(info["drawdown"][i, k]), "max_nav": float(info["max_nav"][i, k]),
-        "num_trades_step": int(info["num_trades_step"][i, k]),
-        "num_passive_fills_step": int(info["num_passive_fills_step"][i, k]),
-        "order_step_placed": int(info["order_step_placed"][i, k]), "num_rejected_step": int(info["num_rejected_step"][i, k]),
-        "is_pass_action": bool(info["is_pass_action"][i, k]),
-        "reward_terms": {n: float(info["reward_terms"][i, k, j]) for j, n in enumerate(_TERM_NAMES)},
-        "last_price": float(info["last_price"][i]), "best_bid": _nan_none(info["best_bid"][i]), "best_ask": _nan_none(info["best_ask"][i]),
-        "spread": _nan_none(info["spread"][i]),
+        "reward": reward, "NAV": _dec_str(rows("nav")[i][k]), "num_trades": rows("num_trades")[i][k],
+        "net_position": rows("net_position")[i][k], "VWAP": rows("vwap")[i][k], "cash": rows("cash")[i][k],
+        "cash_on_hold": rows("cash_on_hold")[i][k], "position_val": rows("position_val")[i][k],
+        "drawdown": rows("drawdown")[i][k], "max_nav": rows("max_nav")[i][k],
+        "num_trades_step": rows("num_trades_step")[i][k],
+        "num_passive_fills_step": rows("num_passive_fills_step")[i][k],
+        "order_step_placed": rows("order_step_placed")[i][k], "num_rejected_step": rows("num_rejected_step")[i][k],
+        "is_pass_action": bool(rows("is_pass_action")[i][k]),
+        "reward_terms": dict(zip(_TERM_NAMES, terms)),
+        "last_price": rows("last_price")[i], "best_bid": _nan_none(rows("best_bid")[i]), "best_ask": _nan_none(rows("best_ask")[i]),
+        "spread": _nan_none(rows("spread")[i]),
     }
     if model_action is not None:
         d["model_action"] = _jsonable(model_action)
     return d
+
+
+class _Snap:
+    """One step's host snapshot of `packed` (a private copy of the pinned block): the info arrays as numpy views, each built on first use - a consumer that reads no
+    info dict pays for none of the ~20 views.  Indexed like the info dict of CDAVecEnv.unpack_host."""
+    __slots__ = ("h", "lay", "cache", "lists")
+    _NP = {torch.uint8: np.uint8, torch.int32: np.int32, torch.float64: np.float64}
+
+    def __init__(self, h, lay):
+        self.h, self.lay, self.cache, self.lists = h, lay, {}, {}
+
+    def rows(self, name):
+        """the field as nested Python lists ([market][agent]...; "nav": the four 32-bit words of each decimal), converted once per step"""
+        v = self.lists.get(name)
+        if v is None:
+            a = self[name]
+            v = self.lists[name] = _nav_words(a) if name == "nav" else a.tolist()
+        return v
+
+    def __getitem__(self, name):
+        v = self.cache.get(name)
+        if v is None:
+            o, dt, shape, nbytes = self.lay[name]
+            v = self.cache[name] = self.h[o:o + nbytes].view(self._NP[dt]).reshape(shape)
+        return v
 
 
 class _LazyInfo(dict):
@@ -209,6 +277,11 @@ class _DictSurface(_Base):
         self._agent_index = {a: i for i, a in enumerate(agent_ids)}
         self.agents = list(agent_ids)
         self.possible_agents = list(agent_ids)
+        self._agents_t = tuple(agent_ids)
+        self._false_t = dict.fromkeys(agent_ids, False)
+        self._present_row = np.arange(1, self.num_of_agents + 1, dtype=np.uint8)
+        lay = vec.slab_layout
+        self._o_obs, self._o_rew, self._o_term, self._o_trunc = lay["obs"], lay["reward"], lay["terminated"], lay["truncated"]
         obs_space = _spaces.observation_space(self.n_hist)
         self.observation_spaces = {a: obs_space for a in agent_ids}
         act_space = _spaces.action_space()              # ONE shared Dict object, as in the reference
@@ -248,6 +321,70 @@ class _DictSurface(_Base):
             sigma[a] = sg
             price[a] = act.get("price", 0)
             off[a] = act.get("price_offset", 1)                 # neutral 'join' (action_helper.py:256-258)
+
+    def _encode_all(self, action_dicts, st):
+        """Every market's action dict -> the staging block `st`.  The common case - every dict lists all agents in their canonical order and every value is a
+        size-1 array or numpy scalar - is gathered column-wise (2 us per market instead of 5); anything else, and anything the per-agent statement would refuse
+        (category outside 0..8, negative sigma), goes through _encode market by market, which raises what the reference raises where it raises it."""
+        agents_t, A = self._agents_t, self.num_of_agents
+        try:
+            for actions in action_dicts:
+                if tuple(actions) != agents_t:
+                    raise LookupError
+            acts = list(chain.from_iterable(map(dict.values, action_dicts)))
+            f = st.flat
+            f["category"][:] = list(map(_G_CAT, acts))
+            f["size_mean"][:] = [x.item() for x in map(_G_MEAN, acts)]
+            f["size_sigma"][:] = [x.item() for x in map(_G_SIGMA, acts)]
+            f["price"][:] = [a.get("price", 0) for a in acts]
+            f["price_offset"][:] = [a.get("price_offset", 1) for a in acts]     # neutral 'join' (action_helper.py:256-258)
+            c, sg = f["category"], f["size_sigma"]
+            if c.min() < 0 or c.max() > 8 or sg.min() < 0:
+                raise LookupError
+            st.np["present"][:] = self._present_row
+            return
+        except (LookupError, AttributeError, ValueError, TypeError, OverflowError):
+            pass
+        st.clear()
+        buf = st.np
+        for i, actions in enumerate(action_dicts):
+            self._encode(actions, buf["category"][i], buf["size_mean"][i], buf["size_sigma"][i], buf["price"][i], buf["price_offset"][i], buf["present"][i])
+
+    def _canonical(self, actions):
+        """(listed agent ids in the dict's order, {canonical agent id: action}): keys are mapped the way _encode resolves them (a key like "agent_02" or "trader_2"
+        addresses agent_2: its order and its model_action must not disappear from the outputs)"""
+        if actions is None:
+            return self.agents, None
+        if tuple(actions) == self._agents_t:
+            return self.agents, actions
+        agents, index, canon = self.agents, self._agent_index, {}
+        for key in actions:
+            k = index.get(key)
+            if k is None:
+                k = int(str(key).split("_")[1])
+            canon[agents[k]] = key
+        return list(canon), {a: actions[key] for a, key in canon.items()}
+
+    def _decode_snap(self, actions, h):
+        """ONE market's step from its own host snapshot `h` of the pinned block (CDAEnv's host-I/O path): the reference's five dicts with lazily built info dicts,
+        LOB_actions, the pass agents and the bankrupt agents (NAV <= 0: sign set or zero coefficient of the 16-byte decimal)."""
+        agents, A = self.agents, self.num_of_agents
+        ob = h[self._o_obs:self._o_obs + self.n_hist * 42 * 4].view(np.float32)
+        rew = h[self._o_rew:self._o_rew + A * 8].view(np.float64).tolist()
+        snap = _Snap(h, self._info_lay)
+        terminateds, truncateds = self._false_t.copy(), self._false_t.copy()
+        terminateds["__all__"], truncateds["__all__"] = bool(h[self._o_term]), bool(h[self._o_trunc])
+        listed, canon = self._canonical(actions)
+        lob = snap["lob_actions"][0].tolist()
+        index = self._agent_index
+        lob_actions = [{"ID": a, "side": _SIDES[row[0]], "type": _TYPES[row[1]], "size": row[2], "price": float(row[3])}
+                       for a, row in ((a, lob[index[a]]) for a in listed) if row[0] >= 0]
+        pass_agents = {a for a, p in zip(agents, snap["is_pass_action"][0].tolist()) if p}
+        nv = snap["nav"][0]
+        bankrupt = {a for a, b in zip(agents, ((nv[:, 14] != 0) | ~nv[:, :12].any(axis=1)).tolist()) if b}
+        get = canon.get if canon is not None else (lambda a: None)
+        infos = {a: _LazyInfo(snap, 0, k, rew[k], get(a)) for k, a in enumerate(agents)}
+        return (dict.fromkeys(agents, ob), dict(zip(agents, rew)), terminateds, truncateds, infos), lob_actions, pass_agents, bankrupt
 
     def _decode(self, i, actions, obs, rew, term, trunc, info):
         """Market i's rows of the host copy -> the reference's five dicts (info_helper.py:30-116)."""
@@ -305,9 +442,15 @@ class CDAEnv(_DictSurface):
         self.model_actions = None
         self._seeded = False
         A = self.num_of_agents
-        # host staging: ONE pinned buffer receives a whole step (obs | reward | flags | info) in one copy
-        self._host = torch.empty(self._vec.packed.numel(), dtype=torch.uint8).pin_memory()
         self._stage = _ActionStage(1, A, self._vec.device)
+        self._info_lay = self._vec.info_layout
+        # Host-resident step I/O (default): the step kernel reads the staged actions from, and writes obs | reward | flags | info into, pinned host memory - a step is
+        # one launch + one stream synchronisation.  CDA_FACADE_HOST_IO=0: ONE pinned buffer receives a whole step in one D2H copy, the actions go up in one H2D copy.
+        self._host_io = _host_io_default()
+        if self._host_io:
+            self._hio = self._vec.bind_host_io()
+        else:
+            self._host = torch.empty(self._vec.packed.numel(), dtype=torch.uint8).pin_memory()
 
     # -- diagnostics some reference tests read --------------------------------------------
     @property
@@ -341,23 +484,38 @@ class CDAEnv(_DictSurface):
         if seed is None and not self._seeded:
             seed = _entropy_seed()
         self._seeded = True
-        obs = self._vec.reset(seed=None if seed is None else np.array([int(seed)], dtype=np.uint64))
+        seeds = None if seed is None else np.array([int(seed)], dtype=np.uint64)
+        if self._host_io:
+            self._vec.reset_host_io(seed=seeds)
+            self._vec.sync_host_io()
+            ob = self._hio[self._o_obs:self._o_obs + self.n_hist * 42 * 4].view(np.float32).copy()
+        else:
+            ob = self._vec.reset(seed=seeds)[0].cpu().numpy()
         self.done_set = set()
         self.LOB_actions = None
         self.pass_agents = set()
         self.t_step = 0
-        ob = obs[0].cpu().numpy()
         observations = {a: ob for a in self.agents}        # the SAME array object for every agent
         infos = {a: {} for a in self._agent_ids}
         return observations, infos
 
     def step(self, actions):
         st = self._stage
+        vec = self._vec
+        if self._host_io:
+            self._encode_all((actions,), st)
+            self.model_actions = actions
+            vec.step_host_io(st.host_ptrs)                     # one launch: actions read from, outputs written to, pinned host memory
+            vec.sync_host_io()
+            # this step's own snapshot (a 2-KB memcpy): the observation row and the lazily built info dicts keep reading it after the block has moved on
+            out, self.LOB_actions, self.pass_agents, bankrupt = self._decode_snap(actions, self._hio.copy())
+            self.done_set |= bankrupt
+            self.t_step += 1
+            return out
         st.clear()
         buf = st.np
         self._encode(actions, buf["category"][0], buf["size_mean"][0], buf["size_sigma"][0], buf["price"][0], buf["price_offset"][0], buf["present"][0])
         self.model_actions = actions
-        vec = self._vec
         t = st.upload()                                        # ONE host-to-device copy of the step's actions
         vec.step(t["category"], t["size_mean"], t["size_sigma"], t["price"], t["price_offset"], t["present"])
         self._host.copy_(vec.packed)                           # the ONE device-to-host copy of the step (synchronous)
@@ -400,6 +558,9 @@ class CDAVecMultiAgentEnv(_DictSurface):
         self._false = torch.zeros(N, dtype=torch.bool, device=self._vec.device)
         self._host = None
         self._stage = None
+        self._info_lay = self._vec.info_layout
+        self._host_io = _host_io_default() and int(groups) == 1 and bool(with_info)    # (see CDAEnv: kernel I/O on pinned host memory; single-launch envs)
+        self._hio = None
 
     @property
     def vec(self):
@@ -475,18 +636,30 @@ class CDAVecMultiAgentEnv(_DictSurface):
         vec = self._vec
         if self._stage is None:
             self._stage = _ActionStage(self.num_envs, self.num_of_agents, vec.device)
-            self._host = torch.empty(vec.packed.numel(), dtype=torch.uint8).pin_memory()
+            if self._host_io:
+                self._hio = vec.bind_host_io()
+            else:
+                self._host = torch.empty(vec.packed.numel(), dtype=torch.uint8).pin_memory()
         st = self._stage
-        st.clear()
-        buf = st.np
-        for i, actions in enumerate(action_dicts):
-            self._encode(actions, buf["category"][i], buf["size_mean"][i], buf["size_sigma"][i], buf["price"][i], buf["price_offset"][i], buf["present"][i])
-        t = st.upload()                                            # ONE host-to-device copy of the batch's actions
-        vec.step(t["category"], t["size_mean"], t["size_sigma"], t["price"], t["price_offset"], t["present"])
-        self._host.copy_(vec.packed)                               # ONE device-to-host copy for the whole batch
-        # this step's own snapshot: the observations rows and the lazily built info dicts keep reading it after the staging buffer
-        # has moved on (one 1.2-KB-per-market memcpy instead of N x A x 25 eager conversions)
-        obs, rew, term, trunc, info = vec.unpack_host(self._host.numpy().copy())
+        self._encode_all(action_dicts, st)
+        if self._host_io:
+            vec.step_host_io(st.host_ptrs)                         # one launch: actions read from, outputs written to, pinned host memory
+            vec.sync_host_io()
+            h = self._hio.copy()                                   # this step's own snapshot (1.2 KB per market)
+            n, A, od = self.num_envs, self.num_of_agents, self.n_hist * 42
+            obs = h[self._o_obs:self._o_obs + n * od * 4].view(np.float32).reshape(n, od)
+            rew = h[self._o_rew:self._o_rew + n * A * 8].view(np.float64).reshape(n, A)
+            term, trunc = h[self._o_term:self._o_term + n], h[self._o_trunc:self._o_trunc + n]
+            info = _Snap(h, self._info_lay)
+        else:
+            t = st.upload()                                        # ONE host-to-device copy of the batch's actions
+            vec.step(t["category"], t["size_mean"], t["size_sigma"], t["price"], t["price_offset"], t["present"])
+            self._host.copy_(vec.packed)                           # ONE device-to-host copy for the whole batch
+            # this step's own snapshot: the observations rows and the lazily built info dicts keep reading it after the staging buffer
+            # has moved on (one 1.2-KB-per-market memcpy instead of N x A x 25 eager conversions)
+            hc = self._host.numpy().copy()
+            obs, rew, term, trunc, _ = vec.unpack_host(hc)
+            info = _Snap(hc, self._info_lay)
         agents = self.agents
         rew_l, term_l, trunc_l = rew.tolist(), term.tolist(), trunc.tolist()
         false_t = dict.fromkeys(agents, False)

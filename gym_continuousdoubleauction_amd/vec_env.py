@@ -19,6 +19,17 @@ DEC_DTYPE = K.DEC_DTYPE
 ACTION_KEYS = ("category", "size_mean", "size_sigma", "price", "price_offset")
 
 
+class _PtrOnly:
+    """stands in for a tensor where only its address is used"""
+    __slots__ = ("_p",)
+
+    def __init__(self, p):
+        self._p = p
+
+    def data_ptr(self):
+        return self._p
+
+
 class CDAVecEnv:
     """Batched env.  Tensors: actions [N,A]; obs f32[N, n_hist*42]; reward f64[N,A];
     terminated/truncated bool[N] (the reference's "__all__" flags); info = dict of SoA tensors."""
@@ -137,6 +148,53 @@ class CDAVecEnv:
             npdt = {torch.uint8: np.uint8, torch.int32: np.int32, torch.float64: np.float64}[dt]
             info[name] = h[o:o + nbytes].view(npdt).reshape(shape)
         return obs, rew, term, trunc, info
+
+    # ------------------------------------------------------------------ host-resident step I/O (the dict facades)
+    def bind_host_io(self):
+        """The dict facades' step I/O without a copy in either direction: ONE pinned host block with the layout of `packed` (slab 0 | info tensors) that the step
+        kernel WRITES over the fabric (its outputs are write-only, nontemporal stores), and action arrays the kernel READS from pinned host memory (pinned host
+        memory is device-addressable at its own address on ROCm).  A one-market step then costs one launch and one stream synchronisation: no H2D / D2H copy call,
+        no second trip through the caching allocator.  Returns the block as a uint8 numpy array (valid after `sync_host_io()`); groups == 1 only."""
+        if self.groups != 1:
+            raise CDAError("host-resident step I/O is for single-launch envs (groups == 1)")
+        if getattr(self, "_hio", None) is None:
+            host = torch.zeros(self._all.numel(), dtype=torch.uint8).pin_memory()
+            base = host.data_ptr()
+            lay = self.slab_layout
+            outs = (base + lay["obs"], base + lay["reward"], base + lay["terminated"], base + lay["truncated"])
+            ptrs = K.InfoPtrs()
+            for name, (o, _dt, _shape, _nbytes) in self.info_layout.items():
+                setattr(ptrs, name, base + o)
+            self._hio = (host, outs, ptrs, C.byref(ptrs) if self.with_info else None)
+        return self._hio[0].numpy()
+
+    def step_host_io(self, action_ptrs):
+        """cda_step with the six action arrays at `action_ptrs` (category, size_mean, size_sigma, price, price_offset, present: pinned host or device addresses) and the
+        outputs into the block of bind_host_io(), on the caller's current stream.  Nothing is valid on the host before sync_host_io()."""
+        self.host_epoch += 1
+        _host, outs, _ptrs, info_ref = self._hio
+        stream = torch.cuda.current_stream(self.device)
+        if torch.cuda.current_device() == self.device_index:
+            rc = self._step_call(self._h, *action_ptrs, *outs, info_ref, stream.cuda_stream)
+        else:
+            with torch.cuda.device(self.device):
+                rc = self._step_call(self._h, *action_ptrs, *outs, info_ref, stream.cuda_stream)
+        if rc != 0:
+            check(rc, "cda_step")
+        self._hio_stream = stream
+
+    def reset_host_io(self, seed=None, mask=None):
+        """reset() whose observation lands in the block of bind_host_io() (slab 0's obs)."""
+        dev_obs = self.obs
+        try:
+            self.obs = _PtrOnly(self._hio[1][0])
+            self.reset(seed=seed, mask=mask)
+        finally:
+            self.obs = dev_obs
+        self._hio_stream = torch.cuda.current_stream(self.device)
+
+    def sync_host_io(self):
+        self._hio_stream.synchronize()
 
     def _bind_outputs(self):
         self.out_slab = self._slabs[self._cur]
