@@ -49,7 +49,7 @@ class League(C.Structure):
 
 class PpoExtra(C.Structure):
     """cda_ppo_extra (include/cda_mlp.h)"""
-    _fields_ = [("rec_stride", C.c_int32), ("kl_coef", C.c_float), ("vf_clip", C.c_float), ("dist_old", C.c_void_p), ("log_std_old", C.c_void_p)]
+    _fields_ = [("rec_stride", C.c_int32), ("kl_coef", C.c_float), ("vf_clip", C.c_float), ("dist_old", C.c_void_p), ("log_std_old", C.c_void_p), ("sd_log_std", C.c_int32)]
 
 
 class CDAError(RuntimeError):

@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             #pragma unroll
             for (int q = 0; q < N_LOGITS; q++) l[q] = outs[row * OUTS_LD + q];
             if (MODE == MODE_SAMPLE && a == 0 && !A.split_halves) A.value[grow] = outs[row * OUTS_LD + N_LOGITS];
-            const SampledAction sa = sample_action(l, key, i, ls0, ls1);         // (cda_mlp_dev.inc: the arithmetic k_policy_step shares)
+            // (log-std = the free vector + the row's outputs 25, 26: the state-dependent head's offsets, zero in a network built without it - include/cda_mlp.h sd_log_std)
+            const SampledAction sa = sample_action(l, key, i, ls0 + outs[row * OUTS_LD + N_LOGITS + 1], ls1 + outs[row * OUTS_LD + N_LOGITS + 2]);         // (cda_mlp_dev.inc: the arithmetic k_policy_step shares)
             const int c = sa.cat, p = sa.price, o = sa.off;
             const float x0 = sa.x0, x1 = sa.x1, lp = sa.logp;
             A.env_cat[i] = c; A.env_price[i] = p; A.env_off[i] = o;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
             }
         }
         if (A.dist && (MODE == MODE_SAMPLE || net < A.n_train)) {
-            // the rollout policy's distribution of every row, for the update's KL term: 22 normalised log-probabilities | 2 means (a thread per row)
+            // the rollout policy's distribution of every row, for the update's KL term: 22 normalised log-probabilities | 2 means | 2 log-stds | 2 zeros (a thread per row)
             float* dist = A.dist + (size_t)net * A.dist_stride;
             for (int row = (int)threadIdx.x; row < M; row += 256) {
                 const long long grow = row0 + row;
@@ -370,9 +371,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(FwdArgs A) {
                 #pragma unroll
                 for (int q = 0; q < N_LOGITS; q++) l[q] = outs[row * OUTS_LD + q];
                 dist_row(l, o24);
-                float4* dp = reinterpret_cast<float4*>(dist + grow * N_LOGITS);
+                float4* dp = reinterpret_cast<float4*>(dist + grow * CDA_MLP_DIST_LD);
                 #pragma unroll
                 for (int q = 0; q < N_LOGITS / 4; q++) dp[q] = make_float4(o24[4 * q], o24[4 * q + 1], o24[4 * q + 2], o24[4 * q + 3]);
+                dp[N_LOGITS / 4] = make_float4(ls0 + outs[row * OUTS_LD + N_LOGITS + 1], ls1 + outs[row * OUTS_LD + N_LOGITS + 2], 0.0f, 0.0f);   // the log-stds the row was sampled with
             }
         }
     }
@@ -741,7 +743,8 @@ struct FbArgs {
     const float* rec; const double* adv_stats; long long adv_count; int agents; float clip, vf_coef, ent_coef;
     int rec_stride;                  // floats between two rows' records (agents * 8 when a row's samples are all the row's agents; league: A * 8 with rec pointing at the trainable slot)
     float kl_coef, vf_clip;          // the KL penalty (coefficient x mean KL(rollout policy || current policy), exact per row) and the clamp of the squared value error (<= 0: off)
-    const float* dist_old; const float* log_std_old;      // kl_coef != 0: the rollout policy's distribution per row, f32 [*][24] (FwdArgs::dist), and its two log_std
+    const float* dist_old; const float* log_std_old;      // kl_coef != 0: the rollout policy's distribution per row, f32 [*][CDA_MLP_DIST_LD] (FwdArgs::dist; its log-stds ride in the row: log_std_old is not read)
+    int sd_log_std;                  // the state-dependent log-std head trains (include/cda_mlp.h cda_ppo_extra)
     __bf16* x_pk; __bf16* h1p; __bf16* h2p; __bf16* dz1p; __bf16* dz2p; __bf16* doutp; float* bias_slab;
     float* out; float* d_out;        // optional f32 [rows][32] copies of the outputs and their gradients (tests, diagnostics)
     double* sums5;
@@ -821,11 +824,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             const int c = (int)threadIdx.x + 256 * u, cc = c < N ? c : N - 1, r = cc / CH, q = cc - r * CH;
             v[u] = *reinterpret_cast<const obsvec*>(A.obs + srow[r] * OBS + (q < OBS / VW ? q : OBS / VW - 1) * VW);
         }
-        const int rp = 2 * A.agents, rpd = rp + (A.dist_old ? N_LOGITS / 4 : 0);    // the records: [agents][8] f32 per row = 2 16-B pieces per agent; then the row's old distribution (6 pieces)
+        const int rp = 2 * A.agents, rpd = rp + (A.dist_old ? CDA_MLP_DIST_LD / 4 : 0);    // the records: [agents][8] f32 per row = 2 16-B pieces per agent; then the row's old distribution (7 pieces)
         for (int c = (int)threadIdx.x; c < M * rpd; c += 256) {
             const int r = c / rpd, q = c - r * rpd;
             reinterpret_cast<float4*>(recs)[c] = q < rp ? reinterpret_cast<const float4*>(A.rec + srow[r] * A.rec_stride)[q]
-                                                        : reinterpret_cast<const float4*>(A.dist_old + srow[r] * N_LOGITS)[q - rp];
+                                                        : reinterpret_cast<const float4*>(A.dist_old + srow[r] * CDA_MLP_DIST_LD)[q - rp];
         }
         #pragma unroll
         for (int u = 0; u < PER; u++) {
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
         // 7.5 k cycles with the other three waves waiting.)
         const int row = 16 * w + (lane >> 2), sq = lane & 3, i0 = 6 * sq;
         const bool live = row0 + row < rows_end;
-        const int rec_ld = A.agents * 8 + (A.dist_old ? N_LOGITS : 0);
+        const int rec_ld = A.agents * 8 + (A.dist_old ? CDA_MLP_DIST_LD : 0);
         const float* rr = recs + (size_t)row * rec_ld;
         float* orow = outs + row * OUTS_LD;
         __bf16* drow = dos + row * DO_LD;
@@ -960,7 +963,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             hh[t] = quad_sum(x);
         }
         const float mean0 = quad_bcast<3>(l[4]), mean1 = quad_bcast<3>(l[5]);   // outputs 22, 23: lane 3's last two
-        const float ls0 = A.theta[CDA_MLP_OFF_LS], ls1 = A.theta[CDA_MLP_OFF_LS + 1];
+        // the row's two log-stds: the free vector + outputs 25, 26 (the state-dependent head's offsets; zero in a network without the head) - read before the
+        // tile's columns 24 .. 31 are overwritten with their gradients below (same wave, program order)
+        const float lo0 = orow[N_LOGITS + 1], lo1 = orow[N_LOGITS + 2];
+        const float ls0 = A.theta[CDA_MLP_OFF_LS] + lo0, ls1 = A.theta[CDA_MLP_OFF_LS + 1] + lo1;
         const float is0 = __expf(-ls0), is1 = __expf(-ls1);
         const float HALF_LOG_2PI = 0.918938533204672742f;
         const float ent = hh[0] + hh[1] + hh[2] + 1.0f + 2.0f * HALF_LOG_2PI + ls0 + ls1;
@@ -1019,21 +1025,30 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             }
             kc = quad_sum(kc);
             const float mo0 = quad_bcast<3>(om[4]), mo1 = quad_bcast<3>(om[5]);
-            const float lso0 = A.log_std_old[0], lso1 = A.log_std_old[1];
+            const float lso0 = rr[A.agents * 8 + N_LOGITS], lso1 = rr[A.agents * 8 + N_LOGITS + 1];     // the log-stds the row was sampled with
             const float q0 = (__expf(2.0f * lso0) + (mo0 - mean0) * (mo0 - mean0)) * is0 * is0, q1 = (__expf(2.0f * lso1) + (mo1 - mean1) * (mo1 - mean1)) * is1 * is1;
             const float kg = (ls0 - lso0) + 0.5f * q0 - 0.5f + (ls1 - lso1) + 0.5f * q1 - 0.5f;
             dm0 += klw * (mean0 - mo0) * is0 * is0; dm1 += klw * (mean1 - mo1) * is1 * is1;
             if (sq == 0) { dls0 += klw * (1.0f - q0); dls1 += klw * (1.0f - q1); klsum = (kc + kg) * (float)A.agents; }
         }
         if (sq == 3) { d[4] = dm0; d[5] = dm1; }
+        // columns 24 .. 31 of the row, two per lane of the quad: 24 is the value workgroup's (zero here), 25 / 26 carry d loss / d log_std of THIS row when the
+        // state-dependent head trains (the row's agents' terms summed over the quad; the free vector's sums are then zero), 27 .. 31 zero
+        float e0 = 0.0f, e1 = 0.0f;
+        if (A.sd_log_std) {
+            const float D0 = quad_sum(dls0), D1 = quad_sum(dls1);
+            if (sq == 0) e1 = D0;
+            if (sq == 1) e0 = D1;
+            dls0 = dls1 = 0.0f;
+        }
         if (A.out && live) {
             #pragma unroll
             for (int k = 0; k < 6; k++) A.out[(row0 + row) * NOUT + i0 + k] = l[k];
-            if (sq != 0) A.out[(row0 + row) * NOUT + N_LOGITS + 2 * sq] = 0.0f;
-            A.out[(row0 + row) * NOUT + N_LOGITS + 2 * sq + 1] = 0.0f;
+            if (sq != 0) A.out[(row0 + row) * NOUT + N_LOGITS + 2 * sq] = sq == 1 ? lo1 : 0.0f;
+            A.out[(row0 + row) * NOUT + N_LOGITS + 2 * sq + 1] = sq == 0 ? lo0 : 0.0f;
         }
         if (!live) {
-            pg = en = dls0 = dls1 = klsum = 0.0f;
+            pg = en = dls0 = dls1 = klsum = e0 = e1 = 0.0f;
             #pragma unroll
             for (int k = 0; k < 6; k++) d[k] = 0.0f;
         }
@@ -1045,13 +1060,13 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
             f32x2 f; f[0] = d[k]; f[1] = d[k + 1];
             *reinterpret_cast<bf16x2*>(drow + i0 + k) = __builtin_convertvector(f, bf16x2);
         }
-        orow[N_LOGITS + 2 * sq] = 0.0f; orow[N_LOGITS + 2 * sq + 1] = 0.0f;     // columns 24 .. 31: zero (24 is the value workgroup's, in its own tile)
-        { f32x2 f; f[0] = 0.0f; f[1] = 0.0f; *reinterpret_cast<bf16x2*>(drow + N_LOGITS + 2 * sq) = __builtin_convertvector(f, bf16x2); }
+        orow[N_LOGITS + 2 * sq] = e0; orow[N_LOGITS + 2 * sq + 1] = e1;         // columns 24 .. 31 (24 is the value workgroup's, in its own tile)
+        { f32x2 f; f[0] = e0; f[1] = e1; *reinterpret_cast<bf16x2*>(drow + N_LOGITS + 2 * sq) = __builtin_convertvector(f, bf16x2); }
         if (A.d_out && live) {
             #pragma unroll
             for (int k = 0; k < 6; k++) A.d_out[(row0 + row) * NOUT + i0 + k] = d[k];
-            if (sq != 0) A.d_out[(row0 + row) * NOUT + N_LOGITS + 2 * sq] = 0.0f;
-            A.d_out[(row0 + row) * NOUT + N_LOGITS + 2 * sq + 1] = 0.0f;
+            if (sq != 0) A.d_out[(row0 + row) * NOUT + N_LOGITS + 2 * sq] = e0;
+            A.d_out[(row0 + row) * NOUT + N_LOGITS + 2 * sq + 1] = e1;
         }
         float v4[5] = {pg, en, dls0, dls1, klsum};
         #pragma unroll
@@ -1069,7 +1084,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fb(FbArgs A) {     // (two workg
     } else if (w == 0) {                                                        // the value loss: a lane per row
         const int row = lane;
         const bool live = row0 + row < rows_end;
-        const float* rr = recs + (size_t)row * (A.agents * 8 + (A.dist_old ? N_LOGITS : 0));
+        const float* rr = recs + (size_t)row * (A.agents * 8 + (A.dist_old ? CDA_MLP_DIST_LD : 0));
         float* orow = outs + row * OUTS_LD;
         __bf16* drow = dos + row * DO_LD;
         const float val = orow[N_LOGITS];
@@ -1295,7 +1310,7 @@ __device__ __forceinline__ int param_of_dense(int d) {
     if (d < CDA_MLP_SLAB_W2) { const int o = d / (32 * XT), i = d - o * (32 * XT); return i < OBS ? CDA_MLP_OFF_W1 + o * OBS + i : -1; }
     if (d < CDA_MLP_SLAB_WO) return CDA_MLP_OFF_W2 + (d - CDA_MLP_SLAB_W2);
     const int q = d - CDA_MLP_SLAB_WO, o = q / CDA_MLP_FEAT, c = q - o * CDA_MLP_FEAT;
-    if (o < N_LOGITS) return c < HID ? CDA_MLP_OFF_WO + o * HID + c : -1;
+    if (o < N_LOGITS || o == N_LOGITS + 1 || o == N_LOGITS + 2) return c < HID ? CDA_MLP_OFF_WO + o * HID + c : -1;     // (25, 26: the log-std head's rows - zero gradient unless it trains)
     if (o == N_LOGITS) return c >= HID ? CDA_MLP_OFF_WO + N_LOGITS * HID + (c - HID) : -1;
     return -1;
 }
@@ -1364,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
             int p = -1;
             if (e < CDA_MLP_FEAT) p = CDA_MLP_OFF_B1 + e;
             else if (e < 2 * CDA_MLP_FEAT) p = CDA_MLP_OFF_B2 + (e - CDA_MLP_FEAT);
-            else if (e < CDA_MLP_BSLAB) { const int o = e - 2 * CDA_MLP_FEAT; p = CDA_MLP_OFF_BO + o; if (o > N_LOGITS) g = 0.0f; }
+            else if (e < CDA_MLP_BSLAB) { const int o = e - 2 * CDA_MLP_FEAT; p = CDA_MLP_OFF_BO + o; if (o > N_LOGITS + 2) g = 0.0f; }
             if (p >= 0) { grad[p] = g; sq = g * g; }
             if (e == CDA_MLP_BSLAB) {
                 // log_std: its gradient comes with the loss sums (words 3, 4); this one thread also finishes the loss statistics (out6, what
@@ -1409,7 +1424,7 @@ __device__ __forceinline__ void pack_one(int p, float v, __bf16* __restrict__ wb
         wb[CDA_MLP_WB_W2T + ((size_t)blk * 4 + (i >> 6)) * 64 * HID + op_index(HID / 16, i & 1, o, (i & 63) >> 1)] = b;
     } else if (p >= CDA_MLP_OFF_WO && p < CDA_MLP_OFF_BO) {                      // Wo[o][i] -> Wop (one tile of 32 outputs per half) and WoTp (rows = features, k = outputs)
         const int q = p - CDA_MLP_OFF_WO, o = q / HID, i = q - o * HID;
-        if (o <= N_LOGITS) {
+        if (o <= N_LOGITS + 2) {                                                 // (25, 26: the log-std head's rows of the policy half)
             const int hf = o == N_LOGITS ? 1 : 0;
             wb[CDA_MLP_WB_WO + (size_t)hf * NOUT * HID + op_index(HID / 16, 0, i, o)] = b;
             wb[CDA_MLP_WB_WOT + ((size_t)hf * 4 + (i >> 6)) * 64 * NOUT + op_index(NOUT / 16, i & 1, o, (i & 63) >> 1)] = b;
@@ -1783,7 +1798,7 @@ int train_mt() {
 }
 size_t fwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * XS_LD * 2 + 2 * M * ACT_LD * 2; }
 size_t bwd8_lds(int mt) { const size_t M = 32 * (size_t)mt; return M * DO_LD * 2 + M * OUTS_LD * 4 + 2 * M * ACT_LD * 2; }
-size_t fb_lds(int agents, bool with_dist) { return (size_t)FB_XS_BYTES + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * (agents * 32 + (with_dist ? N_LOGITS * 4 : 0)); }
+size_t fb_lds(int agents, bool with_dist) { return (size_t)FB_XS_BYTES + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * (agents * 32 + (with_dist ? CDA_MLP_DIST_LD * 4 : 0)); }
 int rollout_mt() {
     static int mt = 0;
     if (!mt) { const char* e = getenv("CDA_MLP_ROLLOUT_MT"); mt = e ? atoi(e) : 1; if (mt != 1 && mt != 2 && mt != 4) mt = 1; }
@@ -1945,7 +1960,7 @@ extern "C" int cda_mlp_forward_backward(const void* wb, const float* theta, cons
                                         double* sums5, float* out6, int32_t clear, int32_t finish, float* out, float* d_out, void* stream) {
     if (!wb || !theta || !obs || !rec || !x_pk || !h1p || !h2p || !dz1p || !dz2p || !doutp || !bias_slab || !sums5 || n_rows < 32 || (n_rows & 31) || norm_rows < 0 ||
         agents_per_row < 1 || agents_per_row > CDA_MAX_AGENTS || (adv_stats2 && adv_count < 2) || (finish && !out6)) return CDA_ERR_INVALID;
-    if (extra && ((extra->rec_stride != 0 && extra->rec_stride < agents_per_row * 8) || (extra->rec_stride & 3) || (extra->kl_coef != 0.0f && (!extra->dist_old || !extra->log_std_old))))
+    if (extra && ((extra->rec_stride != 0 && extra->rec_stride < agents_per_row * 8) || (extra->rec_stride & 3) || (extra->kl_coef != 0.0f && !extra->dist_old)))
         return CDA_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     FbArgs A; memset(&A, 0, sizeof A);
@@ -1953,7 +1968,7 @@ extern "C" int cda_mlp_forward_backward(const void* wb, const float* theta, cons
     A.rec = rec; A.adv_stats = adv_stats2; A.adv_count = adv_count; A.agents = agents_per_row; A.clip = clip; A.vf_coef = vf_coef; A.ent_coef = ent_coef;
     A.rec_stride = extra && extra->rec_stride ? extra->rec_stride : agents_per_row * 8;
     A.kl_coef = extra ? extra->kl_coef : 0.0f; A.vf_clip = extra ? extra->vf_clip : 0.0f;
-    A.dist_old = extra && extra->kl_coef != 0.0f ? extra->dist_old : NULL; A.log_std_old = extra ? extra->log_std_old : NULL;
+    A.dist_old = extra && extra->kl_coef != 0.0f ? extra->dist_old : NULL; A.log_std_old = extra ? extra->log_std_old : NULL; A.sd_log_std = extra ? extra->sd_log_std : 0;
     A.x_pk = (__bf16*)x_pk; A.h1p = (__bf16*)h1p; A.h2p = (__bf16*)h2p; A.dz1p = (__bf16*)dz1p; A.dz2p = (__bf16*)dz2p; A.doutp = (__bf16*)doutp; A.bias_slab = bias_slab;
     A.out = out; A.d_out = d_out; A.sums5 = sums5;
     size_t lds = fb_lds(agents_per_row, A.dist_old != NULL);
@@ -2185,7 +2200,7 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
             const int rc1 = cda_policy_step_range(env, first_market, n_markets, wb, theta, B->obs + (size_t)t * N * OBS, seed, counter_dev, t,
                                                   B->category + o, B->size_mean + o, B->size_sigma + o, B->price + o, B->price_offset + o,
                                                   B->a_cont + 2 * o, B->logp + o, B->value + (size_t)t * N, B->record ? B->record + 8 * o : NULL,
-                                                  B->dist ? B->dist + (size_t)t * N * N_LOGITS : NULL,
+                                                  B->dist ? B->dist + (size_t)t * N * CDA_MLP_DIST_LD : NULL,
                                                   B->obs + (size_t)(t + 1) * N * OBS, B->reward + o, B->terminated + (size_t)t * N, B->truncated + (size_t)t * N,
                                                   B->fin_obs, B->fin_cap, B->fin_count, B->fin_index ? B->fin_index + (size_t)t * N : NULL, stream);
             if (rc1 == CDA_OK) continue;
@@ -2200,12 +2215,12 @@ static int rollout_chain(cda_env* env, const cda_league* L, const void* wb, cons
         P.env_cat = B->category + o; P.env_mean = B->size_mean + o; P.env_sigma = B->size_sigma + o; P.env_price = B->price + o; P.env_off = B->price_offset + o;
         P.a_cont = B->a_cont + 2 * o; P.logp = B->logp + o; P.value = B->value + (size_t)t * N;
         P.rec = B->record ? B->record + 8 * o : NULL;
-        P.dist = B->dist ? B->dist + (size_t)t * N * N_LOGITS : NULL;
+        P.dist = B->dist ? B->dist + (size_t)t * N * CDA_MLP_DIST_LD : NULL;
         P.split_halves = 1;
         int rc;
         if (L) {
             P.n_train = n_train; P.slot_net = L->slot_net; P.random_seed = L->random_seed;
-            P.value_stride = (long long)(n_steps + 1) * N; P.dist_stride = (long long)n_steps * N * N_LOGITS;
+            P.value_stride = (long long)(n_steps + 1) * N; P.dist_stride = (long long)n_steps * N * CDA_MLP_DIST_LD;
             rc = launch_fwd<MODE_LEAGUE>(P, rollout_mt(), st, (unsigned)(L->n_trainable + L->n_nets));
         } else rc = launch_fwd<MODE_SAMPLE>(P, rollout_mt(), st);
         if (rc) return rc;

@@ -16,6 +16,11 @@ import math
 import torch
 
 HID, FEAT, NOUT, N_LOGITS, BSLAB = 256, 512, 32, 24, 1056
+#: floats per row of a rollout's distribution record (include/cda_mlp.h CDA_MLP_DIST_LD): 22 normalised log-probabilities | 2 means | the 2 log-stds sampled with | 2 zeros
+DIST_LD = 28
+#: output rows of the policy half: the 24 logits / means and (rows 25, 26) the state-dependent log-std head's offsets - zero rows in a network built without the head
+LS_ROWS = (N_LOGITS + 1, N_LOGITS + 2)
+POLICY_ROWS = list(range(N_LOGITS)) + list(LS_ROWS)
 #: history depths the network kernels are compiled for (include/cda_mlp.h CDA_MLP_HIST + CDA_MLP_HIST_VARIANTS): 4 = the reference's n_hist, the unsuffixed entry points
 HIST_VARIANTS = (1, 2, 4, 8)
 
@@ -86,8 +91,10 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def init_theta(obs_dim=OBS, generator=None):
-    """A fresh parameter vector with nn.Linear's default initialisation per block (uniform +-1/sqrt(fan_in)), log_std = -0.5; obs_dim = 42 n_hist."""
+def init_theta(obs_dim=OBS, generator=None, state_dependent_log_std=False):
+    """A fresh parameter vector with nn.Linear's default initialisation per block (uniform +-1/sqrt(fan_in)), log_std = -0.5; obs_dim = 42 n_hist.
+    state_dependent_log_std: rows 25, 26 of the output layer - the log-std head's offsets on top of the free vector, RLlib's default module for Box actions
+    (train/policy/policy_handler.py:69-76) - are initialised like every other output row instead of zero (`has_log_std_head(theta)` tells the two apart)."""
     if obs_dim % 42:
         raise ValueError("an observation is n_hist frames of 42 floats")
     L = layout(obs_dim // 42)
@@ -95,11 +102,19 @@ def init_theta(obs_dim=OBS, generator=None):
     th = torch.zeros(L.PARAMS)
     th[L.OFF_W1:L.OFF_B1] = u(FEAT * L.OBS, L.OBS); th[L.OFF_B1:L.OFF_W2] = u(FEAT, L.OBS)
     th[L.OFF_W2:L.OFF_B2] = u(2 * HID * HID, HID); th[L.OFF_B2:L.OFF_WO] = u(FEAT, HID)
-    wo = u(NOUT * HID, HID).view(NOUT, HID); wo[N_LOGITS + 1:] = 0
-    bo = u(NOUT, HID); bo[N_LOGITS + 1:] = 0
+    wo = u(NOUT * HID, HID).view(NOUT, HID); bo = u(NOUT, HID)
+    dead = [r for r in range(N_LOGITS + 1, NOUT) if not (state_dependent_log_std and r in LS_ROWS)]
+    wo[dead] = 0; bo[dead] = 0
     th[L.OFF_WO:L.OFF_BO] = wo.reshape(-1); th[L.OFF_BO:L.OFF_LS] = bo
     th[L.OFF_LS:] = -0.5
     return th
+
+
+def has_log_std_head(theta):
+    """does this parameter vector carry a state-dependent log-std head (non-zero rows 25, 26 of the output layer)?"""
+    L = layout_of_params(theta.numel())
+    wo = theta[L.OFF_WO:L.OFF_BO].view(NOUT, HID)
+    return bool((wo[list(LS_ROWS)] != 0).any() or (theta[L.OFF_BO:L.OFF_LS][list(LS_ROWS)] != 0).any())
 
 
 def theta_from_actor_critic(model):
@@ -117,8 +132,12 @@ def theta_from_actor_critic(model):
         wo = model.out.weight.detach().float().cpu()
         blk = torch.zeros(NOUT, H)
         blk[:N_LOGITS] = wo[:N_LOGITS, :H]; blk[N_LOGITS] = wo[N_LOGITS, H:]
+        bo = model.out.bias.detach().float().cpu().clone()
+        if getattr(model, "state_dependent_log_std", False):
+            blk[list(LS_ROWS)] = wo[list(LS_ROWS), :H]; bo[N_LOGITS + 3:] = 0
+        else:
+            bo[N_LOGITS + 1:] = 0
         th[L.OFF_WO:L.OFF_BO] = blk.reshape(-1)
-        bo = model.out.bias.detach().float().cpu().clone(); bo[N_LOGITS + 1:] = 0
         th[L.OFF_BO:L.OFF_LS] = bo
         th[L.OFF_LS:] = model.log_std.detach().float().cpu()
     return th
@@ -128,7 +147,8 @@ def actor_critic_from_theta(theta, dtype=torch.float32):
     from .ppo import ActorCritic
     th = theta.detach().float().cpu()
     L = layout_of_params(th.numel())
-    m = ActorCritic(L.OBS).to(dtype)
+    sd = has_log_std_head(th)
+    m = ActorCritic(L.OBS, state_dependent_log_std=sd).to(dtype)
     H = HID
     with torch.no_grad():
         m.l1.weight.copy_(th[L.OFF_W1:L.OFF_B1].view(FEAT, L.OBS)); m.l1.bias.copy_(th[L.OFF_B1:L.OFF_W2])
@@ -136,6 +156,8 @@ def actor_critic_from_theta(theta, dtype=torch.float32):
         m.l2.weight.zero_(); m.l2.weight[:H, :H] = w2[0]; m.l2.weight[H:, H:] = w2[1]; m.l2.bias.copy_(th[L.OFF_B2:L.OFF_WO])
         wo = th[L.OFF_WO:L.OFF_BO].view(NOUT, H)
         m.out.weight.zero_(); m.out.weight[:N_LOGITS, :H] = wo[:N_LOGITS]; m.out.weight[N_LOGITS, H:] = wo[N_LOGITS]
+        if sd:
+            m.out.weight[list(LS_ROWS), :H] = wo[list(LS_ROWS)]
         m.out.bias.copy_(th[L.OFF_BO:L.OFF_LS]); m.log_std.copy_(th[L.OFF_LS:])
     return m
 
@@ -159,7 +181,7 @@ def reference_outputs(theta, x, emulate_bf16=True, dtype=torch.float64, keep=Fal
     h1 = rd(torch.tanh(xb @ W1.t() + b1))
     h2 = torch.cat([rd(torch.tanh(h1[:, :HID] @ W2[0].t() + b2[:HID])), rd(torch.tanh(h1[:, HID:] @ W2[1].t() + b2[HID:]))], dim=1)
     out = torch.zeros(x.shape[0], NOUT, dtype=dtype)
-    out[:, :N_LOGITS] = h2[:, :HID] @ Wo[:N_LOGITS].t() + bo[:N_LOGITS]
+    out[:, POLICY_ROWS] = h2[:, :HID] @ Wo[POLICY_ROWS].t() + bo[POLICY_ROWS]          # (rows 25, 26: the log-std head's offsets; zero rows without the head)
     out[:, N_LOGITS] = h2[:, HID:] @ Wo[N_LOGITS] + bo[N_LOGITS]
     return (out, xb, h1, h2) if keep else out
 
@@ -173,7 +195,7 @@ def reference_gradients(theta, xb, h1, h2, d_out, dtype=torch.float64):
     W2 = _r(th[OFF_W2:OFF_B2].view(2, HID, HID)); Wo = _r(th[OFF_WO:OFF_BO].view(NOUT, HID))
     d_out = d_out.detach().cpu().to(dtype)
     dob = _r(d_out)
-    dh2 = torch.cat([dob[:, :N_LOGITS] @ Wo[:N_LOGITS], dob[:, N_LOGITS:N_LOGITS + 1] @ Wo[N_LOGITS:N_LOGITS + 1]], dim=1)
+    dh2 = torch.cat([dob[:, POLICY_ROWS] @ Wo[POLICY_ROWS], dob[:, N_LOGITS:N_LOGITS + 1] @ Wo[N_LOGITS:N_LOGITS + 1]], dim=1)
     dz2 = _r(dh2 * (1 - h2 * h2))
     dh1 = torch.cat([dz2[:, :HID] @ W2[0], dz2[:, HID:] @ W2[1]], dim=1)
     dz1 = _r(dh1 * (1 - h1 * h1))
@@ -181,9 +203,9 @@ def reference_gradients(theta, xb, h1, h2, d_out, dtype=torch.float64):
     g[OFF_W1:OFF_B1] = (dz1.t() @ xb).reshape(-1); g[OFF_B1:OFF_W2] = dz1.sum(0)
     g[OFF_W2:OFF_B2] = torch.stack([dz2[:, :HID].t() @ h1[:, :HID], dz2[:, HID:].t() @ h1[:, HID:]]).reshape(-1); g[OFF_B2:OFF_WO] = dz2.sum(0)
     gwo = torch.zeros(NOUT, HID, dtype=dtype)
-    gwo[:N_LOGITS] = dob[:, :N_LOGITS].t() @ h2[:, :HID]; gwo[N_LOGITS] = dob[:, N_LOGITS] @ h2[:, HID:]
+    gwo[POLICY_ROWS] = dob[:, POLICY_ROWS].t() @ h2[:, :HID]; gwo[N_LOGITS] = dob[:, N_LOGITS] @ h2[:, HID:]
     g[OFF_WO:OFF_BO] = gwo.reshape(-1)
-    gbo = torch.zeros(NOUT, dtype=dtype); gbo[:N_LOGITS + 1] = d_out[:, :N_LOGITS + 1].sum(0)
+    gbo = torch.zeros(NOUT, dtype=dtype); gbo[:N_LOGITS + 3] = d_out[:, :N_LOGITS + 3].sum(0)
     g[OFF_BO:OFF_LS] = gbo
     return g, dz1, dz2
 
@@ -210,15 +232,18 @@ class FusedPolicy:
     """theta (f32 master copy), Adam state and the bf16 operand blob on one HIP device.  storage = (theta row, wb row): views into a PolicyBank's
     banks instead of tensors of its own (the league's kernels address a net as a row of the banks)."""
 
-    def __init__(self, device, theta=None, seed=0, storage=None, n_hist=None):
-        """n_hist: the history depth of the observations (default: the depth `theta` was laid out for, else the reference's 4)"""
+    def __init__(self, device, theta=None, seed=0, storage=None, n_hist=None, state_dependent_log_std=None):
+        """n_hist: the history depth of the observations (default: the depth `theta` was laid out for, else the reference's 4).
+        state_dependent_log_std: RLlib's default head for Box actions - the policy network emits two log-std offsets per row (output rows 25, 26) on top of the free
+        log_std vector, and the update trains them (FusedUpdate reads this attribute); default: what `theta` carries (has_log_std_head), False for a fresh network."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FusedPolicy needs a HIP device; the PyTorch statement of the network is ppo.ActorCritic")
         if theta is None:
             g = torch.Generator().manual_seed(int(seed))
-            theta = init_theta(42 * int(n_hist or 4), generator=g)
+            theta = init_theta(42 * int(n_hist or 4), generator=g, state_dependent_log_std=bool(state_dependent_log_std))
         self.L = L = layout_of_params(theta.numel())
+        self.state_dependent_log_std = has_log_std_head(theta) if state_dependent_log_std is None else bool(state_dependent_log_std)
         if n_hist is not None and int(n_hist) != L.hist:
             raise ValueError(f"theta is laid out for n_hist = {L.hist}, not {n_hist}")
         if storage is None:
@@ -287,7 +312,7 @@ class PolicyBank:
     rollout with no copy), the rows behind them frozen snapshots (champions: league_based_self_play_callback.py:938-1170).  slot_net i32 [N, A] names
     the row that plays each (market, slot), LEAGUE_RANDOM = the uniform random module."""
 
-    def __init__(self, device, n_markets, num_agents, n_trainable, max_frozen=8, seed=0, random_seed=0, n_hist=4):
+    def __init__(self, device, n_markets, num_agents, n_trainable, max_frozen=8, seed=0, random_seed=0, n_hist=4, state_dependent_log_std=False):
         from ._lib import League
         self.device = torch.device(device)
         self.L = L = layout(n_hist)
@@ -298,7 +323,8 @@ class PolicyBank:
         n_max = self.n_trainable + self.max_frozen
         self.theta = torch.zeros((n_max, PARAMS), dtype=torch.float32, device=self.device)
         self.wb = torch.zeros((n_max, WB_ELEMS), dtype=torch.bfloat16, device=self.device)
-        self.policies = [FusedPolicy(self.device, seed=seed + 7919 * p, storage=(self.theta[p], self.wb[p]), n_hist=L.hist) for p in range(self.n_trainable)]
+        self.policies = [FusedPolicy(self.device, seed=seed + 7919 * p, storage=(self.theta[p], self.wb[p]), n_hist=L.hist, state_dependent_log_std=state_dependent_log_std)
+                         for p in range(self.n_trainable)]
         self.slot_net = torch.full((int(n_markets), int(num_agents)), LEAGUE_RANDOM, dtype=torch.int32, device=self.device)
         self.slot_net[:, :self.n_trainable] = torch.arange(self.n_trainable, dtype=torch.int32, device=self.device)
         self.random_seed = int(random_seed) & (2 ** 64 - 1)
@@ -382,7 +408,7 @@ class RolloutChains:
                     "record": e((T, N, A, 8), torch.float32)}          # include/cda_mlp.h CDA_REC_*: what the update's loss reads, one line per row
         ptrs = {k: v.data_ptr() for k, v in self.buf.items()}
         if with_dist:
-            self.buf["dist"] = e((kn, T, N, N_LOGITS) if self.bank else (T, N, N_LOGITS), torch.float32)
+            self.buf["dist"] = e((kn, T, N, DIST_LD) if self.bank else (T, N, DIST_LD), torch.float32)
             self.log_std_old = e((kn, 2), torch.float32)               # the rollout policy's log_std (the update moves theta's)
             ptrs["dist"] = self.buf["dist"].data_ptr()
         self.with_dist = bool(with_dist)
@@ -635,15 +661,21 @@ class FusedUpdate:
         self.x_pk_mb = e(pad64 * 32 * XT, bf) if self.fused else None         # the fused kernel's packed image of the minibatch's observations
         self.shuffle_seed, self._epochs_done = 0x5DEECE66D, 0
         self._extra = None
+        self.set_extra()                                                    # (a policy with the state-dependent log-std head trains it from the first step)
 
-    def set_extra(self, rec_stride=0, kl_coef=0.0, vf_clip=0.0, dist_old=None, log_std_old=None):
-        """what cda_ppo_extra carries (fused path): the record stride of a league update, RLlib's KL penalty and value-error clamp"""
+    def set_extra(self, rec_stride=0, kl_coef=0.0, vf_clip=0.0, dist_old=None, log_std_old=None, sd_log_std=None):
+        """what cda_ppo_extra carries (fused path): the record stride of a league update, RLlib's KL penalty and value-error clamp, and whether the state-dependent
+        log-std head trains (default: the policy's own `state_dependent_log_std`).  dist_old: rows of DIST_LD floats (RolloutChains.buf["dist"]); log_std_old is not
+        read any more (the rows carry the log-stds they were sampled with)."""
         from ._lib import PpoExtra
-        if not (rec_stride or kl_coef or vf_clip):
+        sd = bool(getattr(self.p, "state_dependent_log_std", False)) if sd_log_std is None else bool(sd_log_std)
+        if sd and not self.fused:
+            raise ValueError("the state-dependent log-std head trains on the fused update kernel only (FusedUpdate(fused=True))")
+        if not (rec_stride or kl_coef or vf_clip or sd):
             self._extra, self._kl = None, 0.0
             return
         x = PpoExtra()
-        x.rec_stride, x.kl_coef, x.vf_clip = int(rec_stride), float(kl_coef), float(vf_clip)
+        x.rec_stride, x.kl_coef, x.vf_clip, x.sd_log_std = int(rec_stride), float(kl_coef), float(vf_clip), int(sd)
         x.dist_old = dist_old.data_ptr() if (dist_old is not None and kl_coef) else None
         x.log_std_old = log_std_old.data_ptr() if (log_std_old is not None and kl_coef) else None
         self._extra, self._kl, self._extra_keep = x, float(kl_coef), (dist_old, log_std_old)

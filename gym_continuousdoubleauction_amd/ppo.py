@@ -75,9 +75,12 @@ class ActorCritic(nn.Module):
     backward pass take 12 ms of host time, tools/ppo_probe.py)."""
     N_OUT, N_PAD = CAT_N + PRICE_N + OFF_N + 2, 32
 
-    def __init__(self, obs_dim, hidden=256):
+    def __init__(self, obs_dim, hidden=256, state_dependent_log_std=False):
+        """state_dependent_log_std: RLlib's default module for Box actions (what the reference's PPO modules are, train/policy/policy_handler.py:69-76): rows 25, 26 of
+        the output matrix read the policy half and are per-row log-std OFFSETS on top of the free `log_std` vector (which then stays where it is)."""
         super().__init__()
         self.hidden = hidden
+        self.state_dependent_log_std = bool(state_dependent_log_std)
         H = hidden
         self.l1 = _Linear(obs_dim, 2 * H)                         # [policy | value] first layers
         self.l2 = _Linear(2 * H, 2 * H)
@@ -86,6 +89,8 @@ class ActorCritic(nn.Module):
         m2[:H, :H] = 1; m2[H:, H:] = 1
         mo = torch.zeros(self.N_PAD, 2 * H)
         mo[:self.N_OUT, :H] = 1; mo[self.N_OUT, H:] = 1
+        if self.state_dependent_log_std:
+            mo[self.N_OUT + 1:self.N_OUT + 3, :H] = 1
         self.register_buffer("mask2", m2)
         self.register_buffer("mask_out", mo)
         with torch.no_grad():                                      # every block initialised as the nn.Linear(256, .) it stands for
@@ -93,13 +98,21 @@ class ActorCritic(nn.Module):
                 bound = 1.0 / math.sqrt(H)
                 w.uniform_(-bound, bound); b.uniform_(-bound, bound)
             self.l2.weight.mul_(m2); self.out.weight.mul_(mo)
-            self.out.bias[self.N_OUT + 1:] = 0
-        self.log_std = nn.Parameter(torch.full((2,), -0.5))
+            self.out.bias[self.N_OUT + (3 if self.state_dependent_log_std else 1):] = 0
+        self.log_std = nn.Parameter(torch.full((2,), -0.5), requires_grad=not self.state_dependent_log_std)
 
     def trunk(self, obs):
         """-> (policy outputs [B, 24], value [B])"""
         o = self.trunk_packed(obs)
         return o[:, :self.N_OUT], o[:, self.N_OUT]
+
+    def trunk_ls(self, obs):
+        """-> (policy outputs [B, 24], value [B], log-stds [B, 2]: the free vector, plus the row's offsets with the state-dependent head)"""
+        o = self.trunk_packed(obs)
+        ls = self.log_std.float().expand(o.shape[0], 2)
+        if self.state_dependent_log_std:
+            ls = ls + o[:, self.N_OUT + 1:self.N_OUT + 3].float()
+        return o[:, :self.N_OUT], o[:, self.N_OUT], ls
 
     def trunk_packed(self, obs):
         """-> the padded output matrix [B, 32] as the last product leaves it: policy outputs in columns 0..23, the value in column 24
@@ -114,7 +127,7 @@ class ActorCritic(nn.Module):
     def v(self, obs):
         return self.trunk(obs)[1].unsqueeze(-1)
 
-    def _dists(self, o):
+    def _dists(self, o, log_std=None):
         # validate_args=False: the argument checks read a flag back to the host, which neither a captured HIP graph
         # nor an asynchronous rollout can afford
         o = o.float()
@@ -122,15 +135,16 @@ class ActorCritic(nn.Module):
         price = torch.distributions.Categorical(logits=o[:, CAT_N:CAT_N + PRICE_N], validate_args=False)
         off = torch.distributions.Categorical(logits=o[:, CAT_N + PRICE_N:CAT_N + PRICE_N + OFF_N], validate_args=False)
         mu = o[:, -2:]
-        cont = torch.distributions.Normal(mu, self.log_std.exp().expand_as(mu), validate_args=False)
+        cont = torch.distributions.Normal(mu, (self.log_std if log_std is None else log_std).exp().expand_as(mu), validate_args=False)
         return cat, price, off, cont
 
     def dists(self, obs):
-        return self._dists(self.trunk(obs)[0])
+        o, _, ls = self.trunk_ls(obs)
+        return self._dists(o, ls)
 
     def act(self, obs):
-        o, val = self.trunk(obs)
-        cat, price, off, cont = self._dists(o)
+        o, val, ls = self.trunk_ls(obs)
+        cat, price, off, cont = self._dists(o, ls)
         # Normal.sample() checks std >= 0 on the host (a sync, illegal inside a captured graph): draw the noise directly
         a_cat, a_price, a_off = cat.sample(), price.sample(), off.sample()
         a_cont = (cont.loc + cont.scale * torch.randn_like(cont.loc)).detach()
@@ -143,6 +157,8 @@ class ActorCritic(nn.Module):
         shared=False: `obs` holds one row per (market, agent) pair, [n * a, obs_dim].  shared=True: one row per market, [n, obs_dim] -
         the network runs once per market and its outputs serve the market's `a` agents; `value` is then per market, [n]."""
         from ._lib import check, lib
+        if self.state_dependent_log_std:
+            raise NotImplementedError("cda_policy_sample takes ONE log_std pair: the state-dependent head samples through act() or the fused network kernels (mlp.FusedPolicy)")
         o = self.trunk_packed(obs).float().contiguous()           # [rows, 32]: read in place, the value made contiguous by the sampler
         rows, dev = o.shape[0], o.device
         val = torch.empty(rows, dtype=torch.float32, device=dev)
@@ -166,19 +182,19 @@ class ActorCritic(nn.Module):
         agents_per_row > 1: `obs` holds one row per market-step and serves that many consecutive samples of `actions`; the outputs
         are per sample (the row's outputs repeated)."""
         a_cat, a_price, a_off, a_cont = actions
-        o, val = self.trunk(obs)
+        o, val, log_std = self.trunk_ls(obs)
         o = o.float()
         if agents_per_row > 1:
-            o, val = o.repeat_interleave(agents_per_row, dim=0), val.repeat_interleave(agents_per_row, dim=0)
+            o, val, log_std = o.repeat_interleave(agents_per_row, dim=0), val.repeat_interleave(agents_per_row, dim=0), log_std.repeat_interleave(agents_per_row, dim=0)
         logp = ent = 0.0
         for lo, hi, a in ((0, CAT_N, a_cat), (CAT_N, CAT_N + PRICE_N, a_price), (CAT_N + PRICE_N, CAT_N + PRICE_N + OFF_N, a_off)):
             ls = torch.log_softmax(o[:, lo:hi], dim=-1)
             logp = logp + ls.gather(1, a.view(-1, 1)).squeeze(1)
             ent = ent - (ls.exp() * ls).sum(-1)
-        mu, log_std = o[:, -2:], self.log_std
+        mu = o[:, -2:]
         z = (a_cont - mu) * torch.exp(-log_std)
         logp = logp + (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
-        ent = ent + (0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum()
+        ent = ent + (0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum(-1)
         return logp, ent, val.float()
 
 
@@ -335,6 +351,8 @@ def ppo_update(model, opt, obs, actions, logp_old, adv, ret, epochs=4, minibatch
     B = R * A
     assert adv.numel() == B and logp_old.numel() == B and actions[0].numel() == B, "per-sample tensors must hold rows * agents_per_row entries"
     fused = obs.is_cuda if fused is None else bool(fused)         # the HIP loss kernel (cda_ppo_loss); the PyTorch statement elsewhere
+    if getattr(model, "state_dependent_log_std", False):
+        fused = False                                             # (cda_ppo_loss takes ONE log_std pair: the state-dependent head goes through the PyTorch statement)
     adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).float().contiguous()
     logp_old, ret = logp_old.float().contiguous(), ret.float().contiguous()
     actions = (actions[0].contiguous(), actions[1].contiguous(), actions[2].contiguous(), actions[3].float().contiguous())
@@ -488,7 +506,7 @@ def adapt_kl_coef(kl_coef, sampled_kl, kl_target):
 
 def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, seed=0, log=print, use_graph=True, chains=4, minibatch=262144,
                 gamma=None, lam=None, clip=None, vf_coef=None, ent_coef=None, policy=None, keep=None, sub_batches=None, objective=None, recorder=None, info_markets=0,
-                allreduce=None, world=1, first_market=0, episode_metrics=True, strict_nav_check=True):
+                allreduce=None, world=1, first_market=0, episode_metrics=True, strict_nav_check=True, state_dependent_log_std=False):
     """The PPO loop on the hand-written network kernels (mlp.py, include/cda_mlp.h): rollouts as `chains` independent per-chain launch
     sequences (policy forward + sampling -> env step -> auto reset, one HIP graph per chain, no cross-stream edge inside the horizon), the
     sample records completed by one GAE launch, the update as {gather + forward + loss + back-propagation, weight gradients, reduce, clip + Adam}
@@ -504,6 +522,8 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     in-kernel auto reset (CDAVecEnv.enable_episode_metrics); history[i]["episode_metrics"] holds what the reference's callback logs per episode
     (episode_metrics.summarise: pass / rejection fractions, reward-term means and variance shares, NAV / drawdown / inventory at the episode's end, the most maker-like
     agent's passive share) and a violation raises NavConservationError like the reference's strict_nav_check run (train/train.py:1125-1164); strict_nav_check=False logs it.
+    state_dependent_log_std: a fresh policy gets RLlib's default head for Box actions (two log-stds per row from the policy network: mlp.FusedPolicy); a given `policy`
+    brings its own.
     Needs a HIP CDAVecEnv with auto_reset and 168-float observations.  Returns (FusedPolicy, history); `keep` (a dict) receives the last
     rollout's buffers and the RolloutChains object.  history[i]: losses, `mean_reward` (of the rollout's slice of the episodes - it depends on WHICH part of
     the episodes the slice covers) and `episode_return` (mean return of the episodes that were COMPLETED during the iteration, None if none was)."""
@@ -516,7 +536,7 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     dev = env.obs.device
     N, A, T = env.n_markets, env.num_agents, int(horizon)
     if policy is None:
-        policy = FusedPolicy(dev, seed=seed, n_hist=env.n_hist)
+        policy = FusedPolicy(dev, seed=seed, n_hist=env.n_hist, state_dependent_log_std=state_dependent_log_std)
     env.reset(seed=seed + int(first_market))
     if episode_metrics:
         env.enable_episode_metrics(True)
@@ -691,6 +711,7 @@ def main(argv=None):
     p.add_argument("--out", default=None, help="write a JSON summary (config, per-iteration stats, end-of-run env checks) to this file")
     p.add_argument("--legacy", action="store_true", help="the round-3 loop: PyTorch network (library GEMMs, autograd), one graph per rollout step")
     p.add_argument("--chains", type=int, default=4, help="fused loop: independent rollout chains (market groups on their own streams)")
+    p.add_argument("--log-std-head", action="store_true", help="fused loop: the state-dependent log-std head (RLlib's default module for Box actions) instead of a free log_std vector")
     p.add_argument("--objective", choices=("ppo", "rllib"), default="ppo", help="fused loop: PPO_DEFAULTS, or RLLIB_DEFAULTS = the objective the reference's RLlib run optimises "
                                                                               "(clip 0.3, lambda 1, vf coeff 1, entropy 0, vf clip 10, adaptive KL penalty, no gradient clipping, truncation bootstrap)")
     args = p.parse_args(argv)
@@ -707,7 +728,7 @@ def main(argv=None):
         _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update, shared_obs=not args.per_sample_forward, use_graph=not args.no_graphs)
     else:
         _, hist = train_fused(env, iters=args.iters, horizon=args.horizon, use_graph=not args.no_graphs, chains=args.chains,
-                              objective=RLLIB_DEFAULTS if args.objective == "rllib" else None)
+                              objective=RLLIB_DEFAULTS if args.objective == "rllib" else None, state_dependent_log_std=args.log_std_head)
     flags = env.flags()
     _, bad = env.nav_conservation()
     tail = hist[2:] if len(hist) >= 4 else (hist[1:] or hist)

@@ -172,7 +172,7 @@ typedef struct cda_rollout_bufs {
     uint8_t* terminated;     /* [T][N] */
     uint8_t* truncated;      /* [T][N] */
     float*   record;         /* [T][N][A][8] or NULL: the sample records below (words 0..5 written by the policy step) */
-    float*   dist;           /* [T][N][24] or NULL: the rollout policy's distribution per market-step (22 normalised log-probabilities of the categorical heads | the 2 Gaussian
+    float*   dist;           /* [T][N][CDA_MLP_DIST_LD = 28] or NULL: the rollout policy's distribution per market-step (22 normalised log-probabilities of the categorical heads | the 2 Gaussian
                                 means) - what the update's KL term needs (cda_ppo_extra) */
     const cda_info_ptrs* info_steps;   /* [T] (host array) or NULL: step t of this chain also writes the info tensors info_steps[t] (Info_Helper.set_info; the chain then runs
                                 the step kernel with info outputs - meant for a small chain of SAMPLED markets beside the info-less ones: train/episode_record.py:197
@@ -237,15 +237,23 @@ int cda_ppo_loss_records(const float* outputs, const float* log_std, const float
 /* extra (may be NULL): what RLlib's PPO objective has beyond clip / vf_coef / ent_coef, and the record stride of a league update.
  *   rec_stride   floats between two rows' records; 0 = agents_per_row * 8 (a row's samples are all the row's agents).  League: a row is a market-step of A slots of which
  *                ONE (slot p of trainable net p) feeds net p's update: rec = records + 8 p, rec_stride = 8 A, agents_per_row = 1.
- *   kl_coef      adds kl_coef * mean KL(rollout policy || current policy) to the loss, the KL exact per row from dist_old f32 [rows of obs][24] (cda_rollout_bufs.dist)
- *                and log_std_old f32[2] (the rollout policy's); the mean KL comes back in loss_out6[6] (the caller adapts the coefficient, RLlib: x 1.5 above
- *                2 kl_target, x 0.5 below 0.5 kl_target).  0 = no KL term.
- *   vf_clip      the squared value error is clamped to [0, vf_clip] (RLlib's vf_clip_param: clamped samples carry no gradient); <= 0 = off. */
+ *   kl_coef      adds kl_coef * mean KL(rollout policy || current policy) to the loss, the KL exact per row from dist_old f32 [rows of obs][CDA_MLP_DIST_LD]
+ *                (cda_rollout_bufs.dist: the row's 22 normalised log-probabilities | 2 means | the 2 log-stds it was sampled with | 2 zeros); the mean KL comes back in
+ *                loss_out6[6] (the caller adapts the coefficient, RLlib: x 1.5 above 2 kl_target, x 0.5 below 0.5 kl_target).  0 = no KL term.
+ *                log_std_old: not read any more (the rows carry the log-stds since round 6); may be NULL.
+ *   vf_clip      the squared value error is clamped to [0, vf_clip] (RLlib's vf_clip_param: clamped samples carry no gradient); <= 0 = off.
+ *   sd_log_std   != 0: the STATE-DEPENDENT log-std head (RLlib's default module for Box actions: the policy network emits 2 means AND 2 log-stds per row; the reference's
+ *                modules are that default, train/policy/policy_handler.py:69-76).  Output columns 25, 26 of the policy half are log-std OFFSETS: every kernel samples and
+ *                scores with log_std[i] = theta[CDA_MLP_OFF_LS + i] + out[25 + i] (rows 25, 26 of Wo / bo are zero in a network built without the head, so this
+ *                is the free log_std vector bit for bit).  With the flag the loss sends d loss / d log_std of every row back through columns 25, 26 (rows 25, 26
+ *                of Wo and bo train) and the free vector stays where it is (its gradient is reported as zero); without it those columns' gradient is zero. */
+#define CDA_MLP_DIST_LD 28
 typedef struct cda_ppo_extra {
     int32_t rec_stride;
     float   kl_coef, vf_clip;
     const float* dist_old;
     const float* log_std_old;
+    int32_t sd_log_std;
 } cda_ppo_extra;
 int cda_mlp_forward_backward(const void* wb, const float* theta, const float* obs, const int64_t* perm, int64_t n_rows, int64_t norm_rows,
                              const float* rec, const double* adv_stats2, int64_t adv_count, int32_t agents_per_row, float clip, float vf_coef, float ent_coef,
@@ -277,7 +285,7 @@ int cda_mlp_league_step(const cda_league* league, const float* obs, int32_t firs
                         uint64_t seed, const int64_t* counter_dev, int64_t draw,
                         int32_t* env_category, float* env_size_mean, float* env_size_sigma, int32_t* env_price, int32_t* env_price_offset,
                         float* a_cont, float* logp, float* value, int64_t value_stride, float* rec, float* dist, int64_t dist_stride, void* stream);
-/* cda_mlp_rollout_chain for a league: bufs as there except value f32 [n_trainable][T+1][N] and dist f32 [n_trainable][T][N][24]. */
+/* cda_mlp_rollout_chain for a league: bufs as there except value f32 [n_trainable][T+1][N] and dist f32 [n_trainable][T][N][CDA_MLP_DIST_LD]. */
 int cda_mlp_league_rollout_chain(cda_env* env, const cda_league* league, int32_t first_market, int32_t n_markets, int32_t n_steps,
                                  uint64_t seed, const int64_t* counter_dev, const cda_rollout_bufs* bufs, int32_t copy_first_obs, void* stream);
 /* cda_gae_records for a league: value f32 [n_trainable][T+1][N]; slot p < n_trainable gets advantage / return from net p's values, the other slots' records are left

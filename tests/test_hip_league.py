@@ -93,10 +93,10 @@ def _league_step(bank, obs, A, seed, counter, draw, first=0, n=None, with_dist=T
     e = lambda shape, dt: torch.zeros(shape, dtype=dt, device=DEV)             # noqa: E731
     o = {"category": e((N, A), torch.int32), "size_mean": e((N, A), torch.float32), "size_sigma": e((N, A), torch.float32), "price": e((N, A), torch.int32),
          "price_offset": e((N, A), torch.int32), "a_cont": e((N, A, 2), torch.float32), "logp": e((N, A), torch.float32), "value": e((k, N), torch.float32),
-         "rec": e((N, A, 8), torch.float32), "dist": e((k, N, 24), torch.float32)}
+         "rec": e((N, A, 8), torch.float32), "dist": e((k, N, 28), torch.float32)}
     check(lib().cda_mlp_league_step(C.byref(bank.struct()), obs.data_ptr(), first, n, A, seed, counter.data_ptr(), draw,
                                     *[o[key].data_ptr() for key in (*ACTION_KEYS, "a_cont", "logp", "value")], N, o["rec"].data_ptr(),
-                                    o["dist"].data_ptr() if with_dist else None, N * 24, torch.cuda.current_stream().cuda_stream), "cda_mlp_league_step")
+                                    o["dist"].data_ptr() if with_dist else None, N * 28, torch.cuda.current_stream().cuda_stream), "cda_mlp_league_step")
     torch.cuda.synchronize()
     return o
 
@@ -130,7 +130,8 @@ def test_league_step_routes_every_slot_to_its_module():
         if n < k:
             assert torch.equal(o["value"][n].cpu(), ref["value"].cpu())
             out = pol.forward(obs).cpu().double()
-            want = torch.cat([torch.log_softmax(out[:, :9], -1), torch.log_softmax(out[:, 9:19], -1), torch.log_softmax(out[:, 19:22], -1), out[:, 22:24]], dim=1)
+            want = torch.cat([torch.log_softmax(out[:, :9], -1), torch.log_softmax(out[:, 9:19], -1), torch.log_softmax(out[:, 19:22], -1), out[:, 22:24],
+                              pol.log_std.cpu().double().expand(N, 2), torch.zeros(N, 2, dtype=torch.float64)], dim=1)      # ... | the log-stds sampled with | 2 zeros
             assert (o["dist"][n].cpu().double() - want).abs().max() <= 2e-5
     # the records carry the same words
     rec = o["rec"].cpu()
@@ -305,7 +306,8 @@ def _torch_objective(m, x, acts, lp_old, adv, ret, dist_old, ls_old, clip, vf_co
         ls_new = torch.log_softmax(o[:, lo:hi], -1)
         kl = kl + (dist_old[:, lo:hi].exp() * (dist_old[:, lo:hi] - ls_new)).sum(-1)
     mu_o, mu_n = dist_old[:, 22:24], o[:, 22:24]
-    kl = kl + ((m.log_std - ls_old) + (torch.exp(2 * ls_old) + (mu_o - mu_n) ** 2) / (2 * torch.exp(2 * m.log_std)) - 0.5).sum(-1)
+    ls_new, ls_old = m.trunk_ls(x)[2], dist_old[:, 24:26]               # per row: the free vector (+ the state-dependent head's offsets); the rollout's ride in the row
+    kl = kl + ((ls_new - ls_old) + (torch.exp(2 * ls_old) + (mu_o - mu_n) ** 2) / (2 * torch.exp(2 * ls_new)) - 0.5).sum(-1)
     return pg + vf_coef * vl - ent_coef * ent.mean() + kl_coef * kl.mean(), pg, vl, kl.mean()
 
 
@@ -317,9 +319,12 @@ def _grad_vector(m):
     w2g = m.l2.weight.grad.double()
     gm[mlp.OFF_W2:mlp.OFF_B2] = torch.stack([w2g[:H, :H], w2g[H:, H:]]).reshape(-1); gm[mlp.OFF_B2:mlp.OFF_WO] = m.l2.bias.grad.double()
     wog = m.out.weight.grad.double(); blk = torch.zeros(32, H, dtype=torch.float64); blk[:24] = wog[:24, :H]; blk[24] = wog[24, H:]
+    sd = m.state_dependent_log_std
+    if sd:
+        blk[25:27] = wog[25:27, :H]
     gm[mlp.OFF_WO:mlp.OFF_BO] = blk.reshape(-1)
-    bog = m.out.bias.grad.double().clone(); bog[25:] = 0
-    gm[mlp.OFF_BO:mlp.OFF_LS] = bog; gm[mlp.OFF_LS:] = m.log_std.grad.double()
+    bog = m.out.bias.grad.double().clone(); bog[27 if sd else 25:] = 0
+    gm[mlp.OFF_BO:mlp.OFF_LS] = bog; gm[mlp.OFF_LS:] = 0.0 if m.log_std.grad is None else m.log_std.grad.double()
     return gm
 
 
@@ -336,13 +341,28 @@ def test_masked_and_rllib_objective_gradient_equals_float32_autograd(A, slot, kl
     check_gradient(A, slot, kl_coef, vf_clip)
 
 
-def _loss_gradient_on_outputs(out, log_std, sel, dist_old, ls_old, clip, vf_coef, ent_coef, kl_coef, vf_clip):
+@pytest.mark.parametrize("A,slot,kl_coef,vf_clip", [(4, None, 0.0, 0.0),     # one shared policy, plain PPO objective
+                                                    (4, None, 0.2, 0.7),     # ... RLlib's objective: the KL's Gaussian part with per-row log-stds on both sides
+                                                    (8, 1, 0.3, 0.5)])       # a league update
+def test_state_dependent_log_std_head_gradient_equals_float32_autograd(A, slot, kl_coef, vf_clip):
+    """RLlib's default module for Box actions (the reference's PPO modules, train/policy/policy_handler.py:69-76): the policy network emits two log-stds per row.  Output
+    rows 25, 26 of the fused network are that head (offsets on top of the free vector): the loss scores every sample with its ROW's log-stds, sends d loss / d log_std of
+    every row back through columns 25, 26, rows 25, 26 of Wo / bo get their gradient, the free vector none - against float64 autograd on the kernel's own outputs and
+    float32 autograd through ppo.ActorCritic(state_dependent_log_std=True)."""
+    check_gradient(A, slot, kl_coef, vf_clip, sd=True)
+
+
+def _loss_gradient_on_outputs(out, log_std, sel, dist_old, ls_old, clip, vf_coef, ent_coef, kl_coef, vf_clip, sd=False):
     """d loss / d outputs and d loss / d log_std by float64 autograd, starting from the kernel's OWN float32 outputs [R, 32] (so the clip / clamp decisions are taken
     on the same numbers): sel [R, agents, 8] the rows' sample records, dist_old [R, 24] - all in minibatch order"""
     R, agents = sel.shape[0], sel.shape[1]
     o = out.double().clone().requires_grad_()
-    ls = log_std.double().clone().requires_grad_()
+    ls_free = log_std.double().clone().requires_grad_()
+    ls_row = ls_free + o[:, 25:27]                                  # [R, 2]: the free vector + the head's offsets (the kernel adds them whether or not the head trains)
+    if not sd:
+        ls_row = ls_free + o[:, 25:27].detach()
     O = o.repeat_interleave(agents, 0)
+    ls = ls_row.repeat_interleave(agents, 0)
     flat = sel.reshape(R * agents, 8)
     acts = [flat[:, c].contiguous().view(torch.int32).long() for c in range(3)]
     a_cont, lp_old, adv, ret = flat[:, 3:5].double(), flat[:, 5].double(), flat[:, 6].double(), flat[:, 7].double()
@@ -353,31 +373,33 @@ def _loss_gradient_on_outputs(out, log_std, sel, dist_old, ls_old, clip, vf_coef
         ent = ent - (l.exp() * l).sum(-1)
     z = (a_cont - O[:, 22:24]) * torch.exp(-ls)
     logp = logp + (-0.5 * z * z - ls - 0.5 * math.log(2 * math.pi)).sum(-1)
-    ent = ent + (0.5 + 0.5 * math.log(2 * math.pi) + ls).sum()
+    ent = ent + (0.5 + 0.5 * math.log(2 * math.pi) + ls).sum(-1)
     ratio = (logp - lp_old).exp()
     pg = -torch.min(ratio * adv, ratio.clamp(1 - clip, 1 + clip) * adv).mean()
     sq = (O[:, 24] - ret).pow(2)
     vl = (sq.clamp(max=vf_clip) if vf_clip > 0 else sq).mean()
     loss = pg + vf_coef * vl - ent_coef * ent.mean()
     if kl_coef:
-        d, lo_ = dist_old.double(), ls_old.double()
+        d = dist_old.double()
+        lo_ = d[:, 24:26]                                           # the log-stds every row was sampled with
         kl = 0.0
         for lo, hi in ((0, 9), (9, 19), (19, 22)):
             kl = kl + (d[:, lo:hi].exp() * (d[:, lo:hi] - torch.log_softmax(o[:, lo:hi], -1))).sum(-1)
-        kl = kl + ((ls - lo_) + (torch.exp(2 * lo_) + (d[:, 22:24] - o[:, 22:24]) ** 2) / (2 * torch.exp(2 * ls)) - 0.5).sum(-1)
+        kl = kl + ((ls_row - lo_) + (torch.exp(2 * lo_) + (d[:, 22:24] - o[:, 22:24]) ** 2) / (2 * torch.exp(2 * ls_row)) - 0.5).sum(-1)
         loss = loss + kl_coef * kl.mean()
     loss.backward()
-    return o.grad, ls.grad
+    return o.grad, (torch.zeros(2, dtype=torch.float64) if sd else ls_free.grad)
 
 
-def check_gradient(A, slot, kl_coef, vf_clip, R=512, seed=6, chunks=4, check_clip_share=True, soak=False):
+def check_gradient(A, slot, kl_coef, vf_clip, R=512, seed=6, chunks=4, check_clip_share=True, soak=False, sd=False):
     """(also driven over random shapes by tools/gradient_soak.py, soak=True: there the TIGHT check is the loss gradient on the kernel's own outputs; the whole
     gradient against float32 autograd is held to wider bands - a sample whose ratio / value error sits within bfloat16 noise of a clip / clamp boundary takes the
     other branch in float32, a discrete change of that sample's whole contribution, and random shapes with few samples per minibatch meet that)"""
     from gym_continuousdoubleauction_amd import mlp
     g = torch.Generator().manual_seed(seed)
-    th = mlp.init_theta(generator=torch.Generator().manual_seed(13))
+    th = mlp.init_theta(generator=torch.Generator().manual_seed(13), state_dependent_log_std=sd)
     p = mlp.FusedPolicy(DEV, theta=th)
+    assert p.state_dependent_log_std == sd
     th_old = th.clone(); th_old[:mlp.OFF_LS] += 0.02 * torch.randn(mlp.OFF_LS, generator=g); th_old[mlp.OFF_LS:] = torch.tensor([-0.4, -0.65])
     x = _obs(R, seed=17) * 0.5
     rec = torch.zeros(R, A, 8)
@@ -389,8 +411,9 @@ def check_gradient(A, slot, kl_coef, vf_clip, R=512, seed=6, chunks=4, check_cli
     rec[..., 6] = torch.randn(R, A, generator=g)
     rec[..., 7] = torch.randn(R, A, generator=g)
     old_out = mlp.reference_outputs(th_old, x, emulate_bf16=False, dtype=torch.float32)
-    dist_old = torch.cat([torch.log_softmax(old_out[:, :9], -1), torch.log_softmax(old_out[:, 9:19], -1), torch.log_softmax(old_out[:, 19:22], -1), old_out[:, 22:24]], dim=1).contiguous()
     ls_old = th_old[mlp.OFF_LS:].clone()
+    dist_old = torch.cat([torch.log_softmax(old_out[:, :9], -1), torch.log_softmax(old_out[:, 9:19], -1), torch.log_softmax(old_out[:, 19:22], -1), old_out[:, 22:24],
+                          ls_old + old_out[:, 25:27], torch.zeros(R, 2)], dim=1).contiguous()           # a rollout's row: ... | the log-stds it was sampled with | 2 zeros
     agents = 1 if slot is not None else A
     upd = mlp.FusedUpdate(p, R, R, agents, chunks=chunks)
     upd.perm.copy_(torch.randperm(R, generator=g))
@@ -414,20 +437,23 @@ def check_gradient(A, slot, kl_coef, vf_clip, R=512, seed=6, chunks=4, check_cli
     # (1) tight: the loss gradient the kernel fed its backward pass, against float64 autograd on the kernel's own outputs (same decisions at the clip / clamp
     #     boundaries): every shape-dependent piece - record stride, agents per row, the KL rows, the clamp - is in this step
     pm = perm[:R]
-    g_out, g_ls = _loss_gradient_on_outputs(upd.out[:R].cpu(), p.theta[mlp.OFF_LS:].cpu(), sel[pm], dist_old[pm], ls_old, 0.3, 1.0, 0.01, kl_coef, vf_clip)
+    g_out, g_ls = _loss_gradient_on_outputs(upd.out[:R].cpu(), p.theta[mlp.OFF_LS:].cpu(), sel[pm], dist_old[pm], ls_old, 0.3, 1.0, 0.01, kl_coef, vf_clip, sd=sd)
     d_out = upd.d_out[:R].cpu().double()
     scale = float(g_out.abs().max())
-    row_err = (d_out[:, :25] - g_out[:, :25]).abs().max(1).values
+    NC = 27 if sd else 25                                        # the columns that carry a gradient: 24 policy outputs, the value, (the head's two log-std offsets)
+    row_err = (d_out[:, :NC] - g_out[:, :NC]).abs().max(1).values
+    if sd:
+        assert float(d_out[:, 25:27].abs().max()) > 1e-3 * scale and float(upd.out[:R, 25:27].abs().max()) > 0.05
     off = int((row_err > 1e-4 * scale).sum())
     # (a sample EXACTLY on a clip / clamp boundary - within float32 rounding of it - may take the other branch in float64: at most one row per 20 000 samples)
     assert off <= (R * agents) // 20000, ("d loss / d outputs", off, float(row_err.max()), scale)
-    assert float(d_out[:, 25:].abs().max()) == 0.0
+    assert float(d_out[:, NC:].abs().max()) == 0.0
     assert float((grad[mlp.OFF_LS:] - g_ls).abs().max()) <= 1e-4 * float(g_ls.abs().max()) + 1e-9, ("d loss / d log_std", grad[mlp.OFF_LS:], g_ls)
     # (2) the network's backward pass alone: the kernel's loss gradient pushed through the float32 PyTorch network by autograd - no decision is taken in this
     #     comparison, what is left is bfloat16 operands against float32
     m2 = mlp.actor_critic_from_theta(p.theta).float()
-    o2, v2 = m2.trunk(x[pm])
-    torch.autograd.backward([o2, v2], [d_out[:, :24].float(), d_out[:, 24].float()])
+    o2 = m2.trunk_packed(x[pm])
+    torch.autograd.backward([o2], [torch.cat([d_out[:, :NC], torch.zeros(R, 32 - NC, dtype=torch.float64)], 1).float()])
     m2.log_std.grad = torch.zeros(2)
     g2 = _grad_vector(m2)
     for lo, hi, name in BLOCKS(mlp)[:-1]:
@@ -436,9 +462,10 @@ def check_gradient(A, slot, kl_coef, vf_clip, R=512, seed=6, chunks=4, check_cli
     # (3) the whole gradient against float32 autograd through the PyTorch network
     cos = float((grad * gm).sum() / (grad.norm() * gm.norm()))
     assert cos > (0.9 if soak else 0.999), cos                   # bfloat16 operands against float32: direction within 1e-3, every block's magnitude within 3 %
+    # (with the state-dependent head every row's log-stds are bfloat16-operand products too - they scale the Gaussian heads' whole gradient: 4 %, measured 3.1 % on W1)
     for lo, hi, name in BLOCKS(mlp):
         a, b = grad[lo:hi], gm[lo:hi]
-        assert (a - b).norm() <= (0.5 if soak else 3e-2) * b.norm() + 1e-9, (name, float((a - b).norm() / b.norm()))
+        assert (a - b).norm() <= (0.5 if soak else (4e-2 if sd else 3e-2)) * b.norm() + 1e-9, (name, float((a - b).norm() / b.norm()))
     assert abs(float(out6[3]) - float(loss.detach())) <= 2e-2 * abs(float(loss.detach())) + 1e-3
     assert abs(float(out6[1]) - float(vl.detach())) <= 2e-2 * float(vl.detach()) + 1e-4
     if kl_coef:

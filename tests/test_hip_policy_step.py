@@ -3,6 +3,7 @@ it replaces - cda_mlp_policy_step (k_mlp_fwd<SAMPLE>) followed by cda_step_range
 sample records, the step's observations / rewards / flags, the auto reset and the episode-end capture, markets on the general build (HBM tier of the book)
 included.  What the reference does between two env.step calls (RLlib's policy forward + action sampling, train/train.py:453-541) lives in the step itself."""
 import ctypes as C
+import math
 import os
 import sys
 
@@ -20,14 +21,16 @@ def _bufs(N, A, cap, obs_dim=168):
     e = lambda shape, dt: torch.zeros(shape, dtype=dt, device=DEV)          # noqa: E731
     return {"category": e((N, A), torch.int32), "size_mean": e((N, A), torch.float32), "size_sigma": e((N, A), torch.float32), "price": e((N, A), torch.int32),
             "price_offset": e((N, A), torch.int32), "a_cont": e((N, A, 2), torch.float32), "logp": e((N, A), torch.float32), "value": e((N,), torch.float32),
-            "rec": e((N, A, 8), torch.float32), "dist": e((N, 24), torch.float32), "obs": e((N, obs_dim), torch.float32), "reward": e((N, A), torch.float64),
+            "rec": e((N, A, 8), torch.float32), "dist": e((N, 28), torch.float32), "obs": e((N, obs_dim), torch.float32), "reward": e((N, A), torch.float64),
             "term": e((N,), torch.uint8), "trunc": e((N,), torch.uint8), "fin_obs": e((cap, obs_dim), torch.float32), "fin_count": e((1,), torch.int32),
             "fin_index": torch.full((N,), -1, dtype=torch.int32, device=DEV)}
 
 
-@pytest.mark.parametrize("A,N,max_step,cash,deep,H", [(4, 150, 7, 1000000, False, 4), (8, 70, 5, 20000, False, 4), (2, 33, 40, 1000000, False, 4), (4, 40, 4096, 1000000, True, 4),
-                                                       (4, 70, 6, 1000000, False, 1), (8, 50, 9, 20000, False, 2), (3, 45, 5, 1000000, False, 8), (4, 40, 4096, 1000000, True, 8)])
-def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_step_launch(A, N, max_step, cash, deep, H):
+@pytest.mark.parametrize("A,N,max_step,cash,deep,H,sd", [(4, 150, 7, 1000000, False, 4, False), (8, 70, 5, 20000, False, 4, False), (2, 33, 40, 1000000, False, 4, False),
+                                                          (4, 40, 4096, 1000000, True, 4, False), (4, 70, 6, 1000000, False, 1, False), (8, 50, 9, 20000, False, 2, False),
+                                                          (3, 45, 5, 1000000, False, 8, False), (4, 40, 4096, 1000000, True, 8, False),
+                                                          (4, 150, 7, 1000000, False, 4, True), (8, 50, 9, 20000, False, 2, True)])     # sd: the state-dependent log-std head
+def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_step_launch(A, N, max_step, cash, deep, H, sd):
     from gym_continuousdoubleauction_amd import CDAVecEnv, mlp
     from gym_continuousdoubleauction_amd._lib import check, lib
     L = lib()
@@ -36,8 +39,9 @@ def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_
     envs = [CDAVecEnv(cfg, n_markets=N, with_info=False) for _ in range(2)]
     OBSD = 42 * H
     assert L.cda_policy_step_supported(envs[1]._h) == 1
-    th = mlp.init_theta(OBSD, generator=torch.Generator().manual_seed(5)); th[:mlp.layout(H).OFF_LS] *= 1.5
+    th = mlp.init_theta(OBSD, generator=torch.Generator().manual_seed(5), state_dependent_log_std=sd); th[:mlp.layout(H).OFF_LS] *= 1.5
     p = mlp.FusedPolicy(DEV, theta=th, n_hist=H)
+    assert p.state_dependent_log_std == sd
     obs = [e.reset(seed=900).clone() for e in envs]
     if deep:                                                      # four markets far beyond the LDS tile: the general build (HBM tier) steps them, inside both kernels
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -71,9 +75,19 @@ def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_
         rec = b2["rec"].cpu()
         assert torch.equal(rec[..., 0].contiguous().view(torch.int32), b2["category"].cpu()) and torch.equal(rec[..., 1].contiguous().view(torch.int32), b2["price"].cpu())
         assert torch.equal(rec[..., 2].contiguous().view(torch.int32), b2["price_offset"].cpu()) and torch.equal(rec[..., 3:5], b2["a_cont"].cpu()) and torch.equal(rec[..., 5], b2["logp"].cpu())
-        out = p.forward(obs[1])[:, :24].cpu()
-        want = torch.cat([torch.log_softmax(out[:, :9].double(), -1), torch.log_softmax(out[:, 9:19].double(), -1), torch.log_softmax(out[:, 19:22].double(), -1), out[:, 22:24].double()], 1)
+        out = p.forward(obs[1]).cpu()
+        ls_rows = p.log_std.cpu().double() + out[:, 25:27].double()       # the log-stds every row was sampled with: the free vector + the head's offsets (zero without the head)
+        assert (float(out[:, 25:27].abs().max()) > 0.05) == sd and float(out[:, 27:].abs().max()) == 0.0
+        want = torch.cat([torch.log_softmax(out[:, :9].double(), -1), torch.log_softmax(out[:, 9:19].double(), -1), torch.log_softmax(out[:, 19:22].double(), -1), out[:, 22:24].double(),
+                          ls_rows, torch.zeros(N, 2, dtype=torch.float64)], 1)
         assert (b2["dist"].cpu().double() - want).abs().max() < 1e-5
+        # ... and the recorded log-probability is the sampled action's under exactly those log-stds
+        a_cont, lp = b2["a_cont"].cpu().double(), b2["logp"].cpu().double()
+        z = (a_cont - out[:, None, 22:24].double()) * torch.exp(-ls_rows)[:, None, :]
+        lp_want = (-0.5 * z * z - ls_rows[:, None, :] - 0.5 * math.log(2 * math.pi)).sum(-1)
+        for (lo, hi), key in zip(((0, 9), (9, 19), (19, 22)), ("category", "price", "price_offset")):
+            lp_want = lp_want + want[:, lo:hi].gather(1, b2[key].cpu().long())
+        assert (lp - lp_want).abs().max() < 2e-4
         # episode ends: the same markets captured, the same last observations (slots are handed out by an atomic: compared through the index)
         f1, f2 = b1["fin_index"].cpu(), b2["fin_index"].cpu()
         assert torch.equal(f1 >= 0, f2 >= 0) and int(b1["fin_count"]) == int(b2["fin_count"]) == int((f1 >= 0).sum())

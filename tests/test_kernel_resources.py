@@ -114,9 +114,9 @@ def test_fused_update_kernel_fits_two_workgroups_per_cu():
     def fb_lds(agents, dist, n_hist=4):
         kx = (42 * n_hist + 15) // 16 * 16
         xs = max(64 * (kx + 8) * 2, 64 * 33 * 4 + 64 * 40 * 2)     # FB_XS_BYTES: the observation tile, whose bytes later hold the output tiles
-        return xs + 64 * ACT_LD * 2 + 64 * LPS_LD * 4 + 64 * (agents * 32 + (24 * 4 if dist else 0))
+        return xs + 64 * ACT_LD * 2 + 64 * LPS_LD * 4 + 64 * (agents * 32 + (28 * 4 if dist else 0))           # (a row's distribution: CDA_MLP_DIST_LD floats)
     src = open(os.path.join(ROOT, "gym_continuousdoubleauction_amd", "csrc", "cda_mlp.hip")).read()
-    assert "size_t fb_lds(int agents, bool with_dist) { return (size_t)FB_XS_BYTES + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * (agents * 32 + (with_dist ? N_LOGITS * 4 : 0)); }" in src
+    assert "size_t fb_lds(int agents, bool with_dist) { return (size_t)FB_XS_BYTES + (size_t)64 * ACT_LD * 2 + (size_t)64 * LPS_LD * 4 + (size_t)64 * (agents * 32 + (with_dist ? CDA_MLP_DIST_LD * 4 : 0)); }" in src
     assert "constexpr int FB_XS_BYTES = (64 * XS_LD * 2 > 64 * OUTS_LD * 4 + 64 * DO_LD * 2) ? 64 * XS_LD * 2 : 64 * OUTS_LD * 4 + 64 * DO_LD * 2;" in src
     assert fb_lds(4, False) == 71424
     for agents, dist in ((4, False), (4, True), (8, False), (1, False), (1, True)):

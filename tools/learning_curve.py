@@ -15,13 +15,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def curves(markets=1024, agents=4, episode=32, iters=40, lr=3e-4, seed=0, objective=None, legacy=True, minibatch=None):
+def curves(markets=1024, agents=4, episode=32, iters=40, lr=3e-4, seed=0, objective=None, legacy=True, minibatch=None, log_std_head=False):
     from gym_continuousdoubleauction_amd import CDAVecEnv, ppo
     cfg = {"num_of_agents": agents, "init_cash": 1000000, "max_step": episode, "is_render": False, "auto_reset": True}
     minibatch = minibatch or markets * episode * agents // 2
     out = {}
     env = CDAVecEnv(cfg, n_markets=markets, with_info=False)
-    _, hist = ppo.train_fused(env, iters=iters, horizon=episode, lr=lr, seed=seed, log=lambda s: None, minibatch=minibatch, objective=objective)
+    _, hist = ppo.train_fused(env, iters=iters, horizon=episode, lr=lr, seed=seed, log=lambda s: None, minibatch=minibatch, objective=objective, state_dependent_log_std=log_std_head)
     out["fused"] = [h["episode_return"] for h in hist]
     out["fused_entropy"] = [h["entropy"] for h in hist]
     out["fused_kl"] = [h["kl"] for h in hist]
@@ -45,9 +45,10 @@ def main():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--objective", choices=("ppo", "rllib"), default="ppo")
     p.add_argument("--no-legacy", action="store_true")
+    p.add_argument("--log-std-head", action="store_true", help="the fused loop's policy carries the state-dependent log-std head")
     a = p.parse_args()
     from gym_continuousdoubleauction_amd import ppo
-    c = curves(a.markets, a.agents, a.episode, a.iters, a.lr, a.seed, ppo.RLLIB_DEFAULTS if a.objective == "rllib" else None, legacy=not a.no_legacy)
+    c = curves(a.markets, a.agents, a.episode, a.iters, a.lr, a.seed, ppo.RLLIB_DEFAULTS if a.objective == "rllib" else None, legacy=not a.no_legacy, log_std_head=a.log_std_head)
     r = lambda xs: [None if x is None else round(float(x), 4) for x in xs]          # noqa: E731
     print(json.dumps({"config": vars(a), **{k: r(v) for k, v in c.items()}}))
     f = c["fused"]
