@@ -29,8 +29,9 @@ What the line reports (one MI355X):
                              otherwise a coin flip.
   value_without_info         the same with no info tensors (a learner that asks for none)
   value_one_launch           info on, the whole batch as ONE launch per step (--groups 1)
-  value_ordered_per_step     info on, group chains, every step ordered after the caller's stream and the caller's stream
-                             after it (CDAVecEnv.step's default: what a policy-in-the-loop consumer pays)
+  value_ordered_per_step     info on, the env built with the headline's group chains, every step ordered after the caller's stream and the
+                             caller's stream after it (CDAVecEnv.step's default: what a consumer that calls step() per step pays) - since round 6
+                             ONE launch of the whole batch on the caller's stream instead of a fork + join of G chains per step
   value_policy_in_loop       a CONSUMER between the steps: every chain runs {policy network forward + action sampling -> env step -> auto reset} for its own
                              markets on its own stream - ONE launch per step where the env qualifies (k_policy_step: the policy evaluated inside the step
                              kernel, include/cda.h cda_policy_step_range), else a hand-written MFMA launch + the step launch -, K steps per HIP graph, no

@@ -290,10 +290,12 @@ class CDAVecEnv:
         (optional): 0 = the agent is not in this step's action dict; non-zero values also carry the dict's iteration order
         (agents are processed by ascending value, ties by agent index - see include/cda.h).
 
-        groups > 1: the launches go to the group streams.  By default the step is ordered AFTER everything enqueued on the caller's
-        current stream (the tensors a policy just wrote) and the caller's stream AFTER the step (fork + join: one event edge each
-        way), so it composes like any other stream-ordered op.  pipelined=True leaves both edges out: the caller orders things
-        itself (fork() / join() / sync(), or per-group work on group_streams[g]) - what bench.py's free-running loop does."""
+        groups > 1: pipelined=True sends the launches to the group streams with no edge to the caller's stream: the caller orders things itself (fork() /
+        join() / sync(), or per-group work on group_streams[g]) - what bench.py's free-running loop and the rollout chains do; a group's slowest market
+        then overlaps the other groups' next steps.  The default (pipelined=False) is ordered AFTER everything enqueued on the caller's current stream (the
+        tensors a policy just wrote) and the caller's stream AFTER the step, so it composes like any other stream-ordered op - since round 6 as ONE launch of
+        the whole batch on the caller's stream: a step that is joined at once has no tail to overlap, and the fork + join event edges of G chains cost more
+        than G concurrent launches gain (bench.py value_ordered_per_step: 202 M with the edges, the one launch's rate without; results are identical)."""
         if isinstance(category, dict):
             d = category
             present = d.get("present", present)
@@ -308,8 +310,10 @@ class CDAVecEnv:
         if len(self._views) > 1:
             self._cur = (self._cur + 1) % len(self._views)
             self._bind_outputs()
-        if self.groups > 1:
-            if self._need_fork or not pipelined:
+        if self.groups > 1 and not pipelined and not self._need_fork:
+            self.join()                     # the group streams hold steps the caller's stream has not seen: order it after them (and the next pipelined step forks)
+        if self.groups > 1 and pipelined:
+            if self._need_fork:
                 self.fork()
             fn = self._groups_call
             call = (self._h, self.groups, cat.data_ptr(), sm.data_ptr(), ss.data_ptr(), pr.data_ptr(), po.data_ptr(),
@@ -330,8 +334,6 @@ class CDAVecEnv:
         # when step t+1 is enqueued (the caching allocator would otherwise hand the memory out again on the caller's stream)
         self._keep_prev = getattr(self, "_keep", None)
         self._keep = (cat, sm, ss, pr, po, ps)
-        if self.groups > 1 and not pipelined:
-            self.join()
         return self.obs, self.reward, self._term.view(torch.bool), self._trunc.view(torch.bool), self.info
 
     def run_random(self, n_steps, action_seed=0, market_index_base=0):
