@@ -19,17 +19,6 @@ DEC_DTYPE = K.DEC_DTYPE
 ACTION_KEYS = ("category", "size_mean", "size_sigma", "price", "price_offset")
 
 
-class _PtrOnly:
-    """stands in for a tensor where only its address is used"""
-    __slots__ = ("_p",)
-
-    def __init__(self, p):
-        self._p = p
-
-    def data_ptr(self):
-        return self._p
-
-
 class CDAVecEnv:
     """Batched env.  Tensors: actions [N,A]; obs f32[N, n_hist*42]; reward f64[N,A];
     terminated/truncated bool[N] (the reference's "__all__" flags); info = dict of SoA tensors."""
@@ -184,13 +173,8 @@ class CDAVecEnv:
         self._hio_stream = stream
 
     def reset_host_io(self, seed=None, mask=None):
-        """reset() whose observation lands in the block of bind_host_io() (slab 0's obs)."""
-        dev_obs = self.obs
-        try:
-            self.obs = _PtrOnly(self._hio[1][0])
-            self.reset(seed=seed, mask=mask)
-        finally:
-            self.obs = dev_obs
+        """reset() whose observation lands in the block of bind_host_io() (slab 0's obs) instead of the device tensor."""
+        self.reset(seed=seed, mask=mask, _obs_ptr=self._hio[1][0])
         self._hio_stream = torch.cuda.current_stream(self.device)
 
     def sync_host_io(self):
@@ -216,10 +200,11 @@ class CDAVecEnv:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------ reset / step
-    def reset(self, seed=None, mask=None):
+    def reset(self, seed=None, mask=None, _obs_ptr=None):
         """reset(seed=None): every selected market keeps its RNG stream (a never-seeded market is seeded
         with its index).  seed=int s: market i is seeded SeedSequence(s + i).  seed=array/tensor of N
-        unsigned 64-bit seeds: per market.  mask: bool/uint8 [N] selecting the markets to reset."""
+        unsigned 64-bit seeds: per market.  mask: bool/uint8 [N] selecting the markets to reset.
+        (_obs_ptr: where the first observations go instead of `self.obs` - reset_host_io.)"""
         seeds_t = None
         if seed is not None:
             if isinstance(seed, (int, np.integer)):
@@ -241,7 +226,7 @@ class CDAVecEnv:
         with torch.cuda.device(self.device):
             check(lib().cda_reset(self._h, seeds_t.data_ptr() if seeds_t is not None else None,
                                   mask_t.data_ptr() if mask_t is not None else None,
-                                  self.obs.data_ptr(), self._stream()), "cda_reset")
+                                  self.obs.data_ptr() if _obs_ptr is None else _obs_ptr, self._stream()), "cda_reset")
         self._keep = (seeds_t, mask_t)
         if self.groups > 1:
             self._need_fork = True          # the group streams must see this reset (issued on the caller's stream)
