@@ -146,13 +146,14 @@ def make_config(config=None):
     init_cash = cfg["init_cash"]
     if int(init_cash) != init_cash:
         raise ValueError("init_cash must be integer valued")
-    if cfg["tick_size"] != 1:
-        raise ValueError("only tick_size == 1 is supported (integer tick grid)")
+    tick = cfg["tick_size"]
+    if int(tick) != tick or not 1 <= int(tick) <= 65536:
+        raise ValueError("tick_size must be an integer in 1 .. 65536 (off the integer grid the reference's float price arithmetic is platform dependent: SURVEY A.10)")
     c = Config()
     c.num_agents = int(cfg["num_of_agents"])
     c.max_step = int(cfg["max_step"])
     c.n_hist = int(cfg["n_hist"])
-    c.tick_size = 1
+    c.tick_size = int(tick)
     c.init_cash = int(init_cash)
     c.initial_price_min = int(cfg["initial_price_min"])
     c.initial_price_max = int(cfg["initial_price_max"])

@@ -631,7 +631,7 @@ const char* cda_strerror(int status) {
         case CDA_ERR_INVALID: return "invalid argument or config outside the supported domain";
         case CDA_ERR_NO_DEVICE: return "no HIP device: this library has no CPU fallback";
         case CDA_ERR_HIP: return g_err[0] ? g_err : "HIP runtime error";
-        case CDA_ERR_UNSUPPORTED: return "unsupported configuration (only tick_size == 1)";
+        case CDA_ERR_UNSUPPORTED: return "unsupported configuration (tick_size must be an integer in 1 .. 65536) or a launch this env does not qualify for";
         case CDA_ERR_NOMEM: return "out of memory";
         default: return "unknown status";
     }
@@ -650,7 +650,7 @@ int cda_default_config(cda_config* c) {
 static int cfg_ok(const cda_config* c) {
     if (c->num_agents < 1 || c->num_agents > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
     if (c->n_hist < 1 || c->n_hist > CDA_MAX_HIST) return CDA_ERR_INVALID;
-    if (c->tick_size != 1) return CDA_ERR_UNSUPPORTED;
+    if (c->tick_size < 1 || c->tick_size > CDA_TICK_MAX) return CDA_ERR_UNSUPPORTED;
     if (c->initial_price_max < c->initial_price_min || c->initial_price_min < 0) return CDA_ERR_INVALID;
     if (c->initial_price_max >= (1 << 24)) return CDA_ERR_INVALID;      // prices live below 2^24 ticks (the clamp of step_market; the libm sweeps cover exactly that domain)
     if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;

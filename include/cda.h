@@ -34,6 +34,7 @@ extern "C" {
 #define CDA_SNAPSHOT_DIM  42            /* book_rows*k_rows + extra_dim */
 #define CDA_RAW_DIM       40            /* agg_LOB_raw: state_helper.py:159-160 */
 #define CDA_MAX_HIST      16            /* n_hist upper bound of this build (reference default 4) */
+#define CDA_TICK_MAX      65536         /* tick_size upper bound: prices live below 2^24, a ladder of ten levels of the largest tick still fits */
 #define CDA_MAX_AGENTS    16            /* agents per market upper bound of this build */
 #define CDA_BOOK_CAP      256           /* default LDS book tile: the top of a market's book, both sides together (cda_config.book_capacity) */
 #define CDA_BOOK_CAP_MAX  512           /* the larger compiled tile; also sizes the arrays of the fixed-size parity dump (cda_market_state) */
@@ -47,7 +48,7 @@ typedef enum cda_status {
     CDA_ERR_INVALID = -1,       /* bad argument / config outside the supported domain */
     CDA_ERR_NO_DEVICE = -2,     /* no HIP device (the product path has no CPU fallback) */
     CDA_ERR_HIP = -3,           /* a HIP runtime call failed; see cda_strerror */
-    CDA_ERR_UNSUPPORTED = -4,   /* e.g. tick_size != 1 */
+    CDA_ERR_UNSUPPORTED = -4,   /* a tick_size outside 1 .. CDA_TICK_MAX (the config carries integer ticks only: SURVEY App. A.10); a launch this env does not qualify for */
     CDA_ERR_NOMEM = -5
 } cda_status;
 
@@ -66,7 +67,8 @@ typedef struct cda_config {
     int32_t num_agents;          /* num_of_agents        (5)       */
     int32_t max_step;            /* max_step             (64)      */
     int32_t n_hist;              /* n_hist               (4)       */
-    int32_t tick_size;           /* tick_size            (1) - only 1 is supported */
+    int32_t tick_size;           /* tick_size            (1) - an INTEGER tick, 1 .. CDA_TICK_MAX: the price ladder's step (action_helper.py:341-397) and the unit of the
+                                    observation's spread (state_helper.py:202-206); off the integer grid the reference's float price arithmetic is platform dependent */
     int64_t init_cash;           /* init_cash            (1000000) - integer, > -2^62 */
     int32_t initial_price_min;   /* initial_price_min    (10)      */
     int32_t initial_price_max;   /* initial_price_max    (100)     */

@@ -827,7 +827,7 @@ static void market_step(const struct oracle_env* e, market_t* m, int mi,
 static int cfg_ok(const cda_config* c) {
     if (c->num_agents < 1 || c->num_agents > CDA_MAX_AGENTS) return CDA_ERR_INVALID;
     if (c->n_hist < 1 || c->n_hist > CDA_MAX_HIST) return CDA_ERR_INVALID;
-    if (c->tick_size != 1) return CDA_ERR_UNSUPPORTED;
+    if (c->tick_size < 1 || c->tick_size > CDA_TICK_MAX) return CDA_ERR_UNSUPPORTED;
     if (c->initial_price_max < c->initial_price_min) return CDA_ERR_INVALID;
     if (c->min_size < 0 || c->mkt_max_size < c->min_size || c->limit_size_multiple < 1) return CDA_ERR_INVALID;
     if (c->book_capacity != 0 && c->book_capacity != CDA_BOOK_CAP && c->book_capacity != CDA_BOOK_CAP_MAX) return CDA_ERR_INVALID;

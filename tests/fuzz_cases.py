@@ -17,6 +17,8 @@ def random_config(rng):
                    passive_bonus=float(rng.uniform(0, 1)), loss_multiplier=float(rng.uniform(1, 3)))
     law = str(rng.choice(["uniform", "uniform", "aggressive", "edges", "trend"]))
     present_p = None if rng.random() < 0.7 else float(rng.uniform(0.3, 0.9))
+    if rng.random() < 0.3:                                    # an integer tick other than 1 (round 6): the ladder's step and the unit of the observation's spread
+        cfg["tick_size"] = int(rng.choice([2, 3, 5, 10, 250]))
     return cfg, law, present_p
 
 

@@ -322,6 +322,12 @@ def main():
     add("bigbook_waves_s205", dict(base16, max_step=1280), 205, 1280, 7405, law="trend_waves", book_every=64)     # ~850 orders, both sides deep
     add("bigbook8_waves_s203", dict(base8, max_step=1280), 203, 1280, 7403, law="trend_waves", book_every=64)     # tile 256
     add("bigbook4_s201", dict(base4, max_step=1280), 201, 1280, 7401, law="trend", book_every=64)                 # tile 256, 4 agents
+    # integer tick sizes other than 1 (round 6): the price ladder steps in ticks (action_helper.py:341-397), the observation's spread is counted in them
+    # (state_helper.py:202-206: a NON-integer argument of log1p once a price was clamped off the ladder's grid - the floor traces)
+    add("tick5_s301", dict(base4, tick_size=5), 301, 192, 7301)
+    add("tick3_floor_s302", dict(base4, tick_size=3, initial_price_min=1, initial_price_max=7), 302, 192, 7302)
+    add("tick7_aggr8_s303", dict(base8, tick_size=7, initial_price_min=20, initial_price_max=60), 303, 160, 7303, law="aggressive")
+    add("tick250_edges_s304", dict(base4, tick_size=250, initial_price_min=100, initial_price_max=3000), 304, 160, 7304, law="edges")
     for name, rec in traces.items():
         np.savez_compressed(os.path.join(out_dir, f"trace_{name}.npz"), **rec)
     if only:

@@ -17,8 +17,10 @@ def test_make_config_defaults_and_overrides():
     assert (c.num_agents, c.init_cash, c.max_step, c.loss_multiplier) == (8, 5000, 4096, 2.0)
     with pytest.raises(KeyError):
         K.make_config({"num_agents": 4})            # the env-side spelling is num_of_agents
-    with pytest.raises(ValueError):
-        K.make_config({"tick_size": 0.5})
+    for bad in (0.5, 0, -3, 65537):                         # integer ticks 1 .. CDA_TICK_MAX only (include/cda.h)
+        with pytest.raises(ValueError):
+            K.make_config({"tick_size": bad})
+    assert K.make_config({"tick_size": 5})[0].tick_size == 5 and K.make_config({"tick_size": 250.0})[0].tick_size == 250
     with pytest.raises(ValueError):
         K.make_config({"init_cash": 10.5})
 
