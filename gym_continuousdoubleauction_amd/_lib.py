@@ -33,7 +33,7 @@ MLP_SYMBOLS = [
     "cda_gae_records_league", "cda_league_assign", "cda_mlp_wgrad_jobs",
 ]
 # the same entry points compiled for other history depths carry the suffix _h<H> (include/cda_mlp.h CDA_MLP_HIST_VARIANTS, csrc/cda_mlp_variant.h)
-MLP_HIST_VARIANTS = (1, 2, 8)
+MLP_HIST_VARIANTS = (1, 2, 3, 6, 7, 8)
 
 
 class RolloutBufs(C.Structure):

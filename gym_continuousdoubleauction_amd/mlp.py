@@ -22,7 +22,8 @@ DIST_LD = 28
 LS_ROWS = (N_LOGITS + 1, N_LOGITS + 2)
 POLICY_ROWS = list(range(N_LOGITS)) + list(LS_ROWS)
 #: history depths the network kernels are compiled for (include/cda_mlp.h CDA_MLP_HIST + CDA_MLP_HIST_VARIANTS): 4 = the reference's n_hist, the unsuffixed entry points
-HIST_VARIANTS = (1, 2, 4, 8)
+HIST_VARIANTS = (1, 2, 3, 4, 6, 7, 8)          # (5: the update kernel's gather of 210-float rows spills 14 registers at that width - not built; 9 .. 16: the 128-row forward tile
+#:  no longer fits the LDS - both run the PyTorch loops)
 
 
 def _lib():

@@ -45,7 +45,7 @@ extern "C" {
 #ifndef CDA_MLP_HIST
 #define CDA_MLP_HIST 4
 #endif
-#define CDA_MLP_HIST_VARIANTS "1 2 8"
+#define CDA_MLP_HIST_VARIANTS "1 2 3 6 7 8"
 #define CDA_MLP_OBS       (42 * CDA_MLP_HIST)                       /* 168 */
 #define CDA_MLP_KX        ((CDA_MLP_OBS + 15) / 16 * 16)             /* 176: the observation padded to MFMA k-steps of 16 */
 #define CDA_MLP_XTILES    ((CDA_MLP_KX + 31) / 32)                   /* 6: ... and to feature tiles of 32 in the packed layout */

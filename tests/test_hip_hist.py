@@ -1,5 +1,5 @@
 """GPU: the network kernels at other history depths.  The reference trains with n_hist = 4 (168-float observations: the unsuffixed entry points);
-the library also holds the same kernels compiled for n_hist 1, 2 and 8 (include/cda_mlp.h CDA_MLP_HIST_VARIANTS: <name>_h<H>; mlp.layout(n_hist)) - 42, 84 and 336
+the library also holds the same kernels compiled for n_hist 1, 2, 3, 6, 7 and 8 (include/cda_mlp.h CDA_MLP_HIST_VARIANTS: <name>_h<H>; mlp.layout(n_hist)) - 42 .. 336
 inputs: other k-step counts of layer 1, 8-byte instead of 16-byte row requests for odd depths, another split of the dW1 panel over the weight-gradient jobs (two x-tile
 groups at n_hist 8), one workgroup of the update kernel per CU at n_hist 8.  Same checks as tests/test_hip_mlp.py / test_hip_league.py, per depth."""
 import math
@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-DEPTHS = [1, 2, 8]
+DEPTHS = [1, 2, 3, 6, 7, 8]
 ACTION_KEYS = ("category", "size_mean", "size_sigma", "price", "price_offset")
 
 
@@ -181,7 +181,7 @@ def test_rollout_replays_through_the_oracle_and_the_two_update_paths_agree(h):
     env.close()
 
 
-@pytest.mark.parametrize("h,league", [(1, False), (8, False), (2, True), (8, True)])
+@pytest.mark.parametrize("h,league", [(1, False), (8, False), (2, True), (8, True), (3, False), (6, True)])
 def test_training_loops_run_at_other_depths(h, league):
     from gym_continuousdoubleauction_amd import CDAVecEnv, ppo
     from gym_continuousdoubleauction_amd.league_train import train_league_fused
@@ -202,7 +202,8 @@ def test_training_loops_run_at_other_depths(h, league):
 
 def test_other_depths_are_refused_with_a_reason():
     from gym_continuousdoubleauction_amd import mlp
-    with pytest.raises(ValueError, match="compiled for n_hist"):
-        mlp.layout(3)
+    for h in (5, 9, 16):
+        with pytest.raises(ValueError, match="compiled for n_hist"):
+            mlp.layout(h)
     with pytest.raises(ValueError, match="n_hist"):
         mlp.FusedPolicy(DEV, theta=mlp.init_theta(84), n_hist=4)

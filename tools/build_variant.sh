@@ -15,5 +15,5 @@ for f in cda_ppo cda_mlp; do
 done
 hipcc $FLAGS "$@" -c cda_hip.hip -o $OBJ/cda_hip_$NAME.o
 wait
-hipcc $FLAGS -shared -o $OUT/libcda_hip_$NAME.so $OBJ/cda_hip_$NAME.o $OBJ/cda_ppo.o $OBJ/cda_mlp.o $OBJ/cda_mlp_h1.o $OBJ/cda_mlp_h2.o $OBJ/cda_mlp_h8.o
+hipcc $FLAGS -shared -o $OUT/libcda_hip_$NAME.so $OBJ/cda_hip_$NAME.o $OBJ/cda_ppo.o $OBJ/cda_mlp.o $OBJ/cda_mlp_h1.o $OBJ/cda_mlp_h2.o $OBJ/cda_mlp_h3.o $OBJ/cda_mlp_h6.o $OBJ/cda_mlp_h7.o $OBJ/cda_mlp_h8.o
 echo built $OUT/libcda_hip_$NAME.so
