@@ -636,3 +636,29 @@ def test_a_host_side_reset_between_rollouts_is_where_the_next_rollout_starts(lea
     _replay(cfg, N, 9000, b2, T)
     assert (env.flags() == 0).all() and (env.check_invariants() == 0).all()
     env.close()
+
+
+def test_league_loop_trains_the_state_dependent_log_std_heads_of_both_policies():
+    """train_league_fused(state_dependent_log_std=True) under RLLIB_DEFAULTS (KL rows with per-row log-stds): three iterations at 128 x 8 - losses finite, KL measured, the two
+    trainable policies' head rows (25, 26 of Wo / bo) moved, their free log_std vectors did not, champions snapshot the head with the row, env invariants clean."""
+    from gym_continuousdoubleauction_amd import CDAVecEnv, mlp, ppo
+    from gym_continuousdoubleauction_amd.league_train import train_league_fused
+    N, A, k = 128, 8, 2
+    env = CDAVecEnv({"num_of_agents": A, "init_cash": 1000000, "max_step": 16, "is_render": False, "auto_reset": True}, n_markets=N, with_info=False)
+    keep = {}
+    bank, league, hist = train_league_fused(env, iters=3, horizon=16, num_trainable=k, lr=3e-4, objective=dict(ppo.RLLIB_DEFAULTS), state_dependent_log_std=True,
+                                            std_dev_multiplier=-10.0, min_iterations_between_champions=1, log=lambda s: None, keep=keep)
+    L = mlp.layout(4)
+    for p in range(k):
+        pol = bank.policies[p]
+        assert pol.state_dependent_log_std and mlp.has_log_std_head(pol.theta.cpu())
+        fresh = mlp.init_theta(generator=torch.Generator().manual_seed(0 + 7919 * p), state_dependent_log_std=True)
+        wo_now, wo_0 = pol.theta[L.OFF_WO:L.OFF_BO].view(32, 256).cpu(), fresh[L.OFF_WO:L.OFF_BO].view(32, 256)
+        assert float((wo_now[25:27] - wo_0[25:27]).abs().max()) > 1e-5          # the head trained
+        assert float(wo_now[27:].abs().max()) == 0.0                            # the padding rows stayed zero
+        assert torch.equal(pol.theta[L.OFF_LS:].cpu(), fresh[L.OFF_LS:])          # the free vector is not an optimisation variable with the head
+        for h in hist:
+            assert all(math.isfinite(v) for v in h[f"policy_{p}"].values()) and h[f"policy_{p}"]["kl"] > 0
+    assert len(league.history) >= 1 and mlp.has_log_std_head(bank.theta[k].cpu())     # a champion is a copy of the whole row, head included
+    assert (env.flags() == 0).all() and (env.check_invariants() == 0).all()
+    env.close()
