@@ -47,6 +47,21 @@ namespace cda { namespace mlpdev_h2 {
 #include "cda_mlp_dev.inc"
 } }
 #undef CDA_MLP_HIST
+#define CDA_MLP_HIST 3
+namespace cda { namespace mlpdev_h3 {
+#include "cda_mlp_dev.inc"
+} }
+#undef CDA_MLP_HIST
+#define CDA_MLP_HIST 6
+namespace cda { namespace mlpdev_h6 {
+#include "cda_mlp_dev.inc"
+} }
+#undef CDA_MLP_HIST
+#define CDA_MLP_HIST 7
+namespace cda { namespace mlpdev_h7 {
+#include "cda_mlp_dev.inc"
+} }
+#undef CDA_MLP_HIST
 #define CDA_MLP_HIST 8
 namespace cda { namespace mlpdev_h8 {
 #include "cda_mlp_dev.inc"
@@ -840,21 +855,34 @@ static int policy_step_lds(const cda_env* e) {            // dynamic LDS of k_po
         case 4: return cda::cap256::policy_step_lds_bytes(c.num_agents, c.n_hist);
         case 1: return cda::cap256::policy_step_lds_bytes_h1(c.num_agents, c.n_hist);
         case 2: return cda::cap256::policy_step_lds_bytes_h2(c.num_agents, c.n_hist);
+        case 3: return cda::cap256::policy_step_lds_bytes_h3(c.num_agents, c.n_hist);
+        case 6: return cda::cap256::policy_step_lds_bytes_h6(c.num_agents, c.n_hist);
+        case 7: return cda::cap256::policy_step_lds_bytes_h7(c.num_agents, c.n_hist);
         case 8: return cda::cap256::policy_step_lds_bytes_h8(c.num_agents, c.n_hist);
         default: return 0;
+    }
+}
+// the instance of k_policy_step for a history depth (NULL: none compiled), with / without the episode-metric tallies
+typedef void (*policy_step_kern_t)(cda::cap256::PolicyStepKernArgs);
+static policy_step_kern_t policy_step_kernel(int hist, bool tally) {
+    switch (hist) {
+        case 4: return tally ? cda::cap256::k_policy_step<true> : cda::cap256::k_policy_step<false>;
+#define CDA_PS_CASE(h) case h: return tally ? cda::cap256::k_policy_step_h##h<true> : cda::cap256::k_policy_step_h##h<false>;
+        CDA_PS_CASE(1) CDA_PS_CASE(2) CDA_PS_CASE(3) CDA_PS_CASE(6) CDA_PS_CASE(7) CDA_PS_CASE(8)
+#undef CDA_PS_CASE
+        default: return nullptr;
     }
 }
 // More than 64 KB of dynamic LDS has to be granted per device and kernel instance: once, under a lock (envs are created and stepped from several host threads - one per
 // GPU in the guarded collectives of parallel.py), at cda_create - not lazily inside the launch path, whose first call sits inside a stream capture (round-5 ADVICE).
 static int grant_policy_step_lds(const cda_env* e) {
     static std::mutex mu;
-    static unsigned long long granted[4] = {0, 0, 0, 0};      // per history-depth instance: a bit per device (both tally variants together)
-    const int hist = e->P.cfg.n_hist, slot = hist == 4 ? 0 : (hist == 1 ? 1 : (hist == 2 ? 2 : 3));
+    static unsigned long long granted[CDA_MAX_HIST + 1] = {0};      // per history-depth instance: a bit per device (both tally variants together)
+    const int hist = e->P.cfg.n_hist, slot = hist;
     std::lock_guard<std::mutex> lock(mu);
     if (granted[slot] >> (e->device & 63) & 1ull) return 0;
-    typedef void (*kern_t)(cda::cap256::PolicyStepKernArgs);
-    const kern_t ks[2] = {hist == 4 ? cda::cap256::k_policy_step<false> : (hist == 1 ? cda::cap256::k_policy_step_h1<false> : (hist == 2 ? cda::cap256::k_policy_step_h2<false> : cda::cap256::k_policy_step_h8<false>)),
-                          hist == 4 ? cda::cap256::k_policy_step<true> : (hist == 1 ? cda::cap256::k_policy_step_h1<true> : (hist == 2 ? cda::cap256::k_policy_step_h2<true> : cda::cap256::k_policy_step_h8<true>))};
+    const policy_step_kern_t ks[2] = {policy_step_kernel(hist, false), policy_step_kernel(hist, true)};
+    if (!ks[0] || !ks[1]) return 1;
     for (int k = 0; k < 2; k++)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(ks[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 1;
     granted[slot] |= 1ull << (e->device & 63);
@@ -892,12 +920,8 @@ int cda_policy_step_range(cda_env* e, int32_t first_market, int32_t n_markets, c
     }
     HIPCHK(hipSetDevice(e->device));
     const size_t smem = (size_t)policy_step_lds(e);
-    typedef void (*kern_t)(cda::cap256::PolicyStepKernArgs);
-    const int hist = e->P.cfg.n_hist, slot = hist == 4 ? 0 : (hist == 1 ? 1 : (hist == 2 ? 2 : 3));
-    const bool tally = e->P.lay.ep_on != 0;
-    const kern_t kern = tally ? (hist == 4 ? cda::cap256::k_policy_step<true> : (hist == 1 ? cda::cap256::k_policy_step_h1<true> : (hist == 2 ? cda::cap256::k_policy_step_h2<true> : cda::cap256::k_policy_step_h8<true>)))
-                              : (hist == 4 ? cda::cap256::k_policy_step<false> : (hist == 1 ? cda::cap256::k_policy_step_h1<false> : (hist == 2 ? cda::cap256::k_policy_step_h2<false> : cda::cap256::k_policy_step_h8<false>)));
-    (void)slot;
+    const policy_step_kern_t kern = policy_step_kernel(e->P.cfg.n_hist, e->P.lay.ep_on != 0);
+    if (!kern) return CDA_ERR_UNSUPPORTED;
     if (grant_policy_step_lds(e)) return CDA_ERR_HIP;     // (normally a no-op: cda_create granted it - outside any stream capture)
     cda::cap256::PolicyStepKernArgs KA;
     KA.K.arena = e->arena; KA.K.P = e->P; KA.K.S = S; KA.K.S.first_market = first_market; KA.K.S.end_market = first_market + n_markets;

@@ -29,6 +29,7 @@ def _bufs(N, A, cap, obs_dim=168):
 @pytest.mark.parametrize("A,N,max_step,cash,deep,H,sd", [(4, 150, 7, 1000000, False, 4, False), (8, 70, 5, 20000, False, 4, False), (2, 33, 40, 1000000, False, 4, False),
                                                           (4, 40, 4096, 1000000, True, 4, False), (4, 70, 6, 1000000, False, 1, False), (8, 50, 9, 20000, False, 2, False),
                                                           (3, 45, 5, 1000000, False, 8, False), (4, 40, 4096, 1000000, True, 8, False),
+                                                          (4, 70, 6, 1000000, False, 3, False), (8, 50, 9, 20000, False, 6, False), (4, 45, 5, 1000000, False, 7, False),
                                                           (4, 150, 7, 1000000, False, 4, True), (8, 50, 9, 20000, False, 2, True)])     # sd: the state-dependent log-std head
 def test_policy_inside_the_step_kernel_equals_the_policy_launch_followed_by_the_step_launch(A, N, max_step, cash, deep, H, sd):
     from gym_continuousdoubleauction_amd import CDAVecEnv, mlp
@@ -116,7 +117,8 @@ def test_unsupported_envs_say_so_and_the_rollout_chain_falls_back():
     from gym_continuousdoubleauction_amd import CDAVecEnv
     from gym_continuousdoubleauction_amd._lib import lib
     L = lib()
-    for cfg, want in (({"num_of_agents": 4}, 1), ({"num_of_agents": 4, "n_hist": 8}, 1), ({"num_of_agents": 12}, 0), ({"num_of_agents": 4, "n_hist": 3}, 0), ({"num_of_agents": 4, "book_capacity": 512}, 0)):
+    for cfg, want in (({"num_of_agents": 4}, 1), ({"num_of_agents": 4, "n_hist": 8}, 1), ({"num_of_agents": 4, "n_hist": 3}, 1), ({"num_of_agents": 12}, 0), ({"num_of_agents": 4, "n_hist": 5}, 0), ({"num_of_agents": 4, "n_hist": 10}, 0),
+                      ({"num_of_agents": 4, "book_capacity": 512}, 0)):
         env = CDAVecEnv(dict(cfg, init_cash=1000000, max_step=64, is_render=False, auto_reset=True), n_markets=32, with_info=False)
         assert L.cda_policy_step_supported(env._h) == want, cfg
         if not want:

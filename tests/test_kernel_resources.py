@@ -78,11 +78,12 @@ def test_step_kernels_keep_four_waves_per_simd_and_spill_no_vgpr():
             assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= (32 if "k_run_randomILb1" in n else 16), (n, v)
     # the policy inside the step kernel: sixteen market-waves per workgroup = the same four waves per SIMD, and the same hot body as k_step<false> behind the forward pass
     pol = {n: v for n, v in ks.items() if "k_policy_step" in n}
-    assert len(pol) == 8, sorted(pol)                            # one per compiled history depth (256-order tile only) x with / without the tallies
+    assert len(pol) == 14, sorted(pol)                           # one per compiled history depth (256-order tile only) x with / without the tallies
     for n, v in pol.items():
         assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 2, (n, v)          # (the save / restore around the cold tail's calls)
         body = bodies[n]
-        k1 = {"k_policy_stepI": 11, "k_policy_step_h1I": 3, "k_policy_step_h2I": 6, "k_policy_step_h8I": 21}[[k for k in ("k_policy_step_h1I", "k_policy_step_h2I", "k_policy_step_h8I", "k_policy_stepI") if k in n][0]]
+        depth_k1 = {"k_policy_stepI": 11, "k_policy_step_h1I": 3, "k_policy_step_h2I": 6, "k_policy_step_h3I": 8, "k_policy_step_h6I": 16, "k_policy_step_h7I": 19, "k_policy_step_h8I": 21}
+        k1 = depth_k1[[k for k in depth_k1 if k in n][0]]
         assert sum("v_mfma_f32_32x32x16_bf16" in l for l in body) == k1 + 16 + 16, n      # one tile per wave: layer 1 (KX / 16 k-steps), layer 2, heads
         scratch = [i for i, l in enumerate(body) if "scratch_" in l]
         calls = [i for i, l in enumerate(body) if "s_swappc" in l]
