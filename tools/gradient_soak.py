@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--log-std-head", action="store_true", help="every shape with the state-dependent log-std head (sd_log_std: columns 25, 26 carry the rows' log-std gradients)")
     a = ap.parse_args()
     from test_hip_league import check_gradient
     rng = np.random.default_rng(a.seed)
@@ -38,9 +39,9 @@ def main():
         vf_clip = float(rng.choice([0.0, 0.5, 10.0]))
         chunks = int(rng.integers(1, min(8, R // 32) + 1))
         seed = int(rng.integers(1, 1 << 30))
-        what = f"  {i:3d}: {R:4d} rows x {A:2d} agents, slot {slot}, kl_coef {kl}, vf_clip {vf_clip}, {chunks} chunk(s), seed {seed}"
+        what = f"  {i:3d}: {R:4d} rows x {A:2d} agents, slot {slot}, kl_coef {kl}, vf_clip {vf_clip}, {chunks} chunk(s), seed {seed}{', log-std head' if a.log_std_head else ''}"
         try:
-            cos = check_gradient(A, slot, kl, vf_clip, R=R, seed=seed, chunks=chunks, check_clip_share=False, soak=True)
+            cos = check_gradient(A, slot, kl, vf_clip, R=R, seed=seed, chunks=chunks, check_clip_share=False, soak=True, sd=a.log_std_head)
         except AssertionError as ex:
             print(f"{what}: FAILED {ex}", flush=True)
             failed += 1
