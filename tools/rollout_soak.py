@@ -57,7 +57,7 @@ def say(*a, **k):
 
 def one(rng, index):
     from gym_continuousdoubleauction_amd import CDAVecEnv, mlp
-    H = int(rng.choice([1, 2, 4, 8]))
+    H = int(rng.choice([1, 2, 3, 4, 6, 7, 8]))
     A = int(rng.choice([2, 3, 4, 5, 8, 12, 16]))
     N = int(rng.choice([33, 64, 96, 160, 257, 1024]))
     T = int(rng.integers(5, 25))
@@ -68,9 +68,11 @@ def one(rng, index):
     with_dist, capture = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     cash = int(rng.choice([1000000, 20000, 3000]))                      # small accounts: bankruptcies (terminations) inside the rollout
     seed = int(rng.integers(1, 1 << 30))
-    cfg = {"num_of_agents": A, "init_cash": cash, "max_step": max_step, "is_render": False, "auto_reset": True, "n_hist": H}
+    sd = bool(rng.integers(0, 2))                                       # the state-dependent log-std head on every network of the rollout
+    tick = int(rng.choice([1, 1, 5]))
+    cfg = {"num_of_agents": A, "init_cash": cash, "max_step": max_step, "is_render": False, "auto_reset": True, "n_hist": H, "tick_size": tick}
     say(f"  {index:3d}: {N:3d} markets x {A:2d} agents, n_hist {H}, max_step {max_step:4d}, init_cash {cash:7d}, horizon {T:2d}, {groups} chain(s), "
-          f"{'graphs' if graphs else 'direct'}, {'league' if league else 'one shared policy'}, dist {int(with_dist)}, capture {int(capture)}, seed {seed}", flush=True)
+          f"{'graphs' if graphs else 'direct'}, {'league' if league else 'one shared policy'}, dist {int(with_dist)}, capture {int(capture)}, log-std head {int(sd)}, tick {tick}, seed {seed}", flush=True)
     env = CDAVecEnv(cfg, n_markets=N, with_info=False)
     gen = torch.Generator().manual_seed(seed)
     if league:
@@ -78,11 +80,11 @@ def one(rng, index):
         F = int(rng.integers(0, 4))
         actor = mlp.PolicyBank(DEV, N, A, k, max_frozen=max(F, 1), seed=seed % 1000, random_seed=seed % 7777, n_hist=H)
         for p in range(k):
-            th = mlp.init_theta(42 * H, generator=gen); th[:actor.policies[p].L.OFF_LS] *= 1.5
+            th = mlp.init_theta(42 * H, generator=gen, state_dependent_log_std=sd); th[:actor.policies[p].L.OFF_LS] *= 1.5
             actor.policies[p].theta.copy_(th); actor.policies[p].pack()
         for f in range(F):
             row = actor.snapshot(0)
-            th = mlp.init_theta(42 * H, generator=gen); th[:actor.policies[0].L.OFF_LS] *= 1.5
+            th = mlp.init_theta(42 * H, generator=gen, state_dependent_log_std=sd); th[:actor.policies[0].L.OFF_LS] *= 1.5
             actor.theta[row].copy_(th)
             actor.wb[row].copy_(mlp.FusedPolicy(DEV, theta=th, n_hist=H).wb)
         sn = torch.randint(-1, k + F, (N, A), generator=gen, dtype=torch.int32)
@@ -90,7 +92,7 @@ def one(rng, index):
         actor.set_slots(sn)
         what = f"league k={k} frozen={F}"
     else:
-        th = mlp.init_theta(42 * H, generator=gen); th[:mlp.layout(H).OFF_LS] *= 1.5
+        th = mlp.init_theta(42 * H, generator=gen, state_dependent_log_std=sd); th[:mlp.layout(H).OFF_LS] *= 1.5
         actor = mlp.FusedPolicy(DEV, theta=th, n_hist=H)
         what = "one shared policy"
     env.reset(seed=seed)
