@@ -218,3 +218,41 @@ def test_groups_step_batch_is_stream_ordered_like_any_other_op():
     assert torch.equal(acc1, acc4)
     assert (g4.vec.flags() == 0).all()
     g1.close(); g4.close()
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_host_resident_step_io_equals_the_staged_copies(auto_reset, monkeypatch):
+    """The facades' default step I/O - the step kernel reads the staged actions from and writes obs | reward | flags | info into pinned host memory (CDAVecEnv.bind_host_io) -
+    against the staged path (CDA_FACADE_HOST_IO=0: one H2D copy of the actions, one D2H copy of `packed`): the same dicts step for step, through episode ends with the
+    in-kernel auto reset (the restarted markets' first observations land in the host block too), subsets of agents and shuffled dict orders; CDAEnv likewise."""
+    from gym_continuousdoubleauction_amd import CDAEnv, CDAVecMultiAgentEnv
+    cfg = dict(CFG, max_step=6, auto_reset=auto_reset)
+    n = 9
+    monkeypatch.setenv("CDA_FACADE_HOST_IO", "1")
+    a, one_a = CDAVecMultiAgentEnv(cfg, num_envs=n), CDAEnv(dict(CFG, max_step=40))
+    monkeypatch.setenv("CDA_FACADE_HOST_IO", "0")
+    b, one_b = CDAVecMultiAgentEnv(cfg, num_envs=n), CDAEnv(dict(CFG, max_step=40))
+    assert a._host_io and one_a._host_io and not b._host_io and not one_b._host_io
+    oa, _ = a.reset(seed=5); ob, _ = b.reset(seed=5)
+    assert all(np.array_equal(x["agent_0"], y["agent_0"]) for x, y in zip(oa, ob))
+    o1, _ = one_a.reset(seed=77); o2, _ = one_b.reset(seed=77)
+    assert np.array_equal(o1["agent_0"], o2["agent_0"])
+    rng = np.random.default_rng(8)
+    for t in range(16 if auto_reset else 6):
+        dicts = [_rand_dict(rng, a.agents) for _ in range(n)]
+        if t % 4 == 1:
+            del dicts[2]["agent_1"]
+        if t % 4 == 2:
+            dicts[3] = dict(reversed(list(dicts[3].items())))
+        ra, rb = a.step(dicts), b.step(dicts)
+        for i in range(n):
+            assert np.array_equal(ra[0][i]["agent_0"], rb[0][i]["agent_0"]) and ra[1][i] == rb[1][i] and ra[2][i] == rb[2][i] and ra[3][i] == rb[3][i], (t, i)
+            assert json.dumps(ra[4][i], sort_keys=True) == json.dumps(rb[4][i], sort_keys=True), (t, i)
+        if auto_reset and t >= 6:
+            assert any(tr["__all__"] for tr in ra[3]) or t % 6 != 5                     # episodes end (max_step 6) and the markets restart in place
+        s1, s2 = one_a.step(dicts[0]), one_b.step(dicts[0])
+        assert np.array_equal(s1[0]["agent_0"], s2[0]["agent_0"]) and s1[1] == s2[1] and s1[2] == s2[2] and s1[3] == s2[3]
+        assert json.dumps(s1[4], sort_keys=True) == json.dumps(s2[4], sort_keys=True)
+        assert one_a.LOB_actions == one_b.LOB_actions and one_a.pass_agents == one_b.pass_agents and one_a.done_set == one_b.done_set
+    for e in (a, b, one_a, one_b):
+        e.close()
