@@ -169,7 +169,7 @@ class League:
 def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epochs=4, seed=0, original_opponent_weight=1.0, champion_weight=3.0,
                        std_dev_multiplier=0.1, max_champions=8, min_iterations_between_champions=2, chains=4, minibatch=262144, objective=None, use_graph=True,
                        recorder=None, info_markets=0, run_id="league", log=print, keep=None, allreduce=None, world=1, first_market=0, episode_metrics=True,
-                       strict_nav_check=True, state_dependent_log_std=False):
+                       strict_nav_check=True, state_dependent_log_std=False, hidden=(256, 256)):
     """League self-play on the fused kernels (include/cda_mlp.h `cda_league`): the reference's training topology - `num_trainable` SEPARATELY trained policies
     (policy_p plays slot p), every other slot drawn per episode from the pool of uniform random modules and frozen champions by the reference's mapping rule
     (computed on the device, league.LeagueSlotMapper.assign_device) - at the speed of the fused loop: ONE policy launch per step serves every module of every
@@ -194,7 +194,7 @@ def train_league_fused(env, iters=4, horizon=None, num_trainable=2, lr=5e-5, epo
     if int(env.max_step) % T:
         raise ValueError("the horizon must divide the episode length (max_step)")
     per_episode = int(env.max_step) // T
-    bank = PolicyBank(dev, N, A, k, max_frozen=max_champions, seed=seed, random_seed=seed + 12345 + 104729 * int(first_market), n_hist=env.n_hist, state_dependent_log_std=state_dependent_log_std)
+    bank = PolicyBank(dev, N, A, k, max_frozen=max_champions, seed=seed, random_seed=seed + 12345 + 104729 * int(first_market), n_hist=env.n_hist, state_dependent_log_std=state_dependent_log_std, hidden=hidden)
     mapper = LeagueSlotMapper(A, k, A - k, original_opponent_weight, champion_weight)
     league = League(mapper, bank, std_dev_multiplier, max_champions, min_iterations_between_champions)
     env.reset(seed=seed + int(first_market))

@@ -92,10 +92,14 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def init_theta(obs_dim=OBS, generator=None, state_dependent_log_std=False):
+def init_theta(obs_dim=OBS, generator=None, state_dependent_log_std=False, hidden=(HID, HID)):
     """A fresh parameter vector with nn.Linear's default initialisation per block (uniform +-1/sqrt(fan_in)), log_std = -0.5; obs_dim = 42 n_hist.
     state_dependent_log_std: rows 25, 26 of the output layer - the log-std head's offsets on top of the free vector, RLlib's default module for Box actions
-    (train/policy/policy_handler.py:69-76) - are initialised like every other output row instead of zero (`has_log_std_head(theta)` tells the two apart)."""
+    (train/policy/policy_handler.py:69-76) - are initialised like every other output row instead of zero (`has_log_std_head(theta)` tells the two apart).
+    hidden = (h1, h2), each 1 .. 256: the reference's `fcnet_hiddens` (config/train_config.json:49; 256 x 256 there).  The kernels are compiled for 256-wide layers; a
+    NARROWER network is the same parameter vector with the units beyond h1 / h2 of both halves dead - incoming and outgoing weights and biases exactly zero.  A dead
+    unit outputs tanh(0) = 0 exactly, so every gradient that touches it is an exact zero and Adam never moves it (tests/test_hip_mlp.py): the narrow network trains
+    inside the wide kernels at the wide kernels' cost.  `hidden_widths(theta)` reads the widths back."""
     if obs_dim % 42:
         raise ValueError("an observation is n_hist frames of 42 floats")
     L = layout(obs_dim // 42)
@@ -108,7 +112,31 @@ def init_theta(obs_dim=OBS, generator=None, state_dependent_log_std=False):
     wo[dead] = 0; bo[dead] = 0
     th[L.OFF_WO:L.OFF_BO] = wo.reshape(-1); th[L.OFF_BO:L.OFF_LS] = bo
     th[L.OFF_LS:] = -0.5
+    h1, h2 = (int(hidden[0]), int(hidden[1])) if hasattr(hidden, "__len__") else (int(hidden), int(hidden))
+    if not (1 <= h1 <= HID and 1 <= h2 <= HID):
+        raise ValueError(f"hidden widths must be in 1 .. {HID} (the kernels are compiled for {HID}-wide layers; got {hidden})")
+    if (h1, h2) != (HID, HID):
+        # nn.Linear's bound follows the LIVE fan-in: W2 reads h1 units, Wo reads h2 (the full-width draw above is rescaled, then the dead units are cut)
+        w1 = th[L.OFF_W1:L.OFF_B1].view(2, HID, L.OBS); b1 = th[L.OFF_B1:L.OFF_W2].view(2, HID)
+        w2 = th[L.OFF_W2:L.OFF_B2].view(2, HID, HID); b2 = th[L.OFF_B2:L.OFF_WO].view(2, HID)
+        wo_v = th[L.OFF_WO:L.OFF_BO].view(NOUT, HID); bo_v = th[L.OFF_BO:L.OFF_LS]
+        w2 *= math.sqrt(HID / h1); b2 *= math.sqrt(HID / h1); wo_v *= math.sqrt(HID / h2); bo_v *= math.sqrt(HID / h2)
+        w1[:, h1:] = 0; b1[:, h1:] = 0
+        w2[:, h2:, :] = 0; w2[:, :, h1:] = 0; b2[:, h2:] = 0
+        wo_v[:, h2:] = 0
     return th
+
+
+def hidden_widths(theta):
+    """(h1, h2): the live units of the two hidden layers (the same in the policy and the value half) - a unit is dead when its bias and every weight into it are zero"""
+    L = layout_of_params(theta.numel())
+    th = theta.detach().float().cpu()
+    w1, b1 = th[L.OFF_W1:L.OFF_B1].view(2, HID, L.OBS), th[L.OFF_B1:L.OFF_W2].view(2, HID)
+    w2, b2 = th[L.OFF_W2:L.OFF_B2].view(2, HID, HID), th[L.OFF_B2:L.OFF_WO].view(2, HID)
+    live1 = ((w1 != 0).any(-1) | (b1 != 0)).any(0)
+    live2 = ((w2 != 0).any(-1) | (b2 != 0)).any(0)
+    last = lambda m: int(m.nonzero().max()) + 1 if bool(m.any()) else 0       # noqa: E731
+    return last(live1), last(live2)
 
 
 def has_log_std_head(theta):
@@ -233,16 +261,17 @@ class FusedPolicy:
     """theta (f32 master copy), Adam state and the bf16 operand blob on one HIP device.  storage = (theta row, wb row): views into a PolicyBank's
     banks instead of tensors of its own (the league's kernels address a net as a row of the banks)."""
 
-    def __init__(self, device, theta=None, seed=0, storage=None, n_hist=None, state_dependent_log_std=None):
+    def __init__(self, device, theta=None, seed=0, storage=None, n_hist=None, state_dependent_log_std=None, hidden=(HID, HID)):
         """n_hist: the history depth of the observations (default: the depth `theta` was laid out for, else the reference's 4).
         state_dependent_log_std: RLlib's default head for Box actions - the policy network emits two log-std offsets per row (output rows 25, 26) on top of the free
-        log_std vector, and the update trains them (FusedUpdate reads this attribute); default: what `theta` carries (has_log_std_head), False for a fresh network."""
+        log_std vector, and the update trains them (FusedUpdate reads this attribute); default: what `theta` carries (has_log_std_head), False for a fresh network.
+        hidden: the widths of a FRESH network's two hidden layers, <= 256 each (init_theta: the reference's `fcnet_hiddens`)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FusedPolicy needs a HIP device; the PyTorch statement of the network is ppo.ActorCritic")
         if theta is None:
             g = torch.Generator().manual_seed(int(seed))
-            theta = init_theta(42 * int(n_hist or 4), generator=g, state_dependent_log_std=bool(state_dependent_log_std))
+            theta = init_theta(42 * int(n_hist or 4), generator=g, state_dependent_log_std=bool(state_dependent_log_std), hidden=hidden)
         self.L = L = layout_of_params(theta.numel())
         self.state_dependent_log_std = has_log_std_head(theta) if state_dependent_log_std is None else bool(state_dependent_log_std)
         if n_hist is not None and int(n_hist) != L.hist:
@@ -313,7 +342,7 @@ class PolicyBank:
     rollout with no copy), the rows behind them frozen snapshots (champions: league_based_self_play_callback.py:938-1170).  slot_net i32 [N, A] names
     the row that plays each (market, slot), LEAGUE_RANDOM = the uniform random module."""
 
-    def __init__(self, device, n_markets, num_agents, n_trainable, max_frozen=8, seed=0, random_seed=0, n_hist=4, state_dependent_log_std=False):
+    def __init__(self, device, n_markets, num_agents, n_trainable, max_frozen=8, seed=0, random_seed=0, n_hist=4, state_dependent_log_std=False, hidden=(HID, HID)):
         from ._lib import League
         self.device = torch.device(device)
         self.L = L = layout(n_hist)
@@ -324,7 +353,7 @@ class PolicyBank:
         n_max = self.n_trainable + self.max_frozen
         self.theta = torch.zeros((n_max, PARAMS), dtype=torch.float32, device=self.device)
         self.wb = torch.zeros((n_max, WB_ELEMS), dtype=torch.bfloat16, device=self.device)
-        self.policies = [FusedPolicy(self.device, seed=seed + 7919 * p, storage=(self.theta[p], self.wb[p]), n_hist=L.hist, state_dependent_log_std=state_dependent_log_std)
+        self.policies = [FusedPolicy(self.device, seed=seed + 7919 * p, storage=(self.theta[p], self.wb[p]), n_hist=L.hist, state_dependent_log_std=state_dependent_log_std, hidden=hidden)
                          for p in range(self.n_trainable)]
         self.slot_net = torch.full((int(n_markets), int(num_agents)), LEAGUE_RANDOM, dtype=torch.int32, device=self.device)
         self.slot_net[:, :self.n_trainable] = torch.arange(self.n_trainable, dtype=torch.int32, device=self.device)

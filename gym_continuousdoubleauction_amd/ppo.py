@@ -506,7 +506,7 @@ def adapt_kl_coef(kl_coef, sampled_kl, kl_target):
 
 def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, seed=0, log=print, use_graph=True, chains=4, minibatch=262144,
                 gamma=None, lam=None, clip=None, vf_coef=None, ent_coef=None, policy=None, keep=None, sub_batches=None, objective=None, recorder=None, info_markets=0,
-                allreduce=None, world=1, first_market=0, episode_metrics=True, strict_nav_check=True, state_dependent_log_std=False):
+                allreduce=None, world=1, first_market=0, episode_metrics=True, strict_nav_check=True, state_dependent_log_std=False, hidden=(256, 256)):
     """The PPO loop on the hand-written network kernels (mlp.py, include/cda_mlp.h): rollouts as `chains` independent per-chain launch
     sequences (policy forward + sampling -> env step -> auto reset, one HIP graph per chain, no cross-stream edge inside the horizon), the
     sample records completed by one GAE launch, the update as {gather + forward + loss + back-propagation, weight gradients, reduce, clip + Adam}
@@ -523,7 +523,7 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     (episode_metrics.summarise: pass / rejection fractions, reward-term means and variance shares, NAV / drawdown / inventory at the episode's end, the most maker-like
     agent's passive share) and a violation raises NavConservationError like the reference's strict_nav_check run (train/train.py:1125-1164); strict_nav_check=False logs it.
     state_dependent_log_std: a fresh policy gets RLlib's default head for Box actions (two log-stds per row from the policy network: mlp.FusedPolicy); a given `policy`
-    brings its own.
+    brings its own.  hidden: `fcnet_hiddens` of a fresh policy, <= 256 each (mlp.init_theta).
     Needs a HIP CDAVecEnv with auto_reset and 168-float observations.  Returns (FusedPolicy, history); `keep` (a dict) receives the last
     rollout's buffers and the RolloutChains object.  history[i]: losses, `mean_reward` (of the rollout's slice of the episodes - it depends on WHICH part of
     the episodes the slice covers) and `episode_return` (mean return of the episodes that were COMPLETED during the iteration, None if none was)."""
@@ -536,7 +536,7 @@ def train_fused(env, iters=4, horizon=64, lr=5e-5, epochs=4, reward_scale=None, 
     dev = env.obs.device
     N, A, T = env.n_markets, env.num_agents, int(horizon)
     if policy is None:
-        policy = FusedPolicy(dev, seed=seed, n_hist=env.n_hist, state_dependent_log_std=state_dependent_log_std)
+        policy = FusedPolicy(dev, seed=seed, n_hist=env.n_hist, state_dependent_log_std=state_dependent_log_std, hidden=hidden)
     env.reset(seed=seed + int(first_market))
     if episode_metrics:
         env.enable_episode_metrics(True)
@@ -711,6 +711,7 @@ def main(argv=None):
     p.add_argument("--out", default=None, help="write a JSON summary (config, per-iteration stats, end-of-run env checks) to this file")
     p.add_argument("--legacy", action="store_true", help="the round-3 loop: PyTorch network (library GEMMs, autograd), one graph per rollout step")
     p.add_argument("--chains", type=int, default=4, help="fused loop: independent rollout chains (market groups on their own streams)")
+    p.add_argument("--fcnet-hiddens", type=int, nargs=2, default=(256, 256), metavar=("H1", "H2"), help="fused loop: the two hidden widths (config/train_config.json:49), <= 256 each")
     p.add_argument("--log-std-head", action="store_true", help="fused loop: the state-dependent log-std head (RLlib's default module for Box actions) instead of a free log_std vector")
     p.add_argument("--objective", choices=("ppo", "rllib"), default="ppo", help="fused loop: PPO_DEFAULTS, or RLLIB_DEFAULTS = the objective the reference's RLlib run optimises "
                                                                               "(clip 0.3, lambda 1, vf coeff 1, entropy 0, vf clip 10, adaptive KL penalty, no gradient clipping, truncation bootstrap)")
@@ -728,7 +729,7 @@ def main(argv=None):
         _, hist = train(env, iters=args.iters, horizon=args.horizon, amp=not args.fp32_update, shared_obs=not args.per_sample_forward, use_graph=not args.no_graphs)
     else:
         _, hist = train_fused(env, iters=args.iters, horizon=args.horizon, use_graph=not args.no_graphs, chains=args.chains,
-                              objective=RLLIB_DEFAULTS if args.objective == "rllib" else None, state_dependent_log_std=args.log_std_head)
+                              objective=RLLIB_DEFAULTS if args.objective == "rllib" else None, state_dependent_log_std=args.log_std_head, hidden=tuple(args.fcnet_hiddens))
     flags = env.flags()
     _, bad = env.nav_conservation()
     tail = hist[2:] if len(hist) >= 4 else (hist[1:] or hist)

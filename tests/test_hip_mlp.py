@@ -491,3 +491,57 @@ def test_fused_training_loop_runs_end_to_end():
     assert not bad.any()
     # the first minibatch step of an update recomputes the rollout's own log-probabilities: ratio == 1 up to float32 rounding
     env.close()
+
+
+@pytest.mark.parametrize("hidden,sd", [((128, 64), False), ((64, 256), True), ((200, 100), False)])
+def test_narrow_networks_train_inside_the_wide_kernels(hidden, sd):
+    """The reference's `fcnet_hiddens` is configuration (config/train_config.json:49); the kernels are compiled for 256-wide layers.  A narrower network is the same
+    parameter vector with the units beyond (h1, h2) dead (mlp.init_theta(hidden=...)): their tanh(0) is an exact zero on the device, so every gradient entry that touches a
+    dead unit is an exact zero and Adam never moves it - after optimiser steps on the fused kernels the dead entries are still bit-zero, the live ones moved, and the
+    network's outputs are those of the narrow network (the float64 statement of the live blocks alone)."""
+    import math
+    from gym_continuousdoubleauction_amd import mlp
+    g = torch.Generator().manual_seed(21)
+    th0 = mlp.init_theta(generator=torch.Generator().manual_seed(4), hidden=hidden, state_dependent_log_std=sd)
+    assert mlp.hidden_widths(th0) == hidden
+    p = mlp.FusedPolicy(DEV, theta=th0)
+    R, A = 512, 4
+    x = (torch.randn(R, mlp.OBS, generator=g) * 0.5)
+    rec = torch.zeros(R, A, 8)
+    rec[..., 0] = torch.randint(0, 9, (R, A), generator=g).int().view(torch.float32)
+    rec[..., 1] = torch.randint(0, 10, (R, A), generator=g).int().view(torch.float32)
+    rec[..., 2] = torch.randint(0, 3, (R, A), generator=g).int().view(torch.float32)
+    rec[..., 3:5] = torch.randn(R, A, 2, generator=g)
+    rec[..., 5] = torch.randn(R, A, generator=g) * 0.1 - 7.0
+    rec[..., 6] = torch.randn(R, A, generator=g)
+    rec[..., 7] = torch.randn(R, A, generator=g)
+    upd = mlp.FusedUpdate(p, R, R, A)
+    recd, xd = rec.to(DEV), x.to(DEV)
+    for step in range(6):
+        upd.perm.copy_(torch.randperm(R, generator=g))
+        upd.minibatch_step(0, R, None, None, None, None, 0.3, 1.0, 0.01, 1e-3, (0.9, 0.999), 1e-8, 0.5, records=(recd.data_ptr(), None, 0), obs_rows=xd)
+    torch.cuda.synchronize()
+    th1 = p.theta.cpu()
+    dead = th0 == 0
+    dead[mlp.OFF_LS:] = False
+    assert int(dead.sum()) > 50000 and bool((th1[dead] == 0).all())              # bit-zero, not small
+    assert mlp.hidden_widths(th1) == hidden and mlp.has_log_std_head(th1) == sd
+    live = ~dead
+    live[mlp.OFF_LS:] = False
+    assert float((th1[live] - th0[live]).abs().max()) > 1e-4 and float(((th1 - th0)[live] != 0).float().mean()) > 0.95      # ... while the live network trained
+    # the outputs are the narrow network's: layer by layer over the live blocks only (float64, bf16-rounded operands like the kernels)
+    h1, h2 = hidden
+    t = th1.double()
+    rd = lambda v: v.to(torch.bfloat16).to(torch.float64)                          # noqa: E731
+    W1, b1 = t[mlp.OFF_W1:mlp.OFF_B1].view(2, 256, mlp.OBS), t[mlp.OFF_B1:mlp.OFF_W2].view(2, 256)
+    W2, b2 = t[mlp.OFF_W2:mlp.OFF_B2].view(2, 256, 256), t[mlp.OFF_B2:mlp.OFF_WO].view(2, 256)
+    Wo, bo = t[mlp.OFF_WO:mlp.OFF_BO].view(32, 256), t[mlp.OFF_BO:mlp.OFF_LS]
+    xb = rd(x.double())
+    hid = [rd(torch.tanh(rd(torch.tanh(xb @ rd(W1[k, :h1]).t() + b1[k, :h1])) @ rd(W2[k, :h2, :h1]).t() + b2[k, :h2])) for k in range(2)]
+    want = torch.zeros(R, 32, dtype=torch.float64)
+    rows = mlp.POLICY_ROWS
+    want[:, rows] = hid[0] @ rd(Wo[rows, :h2]).t() + bo[rows]
+    want[:, 24] = hid[1] @ rd(Wo[24, :h2]) + bo[24]
+    got = p.forward(xd).cpu().double()
+    assert float((got - want).abs().max()) <= 3e-3 * max(1.0, float(want.abs().max()))
+    assert math.isfinite(float(upd.out6.cpu()[3]))
