@@ -312,6 +312,7 @@ def main(argv=None):
     p.add_argument("--horizon", type=int, default=None, help="--fused: rollout length (divides --episode; default = --episode)")
     p.add_argument("--chains", type=int, default=4)
     p.add_argument("--objective", choices=("ppo", "rllib"), default="ppo")
+    p.add_argument("--fcnet-hiddens", type=int, nargs=2, default=(256, 256), metavar=("H1", "H2"), help="hidden widths of the trainable policies (config/train_config.json:49), <= 256 each")
     p.add_argument("--log-std-head", action="store_true", help="the trainable policies carry the state-dependent log-std head (RLlib's default module for Box actions)")
     p.add_argument("--out", default=None, help="write a JSON summary to this file")
     args = p.parse_args(argv)
@@ -326,7 +327,7 @@ def main(argv=None):
     env = CDAVecEnv(dict(cfg, auto_reset=True), n_markets=args.markets, device="cuda:0", with_info=False)
     k = args.trainable or 2
     _, league, hist = train_league_fused(env, iters=args.iters, horizon=args.horizon, num_trainable=k, chains=args.chains,
-                                         objective=ppo.RLLIB_DEFAULTS if args.objective == "rllib" else None, state_dependent_log_std=args.log_std_head)
+                                         objective=ppo.RLLIB_DEFAULTS if args.objective == "rllib" else None, state_dependent_log_std=args.log_std_head, hidden=tuple(args.fcnet_hiddens))
     flags = env.flags()
     _, bad = env.nav_conservation()
     tail = hist[2:] if len(hist) >= 4 else (hist[1:] or hist)          # (two warm-up iterations: graph capture, first replays)
